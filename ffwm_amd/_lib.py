@@ -1,0 +1,107 @@
+"""ctypes binding of libffwm_hip.so (C ABI: include/ffwm_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, importing
+an op raises.  Build it with ``python -m ffwm_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libffwm_hip.so")
+
+F32, F64 = 0, 1
+ABI_VERSION = 1
+
+_lib = None
+
+_p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i = ctypes.c_int
+
+_SIGNATURES = {
+    # name: argtypes
+    "ffwm_block_extractor_forward": [_p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_block_extractor_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_local_attn_reshape_forward": [_p, _p] + [_i64] * 3 + [_i, _i, _p],
+    "ffwm_local_attn_reshape_backward": [_p, _p] + [_i64] * 3 + [_i, _i, _i, _p],
+    "ffwm_resample2d_forward": [_p, _p, _p] + [_i64] * 6 + [_i, _i, _i, _p],
+    "ffwm_resample2d_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _i, _i, _p],
+    "ffwm_warp_forward": [_p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_warp_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_prof_enable": [_i],
+    "ffwm_prof_collect": [],
+    "ffwm_prof_get": [_i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),
+                      ctypes.POINTER(ctypes.c_double)],
+    "ffwm_prof_reset": [],
+    "ffwm_set_option": [ctypes.c_char_p, _i],
+    "ffwm_abi_version": [],
+}
+
+EXPORTS = sorted(list(_SIGNATURES) + ["ffwm_last_error"])
+
+
+class FFWMError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FFWMError(
+            "libffwm_hip.so is missing (%s). The HIP extension is the only implementation of the "
+            "ffwm_amd ops -- build it with `python -m ffwm_amd.build`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _i
+    lib.ffwm_last_error.argtypes = []
+    lib.ffwm_last_error.restype = ctypes.c_char_p
+    got = lib.ffwm_abi_version()
+    if got != ABI_VERSION:
+        raise FFWMError("libffwm_hip.so ABI version %d, expected %d: rebuild it" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ffwm_last_error()
+        raise FFWMError("%s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+# ---- profiler / options -------------------------------------------------------------------
+def prof_enable(on=True):
+    return load().ffwm_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    load().ffwm_prof_reset()
+
+
+def prof_collect():
+    """-> {kernel_name: {"launches": n, "total_ms": ms, "avg_ms": ms, "bytes_per_launch": b}}"""
+    lib = load()
+    n = lib.ffwm_prof_collect()
+    rows = {}
+    for i in range(n):
+        name = ctypes.create_string_buffer(128)
+        launches = _i64()
+        ms = ctypes.c_double()
+        nbytes = ctypes.c_double()
+        check(lib.ffwm_prof_get(i, name, 128, ctypes.byref(launches), ctypes.byref(ms),
+                                ctypes.byref(nbytes)), "ffwm_prof_get")
+        k = max(launches.value, 1)
+        rows[name.value.decode()] = {"launches": launches.value, "total_ms": ms.value,
+                                     "avg_ms": ms.value / k, "bytes_per_launch": nbytes.value / k}
+    return rows
+
+
+def set_option(key, value):
+    rc = load().ffwm_set_option(key.encode(), int(value))
+    if rc < 0 and key not in ("be_fwd_variant", "be_bwd_variant", "channel_slab", "xcd_remap"):
+        check(rc, "ffwm_set_option")
+    return rc

@@ -1,0 +1,453 @@
+// block_extractor.hip -- flow-guided bilinear k x k patch extractor for gfx950.
+//
+// Replaces kernel_block_extractor_update_output / kernel_block_extractor_backward of
+// /root/reference/cuda/block_extractor/block_extractor_kernel.cu:21-170 (one thread per OUTPUT
+// element, flow + floor + clamp recomputed per element, C*k*k atomics per grad_flow address).
+//
+// Design here (MI355X-first):
+//   * one thread per FLOW PIXEL, looping over a slab of channels.  All per-pixel state -- the k
+//     x-taps and k y-taps (clamped indices + weights, formed with the reference's exact
+//     operation order) -- is computed once and reused for every channel of the slab.
+//   * a wave covers 64 consecutive xf, so its k contiguous outputs per lane form one contiguous
+//     64*k-element row segment: stores are full-line coalesced; gathers of neighbouring lanes
+//     fall into the same few cache lines.
+//   * neighbouring taps share source pixels: in the (overwhelmingly common) "consistent" case
+//     xR[j] == xL[j+1], yB[i] == yT[i+1] a pixel reads its (k+1) x (k+1) neighbourhood once,
+//     streaming row by row (register use O(k), not O(k^2)).
+//   * backward: grad_flow is accumulated in registers over the window and the channel slab
+//     (one atomic pair per pixel per slab instead of C*k*k); grad_source contributions are merged
+//     per neighbourhood cell in registers before the atomics ((k+1)^2 instead of 4*k^2).
+//   * blockIdx -> tile mapping is XCD-aware (common.hpp:xcd_remap).
+#include "common.hpp"
+
+namespace ffwm {
+namespace {
+
+template <typename T, int K>
+struct Taps {
+    // "consistent" representation: tap (i, j) reads rows row[i], row[i+1] and columns col[j],
+    // col[j+1] (unsigned offsets from the wave-uniform plane base -> saddr + voffset addressing).
+    unsigned col[K + 1];   // x * sizeof(T)           (BYTE offsets: a 32-bit voffset next to an
+    unsigned row[K + 1];   // y * Ws * sizeof(T)        SGPR plane base, no 64-bit VGPR addresses)
+    T wxL[K], wxR[K], wyT[K], wyB[K];
+    bool consistent;
+};
+
+// One tap of one output element, exactly the reference's arithmetic
+// (block_extractor_kernel.cu:52-71): flow + offset, + pixel coordinate, floor, clamp, weights
+// from the unclamped fraction.
+template <typename T>
+struct Tap1 {
+    unsigned lo, hi;   // clamped index of floor(d), floor(d)+1
+    T wlo, whi;        // 1 - frac, frac
+};
+template <typename T>
+__device__ __forceinline__ Tap1<T> make_tap(T flow0, int offset, int coord, int n) {
+    const T f = flow0 + static_cast<T>(offset);
+    const T d = f + static_cast<T>(coord);
+    const T fl = floor_t(d);
+    Tap1<T> t;
+    t.lo = static_cast<unsigned>(clamp_index(fl, n));
+    t.hi = static_cast<unsigned>(clamp_index(fl + 1, n));
+    t.whi = d - fl;
+    t.wlo = 1 - (d - fl);
+    return t;
+}
+
+template <typename T, int K>
+__device__ __forceinline__ void make_taps(Taps<T, K>& t, T flow_x0, T flow_y0, int xf, int yf,
+                                          int Hs, int Ws) {
+    bool ok = true;
+    unsigned prev_xhi = 0, prev_yhi = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const Tap1<T> tx = make_tap<T>(flow_x0, j - K / 2, xf, Ws);
+        const Tap1<T> ty = make_tap<T>(flow_y0, j - K / 2, yf, Hs);
+        if (j > 0) ok = ok && (tx.lo == prev_xhi) && (ty.lo == prev_yhi);
+        prev_xhi = tx.hi;
+        prev_yhi = ty.hi;
+        t.col[j] = tx.lo * static_cast<unsigned>(sizeof(T));
+        t.row[j] = ty.lo * static_cast<unsigned>(Ws) * static_cast<unsigned>(sizeof(T));
+        t.wxL[j] = tx.wlo;
+        t.wxR[j] = tx.whi;
+        t.wyT[j] = ty.wlo;
+        t.wyB[j] = ty.whi;
+    }
+    t.col[K] = prev_xhi * static_cast<unsigned>(sizeof(T));
+    t.row[K] = prev_yhi * static_cast<unsigned>(Ws) * static_cast<unsigned>(sizeof(T));
+    t.consistent = ok;
+}
+
+// ------------------------------------------------------------------------------ forward
+template <typename T, int K>
+__global__ void __launch_bounds__(kBlock)
+be_fwd_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __restrict__ out, int C,
+              int Hs, int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs,
+              int remap) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+    if (tc.xf >= Wf || tc.yf >= Hf) return;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const T* fl = flow + static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(tc.yf) * Wf + tc.xf;
+    const T fx0 = fl[0], fy0 = fl[fplane];
+    Taps<T, K> t;
+    make_taps<T, K>(t, fx0, fy0, tc.xf, tc.yf, Hs, Ws);
+
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int W = K * Wf;
+    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const unsigned sbytes = static_cast<unsigned>(splane * sizeof(T));
+    const unsigned obytes = static_cast<unsigned>(oplane * sizeof(T));
+    const T* sp = src + (static_cast<size_t>(tc.b) * C + c0) * splane;
+    T* op = out + (static_cast<size_t>(tc.b) * C + c0) * oplane;
+    const unsigned obase = (static_cast<unsigned>(tc.yf) * K * W + static_cast<unsigned>(tc.xf) * K) *
+                           static_cast<unsigned>(sizeof(T));
+    const unsigned orow = static_cast<unsigned>(W) * static_cast<unsigned>(sizeof(T));
+
+    if (t.consistent) {
+        for (int c = c0; c < c1; ++c, sp += splane, op += oplane) {
+            const rsrc_t rs = make_rsrc(sp, sbytes);
+            const rsrc_t ro = make_rsrc(op, obytes);
+            T prev[K + 1], cur[K + 1];
+#pragma unroll
+            for (int j = 0; j <= K; ++j) prev[j] = buf_ld<T>(rs, t.row[0] + t.col[j]);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+#pragma unroll
+                for (int j = 0; j <= K; ++j) cur[j] = buf_ld<T>(rs, t.row[i + 1] + t.col[j]);
+                ElemRow<T, K> r;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    T s = 0;   // reference order: block_extractor_kernel.cu:73-77
+                    s += t.wxL[j] * t.wyT[i] * prev[j];
+                    s += t.wxR[j] * t.wyT[i] * prev[j + 1];
+                    s += t.wxL[j] * t.wyB[i] * cur[j];
+                    s += t.wxR[j] * t.wyB[i] * cur[j + 1];
+                    r.v[j] = s;
+                }
+                buf_store_row<T, K>(ro, obase + i * orow, r);
+#pragma unroll
+                for (int j = 0; j <= K; ++j) prev[j] = cur[j];
+            }
+        }
+    } else {
+        // Rare: two neighbouring taps disagree on a floor (fp rounding at an integer boundary).
+        // Recompute every tap per element like the reference does; rolled loops keep it small.
+        for (int c = c0; c < c1; ++c, sp += splane, op += oplane) {
+            const rsrc_t rs = make_rsrc(sp, sbytes);
+            const rsrc_t ro = make_rsrc(op, obytes);
+#pragma unroll 1
+            for (int i = 0; i < K; ++i) {
+                const Tap1<T> ty = make_tap<T>(fy0, i - K / 2, tc.yf, Hs);
+                const unsigned rT = ty.lo * static_cast<unsigned>(Ws), rB = ty.hi * static_cast<unsigned>(Ws);
+#pragma unroll 1
+                for (int j = 0; j < K; ++j) {
+                    const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
+                    constexpr unsigned E = sizeof(T);
+                    T s = 0;
+                    s += tx.wlo * ty.wlo * buf_ld<T>(rs, (rT + tx.lo) * E);
+                    s += tx.whi * ty.wlo * buf_ld<T>(rs, (rT + tx.hi) * E);
+                    s += tx.wlo * ty.whi * buf_ld<T>(rs, (rB + tx.lo) * E);
+                    s += tx.whi * ty.whi * buf_ld<T>(rs, (rB + tx.hi) * E);
+                    ElemRow<T, 1> r;
+                    r.v[0] = s;
+                    buf_store_row<T, 1>(ro, obase + i * orow + j * E, r);
+                }
+            }
+        }
+    }
+}
+
+// Any kernel_size: one thread per output element (the reference's decomposition, 64-bit safe).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+be_fwd_generic(const T* __restrict__ src, const T* __restrict__ flow, T* __restrict__ out,
+               int64_t n, int C, int Hs, int Ws, int Hf, int Wf, int k) {
+    const int H = k * Hf, W = k * Wf;
+    for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
+         index += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int x = static_cast<int>(index % W);
+        const int y = static_cast<int>((index / W) % H);
+        const int64_t bc = index / (static_cast<int64_t>(W) * H);
+        const int64_t b = bc / C;
+        const int yf = y / k, xf = x / k;
+        const size_t fplane = static_cast<size_t>(Hf) * Wf;
+        const T* fl = flow + b * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
+        const T dy = (fl[fplane] + static_cast<T>(y % k - k / 2)) + static_cast<T>(yf);
+        const T dx = (fl[0] + static_cast<T>(x % k - k / 2)) + static_cast<T>(xf);
+        const T flx = floor_t(dx), fly = floor_t(dy);
+        const int xL = clamp_index(flx, Ws), xR = clamp_index(flx + 1, Ws);
+        const int yT = clamp_index(fly, Hs), yB = clamp_index(fly + 1, Hs);
+        const T xLP = 1 - (dx - flx), xRP = dx - flx, yTP = 1 - (dy - fly), yBP = dy - fly;
+        const T* sp = src + bc * static_cast<size_t>(Hs) * Ws;
+        T s = 0;
+        s += xLP * yTP * sp[static_cast<size_t>(yT) * Ws + xL];
+        s += xRP * yTP * sp[static_cast<size_t>(yT) * Ws + xR];
+        s += xLP * yBP * sp[static_cast<size_t>(yB) * Ws + xL];
+        s += xRP * yBP * sp[static_cast<size_t>(yB) * Ws + xR];
+        out[index] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------ backward
+template <typename T, int K>
+__global__ void __launch_bounds__(kBlock)
+be_bwd_kernel(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ gout,
+              T* __restrict__ gsrc, T* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
+              int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+    if (tc.xf >= Wf || tc.yf >= Hf) return;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const size_t foff = static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(tc.yf) * Wf + tc.xf;
+    const T fx0 = flow[foff], fy0 = flow[foff + fplane];
+    Taps<T, K> t;
+    make_taps<T, K>(t, fx0, fy0, tc.xf, tc.yf, Hs, Ws);
+
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int W = K * Wf;
+    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const unsigned sbytes = static_cast<unsigned>(splane * sizeof(T));
+    const unsigned obytes = static_cast<unsigned>(oplane * sizeof(T));
+    const size_t soff = (static_cast<size_t>(tc.b) * C + c0) * splane;
+    const T* sp = src + soff;
+    T* gp = gsrc ? gsrc + soff : nullptr;
+    const T* op = gout + (static_cast<size_t>(tc.b) * C + c0) * oplane;
+    const unsigned obase = (static_cast<unsigned>(tc.yf) * K * W + static_cast<unsigned>(tc.xf) * K) *
+                           static_cast<unsigned>(sizeof(T));
+    const unsigned orow = static_cast<unsigned>(W) * static_cast<unsigned>(sizeof(T));
+    T gx = 0, gy = 0;
+
+    if (t.consistent) {
+        for (int c = c0; c < c1; ++c, sp += splane, op += oplane) {
+            const rsrc_t rs = make_rsrc(sp, sbytes);
+            const rsrc_t rg = make_rsrc(op, obytes);
+            T sprev[K + 1], scur[K + 1], aprev[K + 1], acur[K + 1];
+#pragma unroll
+            for (int j = 0; j <= K; ++j) {
+                sprev[j] = buf_ld<T>(rs, t.row[0] + t.col[j]);
+                aprev[j] = 0;
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                ElemRow<T, K> g;
+                buf_load_row<T, K>(rg, obase + i * orow, g);
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    scur[j] = buf_ld<T>(rs, t.row[i + 1] + t.col[j]);
+                    acur[j] = 0;
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const T gv = g.v[j];
+                    const T xl = t.wxL[j], xr = t.wxR[j], yt = t.wyT[i], yb = t.wyB[i];
+                    aprev[j] += gv * xl * yt;          // block_extractor_kernel.cu:158-161
+                    aprev[j + 1] += gv * xr * yt;
+                    acur[j] += gv * xl * yb;
+                    acur[j + 1] += gv * xr * yb;
+                    gy += gv * (-xl * sprev[j] - xr * sprev[j + 1] + xl * scur[j] + xr * scur[j + 1]);  // :163
+                    gx += gv * (-yt * sprev[j] - yb * scur[j] + yt * sprev[j + 1] + yb * scur[j + 1]);  // :164
+                }
+                if (gp) {
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) atomic_add_off(gp, t.row[i] + t.col[j], aprev[j]);
+                }
+#pragma unroll
+                for (int j = 0; j <= K; ++j) {
+                    sprev[j] = scur[j];
+                    aprev[j] = acur[j];
+                }
+            }
+            if (gp) {
+#pragma unroll
+                for (int j = 0; j <= K; ++j) atomic_add_off(gp, t.row[K] + t.col[j], aprev[j]);
+                gp += splane;
+            }
+        }
+    } else {
+        for (int c = c0; c < c1; ++c, sp += splane, op += oplane) {
+            const rsrc_t rs = make_rsrc(sp, sbytes);
+            const rsrc_t rg = make_rsrc(op, obytes);
+#pragma unroll 1
+            for (int i = 0; i < K; ++i) {
+                constexpr unsigned E = sizeof(T);
+                const Tap1<T> ty = make_tap<T>(fy0, i - K / 2, tc.yf, Hs);
+                const unsigned rT = ty.lo * static_cast<unsigned>(Ws) * E, rB = ty.hi * static_cast<unsigned>(Ws) * E;
+#pragma unroll 1
+                for (int j = 0; j < K; ++j) {
+                    const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
+                    const unsigned cL = tx.lo * E, cR = tx.hi * E;
+                    const T gv = buf_ld<T>(rg, obase + i * orow + j * E);
+                    const T xl = tx.wlo, xr = tx.whi, yt = ty.wlo, yb = ty.whi;
+                    const T sTL = buf_ld<T>(rs, rT + cL), sTR = buf_ld<T>(rs, rT + cR);
+                    const T sBL = buf_ld<T>(rs, rB + cL), sBR = buf_ld<T>(rs, rB + cR);
+                    if (gp) {
+                        atomic_add_off(gp, rT + cL, gv * xl * yt);
+                        atomic_add_off(gp, rT + cR, gv * xr * yt);
+                        atomic_add_off(gp, rB + cL, gv * xl * yb);
+                        atomic_add_off(gp, rB + cR, gv * xr * yb);
+                    }
+                    gy += gv * (-xl * sTL - xr * sTR + xl * sBL + xr * sBR);
+                    gx += gv * (-yt * sTL - yb * sBL + yt * sTR + yb * sBR);
+                }
+            }
+            if (gp) gp += splane;
+        }
+    }
+    if (gflow) {
+        atomic_add(gflow + foff, gx);            // ch 0 = x   (:168)
+        atomic_add(gflow + foff + fplane, gy);   // ch 1 = y   (:167)
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+be_bwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ gout,
+               T* __restrict__ gsrc, T* __restrict__ gflow, int64_t n, int C, int Hs, int Ws,
+               int Hf, int Wf, int k) {
+    const int H = k * Hf, W = k * Wf;
+    for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
+         index += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int x = static_cast<int>(index % W);
+        const int y = static_cast<int>((index / W) % H);
+        const int64_t bc = index / (static_cast<int64_t>(W) * H);
+        const int64_t b = bc / C;
+        const int yf = y / k, xf = x / k;
+        const size_t fplane = static_cast<size_t>(Hf) * Wf;
+        const size_t foff = b * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
+        const T dy = (flow[foff + fplane] + static_cast<T>(y % k - k / 2)) + static_cast<T>(yf);
+        const T dx = (flow[foff] + static_cast<T>(x % k - k / 2)) + static_cast<T>(xf);
+        const T flx = floor_t(dx), fly = floor_t(dy);
+        const int xL = clamp_index(flx, Ws), xR = clamp_index(flx + 1, Ws);
+        const size_t yT = static_cast<size_t>(clamp_index(fly, Hs)) * Ws;
+        const size_t yB = static_cast<size_t>(clamp_index(fly + 1, Hs)) * Ws;
+        const T xLP = 1 - (dx - flx), xRP = dx - flx, yTP = 1 - (dy - fly), yBP = dy - fly;
+        const size_t soff = bc * static_cast<size_t>(Hs) * Ws;
+        const T* sp = src + soff;
+        const T sTL = sp[yT + xL], sTR = sp[yT + xR], sBL = sp[yB + xL], sBR = sp[yB + xR];
+        const T g = gout[index];
+        if (gsrc) {
+            T* gp = gsrc + soff;
+            atomic_add(gp + yT + xL, g * xLP * yTP);
+            atomic_add(gp + yT + xR, g * xRP * yTP);
+            atomic_add(gp + yB + xL, g * xLP * yBP);
+            atomic_add(gp + yB + xR, g * xRP * yBP);
+        }
+        if (gflow) {
+            atomic_add(gflow + foff + fplane, g * (-xLP * sTL - xRP * sTR + xLP * sBL + xRP * sBR));
+            atomic_add(gflow + foff, g * (-yTP * sTL - yBP * sBL + yTP * sTR + yBP * sBR));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host
+template <typename T>
+int launch_fwd(const T* src, const T* flow, T* out, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+               int64_t Hf, int64_t Wf, int k, hipStream_t st) {
+    const double bytes = sizeof(T) * static_cast<double>(B) * (C * Hs * Ws + 2.0 * Hf * Wf + static_cast<double>(C) * k * k * Hf * Wf);
+    const Geometry g = plan(B, C, Hf, Wf, 16);
+    const int remap = options().xcd_remap;
+#define FFWM_BE_FWD(KK)                                                                            \
+    case KK: {                                                                                     \
+        LaunchScope ls("block_extractor_fwd", st, bytes);                                          \
+        hipLaunchKernelGGL((be_fwd_kernel<T, KK>), dim3(g.grid), dim3(kBlock), 0, st, src, flow,   \
+                           out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, g.tiles_y,  \
+                           g.cslabs, g.cs, remap);                                                 \
+    } break;
+    const bool generic = options().be_fwd_variant == 9;
+    switch (generic ? 0 : k) {
+        FFWM_BE_FWD(1) FFWM_BE_FWD(2) FFWM_BE_FWD(3) FFWM_BE_FWD(4) FFWM_BE_FWD(5) FFWM_BE_FWD(6)
+        FFWM_BE_FWD(7)
+        default: {
+            const int64_t n = B * C * k * Hf * k * Wf;
+            const unsigned grid = static_cast<unsigned>(n / kBlock + 1 < 16384 ? n / kBlock + 1 : 16384);
+            LaunchScope ls("block_extractor_fwd_generic", st, bytes);
+            hipLaunchKernelGGL((be_fwd_generic<T>), dim3(grid), dim3(kBlock), 0, st, src, flow, out,
+                               n, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k);
+        }
+    }
+#undef FFWM_BE_FWD
+    return check_launch("ffwm_block_extractor_forward");
+}
+
+template <typename T>
+int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, int64_t B, int64_t C,
+               int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, hipStream_t st) {
+    const double bytes = sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * k * k * Hf * Wf + 2.0 * C * Hs * Ws + 4.0 * Hf * Wf);
+    const Geometry g = plan(B, C, Hf, Wf, 32);
+    const int remap = options().xcd_remap;
+#define FFWM_BE_BWD(KK)                                                                            \
+    case KK: {                                                                                     \
+        LaunchScope ls("block_extractor_bwd", st, bytes);                                          \
+        hipLaunchKernelGGL((be_bwd_kernel<T, KK>), dim3(g.grid), dim3(kBlock), 0, st, src, flow,   \
+                           gout, gsrc, gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf,          \
+                           g.tiles_x, g.tiles_y, g.cslabs, g.cs, remap);                           \
+    } break;
+    const bool generic = options().be_bwd_variant == 9;
+    switch (generic ? 0 : k) {
+        FFWM_BE_BWD(1) FFWM_BE_BWD(2) FFWM_BE_BWD(3) FFWM_BE_BWD(4) FFWM_BE_BWD(5) FFWM_BE_BWD(6)
+        FFWM_BE_BWD(7)
+        default: {
+            const int64_t n = B * C * k * Hf * k * Wf;
+            const unsigned grid = static_cast<unsigned>(n / kBlock + 1 < 16384 ? n / kBlock + 1 : 16384);
+            LaunchScope ls("block_extractor_bwd_generic", st, bytes);
+            hipLaunchKernelGGL((be_bwd_generic<T>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout,
+                               gsrc, gflow, n, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, k);
+        }
+    }
+#undef FFWM_BE_BWD
+    return check_launch("ffwm_block_extractor_backward");
+}
+
+int check_dims(const char* fn, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+               int k, int dtype) {
+    FFWM_REQUIRE(dtype_ok(dtype), FFWM_ERR_DTYPE, "%s: dtype %d is not FFWM_F32/FFWM_F64", fn, dtype);
+    FFWM_REQUIRE(B > 0 && C > 0 && Hs > 0 && Ws > 0 && Hf > 0 && Wf > 0 && k >= 1, FFWM_ERR_ARG,
+                 "%s: sizes must be positive (B=%lld C=%lld Hs=%lld Ws=%lld Hf=%lld Wf=%lld k=%d)", fn,
+                 (long long)B, (long long)C, (long long)Hs, (long long)Ws, (long long)Hf, (long long)Wf, k);
+    FFWM_REQUIRE(Hs * Ws < (1LL << 29) && static_cast<int64_t>(k) * Hf * k * Wf < (1LL << 29), FFWM_ERR_SIZE,
+                 "%s: a single H*W plane must stay below 2^29 elements (32-bit byte offsets)", fn);
+    const int64_t spatial = B * ((Wf + kTileX - 1) / kTileX) * ((Hf + kTileY - 1) / kTileY);
+    FFWM_REQUIRE(spatial * C < (1LL << 31), FFWM_ERR_SIZE, "%s: grid too large", fn);
+    return FFWM_OK;
+}
+
+}  // namespace
+}  // namespace ffwm
+
+using namespace ffwm;
+
+extern "C" int ffwm_block_extractor_forward(const void* source, const void* flow_field, void* output,
+                                            int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
+                                            int64_t Wf, int kernel_size, int dtype, void* stream) {
+    const char* fn = "ffwm_block_extractor_forward";
+    FFWM_REQUIRE(source && flow_field && output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hs, Ws, Hf, Wf, kernel_size, dtype)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_fwd<float>((const float*)source, (const float*)flow_field, (float*)output, B, C,
+                                 Hs, Ws, Hf, Wf, kernel_size, st);
+    return launch_fwd<double>((const double*)source, (const double*)flow_field, (double*)output, B, C,
+                              Hs, Ws, Hf, Wf, kernel_size, st);
+}
+
+extern "C" int ffwm_block_extractor_backward(const void* source, const void* flow_field,
+                                             const void* grad_output, void* grad_source,
+                                             void* grad_flow_field, int64_t B, int64_t C, int64_t Hs,
+                                             int64_t Ws, int64_t Hf, int64_t Wf, int kernel_size,
+                                             int dtype, void* stream) {
+    const char* fn = "ffwm_block_extractor_backward";
+    FFWM_REQUIRE(source && flow_field && grad_output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hs, Ws, Hf, Wf, kernel_size, dtype)) return rc;
+    if (!grad_source && !grad_flow_field) return FFWM_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_bwd<float>((const float*)source, (const float*)flow_field, (const float*)grad_output,
+                                 (float*)grad_source, (float*)grad_flow_field, B, C, Hs, Ws, Hf, Wf,
+                                 kernel_size, st);
+    return launch_bwd<double>((const double*)source, (const double*)flow_field, (const double*)grad_output,
+                              (double*)grad_source, (double*)grad_flow_field, B, C, Hs, Ws, Hf, Wf,
+                              kernel_size, st);
+}

@@ -1,0 +1,232 @@
+// common.hpp -- shared host/device helpers of libffwm_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ffwm_hip.h"
+
+namespace ffwm {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 waves, one per SIMD
+constexpr int kTileX = 64;         // one wave covers 64 consecutive x: full-line coalescing
+constexpr int kTileY = kBlock / kTileX;
+
+// ---------------------------------------------------------------- host side
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+struct Options {
+    int be_fwd_variant = 0;   // 0 = auto
+    int be_bwd_variant = 0;
+    int channel_slab = 0;     // 0 = auto
+    int xcd_remap = 1;
+};
+Options& options();
+
+// Per-launch timing scope: records HIP events on `stream` around the enclosed launch when
+// profiling is enabled (ffwm_prof_enable).  `bytes` = algorithmic bytes of that launch.
+class LaunchScope {
+  public:
+    LaunchScope(const char* name, hipStream_t stream, double bytes);
+    ~LaunchScope();
+
+  private:
+    int slot_;
+    hipStream_t stream_;
+};
+
+// Pixel-tile launch geometry shared by the per-pixel kernels: a 64 x 4 pixel tile per block
+// (kTileX x kTileY), a slab of `cs` channels per block.
+struct Geometry {
+    int tiles_x, tiles_y, cslabs, cs;
+    unsigned grid;
+};
+Geometry plan(int64_t B, int64_t C, int64_t H, int64_t W, int cs_default);
+
+inline bool dtype_ok(int dtype) { return dtype == FFWM_F32 || dtype == FFWM_F64; }
+
+#define FFWM_REQUIRE(cond, code, ...)  \
+    do {                               \
+        if (!(cond)) {                 \
+            ::ffwm::set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+// ---------------------------------------------------------------- device side
+#ifdef __HIPCC__
+
+// Observed dispatch: workgroup b runs on XCD b % 8, each XCD has its own 4 MiB L2.  Give every
+// XCD a CONTIGUOUS range of logical tiles so neighbouring tiles (which share source halo rows)
+// hit the same L2.  Bijective for any grid size.  Speed only -- never correctness.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk, int enable) {
+    if (!enable) return bid;
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned q = nblk >> 3, r = nblk & 7u;
+    const unsigned start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return start + idx;
+}
+
+__device__ __forceinline__ float floor_t(float v) { return floorf(v); }
+__device__ __forceinline__ double floor_t(double v) { return floor(v); }
+
+// max(min(int(v), n-1), 0) with the float->int conversion made safe for NaN / huge values
+// (the hardware conversion saturates and maps NaN to 0, as CUDA's does; C++ leaves it undefined).
+template <typename T>
+__device__ __forceinline__ int clamp_index(T v, int n) {
+    T lo = static_cast<T>(-1), hi = static_cast<T>(n);
+    T c = v < lo ? lo : (v > hi ? hi : v);   // NaN compares false twice -> stays NaN
+    int i = (c != c) ? 0 : static_cast<int>(c);
+    i = i < n - 1 ? i : n - 1;
+    return i > 0 ? i : 0;
+}
+
+// int(v): C truncation toward zero, made safe the way the hardware conversion behaves
+// (saturating, NaN -> 0).  Used for the reference's `alpha = xf - int(xf)` quirk.
+template <typename T>
+__device__ __forceinline__ int clamp_index_wide(T v) {
+    if (v != v) return 0;
+    if (v >= static_cast<T>(2147483647.0)) return 2147483647;
+    if (v <= static_cast<T>(-2147483648.0)) return -2147483647 - 1;
+    return static_cast<int>(v);
+}
+
+// SAFE_DIV(a, b) = (b == 0) ? a / 1e-8 : a / b, evaluated as the reference's macro is:
+// the conditional has type double (EPS is a double literal), the a/b arm is a T division.
+template <typename T>
+__device__ __forceinline__ double safe_div(T a, T b) {
+    if (b == static_cast<T>(0)) return static_cast<double>(a) / 1e-8;
+    return static_cast<double>(static_cast<T>(a / b));
+}
+
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// ---- buffer addressing -------------------------------------------------------------------
+// A tensor plane is addressed as (wave-uniform 128-bit buffer resource in SGPRs) + (32-bit
+// per-lane BYTE offset in one VGPR): `buffer_load_dword v, v_off, s[rsrc], 0 offen`.  This is the
+// CDNA way to do "uniform base + per-lane gather": no 64-bit VGPR address per tap, and the
+// hardware range check (offset >= num_records reads 0 / drops the store) comes for free.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, static_cast<int>(bytes), 0x00020000);
+}
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned boff, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, boff, 0, 0));
+}
+__device__ __forceinline__ double buf_load(rsrc_t r, unsigned boff, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, boff, 0, 0));
+}
+template <typename T>
+__device__ __forceinline__ T buf_ld(rsrc_t r, unsigned boff) {
+    return buf_load(r, boff, T());
+}
+
+// N consecutive dwords starting at dword `POS` of w[], as the widest instructions available.
+template <int N, int POS = 0>
+__device__ __forceinline__ void buf_load_dwords(rsrc_t r, unsigned boff, unsigned* w) {
+    if constexpr (N - POS >= 4) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, boff + 4u * POS, 0, 0);
+        w[POS] = v.x; w[POS + 1] = v.y; w[POS + 2] = v.z; w[POS + 3] = v.w;
+        buf_load_dwords<N, POS + 4>(r, boff, w);
+    } else if constexpr (N - POS == 3) {
+        u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, boff + 4u * POS, 0, 0);
+        w[POS] = v.x; w[POS + 1] = v.y; w[POS + 2] = v.z;
+    } else if constexpr (N - POS == 2) {
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, boff + 4u * POS, 0, 0);
+        w[POS] = v.x; w[POS + 1] = v.y;
+    } else if constexpr (N - POS == 1) {
+        w[POS] = __builtin_amdgcn_raw_buffer_load_b32(r, boff + 4u * POS, 0, 0);
+    }
+}
+template <int N, int POS = 0>
+__device__ __forceinline__ void buf_store_dwords(rsrc_t r, unsigned boff, const unsigned* w) {
+    if constexpr (N - POS >= 4) {
+        u32x4 v = {w[POS], w[POS + 1], w[POS + 2], w[POS + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, boff + 4u * POS, 0, 0);
+        buf_store_dwords<N, POS + 4>(r, boff, w);
+    } else if constexpr (N - POS == 3) {
+        u32x3 v = {w[POS], w[POS + 1], w[POS + 2]};
+        __builtin_amdgcn_raw_buffer_store_b96(v, r, boff + 4u * POS, 0, 0);
+    } else if constexpr (N - POS == 2) {
+        u32x2 v = {w[POS], w[POS + 1]};
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, boff + 4u * POS, 0, 0);
+    } else if constexpr (N - POS == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(w[POS], r, boff + 4u * POS, 0, 0);
+    }
+}
+
+// K consecutive elements of T (a row of one k x k window).
+template <typename T, int K>
+struct ElemRow {
+    union {
+        T v[K];
+        unsigned w[K * sizeof(T) / 4];
+    };
+};
+template <typename T, int K>
+__device__ __forceinline__ void buf_load_row(rsrc_t r, unsigned boff, ElemRow<T, K>& row) {
+    buf_load_dwords<K * sizeof(T) / 4>(r, boff, row.w);
+}
+template <typename T, int K>
+__device__ __forceinline__ void buf_store_row(rsrc_t r, unsigned boff, const ElemRow<T, K>& row) {
+    buf_store_dwords<K * sizeof(T) / 4>(r, boff, row.w);
+}
+
+struct TileCoord {
+    int b, slab, yf, xf;
+};
+
+__device__ __forceinline__ TileCoord decode_tile(int tiles_x, int tiles_y, int cslabs, int remap) {
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    TileCoord tc;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    t /= tiles_y;
+    tc.slab = t % cslabs;
+    tc.b = t / cslabs;
+    tc.xf = tx * kTileX + (threadIdx.x & (kTileX - 1));
+    tc.yf = ty * kTileY + (threadIdx.x / kTileX);
+    return tc;
+}
+
+template <typename T>
+__device__ __forceinline__ void atomic_add_off(T* base, unsigned boff, T v) {
+    atomic_add(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + boff), v);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T u = __shfl_xor(v, o, 64);
+        v = u < v ? u : v;
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T u = __shfl_xor(v, o, 64);
+        v = u > v ? u : v;
+    }
+    return v;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace ffwm

@@ -1,0 +1,567 @@
+// resample2d.hip -- Gaussian-weighted kernel_size x kernel_size flow resampler for gfx950.
+//
+// Replaces the three kernels of /root/reference/cuda/resample2d_package/resample2d_kernel.cu:
+//   K1 kernel_resample2d_update_output   :21-95   (one thread per output element; dx/dy/sigma and
+//                                                  4*(ks/2)^2 exp() recomputed for every channel)
+//   K2 kernel_resample2d_backward_input1 :98-202  (same redundancy, 4*(ks/2)^2 atomics per element)
+//   K3 kernel_resample2d_backward_input2 :204-330 (3 threads per pixel, each looping C x taps TWICE
+//                                                  with 8 gathers per (channel, tap))
+//
+// Here every kernel is one thread per PIXEL looping over channels: the tap indices and the
+// Gaussian weights (double-precision exp, as the reference's SAFE_DIV promotion implies) are
+// computed once per pixel.  K3 produces all three gradients (dx, dy, sigma) from ONE pass over the
+// channels: the four waves of a block split the channels, keep one accumulator per tap
+// (sum_ch gO * in1[tap]) and combine them through LDS; the quotient-rule terms are applied once at
+// the end.  ks in {2, 4, 6} (HALF = 1..3) is templated; any other even ks falls back to a literal
+// per-element kernel.
+#include "common.hpp"
+
+namespace ffwm {
+namespace {
+
+// exp(SAFE_DIV(-v*v, 2*sigma*sigma)) -> T  (resample2d_kernel.cu:72-75); the macro's conditional
+// has type double, so it is the double exp() that runs in both instantiations.
+template <typename T>
+__device__ __forceinline__ T gauss(T v, T sigma) {
+    const T num = -v * v;
+    const T den = 2 * sigma * sigma;
+    return static_cast<T>(exp(safe_div<T>(num, den)));
+}
+
+template <typename T, int HALF>
+struct RsTaps {
+    static constexpr int N = 2 * HALF;   // entry 2f = "left/top" tap f, 2f+1 = "right/bottom" tap f
+    unsigned col[N], row[N];             // byte offsets
+    T wx[N], wy[N];                      // xL_P, xR_P / yT_P, yB_P
+    T dx_[N], dy_[N];                    // xL_, xR_ / yT_, yB_ (distances)
+    T sum;
+};
+
+// `trunc_alpha`: the reference's d_input1 kernel forms alpha/beta with C truncation, int(xf)
+// (:137-138), everything else uses floor.
+template <typename T, int HALF>
+__device__ __forceinline__ void make_rs_taps(RsTaps<T, HALF>& t, T dx, T dy, T sigma, int x, int y,
+                                             int Hi, int Wi, int dil, bool trunc_alpha) {
+    const T xf = static_cast<T>(x) + dx;
+    const T yf = static_cast<T>(y) + dy;
+    const T flx = floor_t(xf), fly = floor_t(yf);
+    T alpha, beta;
+    if (trunc_alpha) {
+        alpha = xf - static_cast<T>(clamp_index_wide(xf));
+        beta = yf - static_cast<T>(clamp_index_wide(yf));
+    } else {
+        alpha = xf - flx;
+        beta = yf - fly;
+    }
+    constexpr unsigned E = sizeof(T);
+#pragma unroll
+    for (int f = 0; f < HALF; ++f) {
+        t.col[2 * f] = static_cast<unsigned>(clamp_index(flx - static_cast<T>(f * dil), Wi)) * E;
+        t.col[2 * f + 1] = static_cast<unsigned>(clamp_index(flx + static_cast<T>((f + 1) * dil), Wi)) * E;
+        t.row[2 * f] = static_cast<unsigned>(clamp_index(fly - static_cast<T>(f * dil), Hi)) * static_cast<unsigned>(Wi) * E;
+        t.row[2 * f + 1] = static_cast<unsigned>(clamp_index(fly + static_cast<T>((f + 1) * dil), Hi)) * static_cast<unsigned>(Wi) * E;
+        t.dx_[2 * f] = static_cast<T>(f * dil) + alpha;
+        t.dx_[2 * f + 1] = static_cast<T>((1. + f) * dil) - alpha;
+        t.dy_[2 * f] = static_cast<T>(f * dil) + beta;
+        t.dy_[2 * f + 1] = static_cast<T>((1. + f) * dil) - beta;
+        t.wx[2 * f] = gauss<T>(t.dx_[2 * f], sigma);
+        t.wx[2 * f + 1] = gauss<T>(t.dx_[2 * f + 1], sigma);
+        t.wy[2 * f] = gauss<T>(t.dy_[2 * f], sigma);
+        t.wy[2 * f + 1] = gauss<T>(t.dy_[2 * f + 1], sigma);
+    }
+    T sum = 0;
+#pragma unroll
+    for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+        for (int fx = 0; fx < HALF; ++fx) {
+            const T yT = t.wy[2 * fy], yB = t.wy[2 * fy + 1], xL = t.wx[2 * fx], xR = t.wx[2 * fx + 1];
+            sum += (yT * xL + yT * xR + yB * xL + yB * xR);   // :87
+        }
+    t.sum = sum;
+}
+
+// ------------------------------------------------------------------------------------ K1
+template <typename T, int HALF>
+__global__ void __launch_bounds__(kBlock)
+rs_fwd_kernel(const T* __restrict__ in1, const T* __restrict__ in2, T* __restrict__ out, int C,
+              int Hi, int Wi, int H, int W, int dil, int tiles_x, int tiles_y, int cslabs, int cs,
+              int remap) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+    const int x = tc.xf, y = tc.yf;
+    if (x >= W || y >= H) return;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const size_t poff = static_cast<size_t>(y) * W + x;
+    const T* f = in2 + static_cast<size_t>(tc.b) * 3 * plane + poff;
+    RsTaps<T, HALF> t;
+    make_rs_taps<T, HALF>(t, f[0], f[plane], f[2 * plane], x, y, Hi, Wi, dil, false);
+
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * sizeof(T));
+    const T* ip = in1 + (static_cast<size_t>(tc.b) * C + c0) * iplane;
+    T* op = out + (static_cast<size_t>(tc.b) * C + c0) * plane + poff;
+    for (int c = c0; c < c1; ++c, ip += iplane, op += plane) {
+        const rsrc_t r = make_rsrc(ip, ibytes);
+        T val = 0;
+#pragma unroll
+        for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < HALF; ++fx) {
+                const T yT = t.wy[2 * fy], yB = t.wy[2 * fy + 1], xL = t.wx[2 * fx], xR = t.wx[2 * fx + 1];
+                const unsigned rT = t.row[2 * fy], rB = t.row[2 * fy + 1];
+                const unsigned cL = t.col[2 * fx], cR = t.col[2 * fx + 1];
+                val += yT * xL * buf_ld<T>(r, rT + cL);   // :82-85
+                val += yT * xR * buf_ld<T>(r, rT + cR);
+                val += yB * xL * buf_ld<T>(r, rB + cL);
+                val += yB * xR * buf_ld<T>(r, rB + cR);
+            }
+        *op = static_cast<T>(safe_div<T>(val, t.sum));    // :93
+    }
+}
+
+// ------------------------------------------------------------------------------------ K2
+template <typename T, int HALF>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd1_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* __restrict__ gin1, int C,
+               int Hi, int Wi, int H, int W, int dil, int quirk, int tiles_x, int tiles_y,
+               int cslabs, int cs, int remap) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+    const int x = tc.xf, y = tc.yf;
+    if (x >= W || y >= H) return;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const size_t poff = static_cast<size_t>(y) * W + x;
+    const T* f = in2 + static_cast<size_t>(tc.b) * 3 * plane + poff;
+    RsTaps<T, HALF> t;
+    make_rs_taps<T, HALF>(t, f[0], f[plane], f[2 * plane], x, y, Hi, Wi, dil, quirk != 0);
+
+    // normalised tap weights SAFE_DIV(w, sum) (:196-199), once per pixel
+    T wn[HALF][HALF][4];
+#pragma unroll
+    for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+        for (int fx = 0; fx < HALF; ++fx) {
+            const T yT = t.wy[2 * fy], yB = t.wy[2 * fy + 1], xL = t.wx[2 * fx], xR = t.wx[2 * fx + 1];
+            wn[fy][fx][0] = static_cast<T>(safe_div<T>(yT * xL, t.sum));
+            wn[fy][fx][1] = static_cast<T>(safe_div<T>(yT * xR, t.sum));
+            wn[fy][fx][2] = static_cast<T>(safe_div<T>(yB * xL, t.sum));
+            wn[fy][fx][3] = static_cast<T>(safe_div<T>(yB * xR, t.sum));
+        }
+
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    T* gp = gin1 + (static_cast<size_t>(tc.b) * C + c0) * iplane;
+    const T* op = gout + (static_cast<size_t>(tc.b) * C + c0) * plane + poff;
+    for (int c = c0; c < c1; ++c, gp += iplane, op += plane) {
+        const T g = *op;
+#pragma unroll
+        for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < HALF; ++fx) {
+                const unsigned rT = t.row[2 * fy], rB = t.row[2 * fy + 1];
+                const unsigned cL = t.col[2 * fx], cR = t.col[2 * fx + 1];
+                atomic_add_off(gp, rT + cL, wn[fy][fx][0] * g);
+                atomic_add_off(gp, rT + cR, wn[fy][fx][1] * g);
+                atomic_add_off(gp, rB + cL, wn[fy][fx][2] * g);
+                atomic_add_off(gp, rB + cR, wn[fy][fx][3] * g);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------ K3
+// Block = 64 consecutive x of one row (one lane per pixel) x 4 waves that split the channels.
+template <typename T, int HALF>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd2_kernel(const T* __restrict__ in1, const T* __restrict__ in2, const T* __restrict__ gout,
+               T* __restrict__ gin2, int C, int Hi, int Wi, int H, int W, int dil, int tiles_x) {
+    constexpr int NT = 4 * HALF * HALF;
+    __shared__ T red[3][NT][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    unsigned t_id = blockIdx.x;
+    const int tx = t_id % tiles_x;
+    t_id /= tiles_x;
+    const int y = t_id % H;
+    const int b = t_id / H;
+    const int x = tx * kWave + lane;
+    const bool active = x < W;
+    const int xc = active ? x : W - 1;   // inactive lanes shadow the last pixel, never store
+
+    const size_t plane = static_cast<size_t>(H) * W;
+    const size_t poff = static_cast<size_t>(y) * W + xc;
+    const T* f = in2 + static_cast<size_t>(b) * 3 * plane + poff;
+    const T sigma = f[2 * plane];
+    RsTaps<T, HALF> t;
+    make_rs_taps<T, HALF>(t, f[0], f[plane], sigma, xc, y, Hi, Wi, dil, false);
+
+    T acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) acc[k] = 0;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * sizeof(T));
+    const T* ip = in1 + (static_cast<size_t>(b) * C + wave) * iplane;
+    const T* op = gout + (static_cast<size_t>(b) * C + wave) * plane + poff;
+    for (int c = wave; c < C; c += kBlock / kWave, ip += (kBlock / kWave) * iplane, op += (kBlock / kWave) * plane) {
+        const rsrc_t r = make_rsrc(ip, ibytes);
+        const T g = *op;
+#pragma unroll
+        for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < HALF; ++fx) {
+                const unsigned rT = t.row[2 * fy], rB = t.row[2 * fy + 1];
+                const unsigned cL = t.col[2 * fx], cR = t.col[2 * fx + 1];
+                T* a = acc + 4 * (fy * HALF + fx);
+                a[0] += g * buf_ld<T>(r, rT + cL);
+                a[1] += g * buf_ld<T>(r, rT + cR);
+                a[2] += g * buf_ld<T>(r, rB + cL);
+                a[3] += g * buf_ld<T>(r, rB + cR);
+            }
+    }
+    // combine the 4 channel groups: waves 1..3 publish, wave 0 folds
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) red[wave - 1][k][lane] = acc[k];
+    }
+    __syncthreads();
+    if (wave != 0 || !active) return;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) acc[k] += red[0][k][lane] + red[1][k][lane] + red[2][k][lane];
+
+    // quotient rule, resample2d_kernel.cu:252-328, with sum_ch(gO * in1[tap]) factored out.
+    const T ns2 = -sigma * sigma, s3 = sigma * sigma * sigma;
+    T g1x = 0, g1y = 0, g1s = 0, sgx = 0, sgy = 0, sgs = 0, S = 0;
+#pragma unroll
+    for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+        for (int fx = 0; fx < HALF; ++fx) {
+            const T yT = t.wy[2 * fy], yB = t.wy[2 * fy + 1], xL = t.wx[2 * fx], xR = t.wx[2 * fx + 1];
+            const T yT_ = t.dy_[2 * fy], yB_ = t.dy_[2 * fy + 1], xL_ = t.dx_[2 * fx], xR_ = t.dx_[2 * fx + 1];
+            const T* a = acc + 4 * (fy * HALF + fx);   // TL, TR, BL, BR
+            // d/d dx (:272-278)
+            g1x += static_cast<T>(safe_div<T>(xL_ * yT * xL * a[0], ns2));
+            g1x -= static_cast<T>(safe_div<T>(xR_ * yT * xR * a[1], ns2));
+            g1x += static_cast<T>(safe_div<T>(xL_ * yB * xL * a[2], ns2));
+            g1x -= static_cast<T>(safe_div<T>(xR_ * yB * xR * a[3], ns2));
+            sgx += static_cast<T>(safe_div<T>(xL_ * yT * xL - xR_ * yT * xR + xL_ * yB * xL - xR_ * yB * xR, ns2));
+            // d/d dy (:279-285)
+            g1y += static_cast<T>(safe_div<T>(yT_ * yT * xL * a[0], ns2));
+            g1y += static_cast<T>(safe_div<T>(yT_ * yT * xR * a[1], ns2));
+            g1y -= static_cast<T>(safe_div<T>(yB_ * yB * xL * a[2], ns2));
+            g1y -= static_cast<T>(safe_div<T>(yB_ * yB * xR * a[3], ns2));
+            sgy += static_cast<T>(safe_div<T>(yT_ * yT * xL + yT_ * yT * xR - yB_ * yB * xL - yB_ * yB * xR, ns2));
+            // d/d sigma (:286-293)
+            const T dTL = yT_ * yT_ + xL_ * xL_, dTR = yT_ * yT_ + xR_ * xR_;
+            const T dBL = yB_ * yB_ + xL_ * xL_, dBR = yB_ * yB_ + xR_ * xR_;
+            g1s += static_cast<T>(safe_div<T>(dTL * yT * xL * a[0], s3));
+            g1s += static_cast<T>(safe_div<T>(dTR * yT * xR * a[1], s3));
+            g1s += static_cast<T>(safe_div<T>(dBL * yB * xL * a[2], s3));
+            g1s += static_cast<T>(safe_div<T>(dBR * yB * xR * a[3], s3));
+            sgs += static_cast<T>(safe_div<T>(dTL * yT * xL + dTR * yT * xR + dBL * yB * xL + dBR * yB * xR, s3));
+            // grad2's common factor (:317-322)
+            S += yT * xL * a[0];
+            S += yT * xR * a[1];
+            S += yB * xL * a[2];
+            S += yB * xR * a[3];
+        }
+    const T sum = t.sum;
+    T* gp = gin2 + static_cast<size_t>(b) * 3 * plane + poff;
+    gp[0] = static_cast<T>(safe_div<T>(g1x, sum) - safe_div<T>(sgx * S, sum * sum));          // :328
+    gp[plane] = static_cast<T>(safe_div<T>(g1y, sum) - safe_div<T>(sgy * S, sum * sum));
+    gp[2 * plane] = static_cast<T>(safe_div<T>(g1s, sum) - safe_div<T>(sgs * S, sum * sum));
+}
+
+// ------------------------------------------------------------------- any even kernel_size
+// Literal per-element kernels (the reference's decomposition, 64-bit safe indices).
+template <typename T>
+struct GenTap {
+    int yT, yB, xL, xR;
+    T xL_, xR_, yT_, yB_, xLP, xRP, yTP, yBP;
+};
+template <typename T>
+__device__ __forceinline__ GenTap<T> gen_tap(T flx, T fly, T alpha, T beta, T sigma, int fx, int fy,
+                                             int dil, int Hi, int Wi) {
+    GenTap<T> g;
+    g.yT = clamp_index(fly - static_cast<T>(fy * dil), Hi);
+    g.yB = clamp_index(fly + static_cast<T>((fy + 1) * dil), Hi);
+    g.xL = clamp_index(flx - static_cast<T>(fx * dil), Wi);
+    g.xR = clamp_index(flx + static_cast<T>((fx + 1) * dil), Wi);
+    g.xL_ = static_cast<T>(fx * dil) + alpha;
+    g.xR_ = static_cast<T>((1. + fx) * dil) - alpha;
+    g.yT_ = static_cast<T>(fy * dil) + beta;
+    g.yB_ = static_cast<T>((1. + fy) * dil) - beta;
+    g.xLP = gauss<T>(g.xL_, sigma);
+    g.xRP = gauss<T>(g.xR_, sigma);
+    g.yTP = gauss<T>(g.yT_, sigma);
+    g.yBP = gauss<T>(g.yB_, sigma);
+    return g;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+rs_fwd_generic(const T* __restrict__ in1, const T* __restrict__ in2, T* __restrict__ out, int64_t n,
+               int C, int Hi, int Wi, int H, int W, int ks, int dil) {
+    const int half = ks / 2;
+    const size_t plane = static_cast<size_t>(H) * W, iplane = static_cast<size_t>(Hi) * Wi;
+    for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
+         index += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int x = static_cast<int>(index % W);
+        const int y = static_cast<int>((index / W) % H);
+        const int64_t bc = index / plane;
+        const int64_t b = bc / C;
+        const T* f = in2 + b * 3 * plane + static_cast<size_t>(y) * W + x;
+        const T sigma = f[2 * plane];
+        const T xf = static_cast<T>(x) + f[0], yf = static_cast<T>(y) + f[plane];
+        const T flx = floor_t(xf), fly = floor_t(yf);
+        const T alpha = xf - flx, beta = yf - fly;
+        const T* ip = in1 + bc * iplane;
+        T val = 0, sum = 0;
+        for (int fy = 0; fy < half; ++fy)
+            for (int fx = 0; fx < half; ++fx) {
+                const GenTap<T> g = gen_tap<T>(flx, fly, alpha, beta, sigma, fx, fy, dil, Hi, Wi);
+                val += g.yTP * g.xLP * ip[static_cast<size_t>(g.yT) * Wi + g.xL];
+                val += g.yTP * g.xRP * ip[static_cast<size_t>(g.yT) * Wi + g.xR];
+                val += g.yBP * g.xLP * ip[static_cast<size_t>(g.yB) * Wi + g.xL];
+                val += g.yBP * g.xRP * ip[static_cast<size_t>(g.yB) * Wi + g.xR];
+                sum += (g.yTP * g.xLP + g.yTP * g.xRP + g.yBP * g.xLP + g.yBP * g.xRP);
+            }
+        out[index] = static_cast<T>(safe_div<T>(val, sum));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd1_generic(const T* __restrict__ in2, const T* __restrict__ gout, T* __restrict__ gin1, int64_t n,
+                int C, int Hi, int Wi, int H, int W, int ks, int dil, int quirk) {
+    const int half = ks / 2;
+    const size_t plane = static_cast<size_t>(H) * W, iplane = static_cast<size_t>(Hi) * Wi;
+    for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
+         index += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int x = static_cast<int>(index % W);
+        const int y = static_cast<int>((index / W) % H);
+        const int64_t bc = index / plane;
+        const int64_t b = bc / C;
+        const T* f = in2 + b * 3 * plane + static_cast<size_t>(y) * W + x;
+        const T sigma = f[2 * plane];
+        const T xf = static_cast<T>(x) + f[0], yf = static_cast<T>(y) + f[plane];
+        const T flx = floor_t(xf), fly = floor_t(yf);
+        const T alpha = quirk ? xf - static_cast<T>(clamp_index_wide(xf)) : xf - flx;
+        const T beta = quirk ? yf - static_cast<T>(clamp_index_wide(yf)) : yf - fly;
+        T sum = 0;
+        for (int fy = 0; fy < half; ++fy)
+            for (int fx = 0; fx < half; ++fx) {
+                const GenTap<T> g = gen_tap<T>(flx, fly, alpha, beta, sigma, fx, fy, dil, Hi, Wi);
+                sum += (g.yTP * g.xLP + g.yTP * g.xRP + g.yBP * g.xLP + g.yBP * g.xRP);
+            }
+        const T go = gout[index];
+        T* gp = gin1 + bc * iplane;
+        for (int fy = 0; fy < half; ++fy)
+            for (int fx = 0; fx < half; ++fx) {
+                const GenTap<T> g = gen_tap<T>(flx, fly, alpha, beta, sigma, fx, fy, dil, Hi, Wi);
+                atomic_add(gp + static_cast<size_t>(g.yT) * Wi + g.xL, static_cast<T>(safe_div<T>(g.yTP * g.xLP, sum) * go));
+                atomic_add(gp + static_cast<size_t>(g.yT) * Wi + g.xR, static_cast<T>(safe_div<T>(g.yTP * g.xRP, sum) * go));
+                atomic_add(gp + static_cast<size_t>(g.yB) * Wi + g.xL, static_cast<T>(safe_div<T>(g.yBP * g.xLP, sum) * go));
+                atomic_add(gp + static_cast<size_t>(g.yB) * Wi + g.xR, static_cast<T>(safe_div<T>(g.yBP * g.xRP, sum) * go));
+            }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd2_generic(const T* __restrict__ in1, const T* __restrict__ in2, const T* __restrict__ gout,
+                T* __restrict__ gin2, int64_t n, int C, int Hi, int Wi, int H, int W, int ks, int dil) {
+    const int half = ks / 2;
+    const size_t plane = static_cast<size_t>(H) * W, iplane = static_cast<size_t>(Hi) * Wi;
+    for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
+         index += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int x = static_cast<int>(index % W);
+        const int y = static_cast<int>((index / W) % H);
+        const int64_t bc = index / plane;
+        const int c = static_cast<int>(bc % 3);
+        const int64_t b = bc / 3;
+        const size_t poff = static_cast<size_t>(y) * W + x;
+        const T* f = in2 + b * 3 * plane + poff;
+        const T sigma = f[2 * plane];
+        const T xf = static_cast<T>(x) + f[0], yf = static_cast<T>(y) + f[plane];
+        const T flx = floor_t(xf), fly = floor_t(yf);
+        const T alpha = xf - flx, beta = yf - fly;
+        const T ns2 = -sigma * sigma, s3 = sigma * sigma * sigma;
+        const T* ip = in1 + b * C * iplane;
+        const T* op = gout + b * C * plane + poff;
+        T grad1 = 0, sumgrad = 0, sum = 0, S = 0;
+        for (int fy = 0; fy < half; ++fy)
+            for (int fx = 0; fx < half; ++fx) {
+                const GenTap<T> g = gen_tap<T>(flx, fly, alpha, beta, sigma, fx, fy, dil, Hi, Wi);
+                sum += (g.yTP * g.xLP + g.yTP * g.xRP + g.yBP * g.xLP + g.yBP * g.xRP);
+                T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                for (int ch = 0; ch < C; ++ch) {
+                    const T go = op[ch * plane];
+                    const T* p = ip + ch * iplane;
+                    a0 += go * p[static_cast<size_t>(g.yT) * Wi + g.xL];
+                    a1 += go * p[static_cast<size_t>(g.yT) * Wi + g.xR];
+                    a2 += go * p[static_cast<size_t>(g.yB) * Wi + g.xL];
+                    a3 += go * p[static_cast<size_t>(g.yB) * Wi + g.xR];
+                }
+                if (c == 0) {
+                    grad1 += static_cast<T>(safe_div<T>(g.xL_ * g.yTP * g.xLP * a0, ns2));
+                    grad1 -= static_cast<T>(safe_div<T>(g.xR_ * g.yTP * g.xRP * a1, ns2));
+                    grad1 += static_cast<T>(safe_div<T>(g.xL_ * g.yBP * g.xLP * a2, ns2));
+                    grad1 -= static_cast<T>(safe_div<T>(g.xR_ * g.yBP * g.xRP * a3, ns2));
+                    sumgrad += static_cast<T>(safe_div<T>(g.xL_ * g.yTP * g.xLP - g.xR_ * g.yTP * g.xRP + g.xL_ * g.yBP * g.xLP - g.xR_ * g.yBP * g.xRP, ns2));
+                } else if (c == 1) {
+                    grad1 += static_cast<T>(safe_div<T>(g.yT_ * g.yTP * g.xLP * a0, ns2));
+                    grad1 += static_cast<T>(safe_div<T>(g.yT_ * g.yTP * g.xRP * a1, ns2));
+                    grad1 -= static_cast<T>(safe_div<T>(g.yB_ * g.yBP * g.xLP * a2, ns2));
+                    grad1 -= static_cast<T>(safe_div<T>(g.yB_ * g.yBP * g.xRP * a3, ns2));
+                    sumgrad += static_cast<T>(safe_div<T>(g.yT_ * g.yTP * g.xLP + g.yT_ * g.yTP * g.xRP - g.yB_ * g.yBP * g.xLP - g.yB_ * g.yBP * g.xRP, ns2));
+                } else {
+                    const T dTL = g.yT_ * g.yT_ + g.xL_ * g.xL_, dTR = g.yT_ * g.yT_ + g.xR_ * g.xR_;
+                    const T dBL = g.yB_ * g.yB_ + g.xL_ * g.xL_, dBR = g.yB_ * g.yB_ + g.xR_ * g.xR_;
+                    grad1 += static_cast<T>(safe_div<T>(dTL * g.yTP * g.xLP * a0, s3));
+                    grad1 += static_cast<T>(safe_div<T>(dTR * g.yTP * g.xRP * a1, s3));
+                    grad1 += static_cast<T>(safe_div<T>(dBL * g.yBP * g.xLP * a2, s3));
+                    grad1 += static_cast<T>(safe_div<T>(dBR * g.yBP * g.xRP * a3, s3));
+                    sumgrad += static_cast<T>(safe_div<T>(dTL * g.yTP * g.xLP + dTR * g.yTP * g.xRP + dBL * g.yBP * g.xLP + dBR * g.yBP * g.xRP, s3));
+                }
+                S += g.yTP * g.xLP * a0;
+                S += g.yTP * g.xRP * a1;
+                S += g.yBP * g.xLP * a2;
+                S += g.yBP * g.xRP * a3;
+            }
+        gin2[index] = static_cast<T>(safe_div<T>(grad1, sum) - safe_div<T>(sumgrad * S, sum * sum));
+    }
+}
+
+// ------------------------------------------------------------------------------------ host
+int check_dims(const char* fn, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
+               int ks, int dil, int dtype) {
+    FFWM_REQUIRE(dtype_ok(dtype), FFWM_ERR_DTYPE, "%s: dtype %d is not FFWM_F32/FFWM_F64", fn, dtype);
+    FFWM_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0, FFWM_ERR_ARG,
+                 "%s: sizes must be positive (B=%lld C=%lld Hi=%lld Wi=%lld H=%lld W=%lld)", fn, (long long)B,
+                 (long long)C, (long long)Hi, (long long)Wi, (long long)H, (long long)W);
+    FFWM_REQUIRE(ks >= 2 && dil >= 1, FFWM_ERR_ARG, "%s: need kernel_size >= 2 and dilation >= 1 (got %d, %d)",
+                 fn, ks, dil);
+    FFWM_REQUIRE(Hi * Wi < (1LL << 28) && H * W < (1LL << 28), FFWM_ERR_SIZE,
+                 "%s: a single H*W plane must stay below 2^28 elements (32-bit byte offsets)", fn);
+    const int64_t spatial = B * ((W + kTileX - 1) / kTileX) * ((H + kTileY - 1) / kTileY);
+    FFWM_REQUIRE(spatial * C < (1LL << 31) && B * H * ((W + kWave - 1) / kWave) < (1LL << 31), FFWM_ERR_SIZE,
+                 "%s: grid too large", fn);
+    return FFWM_OK;
+}
+
+unsigned generic_grid(int64_t n) {
+    const int64_t blocks = (n + kBlock - 1) / kBlock;
+    return static_cast<unsigned>(blocks < 16384 ? blocks : 16384);
+}
+
+template <typename T>
+int launch_fwd(const T* in1, const T* in2, T* out, int64_t B, int64_t C, int64_t Hi, int64_t Wi,
+               int64_t H, int64_t W, int ks, int dil, hipStream_t st) {
+    const double bytes = sizeof(T) * static_cast<double>(B) * H * W * (2.0 * C + 3.0);
+    const Geometry g = plan(B, C, H, W, 16);
+    const int remap = options().xcd_remap;
+    LaunchScope ls("resample2d_fwd", st, bytes);
+#define FFWM_RS_FWD(HH)                                                                             \
+    case 2 * HH:                                                                                    \
+        hipLaunchKernelGGL((rs_fwd_kernel<T, HH>), dim3(g.grid), dim3(kBlock), 0, st, in1, in2, out, \
+                           (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, g.tiles_x, g.tiles_y,      \
+                           g.cslabs, g.cs, remap);                                                  \
+        break;
+    switch (ks & ~1) {
+        FFWM_RS_FWD(1) FFWM_RS_FWD(2) FFWM_RS_FWD(3)
+        default: {
+            const int64_t n = B * C * H * W;
+            hipLaunchKernelGGL((rs_fwd_generic<T>), dim3(generic_grid(n)), dim3(kBlock), 0, st, in1, in2,
+                               out, n, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, ks, dil);
+        }
+    }
+#undef FFWM_RS_FWD
+    return check_launch("ffwm_resample2d_forward");
+}
+
+template <typename T>
+int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int64_t B, int64_t C,
+               int64_t Hi, int64_t Wi, int64_t H, int64_t W, int ks, int dil, int quirk,
+               hipStream_t st) {
+    const int remap = options().xcd_remap;
+    if (gin1) {
+        const double bytes = sizeof(T) * static_cast<double>(B) * H * W * (2.0 * C + 3.0);
+        const Geometry g = plan(B, C, H, W, 32);
+        LaunchScope ls("resample2d_bwd_input1", st, bytes);
+#define FFWM_RS_B1(HH)                                                                               \
+    case 2 * HH:                                                                                     \
+        hipLaunchKernelGGL((rs_bwd1_kernel<T, HH>), dim3(g.grid), dim3(kBlock), 0, st, in2, gout,     \
+                           gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, g.tiles_x,     \
+                           g.tiles_y, g.cslabs, g.cs, remap);                                        \
+        break;
+        switch (ks & ~1) {
+            FFWM_RS_B1(1) FFWM_RS_B1(2) FFWM_RS_B1(3)
+            default: {
+                const int64_t n = B * C * H * W;
+                hipLaunchKernelGGL((rs_bwd1_generic<T>), dim3(generic_grid(n)), dim3(kBlock), 0, st, in2,
+                                   gout, gin1, n, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, ks, dil, quirk);
+            }
+        }
+#undef FFWM_RS_B1
+        if (int rc = check_launch("ffwm_resample2d_backward(input1)")) return rc;
+    }
+    if (gin2) {
+        const double bytes = sizeof(T) * static_cast<double>(B) * H * W * (2.0 * C + 6.0);
+        const int tiles_x = static_cast<int>((W + kWave - 1) / kWave);
+        const unsigned grid = static_cast<unsigned>(B * H * tiles_x);
+        LaunchScope ls("resample2d_bwd_input2", st, bytes);
+#define FFWM_RS_B2(HH)                                                                               \
+    case 2 * HH:                                                                                     \
+        hipLaunchKernelGGL((rs_bwd2_kernel<T, HH>), dim3(grid), dim3(kBlock), 0, st, in1, in2, gout,  \
+                           gin2, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, tiles_x);            \
+        break;
+        switch (ks & ~1) {
+            FFWM_RS_B2(1) FFWM_RS_B2(2) FFWM_RS_B2(3)
+            default: {
+                const int64_t n = B * 3 * H * W;
+                hipLaunchKernelGGL((rs_bwd2_generic<T>), dim3(generic_grid(n)), dim3(kBlock), 0, st, in1,
+                                   in2, gout, gin2, n, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, ks, dil);
+            }
+        }
+#undef FFWM_RS_B2
+        if (int rc = check_launch("ffwm_resample2d_backward(input2)")) return rc;
+    }
+    return FFWM_OK;
+}
+
+}  // namespace
+}  // namespace ffwm
+
+using namespace ffwm;
+
+extern "C" int ffwm_resample2d_forward(const void* input1, const void* input2, void* output, int64_t B,
+                                       int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
+                                       int kernel_size, int dilation, int dtype, void* stream) {
+    const char* fn = "ffwm_resample2d_forward";
+    FFWM_REQUIRE(input1 && input2 && output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hi, Wi, H, W, kernel_size, dilation, dtype)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_fwd<float>((const float*)input1, (const float*)input2, (float*)output, B, C, Hi, Wi,
+                                 H, W, kernel_size, dilation, st);
+    return launch_fwd<double>((const double*)input1, (const double*)input2, (double*)output, B, C, Hi, Wi,
+                              H, W, kernel_size, dilation, st);
+}
+
+extern "C" int ffwm_resample2d_backward(const void* input1, const void* input2, const void* grad_output,
+                                        void* grad_input1, void* grad_input2, int64_t B, int64_t C,
+                                        int64_t Hi, int64_t Wi, int64_t H, int64_t W, int kernel_size,
+                                        int dilation, int reference_quirk, int dtype, void* stream) {
+    const char* fn = "ffwm_resample2d_backward";
+    FFWM_REQUIRE(input1 && input2 && grad_output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hi, Wi, H, W, kernel_size, dilation, dtype)) return rc;
+    if (!grad_input1 && !grad_input2) return FFWM_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_bwd<float>((const float*)input1, (const float*)input2, (const float*)grad_output,
+                                 (float*)grad_input1, (float*)grad_input2, B, C, Hi, Wi, H, W, kernel_size,
+                                 dilation, reference_quirk, st);
+    return launch_bwd<double>((const double*)input1, (const double*)input2, (const double*)grad_output,
+                              (double*)grad_input1, (double*)grad_input2, B, C, Hi, Wi, H, W, kernel_size,
+                              dilation, reference_quirk, st);
+}

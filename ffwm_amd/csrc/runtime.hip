@@ -1,0 +1,184 @@
+// runtime.hip -- error reporting, option switches and the built-in HIP-event launch profiler.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace ffwm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return FFWM_ERR_LAUNCH;
+    }
+    return FFWM_OK;
+}
+
+Options& options() {
+    static Options o;
+    return o;
+}
+
+// Channel slab per block: large enough to amortise the per-pixel set-up, small enough that the
+// grid has many blocks per CU on all 256 CUs.
+Geometry plan(int64_t B, int64_t C, int64_t H, int64_t W, int cs_default) {
+    Geometry g;
+    g.tiles_x = static_cast<int>((W + kTileX - 1) / kTileX);
+    g.tiles_y = static_cast<int>((H + kTileY - 1) / kTileY);
+    const int64_t spatial = B * g.tiles_x * g.tiles_y;
+    int cs = options().channel_slab > 0 ? options().channel_slab : cs_default;
+    if (cs > C) cs = static_cast<int>(C);
+    while (cs > 1 && spatial * ((C + cs - 1) / cs) < 4096) cs = (cs + 1) / 2;   // >= 16 blocks per CU
+    g.cs = cs;
+    g.cslabs = static_cast<int>((C + cs - 1) / cs);
+    g.grid = static_cast<unsigned>(spatial * g.cslabs);
+    return g;
+}
+
+// ------------------------------------------------------------------ profiler
+namespace {
+struct Pending {
+    const char* name;
+    hipEvent_t start, stop;
+    double bytes;
+};
+struct Row {
+    int64_t launches = 0;
+    double ms = 0, bytes = 0;
+};
+std::mutex g_mu;
+bool g_prof = false;
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_pool;
+std::map<std::string, Row> g_rows;
+std::vector<std::pair<std::string, Row>> g_snapshot;
+
+hipEvent_t take_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+LaunchScope::LaunchScope(const char* name, hipStream_t stream, double bytes)
+    : slot_(-1), stream_(stream) {
+    if (!g_prof) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Pending p{name, take_event(), take_event(), bytes};
+    if (!p.start || !p.stop) return;
+    (void)hipEventRecord(p.start, stream);
+    g_pending.push_back(p);
+    slot_ = static_cast<int>(g_pending.size()) - 1;
+}
+
+LaunchScope::~LaunchScope() {
+    if (slot_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (slot_ < static_cast<int>(g_pending.size())) (void)hipEventRecord(g_pending[slot_].stop, stream_);
+}
+
+}  // namespace ffwm
+
+using namespace ffwm;
+
+extern "C" {
+
+int ffwm_abi_version(void) { return FFWM_ABI_VERSION; }
+
+const char* ffwm_last_error(void) { return g_err; }
+
+int ffwm_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int prev = g_prof ? 1 : 0;
+    g_prof = on != 0;
+    return prev;
+}
+
+int ffwm_prof_collect(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.stop) == hipSuccess &&
+            hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            Row& r = g_rows[p.name];
+            r.launches += 1;
+            r.ms += ms;
+            r.bytes += p.bytes;
+        }
+        g_pool.push_back(p.start);
+        g_pool.push_back(p.stop);
+    }
+    g_pending.clear();
+    g_snapshot.assign(g_rows.begin(), g_rows.end());
+    return static_cast<int>(g_snapshot.size());
+}
+
+int ffwm_prof_get(int row, char* name, int name_len, int64_t* launches, double* total_ms,
+                  double* algorithmic_bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (row < 0 || row >= static_cast<int>(g_snapshot.size())) {
+        set_error("ffwm_prof_get: row %d out of range", row);
+        return FFWM_ERR_ARG;
+    }
+    const auto& kv = g_snapshot[row];
+    if (name && name_len > 0) {
+        strncpy(name, kv.first.c_str(), name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (launches) *launches = kv.second.launches;
+    if (total_ms) *total_ms = kv.second.ms;
+    if (algorithmic_bytes) *algorithmic_bytes = kv.second.bytes;
+    return FFWM_OK;
+}
+
+int ffwm_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& p : g_pending) {
+        (void)hipEventSynchronize(p.stop);
+        g_pool.push_back(p.start);
+        g_pool.push_back(p.stop);
+    }
+    g_pending.clear();
+    g_rows.clear();
+    g_snapshot.clear();
+    return FFWM_OK;
+}
+
+int ffwm_set_option(const char* key, int value) {
+    if (!key) return FFWM_ERR_ARG;
+    Options& o = options();
+    int* slot = nullptr;
+    if (!strcmp(key, "be_fwd_variant")) slot = &o.be_fwd_variant;
+    else if (!strcmp(key, "be_bwd_variant")) slot = &o.be_bwd_variant;
+    else if (!strcmp(key, "channel_slab")) slot = &o.channel_slab;
+    else if (!strcmp(key, "xcd_remap")) slot = &o.xcd_remap;
+    if (!slot) {
+        set_error("ffwm_set_option: unknown key '%s'", key);
+        return FFWM_ERR_ARG;
+    }
+    int prev = *slot;
+    *slot = value;
+    return prev;
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+// warp.hip -- WarpNet (flow-guided bilinear feature warp) for gfx950, optionally fused with the
+// flip + concat that FFWM's warp-attention module applies right after it.
+//
+// Reference: models/base_networks.py:168-173 -- F.grid_sample(images, flow.permute(0,2,3,1),
+// mode='bilinear') with padding_mode='zeros', align_corners=False -- followed in FFWM.forward
+// (:326-329) by torch.flip(w, (3,)) and torch.cat((w, flipped), 1): three full-tensor passes
+// (3 reads, 3 writes).  Here: 1 read of the features, 2 writes, one kernel.
+//
+//   * one thread per OUTPUT PIXEL looping over a channel slab: the unnormalised coordinate, the
+//     four corner weights and the four (validity-masked) byte offsets are computed once;
+//   * zeros padding is done by the hardware: an out-of-range corner gets the byte offset
+//     0xFFFFFFF0, the buffer range check returns 0 for it, and its weight is forced to 0 so
+//     0 * w never produces NaN;
+//   * a wave covers 64 consecutive x: the direct store is one contiguous run, the flipped store
+//     is the mirrored contiguous run;
+//   * backward: d(flow) accumulates in registers over the channel slab (2 atomics per pixel per
+//     slab); d(feat) is the 4-corner scatter.
+#include "common.hpp"
+
+namespace ffwm {
+namespace {
+
+constexpr unsigned kOob = 0xFFFFFFF0u;
+
+template <typename T>
+struct Corners {
+    unsigned off[4];   // nw, ne, sw, se byte offsets (kOob when outside the image)
+    T w[4];            // matching weights (0 when outside)
+    T dxw[2], dyw[2];  // (x1 - ix), (ix - x0), (y1 - iy), (iy - y0): for d(flow)
+    bool valid[4];
+};
+
+// ATen grid_sampler_2d, bilinear / zeros / align_corners=False:
+//   ix = ((gx + 1) * W_in - 1) / 2, corner weights from the opposite corner.
+template <typename T>
+__device__ __forceinline__ void make_corners(Corners<T>& c, T gx, T gy, int Hi, int Wi) {
+    const T ix = ((gx + 1) * static_cast<T>(Wi) - 1) / 2;
+    const T iy = ((gy + 1) * static_cast<T>(Hi) - 1) / 2;
+    const T fx = floor_t(ix), fy = floor_t(iy);
+    // corner indices as floats are exact for |f| < 2^24 (2^53); anything outside [-1, size] is
+    // out of range on both corners anyway, so clamp before converting (NaN -> out of range).
+    const T lim_x = static_cast<T>(Wi), lim_y = static_cast<T>(Hi);
+    const bool okx = (fx >= static_cast<T>(-1)) && (fx <= lim_x);
+    const bool oky = (fy >= static_cast<T>(-1)) && (fy <= lim_y);
+    const int x0 = okx ? static_cast<int>(fx) : -2;
+    const int y0 = oky ? static_cast<int>(fy) : -2;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const T x1f = fx + 1, y1f = fy + 1;     // == (T)x1, (T)y1 whenever a corner is valid
+    const bool finite = okx && oky;         // otherwise every corner is outside: all terms drop out
+    c.dxw[0] = finite ? x1f - ix : static_cast<T>(0);
+    c.dxw[1] = finite ? ix - fx : static_cast<T>(0);
+    c.dyw[0] = finite ? y1f - iy : static_cast<T>(0);
+    c.dyw[1] = finite ? iy - fy : static_cast<T>(0);
+    const bool vx0 = x0 >= 0 && x0 < Wi, vx1 = x1 >= 0 && x1 < Wi;
+    const bool vy0 = y0 >= 0 && y0 < Hi, vy1 = y1 >= 0 && y1 < Hi;
+    c.valid[0] = vy0 && vx0;
+    c.valid[1] = vy0 && vx1;
+    c.valid[2] = vy1 && vx0;
+    c.valid[3] = vy1 && vx1;
+    const T w[4] = {c.dxw[0] * c.dyw[0], c.dxw[1] * c.dyw[0], c.dxw[0] * c.dyw[1], c.dxw[1] * c.dyw[1]};
+    const int xs[4] = {x0, x1, x0, x1};
+    const int ys[4] = {y0, y0, y1, y1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        c.off[q] = c.valid[q] ? static_cast<unsigned>(ys[q] * Wi + xs[q]) * static_cast<unsigned>(sizeof(T)) : kOob;
+        c.w[q] = c.valid[q] ? w[q] : static_cast<T>(0);
+    }
+}
+
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_fwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, T* __restrict__ out, int C,
+                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs,
+                int remap) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+    const int x = tc.xf, y = tc.yf;
+    if (x >= W || y >= H) return;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const size_t foff = static_cast<size_t>(tc.b) * 2 * plane + static_cast<size_t>(y) * W + x;
+    Corners<T> cn;
+    make_corners<T>(cn, flow[foff], flow[foff + plane], Hi, Wi);
+
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int Co = FLIP ? 2 * C : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * sizeof(T));
+    const unsigned obytes = static_cast<unsigned>(plane * sizeof(T));
+    const T* fp = feat + (static_cast<size_t>(tc.b) * C + c0) * iplane;
+    T* op = out + (static_cast<size_t>(tc.b) * Co + c0) * plane;
+    const unsigned o_direct = static_cast<unsigned>(y * W + x) * static_cast<unsigned>(sizeof(T));
+    const unsigned o_flip = static_cast<unsigned>(y * W + (W - 1 - x)) * static_cast<unsigned>(sizeof(T));
+    const size_t flip_planes = static_cast<size_t>(C) * plane;
+
+    for (int c = c0; c < c1; ++c, fp += iplane, op += plane) {
+        const rsrc_t rf = make_rsrc(fp, ibytes);
+        T v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v += buf_ld<T>(rf, cn.off[q]) * cn.w[q];
+        ElemRow<T, 1> r;
+        r.v[0] = v;
+        buf_store_row<T, 1>(make_rsrc(op, obytes), o_direct, r);
+        if (FLIP) buf_store_row<T, 1>(make_rsrc(op + flip_planes, obytes), o_flip, r);
+    }
+}
+
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T* __restrict__ gout,
+                T* __restrict__ gfeat, T* __restrict__ gflow, int C, int Hi, int Wi, int H, int W,
+                int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+    const int x = tc.xf, y = tc.yf;
+    if (x >= W || y >= H) return;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const size_t foff = static_cast<size_t>(tc.b) * 2 * plane + static_cast<size_t>(y) * W + x;
+    Corners<T> cn;
+    make_corners<T>(cn, flow[foff], flow[foff + plane], Hi, Wi);
+
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int Co = FLIP ? 2 * C : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * sizeof(T));
+    const unsigned obytes = static_cast<unsigned>(plane * sizeof(T));
+    const size_t ioff = (static_cast<size_t>(tc.b) * C + c0) * iplane;
+    const T* fp = feat + ioff;
+    T* gp = gfeat ? gfeat + ioff : nullptr;
+    const T* op = gout + (static_cast<size_t>(tc.b) * Co + c0) * plane;
+    const unsigned o_direct = static_cast<unsigned>(y * W + x) * static_cast<unsigned>(sizeof(T));
+    const unsigned o_flip = static_cast<unsigned>(y * W + (W - 1 - x)) * static_cast<unsigned>(sizeof(T));
+    const size_t flip_planes = static_cast<size_t>(C) * plane;
+    T gix = 0, giy = 0;
+
+    for (int c = c0; c < c1; ++c, fp += iplane, op += plane) {
+        T g = buf_ld<T>(make_rsrc(op, obytes), o_direct);
+        if (FLIP) g += buf_ld<T>(make_rsrc(op + flip_planes, obytes), o_flip);
+        if (gp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (cn.valid[q]) atomic_add_off(gp, cn.off[q], cn.w[q] * g);
+            gp += iplane;
+        }
+        if (gflow) {
+            const rsrc_t rf = make_rsrc(fp, ibytes);
+            const T s0 = buf_ld<T>(rf, cn.off[0]), s1 = buf_ld<T>(rf, cn.off[1]);
+            const T s2 = buf_ld<T>(rf, cn.off[2]), s3 = buf_ld<T>(rf, cn.off[3]);
+            // ATen grid_sampler_2d_backward; invalid corners read 0 and drop out.
+            gix -= s0 * cn.dyw[0] * g;
+            giy -= s0 * cn.dxw[0] * g;
+            gix += s1 * cn.dyw[0] * g;
+            giy -= s1 * cn.dxw[1] * g;
+            gix -= s2 * cn.dyw[1] * g;
+            giy += s2 * cn.dxw[0] * g;
+            gix += s3 * cn.dyw[1] * g;
+            giy += s3 * cn.dxw[1] * g;
+        }
+    }
+    if (gflow) {
+        atomic_add(gflow + foff, (static_cast<T>(Wi) / 2) * gix);
+        atomic_add(gflow + foff + plane, (static_cast<T>(Hi) / 2) * giy);
+    }
+}
+
+int check_dims(const char* fn, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
+               int dtype) {
+    FFWM_REQUIRE(dtype_ok(dtype), FFWM_ERR_DTYPE, "%s: dtype %d is not FFWM_F32/FFWM_F64", fn, dtype);
+    FFWM_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && H > 0 && W > 0, FFWM_ERR_ARG,
+                 "%s: sizes must be positive (B=%lld C=%lld Hi=%lld Wi=%lld H=%lld W=%lld)", fn, (long long)B,
+                 (long long)C, (long long)Hi, (long long)Wi, (long long)H, (long long)W);
+    FFWM_REQUIRE(Hi * Wi < (1LL << 28) && H * W < (1LL << 28), FFWM_ERR_SIZE,
+                 "%s: a single H*W plane must stay below 2^28 elements (32-bit byte offsets)", fn);
+    const int64_t spatial = B * ((W + kTileX - 1) / kTileX) * ((H + kTileY - 1) / kTileY);
+    FFWM_REQUIRE(spatial * C < (1LL << 31), FFWM_ERR_SIZE, "%s: grid too large", fn);
+    return FFWM_OK;
+}
+
+template <typename T>
+int launch_fwd(const T* feat, const T* flow, T* out, int64_t B, int64_t C, int64_t Hi, int64_t Wi,
+               int64_t H, int64_t W, int flip, hipStream_t st) {
+    const double bytes = sizeof(T) * static_cast<double>(B) *
+                         (static_cast<double>(C) * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W);
+    const Geometry g = plan(B, C, H, W, 16);
+    const int remap = options().xcd_remap;
+    LaunchScope ls(flip ? "warp_flipcat_fwd" : "warp_fwd", st, bytes);
+    if (flip)
+        hipLaunchKernelGGL((warp_fwd_kernel<T, true>), dim3(g.grid), dim3(kBlock), 0, st, feat, flow, out,
+                           (int)C, (int)Hi, (int)Wi, (int)H, (int)W, g.tiles_x, g.tiles_y, g.cslabs, g.cs, remap);
+    else
+        hipLaunchKernelGGL((warp_fwd_kernel<T, false>), dim3(g.grid), dim3(kBlock), 0, st, feat, flow, out,
+                           (int)C, (int)Hi, (int)Wi, (int)H, (int)W, g.tiles_x, g.tiles_y, g.cslabs, g.cs, remap);
+    return check_launch("ffwm_warp_forward");
+}
+
+template <typename T>
+int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, int64_t B, int64_t C,
+               int64_t Hi, int64_t Wi, int64_t H, int64_t W, int flip, hipStream_t st) {
+    const double bytes = sizeof(T) * static_cast<double>(B) *
+                         (2.0 * C * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W);
+    const Geometry g = plan(B, C, H, W, 32);
+    const int remap = options().xcd_remap;
+    LaunchScope ls(flip ? "warp_flipcat_bwd" : "warp_bwd", st, bytes);
+    if (flip)
+        hipLaunchKernelGGL((warp_bwd_kernel<T, true>), dim3(g.grid), dim3(kBlock), 0, st, feat, flow, gout,
+                           gfeat, gflow, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, g.tiles_x, g.tiles_y,
+                           g.cslabs, g.cs, remap);
+    else
+        hipLaunchKernelGGL((warp_bwd_kernel<T, false>), dim3(g.grid), dim3(kBlock), 0, st, feat, flow, gout,
+                           gfeat, gflow, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, g.tiles_x, g.tiles_y,
+                           g.cslabs, g.cs, remap);
+    return check_launch("ffwm_warp_backward");
+}
+
+}  // namespace
+}  // namespace ffwm
+
+using namespace ffwm;
+
+extern "C" int ffwm_warp_forward(const void* feat, const void* flow, void* output, int64_t B, int64_t C,
+                                 int64_t Hi, int64_t Wi, int64_t H, int64_t W, int flipcat, int dtype,
+                                 void* stream) {
+    const char* fn = "ffwm_warp_forward";
+    FFWM_REQUIRE(feat && flow && output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hi, Wi, H, W, dtype)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_fwd<float>((const float*)feat, (const float*)flow, (float*)output, B, C, Hi, Wi, H, W,
+                                 flipcat, st);
+    return launch_fwd<double>((const double*)feat, (const double*)flow, (double*)output, B, C, Hi, Wi, H, W,
+                              flipcat, st);
+}
+
+extern "C" int ffwm_warp_backward(const void* feat, const void* flow, const void* grad_output,
+                                  void* grad_feat, void* grad_flow, int64_t B, int64_t C, int64_t Hi,
+                                  int64_t Wi, int64_t H, int64_t W, int flipcat, int dtype, void* stream) {
+    const char* fn = "ffwm_warp_backward";
+    FFWM_REQUIRE(feat && flow && grad_output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hi, Wi, H, W, dtype)) return rc;
+    if (!grad_feat && !grad_flow) return FFWM_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_bwd<float>((const float*)feat, (const float*)flow, (const float*)grad_output,
+                                 (float*)grad_feat, (float*)grad_flow, B, C, Hi, Wi, H, W, flipcat, st);
+    return launch_bwd<double>((const double*)feat, (const double*)flow, (const double*)grad_output,
+                              (double*)grad_feat, (double*)grad_flow, B, C, Hi, Wi, H, W, flipcat, st);
+}

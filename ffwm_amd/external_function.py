@@ -1,0 +1,180 @@
+"""Drop-in mirror of the reference's operator API for the flow-warp hot path.
+
+Same names, call signatures and error behaviour as /root/reference/models/external_function.py:19-158
+(``BlockExtractorFunction``, ``LocalAttnReshapeFunction``, ``Resample2dFunction`` and their ``nn.Module``
+shells), so ``models/losses.py:161`` style imports keep working::
+
+    from ffwm_amd.external_function import Resample2d, LocalAttnReshape, BlockExtractor
+
+Underneath, every call goes through the C ABI of libffwm_hip.so (hand-written gfx950 kernels).
+Differences from the reference, all deliberate:
+  * outputs are allocated uninitialised where the kernel overwrites them (the reference zero-fills
+    and then overwrites); gradients that are scattered into are still zero-filled;
+  * ``grad_output`` is made contiguous for real (the reference calls ``.contiguous()`` and drops
+    the result, external_function.py:46-47,93-94,132-133);
+  * gradients nobody asked for (``ctx.needs_input_grad``) are not computed;
+  * a device guard: kernels launch on the tensors' device and its current stream.
+Plus ``WarpNet`` (models/base_networks.py:168-173) and the fused warp + flip + concat that
+FFWM.forward performs at models/base_networks.py:326-329.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        # the reference raises the same for CPU tensors (external_function.py:37-38,84-85)
+        raise NotImplementedError
+
+
+class BlockExtractorFunction(Function):
+    """apply(source[B,C,Hs,Ws], flow_field[B,2,Hf,Wf], kernel_size) -> [B,C,k*Hf,k*Wf]"""
+
+    @staticmethod
+    def forward(ctx, source, flow_field, kernel_size):
+        assert source.is_contiguous()
+        assert flow_field.is_contiguous()
+        assert flow_field.size(1) == 2
+        _require_cuda(source)
+        ctx.save_for_backward(source, flow_field)
+        ctx.kernel_size = kernel_size
+        return ops.block_extractor_forward(source, flow_field, kernel_size)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        source, flow_field = ctx.saved_tensors
+        need_src, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_source = torch.zeros_like(source) if need_src else None
+        grad_flow = torch.zeros_like(flow_field) if need_flow else None
+        if need_src or need_flow:
+            ops.block_extractor_backward(source, flow_field, grad_output.contiguous(), ctx.kernel_size,
+                                         grad_source, grad_flow)
+        return grad_source, grad_flow, None
+
+
+class BlockExtractor(nn.Module):
+    def __init__(self, kernel_size=3):
+        super().__init__()
+        self.kernel_size = kernel_size
+
+    def forward(self, source, flow_field):
+        return BlockExtractorFunction.apply(source.contiguous(), flow_field.contiguous(), self.kernel_size)
+
+
+class LocalAttnReshapeFunction(Function):
+    """apply(inputs[B,k*k,H,W], kernel_size) -> [B,1,k*H,k*W]"""
+
+    @staticmethod
+    def forward(ctx, inputs, kernel_size):
+        assert inputs.is_contiguous()
+        assert inputs.size(1) == kernel_size * kernel_size
+        _require_cuda(inputs)
+        ctx.kernel_size = kernel_size
+        return ops.local_attn_reshape_forward(inputs, kernel_size)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        # the map is a bijection: write the inverse permutation, no zero-fill, no atomics
+        return ops.local_attn_reshape_backward(grad_output.contiguous(), ctx.kernel_size), None
+
+
+class LocalAttnReshape(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, inputs, kernel_size=3):
+        return LocalAttnReshapeFunction.apply(inputs.contiguous(), kernel_size)
+
+
+class Resample2dFunction(Function):
+    """apply(input1[B1,C,Hi,Wi], input2[B,3,H,W]=(dx,dy,sigma), kernel_size=2, dilation=1) -> [B,C,H,W]
+
+    ``reference_quirk`` (class attribute, default True) keeps the reference's ``int()`` truncation in
+    the d_input1 weights (resample2d_kernel.cu:137-138); set it False for the true gradient."""
+
+    reference_quirk = True
+
+    @staticmethod
+    def forward(ctx, input1, input2, kernel_size=2, dilation=1):
+        assert input1.is_contiguous()
+        assert input2.is_contiguous()
+        _require_cuda(input1)
+        ctx.save_for_backward(input1, input2)
+        ctx.kernel_size = kernel_size
+        ctx.dilation = dilation
+        return ops.resample2d_forward(input1, input2, kernel_size, dilation)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_input1 = torch.zeros_like(input1) if need1 else None
+        grad_input2 = torch.empty_like(input2) if need2 else None
+        if need1 or need2:
+            ops.resample2d_backward(input1, input2, grad_output.contiguous(), ctx.kernel_size, ctx.dilation,
+                                    grad_input1, grad_input2, Resample2dFunction.reference_quirk)
+        return grad_input1, grad_input2, None, None
+
+
+class Resample2d(nn.Module):
+    """Resample2d(kernel_size, dilation, sigma)(input1, flow[B,2,H,W]): appends the constant sigma
+    channel (external_function.py:154-158).  sigma follows the flow's device, so -- unlike the
+    reference module -- it also works for GPU tensors."""
+
+    def __init__(self, kernel_size=2, dilation=1, sigma=5):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.dilation = dilation
+        self.sigma = float(sigma)
+
+    def forward(self, input1, input2):
+        b, _, h, w = input2.shape
+        sigma = input2.new_full((b, 1, h, w), self.sigma)
+        packed = torch.cat((input2, sigma), 1)
+        return Resample2dFunction.apply(input1.contiguous(), packed, self.kernel_size, self.dilation)
+
+
+class WarpFunction(Function):
+    """apply(feat[B,C,Hi,Wi], flow[B,2,H,W] in [-1,1], flipcat=False): F.grid_sample(feat,
+    flow.permute(0,2,3,1)) -- bilinear, zeros, align_corners=False -- and, with flipcat, the
+    cat((w, flip(w, 3)), 1) of FFWM.forward in the same kernel."""
+
+    @staticmethod
+    def forward(ctx, feat, flow, flipcat=False):
+        _require_cuda(feat)
+        feat = feat.contiguous()
+        flow = flow.contiguous()
+        ctx.save_for_backward(feat, flow)
+        ctx.flipcat = bool(flipcat)
+        return ops.warp_forward(feat, flow, ctx.flipcat)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        feat, flow = ctx.saved_tensors
+        need_feat, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_feat = torch.zeros_like(feat) if need_feat else None
+        grad_flow = torch.zeros_like(flow) if need_flow else None
+        if need_feat or need_flow:
+            ops.warp_backward(feat, flow, grad_output.contiguous(), ctx.flipcat, grad_feat, grad_flow)
+        return grad_feat, grad_flow, None
+
+
+class WarpNet(nn.Module):
+    """Same call as the reference's WarpNet (models/base_networks.py:168-173); bilinear only."""
+
+    def forward(self, images, flow, mode='bilinear'):
+        if mode != 'bilinear':
+            raise NotImplementedError("WarpNet: only mode='bilinear' is implemented (every reference caller uses it)")
+        return WarpFunction.apply(images, flow, False)
+
+
+class WarpFlipCat(nn.Module):
+    """w = WarpNet(feat, flow); return cat((w, flip(w, (3,))), 1) -- models/base_networks.py:326-329."""
+
+    def forward(self, feat, flow):
+        return WarpFunction.apply(feat, flow, True)

@@ -1,0 +1,227 @@
+"""Tensor-level entry points of the HIP hot path: torch tensors in, C ABI underneath.
+
+PyTorch is plumbing here (device memory, the current HIP stream); every function below is one
+call into libffwm_hip.so through ``include/ffwm_hip.h``.  CPU tensors are refused, as the
+reference's wrappers refuse them (/root/reference/models/external_function.py:37-38,84-85):
+there is no CPU or eager fallback in this package.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _dtype_code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("ffwm_amd ops support float32/float64 (AT_DISPATCH_FLOATING_TYPES), got %s" % t.dtype)
+
+
+def _check(name, *tensors):
+    ref = tensors[0]
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError("%s: ffwm_amd ops run on the GPU only (got a %s tensor)" % (name, t.device))
+        if t.device != ref.device:
+            raise ValueError("%s: tensors live on different devices (%s vs %s)" % (name, t.device, ref.device))
+        if t.dtype != ref.dtype:
+            raise TypeError("%s: mixed dtypes (%s vs %s)" % (name, t.dtype, ref.dtype))
+        if t.dim() != 4:
+            raise ValueError("%s: expected 4-D NCHW tensors, got %d-D" % (name, t.dim()))
+        if not t.is_contiguous():
+            raise ValueError("%s: tensors must be contiguous NCHW" % name)
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _on_device(object):
+    """Launch on the tensors' device and its current stream (the reference has no device guard)."""
+
+    __slots__ = ("dev", "prev")
+
+    def __init__(self, t):
+        self.dev = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+# ---------------------------------------------------------------- block_extractor
+def block_extractor_forward(source, flow_field, kernel_size, out=None):
+    """-> out[B,C,k*Hf,k*Wf]; reference block_extractor_kernel.cu:21-85."""
+    _check("block_extractor_forward", source, flow_field, out)
+    B, C, Hs, Ws = source.shape
+    Bf, two, Hf, Wf = flow_field.shape
+    if two != 2:
+        raise ValueError("block_extractor_forward: flow_field must have 2 channels")
+    if Bf < B:
+        raise ValueError("block_extractor_forward: flow_field batch %d < source batch %d" % (Bf, B))
+    k = int(kernel_size)
+    if out is None:
+        out = source.new_empty((B, C, k * Hf, k * Wf))
+    elif tuple(out.shape) != (B, C, k * Hf, k * Wf):
+        raise ValueError("block_extractor_forward: output has the wrong shape")
+    if out.numel() == 0:
+        return out
+    with _on_device(source) as stream:
+        _lib.check(_lib.load().ffwm_block_extractor_forward(
+            _ptr(source), _ptr(flow_field), _ptr(out), B, C, Hs, Ws, Hf, Wf, k, _dtype_code(source), stream),
+            "ffwm_block_extractor_forward")
+    return out
+
+
+def block_extractor_backward(source, flow_field, grad_output, kernel_size, grad_source=None,
+                             grad_flow_field=None):
+    """Accumulates (+=) into the given, zero-filled gradient buffers; None skips one."""
+    _check("block_extractor_backward", source, flow_field, grad_output, grad_source, grad_flow_field)
+    B, C, Hs, Ws = source.shape
+    _, _, Hf, Wf = flow_field.shape
+    k = int(kernel_size)
+    if tuple(grad_output.shape) != (B, C, k * Hf, k * Wf):
+        raise ValueError("block_extractor_backward: grad_output has the wrong shape")
+    if grad_output.numel() == 0:
+        return grad_source, grad_flow_field
+    with _on_device(source) as stream:
+        _lib.check(_lib.load().ffwm_block_extractor_backward(
+            _ptr(source), _ptr(flow_field), _ptr(grad_output), _ptr(grad_source), _ptr(grad_flow_field),
+            B, C, Hs, Ws, Hf, Wf, k, _dtype_code(source), stream), "ffwm_block_extractor_backward")
+    return grad_source, grad_flow_field
+
+
+# ---------------------------------------------------------------- local_attn_reshape
+def local_attn_reshape_forward(inputs, kernel_size, out=None):
+    """-> out[B,1,k*H,k*W]; reference local_attn_reshape_kernel.cu:21-61."""
+    _check("local_attn_reshape_forward", inputs, out)
+    B, C, H, W = inputs.shape
+    k = int(kernel_size)
+    if C != k * k:
+        raise ValueError("local_attn_reshape_forward: need C == k*k (C=%d, k=%d)" % (C, k))
+    if out is None:
+        out = inputs.new_empty((B, 1, k * H, k * W))
+    elif tuple(out.shape) != (B, 1, k * H, k * W):
+        raise ValueError("local_attn_reshape_forward: output has the wrong shape")
+    if out.numel() == 0:
+        return out
+    with _on_device(inputs) as stream:
+        _lib.check(_lib.load().ffwm_local_attn_reshape_forward(
+            _ptr(inputs), _ptr(out), B, H, W, k, _dtype_code(inputs), stream),
+            "ffwm_local_attn_reshape_forward")
+    return out
+
+
+def local_attn_reshape_backward(grad_output, kernel_size, grad_inputs=None, accumulate=False):
+    """grad_inputs[B,k*k,H,W]; accumulate=True is the reference's += into a zero-filled buffer."""
+    _check("local_attn_reshape_backward", grad_output, grad_inputs)
+    B, one, Ho, Wo = grad_output.shape
+    k = int(kernel_size)
+    if one != 1 or Ho % k or Wo % k:
+        raise ValueError("local_attn_reshape_backward: grad_output must be [B,1,k*H,k*W]")
+    H, W = Ho // k, Wo // k
+    if grad_inputs is None:
+        if accumulate:
+            raise ValueError("local_attn_reshape_backward: accumulate=True needs a grad_inputs buffer")
+        grad_inputs = grad_output.new_empty((B, k * k, H, W))
+    elif tuple(grad_inputs.shape) != (B, k * k, H, W):
+        raise ValueError("local_attn_reshape_backward: grad_inputs has the wrong shape")
+    if grad_output.numel() == 0:
+        return grad_inputs
+    with _on_device(grad_output) as stream:
+        _lib.check(_lib.load().ffwm_local_attn_reshape_backward(
+            _ptr(grad_output), _ptr(grad_inputs), B, H, W, k, 1 if accumulate else 0,
+            _dtype_code(grad_output), stream), "ffwm_local_attn_reshape_backward")
+    return grad_inputs
+
+
+# ---------------------------------------------------------------- resample2d
+def resample2d_forward(input1, input2, kernel_size=2, dilation=1, out=None):
+    """-> out[B,C,H,W]; reference resample2d_kernel.cu:21-95."""
+    _check("resample2d_forward", input1, input2, out)
+    B1, C, Hi, Wi = input1.shape
+    B, three, H, W = input2.shape
+    if three != 3:
+        raise ValueError("resample2d_forward: input2 must be [B,3,H,W] = (dx, dy, sigma)")
+    if B1 < B:
+        raise ValueError("resample2d_forward: input1 batch %d < input2 batch %d" % (B1, B))
+    if out is None:
+        out = input1.new_empty((B, C, H, W))
+    elif tuple(out.shape) != (B, C, H, W):
+        raise ValueError("resample2d_forward: output has the wrong shape")
+    if out.numel() == 0:
+        return out
+    with _on_device(input1) as stream:
+        _lib.check(_lib.load().ffwm_resample2d_forward(
+            _ptr(input1), _ptr(input2), _ptr(out), B, C, Hi, Wi, H, W, int(kernel_size), int(dilation),
+            _dtype_code(input1), stream), "ffwm_resample2d_forward")
+    return out
+
+
+def resample2d_backward(input1, input2, grad_output, kernel_size=2, dilation=1, grad_input1=None,
+                        grad_input2=None, reference_quirk=True):
+    """grad_input1 += (zero-fill it first), grad_input2 is overwritten; None skips one."""
+    _check("resample2d_backward", input1, input2, grad_output, grad_input1, grad_input2)
+    _, C, Hi, Wi = input1.shape
+    B, _, H, W = input2.shape
+    if tuple(grad_output.shape) != (B, C, H, W):
+        raise ValueError("resample2d_backward: grad_output has the wrong shape")
+    if grad_output.numel() == 0:
+        return grad_input1, grad_input2
+    with _on_device(input1) as stream:
+        _lib.check(_lib.load().ffwm_resample2d_backward(
+            _ptr(input1), _ptr(input2), _ptr(grad_output), _ptr(grad_input1), _ptr(grad_input2), B, C, Hi,
+            Wi, H, W, int(kernel_size), int(dilation), 1 if reference_quirk else 0, _dtype_code(input1),
+            stream), "ffwm_resample2d_backward")
+    return grad_input1, grad_input2
+
+
+# ---------------------------------------------------------------- warp (WarpNet)
+def warp_forward(feat, flow, flipcat=False, out=None):
+    """grid_sample(bilinear, zeros, align_corners=False) [+ flip + cat]; base_networks.py:168-173,326-329."""
+    _check("warp_forward", feat, flow, out)
+    B, C, Hi, Wi = feat.shape
+    Bf, two, H, W = flow.shape
+    if two != 2 or Bf != B:
+        raise ValueError("warp_forward: flow must be [B,2,H,W] with the features' batch size")
+    Co = 2 * C if flipcat else C
+    if out is None:
+        out = feat.new_empty((B, Co, H, W))
+    elif tuple(out.shape) != (B, Co, H, W):
+        raise ValueError("warp_forward: output has the wrong shape")
+    if out.numel() == 0:
+        return out
+    with _on_device(feat) as stream:
+        _lib.check(_lib.load().ffwm_warp_forward(
+            _ptr(feat), _ptr(flow), _ptr(out), B, C, Hi, Wi, H, W, 1 if flipcat else 0, _dtype_code(feat),
+            stream), "ffwm_warp_forward")
+    return out
+
+
+def warp_backward(feat, flow, grad_output, flipcat=False, grad_feat=None, grad_flow=None):
+    """Both gradients accumulate (+=) into zero-filled buffers; None skips one."""
+    _check("warp_backward", feat, flow, grad_output, grad_feat, grad_flow)
+    B, C, Hi, Wi = feat.shape
+    _, _, H, W = flow.shape
+    if tuple(grad_output.shape) != (B, 2 * C if flipcat else C, H, W):
+        raise ValueError("warp_backward: grad_output has the wrong shape")
+    if grad_output.numel() == 0:
+        return grad_feat, grad_flow
+    with _on_device(feat) as stream:
+        _lib.check(_lib.load().ffwm_warp_backward(
+            _ptr(feat), _ptr(flow), _ptr(grad_output), _ptr(grad_feat), _ptr(grad_flow), B, C, Hi, Wi, H, W,
+            1 if flipcat else 0, _dtype_code(feat), stream), "ffwm_warp_backward")
+    return grad_feat, grad_flow

@@ -1,0 +1,138 @@
+/*
+ * ffwm_hip.h -- C ABI of libffwm_hip.so, the MI355X (gfx950) implementation of the
+ * flow-guided feature-warping hot path of csyxwei/FFWM.
+ *
+ * This is the drop-in boundary: each entry point below replaces one native function the
+ * reference binds through pybind11 (citations are into the reference repository).  The
+ * reference passes `at::Tensor&`; here every tensor is a raw device pointer to a
+ * CONTIGUOUS NCHW buffer plus its sizes, so the library has no PyTorch dependency:
+ *
+ *   ffwm_block_extractor_forward    <- block_extractor_cuda.forward     cuda/block_extractor/block_extractor_cuda.cc:5-12
+ *   ffwm_block_extractor_backward   <- block_extractor_cuda.backward    cuda/block_extractor/block_extractor_cuda.cc:14-25
+ *   ffwm_local_attn_reshape_forward <- local_attn_reshape_cuda.forward  cuda/local_attn_reshape/local_attn_reshape_cuda.cc:5-11
+ *   ffwm_local_attn_reshape_backward<- local_attn_reshape_cuda.backward cuda/local_attn_reshape/local_attn_reshape_cuda.cc:13-21
+ *   ffwm_resample2d_forward         <- resample2d_cuda.forward          cuda/resample2d_package/resample2d_cuda.cc:6-14
+ *   ffwm_resample2d_backward        <- resample2d_cuda.backward         cuda/resample2d_package/resample2d_cuda.cc:16-26
+ *   ffwm_warp_forward / _backward   <- WarpNet.forward (F.grid_sample)  models/base_networks.py:168-173, fused with the
+ *                                      flip + concat of FFWM.forward    models/base_networks.py:326-329
+ *
+ * Conventions
+ *   - dtype: FFWM_F32 or FFWM_F64 (the reference dispatches AT_DISPATCH_FLOATING_TYPES).
+ *   - stream: a hipStream_t passed as void* (NULL = the null stream).  Launches are
+ *     asynchronous, never synchronise, never allocate; the library keeps no tensor state.
+ *   - The kernels run on the CURRENT HIP device of the calling thread; the caller selects the
+ *     device that owns the pointers (one process per GPU in this project).
+ *   - Ownership: the caller allocates every output.  Forward outputs are fully overwritten
+ *     (no zero-fill needed).  Gradient outputs marked "+=" are accumulated into, exactly as
+ *     the reference's atomicAdd kernels do, so the caller zero-fills them first
+ *     (models/external_function.py:49-50,96,137-138).  A NULL gradient pointer skips that
+ *     gradient.
+ *   - Return: 0 on success, a negative ffwm_status otherwise; ffwm_last_error() returns a
+ *     thread-local message.  (The reference returns 1 unconditionally and checks nothing.)
+ *   - Index arithmetic is 64-bit for flat offsets (the reference overflows 32-bit `int`
+ *     above 2^31 elements); a single H*W plane must stay below 2^31 elements.
+ */
+#ifndef FFWM_HIP_H_
+#define FFWM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFWM_ABI_VERSION 1
+
+typedef enum {
+    FFWM_OK = 0,
+    FFWM_ERR_ARG = -1,     /* NULL pointer, non-positive size, bad kernel_size/dilation */
+    FFWM_ERR_DTYPE = -2,   /* dtype is not FFWM_F32 / FFWM_F64 */
+    FFWM_ERR_SIZE = -3,    /* a plane exceeds 2^31 elements */
+    FFWM_ERR_LAUNCH = -4   /* HIP reported a launch error */
+} ffwm_status;
+
+typedef enum { FFWM_F32 = 0, FFWM_F64 = 1 } ffwm_dtype;
+
+int ffwm_abi_version(void);
+const char* ffwm_last_error(void);
+
+/* out[B,C,k*Hf,k*Wf][b,c,yf*k+i,xf*k+j] = bilinear(source[b,c], yf + flow[b,1,yf,xf] + i - k/2,
+ *                                                  xf + flow[b,0,yf,xf] + j - k/2)
+ * index-clamped border, weights from the unclamped fraction.
+ * source[B,C,Hs,Ws], flow_field[>=B,2,Hf,Wf] (pixel units, ch0 = x, ch1 = y).
+ * Reference: block_extractor_kernel.cu:21-85. */
+int ffwm_block_extractor_forward(const void* source, const void* flow_field, void* output,
+                                 int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
+                                 int64_t Wf, int kernel_size, int dtype, void* stream);
+
+/* grad_source[B,C,Hs,Ws] += 4-tap scatter of grad_output; grad_flow_field[B,2,Hf,Wf] += sum over
+ * c and the k x k window of grad_output * d(bilinear)/d(x,y).  Either may be NULL.
+ * Reference: block_extractor_kernel.cu:89-170. */
+int ffwm_block_extractor_backward(const void* source, const void* flow_field,
+                                  const void* grad_output, void* grad_source,
+                                  void* grad_flow_field, int64_t B, int64_t C, int64_t Hs,
+                                  int64_t Ws, int64_t Hf, int64_t Wf, int kernel_size,
+                                  int dtype, void* stream);
+
+/* out[B,1,k*H,k*W][b,0,y,x] = inputs[B,k*k,H,W][b,(y%k)*k + x%k, y/k, x/k].
+ * Reference: local_attn_reshape_kernel.cu:21-61. */
+int ffwm_local_attn_reshape_forward(const void* inputs, void* output, int64_t B, int64_t H,
+                                    int64_t W, int kernel_size, int dtype, void* stream);
+
+/* Inverse permutation.  accumulate != 0: grad_inputs += (reference semantics, atomicAdd into a
+ * zero-filled buffer, local_attn_reshape_kernel.cu:66-108); accumulate == 0: grad_inputs is
+ * overwritten (no zero-fill, half the traffic -- identical result on a zero-filled buffer). */
+int ffwm_local_attn_reshape_backward(const void* grad_output, void* grad_inputs, int64_t B,
+                                     int64_t H, int64_t W, int kernel_size, int accumulate,
+                                     int dtype, void* stream);
+
+/* Gaussian-weighted kernel_size x kernel_size tap resampler.  input1[>=B,C,Hi,Wi],
+ * input2[B,3,H,W] = (dx, dy, sigma) in pixels, out[B,C,H,W].
+ * Reference: resample2d_kernel.cu:21-95.  kernel_size even >= 2, dilation >= 1. */
+int ffwm_resample2d_forward(const void* input1, const void* input2, void* output, int64_t B,
+                            int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
+                            int kernel_size, int dilation, int dtype, void* stream);
+
+/* grad_input1[B,C,Hi,Wi] += scatter (resample2d_kernel.cu:98-202); grad_input2[B,3,H,W] is
+ * OVERWRITTEN (resample2d_kernel.cu:204-330).  reference_quirk != 0 keeps the reference's
+ * `alpha = xf - int(xf)` truncation in the grad_input1 weights (:137-138); 0 uses floor (the
+ * true gradient).  Either gradient may be NULL. */
+int ffwm_resample2d_backward(const void* input1, const void* input2, const void* grad_output,
+                             void* grad_input1, void* grad_input2, int64_t B, int64_t C,
+                             int64_t Hi, int64_t Wi, int64_t H, int64_t W, int kernel_size,
+                             int dilation, int reference_quirk, int dtype, void* stream);
+
+/* WarpNet: out[b,c,y,x] = grid_sample(feat[B,C,Hi,Wi], flow[B,2,H,W]) bilinear, zeros padding,
+ * align_corners=False; flow = normalised absolute coordinates, ch0 = x, ch1 = y.
+ * flipcat != 0: out is [B,2C,H,W] = cat(w, flip(w, dim 3)) (one read, two writes instead of
+ * grid_sample + flip + cat).  Reference: models/base_networks.py:168-173,326-329. */
+int ffwm_warp_forward(const void* feat, const void* flow, void* output, int64_t B, int64_t C,
+                      int64_t Hi, int64_t Wi, int64_t H, int64_t W, int flipcat, int dtype,
+                      void* stream);
+
+/* grad_feat[B,C,Hi,Wi] += ; grad_flow[B,2,H,W] += .  Either may be NULL.  grad_output is
+ * [B,C,H,W] or, with flipcat, [B,2C,H,W]. */
+int ffwm_warp_backward(const void* feat, const void* flow, const void* grad_output,
+                       void* grad_feat, void* grad_flow, int64_t B, int64_t C, int64_t Hi,
+                       int64_t Wi, int64_t H, int64_t W, int flipcat, int dtype, void* stream);
+
+/* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
+ * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
+ * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded
+ * events, folds them into per-kernel totals and returns the number of distinct kernels seen;
+ * ffwm_prof_get() reads one row.  ffwm_prof_reset() drops everything. */
+int ffwm_prof_enable(int on);
+int ffwm_prof_collect(void);
+int ffwm_prof_get(int row, char* name, int name_len, int64_t* launches, double* total_ms,
+                  double* algorithmic_bytes);
+int ffwm_prof_reset(void);
+
+/* Tuning/ablation switches (bench and tests only): returns the previous value, or
+ * FFWM_ERR_ARG for an unknown key.  Keys: "be_fwd_variant", "be_bwd_variant",
+ * "channel_slab", "xcd_remap". */
+int ffwm_set_option(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFWM_HIP_H_ */

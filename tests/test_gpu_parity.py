@@ -1,0 +1,434 @@
+"""GPU parity: the HIP path (through the C ABI, via ffwm_amd.ops / external_function) against the
+CPU oracle on the same seeded inputs.  Run with ``-m gpu`` on the MI355X box.
+
+Tolerances (written here, per north_star "<= 1e-4 max abs diff, fp32"):
+  forward, fp32 : 2e-6 abs on O(1) data (block_extractor / local_attn_reshape / warp are expected
+                  bit-exact: same operation order, -ffp-contract=off on both sides)
+  forward, fp64 : 1e-13
+  backward      : sums are re-associated (register/LDS partial sums, atomics), so the bound is
+                  1e-5 * (1 + max|ref|) in fp32 and 1e-11 * (1 + max|ref|) in fp64.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+FWD_TOL = {torch.float32: 2e-6, torch.float64: 1e-13}
+BWD_TOL = {torch.float32: 1e-5, torch.float64: 1e-11}
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _close(got, ref, tol, relative=False):
+    got = got.detach().cpu()
+    diff = (got - ref).abs().max().item()
+    bound = tol * (1 + ref.abs().max().item()) if relative else tol
+    assert diff <= bound, "max abs diff %.3e > %.3e" % (diff, bound)
+    return diff
+
+
+# ------------------------------------------------------------------------- block_extractor
+BE_CASES = [
+    # (B, C, Hs, Ws, Hf, Wf, k, flow_scale, seed)
+    (2, 3, 14, 10, 14, 10, 3, 1.8, 0),      # the reference's gradcheck shape (test_block_extractor.py:77-81)
+    (1, 5, 37, 70, 37, 70, 3, 4.0, 1),      # ragged tile edges, bounded flow
+    (2, 4, 20, 33, 20, 33, 3, 64.0, 2),     # flow leaves the image: border clamping everywhere
+    (1, 2, 16, 16, 9, 21, 3, 3.0, 3),       # flow grid != source grid
+    (1, 3, 12, 12, 12, 12, 1, 2.0, 4),
+    (1, 3, 12, 13, 12, 13, 2, 2.0, 5),      # even k: asymmetric offsets
+    (1, 2, 12, 13, 12, 13, 4, 2.0, 6),
+    (2, 1, 64, 64, 60, 60, 5, 0.0, 7),      # reference usage: kz=5 on 64^2, constant flow (losses.py:214-216)
+    (2, 1, 128, 128, 122, 122, 7, 0.0, 8),  # kz=7 on 128^2
+    (1, 2, 10, 10, 10, 10, 6, 2.0, 9),
+    (1, 2, 9, 9, 4, 4, 9, 1.0, 10),         # k > 7: generic per-element kernel
+]
+
+
+def _be_inputs(case, dtype):
+    B, C, Hs, Ws, Hf, Wf, k, scale, seed = case
+    g = _gen(seed)
+    src = torch.rand(B, C, Hs, Ws, generator=g, dtype=dtype)
+    if scale == 0.0:
+        flow = torch.zeros(B, 2, Hf, Wf, dtype=dtype) + float(k // 2)
+    else:
+        flow = (torch.rand(B, 2, Hf, Wf, generator=g, dtype=dtype) * 2 - 1) * scale
+    go = torch.rand(B, C, k * Hf, k * Wf, generator=g, dtype=dtype)
+    return src, flow, go, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", BE_CASES)
+def test_block_extractor_forward(oracle, case, dtype):
+    from ffwm_amd import ops
+    src, flow, _, k = _be_inputs(case, dtype)
+    ref = oracle.block_extractor_forward(src, flow, k)
+    out = ops.block_extractor_forward(src.to(DEV), flow.to(DEV), k)
+    _close(out, ref, FWD_TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", BE_CASES)
+def test_block_extractor_backward(oracle, case, dtype):
+    from ffwm_amd import ops
+    src, flow, go, k = _be_inputs(case, dtype)
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, k)
+    gs = torch.zeros_like(src, device=DEV)
+    gf = torch.zeros_like(flow, device=DEV)
+    ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), k, gs, gf)
+    _close(gs, gs_ref, BWD_TOL[dtype], relative=True)
+    _close(gf, gf_ref, BWD_TOL[dtype], relative=True)
+
+
+def test_block_extractor_forward_is_bit_exact_fp32(oracle):
+    from ffwm_amd import ops
+    src, flow, _, k = _be_inputs(BE_CASES[1], torch.float32)
+    ref = oracle.block_extractor_forward(src, flow, k)
+    out = ops.block_extractor_forward(src.to(DEV), flow.to(DEV), k).cpu()
+    assert torch.equal(out, ref)
+
+
+def test_block_extractor_integer_boundary_flows(oracle):
+    """Sample coordinates that sit exactly on / one ulp around integers: the 'consistent taps' fast
+    path and the per-element slow path must both agree with the oracle."""
+    from ffwm_amd import ops
+    g = _gen(11)
+    src = torch.rand(1, 3, 40, 70, generator=g)
+    base = torch.randint(-3, 4, (1, 2, 40, 70), generator=g).float()
+    eps = torch.tensor([0.0, 1e-7, -1e-7, 5e-7, -5e-7])[torch.randint(0, 5, (1, 2, 40, 70), generator=g)]
+    flow = base + eps * (1 + torch.arange(70.).view(1, 1, 1, 70))
+    ref = oracle.block_extractor_forward(src, flow, 3)
+    out = ops.block_extractor_forward(src.to(DEV), flow.to(DEV), 3)
+    _close(out, ref, FWD_TOL[torch.float32])
+    go = torch.rand(1, 3, 120, 210, generator=g)
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, 3)
+    gs, gf = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV)
+    ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), 3, gs, gf)
+    _close(gs, gs_ref, BWD_TOL[torch.float32], relative=True)
+    _close(gf, gf_ref, BWD_TOL[torch.float32], relative=True)
+
+
+def test_block_extractor_generic_kernel_matches_tiled(oracle):
+    from ffwm_amd import ops, _lib
+    src, flow, go, k = _be_inputs(BE_CASES[1], torch.float32)
+    a = ops.block_extractor_forward(src.to(DEV), flow.to(DEV), k).cpu()
+    _lib.set_option("be_fwd_variant", 9)
+    try:
+        b = ops.block_extractor_forward(src.to(DEV), flow.to(DEV), k).cpu()
+    finally:
+        _lib.set_option("be_fwd_variant", 0)
+    assert torch.equal(a, b)
+
+
+def test_block_extractor_nan_and_huge_flow(oracle):
+    from ffwm_amd import ops
+    src = torch.rand(1, 2, 8, 8, generator=_gen(12))
+    flow = torch.zeros(1, 2, 8, 8)
+    flow[0, 0, 0, 0] = 1e30
+    flow[0, 1, 1, 1] = -1e30
+    flow[0, 0, 2, 2] = float("nan")
+    ref = oracle.block_extractor_forward(src, flow, 3)
+    out = ops.block_extractor_forward(src.to(DEV), flow.to(DEV), 3).cpu()
+    assert torch.equal(torch.isnan(out), torch.isnan(ref))
+    ok = ~torch.isnan(ref)
+    assert (out[ok] - ref[ok]).abs().max().item() <= FWD_TOL[torch.float32]
+
+
+def test_block_extractor_function_gradcheck_reference_recipe():
+    # /root/reference/cuda/block_extractor/test_block_extractor.py:77-81
+    from ffwm_amd.external_function import BlockExtractor
+    g = _gen(0)
+    source = torch.rand(4, 6, 14, 10, generator=g).double().to(DEV).requires_grad_(True)
+    flow = (torch.rand(4, 2, 14, 10, generator=g).double() * 1.8).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(BlockExtractor(3), (source, flow))
+
+
+def test_block_extractor_constant_flow_is_unfold_on_gpu():
+    # the only way the reference really calls the op (models/losses.py:214-216): exact identity
+    from ffwm_amd.external_function import BlockExtractor
+    for kz, hw in ((3, 32), (5, 64), (7, 128)):
+        grid = (torch.rand(6, 1, hw, hw, generator=_gen(kz)) * 128).to(DEV)
+        h = hw - kz + 1
+        f = torch.zeros(6, 2, h, h, device=DEV) + float(kz // 2)
+        out = BlockExtractor(kz)(grid, f)
+        unf = F.unfold(grid, kz).view(6, kz, kz, h, h).permute(0, 3, 1, 4, 2).reshape(6, 1, h * kz, h * kz)
+        assert torch.equal(out, unf)
+
+
+# ------------------------------------------------------------------------- local_attn_reshape
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("k,B,H,W", [(3, 2, 10, 10), (2, 1, 7, 9), (5, 2, 60, 60), (7, 1, 122, 122),
+                                     (4, 1, 5, 6), (9, 1, 3, 4), (3, 4, 256, 256)])
+def test_local_attn_reshape_bit_exact(oracle, k, B, H, W, dtype):
+    from ffwm_amd import ops
+    g = _gen(k)
+    x = torch.rand(B, k * k, H, W, generator=g, dtype=dtype)
+    out = ops.local_attn_reshape_forward(x.to(DEV), k).cpu()
+    assert torch.equal(out, oracle.local_attn_reshape_forward(x, k))
+    go = torch.rand(out.shape, generator=g, dtype=dtype)
+    ref = oracle.local_attn_reshape_backward(go, k)
+    assert torch.equal(ops.local_attn_reshape_backward(go.to(DEV), k).cpu(), ref)
+    # reference semantics: += into the caller's buffer
+    buf = torch.ones(B, k * k, H, W, dtype=dtype, device=DEV)
+    ops.local_attn_reshape_backward(go.to(DEV), k, buf, accumulate=True)
+    assert torch.equal(buf.cpu(), ref + 1)
+
+
+def test_local_attn_reshape_range9_known_answer():
+    # /root/reference/cuda/local_attn_reshape/test_local_attn_reshape.py:29-43
+    from ffwm_amd.external_function import LocalAttnReshape
+    x = torch.arange(9.).view(1, -1, 1, 1).repeat(2, 1, 10, 10).float().to(DEV)
+    out = LocalAttnReshape()(x, 3)
+    assert out.shape == (2, 1, 30, 30)
+    assert torch.equal(out[0, 0, :3, :3].cpu(), torch.tensor([[0., 1, 2], [3, 4, 5], [6, 7, 8]]))
+
+
+def test_local_attn_reshape_gradcheck_reference_recipe():
+    # test_local_attn_reshape.py:66-70
+    from ffwm_amd.external_function import LocalAttnReshape
+    x = torch.rand(4, 9, 14, 10, generator=_gen(1)).double().to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda t: LocalAttnReshape()(t, 3), (x,))
+
+
+# ------------------------------------------------------------------------- resample2d
+RS_CASES = [
+    # (B, C, Hi, Wi, H, W, ks, dil, sigma, seed)
+    (1, 8, 20, 24, 20, 24, 2, 1, 5.0, 0),
+    (2, 5, 17, 70, 17, 70, 4, 1, 2.0, 1),     # FFWM's instantiation Resample2d(4,1,sigma=2) (losses.py:329)
+    (1, 3, 16, 16, 16, 16, 4, 2, 0.3, 2),
+    (1, 4, 12, 12, 7, 9, 4, 1, 2.0, 3),       # output grid != input grid
+    (1, 3, 14, 14, 14, 14, 6, 1, 2.0, 4),
+    (1, 2, 14, 14, 14, 14, 8, 1, 2.0, 5),     # generic per-element kernels
+    (1, 2, 10, 10, 10, 10, 4, 1, 0.0, 6),     # sigma == 0: SAFE_DIV's EPS arm
+    (1, 9, 11, 13, 11, 13, 5, 1, 1.0, 7),     # odd kernel_size behaves as ks-1
+]
+
+
+def _rs_inputs(case, dtype, varying_sigma=False):
+    B, C, Hi, Wi, H, W, ks, dil, sigma, seed = case
+    g = _gen(seed)
+    in1 = torch.rand(B, C, Hi, Wi, generator=g, dtype=dtype)
+    flow = torch.rand(B, 2, H, W, generator=g, dtype=dtype) * 6 - 3
+    if varying_sigma:
+        sg = torch.rand(B, 1, H, W, generator=g, dtype=dtype) * 2 + 0.5
+    else:
+        sg = torch.full((B, 1, H, W), sigma, dtype=dtype)
+    in2 = torch.cat((flow, sg), 1).contiguous()
+    go = torch.rand(B, C, H, W, generator=g, dtype=dtype)
+    return in1, in2, go, ks, dil
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", RS_CASES)
+def test_resample2d_forward(oracle, case, dtype):
+    from ffwm_amd import ops
+    in1, in2, _, ks, dil = _rs_inputs(case, dtype)
+    ref = oracle.resample2d_forward(in1, in2, ks, dil)
+    out = ops.resample2d_forward(in1.to(DEV), in2.to(DEV), ks, dil)
+    _close(out, ref, FWD_TOL[dtype] * 2)
+
+
+@pytest.mark.parametrize("quirk", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", RS_CASES)
+def test_resample2d_backward(oracle, case, dtype, quirk):
+    from ffwm_amd import ops
+    in1, in2, go, ks, dil = _rs_inputs(case, dtype, varying_sigma=case[8] not in (0.0,))
+    g1_ref, g2_ref = oracle.resample2d_backward(in1, in2, go, ks, dil, reference_quirk=quirk)
+    g1 = torch.zeros_like(in1, device=DEV)
+    g2 = torch.empty_like(in2, device=DEV)
+    ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), ks, dil, g1, g2, reference_quirk=quirk)
+    _close(g1, g1_ref, BWD_TOL[dtype], relative=True)
+    if case[8] == 0.0:
+        # sigma == 0 divides by EPS: values ~1e8 * O(1); compare relatively
+        ref = g2_ref
+        d = (g2.cpu() - ref).abs()
+        assert (d <= 1e-4 * (1 + ref.abs())).all()
+    else:
+        _close(g2, g2_ref, BWD_TOL[dtype] * 10, relative=True)
+
+
+def test_resample2d_cfg1_shape_within_1e4(oracle):
+    """BASELINE configs[0]: 1x64x128x128 feature + flow ~ U[-3,3) px, sigma in {0.3, 2, 5},
+    (ks,dil) in {(2,1),(4,1)}; target <= 1e-4 max abs diff (fp32)."""
+    from ffwm_amd import ops
+    g = _gen(0)
+    in1 = torch.rand(1, 64, 128, 128, generator=g)
+    flow = torch.rand(1, 2, 128, 128, generator=g) * 6 - 3
+    go = torch.rand(1, 64, 128, 128, generator=g)
+    for sigma in (0.3, 2.0, 5.0):
+        in2 = torch.cat((flow, torch.full((1, 1, 128, 128), sigma)), 1).contiguous()
+        for ks, dil in ((2, 1), (4, 1)):
+            ref = oracle.resample2d_forward(in1, in2, ks, dil)
+            out = ops.resample2d_forward(in1.to(DEV), in2.to(DEV), ks, dil)
+            assert _close(out, ref, 1e-4) < 5e-6
+            g1_ref, g2_ref = oracle.resample2d_backward(in1, in2, go, ks, dil)
+            g1 = torch.zeros_like(in1, device=DEV)
+            g2 = torch.empty_like(in2, device=DEV)
+            ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), ks, dil, g1, g2)
+            _close(g1, g1_ref, 1e-4)
+            _close(g2, g2_ref, 1e-5, relative=True)
+
+
+def test_resample2d_module_appends_sigma_and_differentiates():
+    from ffwm_amd.external_function import Resample2d
+    g = _gen(3)
+    src = torch.rand(2, 4, 16, 16, generator=g).double().to(DEV).requires_grad_(True)
+    flow = (torch.rand(2, 2, 16, 16, generator=g).double() * 3 + 0.25).to(DEV).requires_grad_(True)
+    mod = Resample2d(4, 1, sigma=2)
+    out = mod(src, flow)
+    assert out.shape == (2, 4, 16, 16)
+    # positive sample coordinates: the int() quirk is inert, so the analytic backward is the true
+    # gradient (floor treated as constant) and gradcheck must pass away from integer crossings
+    assert torch.autograd.gradcheck(mod, (src, flow), eps=1e-7, atol=1e-5)
+
+
+# ------------------------------------------------------------------------- warp (WarpNet)
+WARP_CASES = [
+    # (B, C, Hi, Wi, H, W, seed)
+    (2, 5, 12, 10, 12, 10, 0),
+    (1, 7, 33, 70, 33, 70, 1),
+    (2, 3, 128, 128, 32, 32, 2),     # part crops: 32x32 out of 128x128 (ffwm_model.py:84-88)
+    (1, 3, 128, 128, 98, 98, 3),     # identity-loss crop grid (98x98)
+    (8, 128, 32, 32, 32, 32, 4),     # netG level 0 (base_networks.py:326)
+    (2, 64, 64, 64, 64, 64, 5),      # netG level 1
+]
+
+
+@pytest.mark.parametrize("flipcat", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", WARP_CASES)
+def test_warp_forward_backward(oracle, case, dtype, flipcat):
+    from ffwm_amd import ops
+    B, C, Hi, Wi, H, W, seed = case
+    g = _gen(seed)
+    feat = torch.rand(B, C, Hi, Wi, generator=g, dtype=dtype)
+    flow = torch.rand(B, 2, H, W, generator=g, dtype=dtype) * 2.4 - 1.2     # partly outside [-1,1]
+    ref = oracle.warp_forward(feat, flow, flipcat)
+    out = ops.warp_forward(feat.to(DEV), flow.to(DEV), flipcat)
+    _close(out, ref, FWD_TOL[dtype])
+    go = torch.rand(ref.shape, generator=g, dtype=dtype)
+    gfe_ref, gfl_ref = oracle.warp_backward(feat, flow, go, flipcat)
+    gfe = torch.zeros_like(feat, device=DEV)
+    gfl = torch.zeros_like(flow, device=DEV)
+    ops.warp_backward(feat.to(DEV), flow.to(DEV), go.to(DEV), flipcat, gfe, gfl)
+    _close(gfe, gfe_ref, BWD_TOL[dtype], relative=True)
+    _close(gfl, gfl_ref, BWD_TOL[dtype], relative=True)
+
+
+def test_warpnet_matches_torch_grid_sample_on_gpu():
+    """The reference's WarpNet is F.grid_sample: compare against ATen's own GPU kernel too."""
+    from ffwm_amd.external_function import WarpNet, WarpFlipCat
+    g = _gen(9)
+    feat = torch.rand(4, 16, 64, 64, generator=g).to(DEV).requires_grad_(True)
+    flow = (torch.rand(4, 2, 64, 64, generator=g) * 2.2 - 1.1).to(DEV).requires_grad_(True)
+    ref = F.grid_sample(feat, flow.permute(0, 2, 3, 1), mode="bilinear", padding_mode="zeros",
+                        align_corners=False)
+    out = WarpNet()(feat, flow)
+    assert (out - ref).abs().max().item() < 2e-6
+    cat_ref = torch.cat((ref, torch.flip(ref, (3,))), 1)
+    cat = WarpFlipCat()(feat, flow)
+    assert (cat - cat_ref).abs().max().item() < 2e-6
+    go = torch.rand(cat.shape, generator=g).to(DEV)
+    a = torch.autograd.grad(cat, (feat, flow), go)
+    b = torch.autograd.grad(cat_ref, (feat, flow), go)
+    assert (a[0] - b[0]).abs().max().item() < 1e-4
+    assert (a[1] - b[1]).abs().max().item() < 1e-3 * (1 + b[1].abs().max().item())
+
+
+def test_warp_nan_and_far_flow(oracle):
+    from ffwm_amd import ops
+    feat = torch.rand(1, 2, 8, 8, generator=_gen(13))
+    flow = torch.zeros(1, 2, 8, 8)
+    flow[0, 0, 0, 0] = float("nan")
+    flow[0, 1, 1, 1] = 1e30
+    flow[0, 0, 2, 2] = -1e30
+    flow[0, 0, 3, 3] = float("inf")
+    ref = oracle.warp_forward(feat, flow, True)
+    out = ops.warp_forward(feat.to(DEV), flow.to(DEV), True).cpu()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= FWD_TOL[torch.float32]
+
+
+def test_warp_gradcheck():
+    from ffwm_amd.external_function import WarpFunction
+    g = _gen(14)
+    feat = torch.rand(2, 3, 6, 7, generator=g).double().to(DEV).requires_grad_(True)
+    flow = (torch.rand(2, 2, 5, 6, generator=g).double() * 1.6 - 0.8).to(DEV).requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, b: WarpFunction.apply(a, b, True), (feat, flow))
+
+
+# ------------------------------------------------------------------------- compat shims
+def test_compat_modules_run_the_reference_calling_convention(oracle):
+    from ffwm_amd import compat
+    compat.install(force=True)
+    import block_extractor_cuda, local_attn_reshape_cuda, resample2d_cuda   # noqa: E401
+    g = _gen(20)
+    src = torch.rand(2, 3, 9, 11, generator=g)
+    flow = torch.rand(2, 2, 9, 11, generator=g) * 4 - 2
+    out = torch.zeros(2, 3, 27, 33, device=DEV)
+    assert block_extractor_cuda.forward(src.to(DEV), flow.to(DEV), out, 3) == 1
+    _close(out, oracle.block_extractor_forward(src, flow, 3), 2e-6)
+    go = torch.rand(2, 3, 27, 33, generator=g)
+    gs, gf = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV)
+    # non-contiguous grad_output is legal in the reference (kernels read strides)
+    go_nc = go.to(DEV).transpose(2, 3).contiguous().transpose(2, 3)
+    assert not go_nc.is_contiguous()
+    assert block_extractor_cuda.backward(src.to(DEV), flow.to(DEV), go_nc, gs, gf, 3) == 1
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, 3)
+    _close(gs, gs_ref, 1e-5, relative=True)
+    _close(gf, gf_ref, 1e-5, relative=True)
+
+    x = torch.rand(2, 9, 5, 6, generator=g)
+    o = torch.zeros(2, 1, 15, 18, device=DEV)
+    assert local_attn_reshape_cuda.forward(x.to(DEV), o, 3) == 1
+    assert torch.equal(o.cpu(), F.pixel_shuffle(x, 3))
+    gi = torch.zeros(2, 9, 5, 6, device=DEV)
+    assert local_attn_reshape_cuda.backward(x.to(DEV), o, gi, 3) == 1
+    assert torch.equal(gi.cpu(), x)
+
+    in1 = torch.rand(1, 4, 10, 10, generator=g)
+    in2 = torch.cat((torch.rand(1, 2, 10, 10, generator=g) * 4 - 2, torch.full((1, 1, 10, 10), 2.0)), 1)
+    o = torch.zeros(1, 4, 10, 10, device=DEV)
+    assert resample2d_cuda.forward(in1.to(DEV), in2.to(DEV), o, 4, 1) == 1
+    _close(o, oracle.resample2d_forward(in1, in2, 4, 1), 4e-6)
+    go = torch.rand(1, 4, 10, 10, generator=g)
+    g1, g2 = torch.zeros_like(in1, device=DEV), torch.zeros_like(in2, device=DEV)
+    assert resample2d_cuda.backward(in1.to(DEV), in2.to(DEV), go.to(DEV), g1, g2, 4, 1) == 1
+    g1_ref, g2_ref = oracle.resample2d_backward(in1, in2, go, 4, 1)
+    _close(g1, g1_ref, 1e-5, relative=True)
+    _close(g2, g2_ref, 1e-4, relative=True)
+
+
+def test_shape_errors_raise():
+    from ffwm_amd import ops
+    a = torch.rand(1, 2, 4, 4, device=DEV)
+    with pytest.raises(ValueError):
+        ops.block_extractor_forward(a, torch.zeros(1, 3, 4, 4, device=DEV), 3)
+    with pytest.raises(ValueError):
+        ops.local_attn_reshape_forward(a, 3)
+    with pytest.raises(ValueError):
+        ops.resample2d_forward(a, torch.zeros(1, 2, 4, 4, device=DEV))
+    with pytest.raises(TypeError):
+        ops.warp_forward(a.half(), torch.zeros(1, 2, 4, 4, device=DEV).half())
+    with pytest.raises(ValueError):
+        ops.block_extractor_forward(a.transpose(2, 3), torch.zeros(1, 2, 4, 4, device=DEV), 3)
+
+
+def test_launches_follow_the_current_stream():
+    from ffwm_amd import ops
+    s = torch.cuda.Stream()
+    src = torch.rand(2, 8, 64, 64, device=DEV)
+    flow = torch.zeros(2, 2, 64, 64, device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        big = torch.rand(64, 1024, 1024, device=DEV)
+        for _ in range(4):
+            big = big * 1.0001          # keep the side stream busy
+        src2 = src * 2                   # ordered after `big` on stream s
+        out = ops.block_extractor_forward(src2, flow, 3)
+    s.synchronize()
+    assert torch.equal(out[:, :, 1::3, 1::3], src * 2)

@@ -1,0 +1,117 @@
+"""Per-kernel microbenchmark of the HIP ops (HIP-event timing through the library's own profiler).
+
+    python tools/kbench.py [--reps 20] [--only be_fwd,warp_fwd,...] [--opt key=value ...]
+
+Prints one line per kernel: avg ms, algorithmic GB/s, fraction of 8 TB/s.  Shapes are the
+BASELINE.json configs (cfg-5 per-GPU for block_extractor / local_attn_reshape, cfg-1 for resample2d,
+the three netG levels at bs=8 for the fused warp).
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from ffwm_amd import _lib, ops  # noqa: E402
+
+PEAK = 8.0e12
+
+
+def run(name, fn, reps, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    rows = _lib.prof_collect()
+    _lib.prof_enable(False)
+    out = []
+    for k, r in rows.items():
+        gbs = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9 if r["avg_ms"] > 0 else 0.0
+        out.append({"case": name, "kernel": k, "avg_ms": round(r["avg_ms"], 5), "GBps": round(gbs, 1),
+                    "frac_hbm_peak": round(gbs * 1e9 / PEAK, 4), "launches": r["launches"],
+                    "MB": round(r["bytes_per_launch"] / 1e6, 2)})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--flow", type=float, default=2.0, help="block_extractor flow ~ U[-f, f) px")
+    ap.add_argument("--B", type=int, default=4)
+    args = ap.parse_args()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
+    only = set(filter(None, args.only.split(",")))
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(0)
+    results = []
+
+    def want(n):
+        return not only or n in only
+
+    # cfg-5 per GPU: src [4,128,256,256], flow [4,2,256,256], k=3
+    B = args.B
+    if want("be_fwd") or want("be_bwd"):
+        src = torch.rand(B, 128, 256, 256, generator=g).to(dev)
+        flow = ((torch.rand(B, 2, 256, 256, generator=g) * 2 - 1) * args.flow).to(dev)
+        out = torch.empty(B, 128, 768, 768, device=dev)
+        if want("be_fwd"):
+            results += run("cfg5 block_extractor fwd flow=U[-%g,%g)" % (args.flow, args.flow),
+                           lambda: ops.block_extractor_forward(src, flow, 3, out=out), args.reps)
+        if want("be_bwd"):
+            go = torch.rand(B, 128, 768, 768, device=dev)
+            gs = torch.zeros_like(src)
+            gf = torch.zeros_like(flow)
+            results += run("cfg5 block_extractor bwd", lambda: ops.block_extractor_backward(src, flow, go, 3, gs, gf), args.reps)
+            del go, gs, gf
+        del src, flow, out
+    if want("lar"):
+        attn = torch.rand(B, 9, 256, 256, generator=g).to(dev)
+        o = torch.empty(B, 1, 768, 768, device=dev)
+        results += run("cfg5 local_attn_reshape fwd", lambda: ops.local_attn_reshape_forward(attn, 3, out=o), args.reps)
+        gi = torch.empty_like(attn)
+        results += run("cfg5 local_attn_reshape bwd", lambda: ops.local_attn_reshape_backward(o, 3, gi), args.reps)
+    if want("rs"):
+        in1 = torch.rand(1, 64, 128, 128, generator=g).to(dev)
+        in2 = torch.cat((torch.rand(1, 2, 128, 128, generator=g) * 6 - 3, torch.full((1, 1, 128, 128), 2.0)), 1).to(dev)
+        o = torch.empty(1, 64, 128, 128, device=dev)
+        go = torch.rand(1, 64, 128, 128, device=dev)
+        g1, g2 = torch.zeros_like(in1), torch.empty_like(in2)
+        for ks in (2, 4):
+            results += run("cfg1 resample2d fwd ks=%d" % ks, lambda: ops.resample2d_forward(in1, in2, ks, 1, out=o), args.reps)
+            results += run("cfg1 resample2d bwd ks=%d" % ks, lambda: ops.resample2d_backward(in1, in2, go, ks, 1, g1, g2), args.reps)
+        # same op at an HBM-sized shape
+        in1 = torch.rand(8, 64, 512, 512, generator=g).to(dev)
+        in2 = torch.cat((torch.rand(8, 2, 512, 512, generator=g) * 6 - 3, torch.full((8, 1, 512, 512), 2.0)), 1).to(dev)
+        o = torch.empty_like(in1)
+        results += run("big resample2d fwd ks=4 [8,64,512,512]", lambda: ops.resample2d_forward(in1, in2, 4, 1, out=o), args.reps)
+        del in1, in2, o
+    if want("warp"):
+        for (C, S) in ((128, 32), (64, 64), (64, 128)):
+            feat = torch.rand(8, C, S, S, generator=g).to(dev)
+            fl = (torch.rand(8, 2, S, S, generator=g) * 2.2 - 1.1).to(dev)
+            o = torch.empty(8, 2 * C, S, S, device=dev)
+            go = torch.rand(8, 2 * C, S, S, device=dev)
+            gfe, gfl = torch.zeros_like(feat), torch.zeros_like(fl)
+            results += run("netG warp+flip+cat fwd [8,%d,%d,%d]" % (C, S, S), lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
+            results += run("netG warp+flip+cat bwd [8,%d,%d,%d]" % (C, S, S), lambda: ops.warp_backward(feat, fl, go, True, gfe, gfl), args.reps)
+        feat = torch.rand(32, 64, 256, 256, generator=g).to(dev)
+        fl = (torch.rand(32, 2, 256, 256, generator=g) * 2.2 - 1.1).to(dev)
+        o = torch.empty(32, 128, 256, 256, device=dev)
+        results += run("big warp+flip+cat fwd [32,64,256,256]", lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
+        del feat, fl, o
+    for r in results:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()
