@@ -1,0 +1,310 @@
+#!/usr/bin/env python
+"""bench.py -- FFWM flow-warp hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|flownet|warp|ops]
+
+Default workload = BASELINE.json configs[2]: the full FFWM train step (netG + netD + flowNetF +
+flowNetB, all losses, three Adam optimizers) on synthetic MultiPIE-shaped 128x128 tensors, batch 8
+PER GPU (weak scaling; N > 1 is configs[3]: DP with RCCL all-reduce of gradient buckets overlapped
+with backward).  One "step" = one optimisation step on one batch resident in HBM.  fp32 throughout
+(the reference's dtype).  Rank 0 prints ONE JSON line:
+
+  metric/value/unit : train img/s, whole job
+  roofline          : the hand-written HIP kernel with the largest total time inside the timed
+                      region, timed live with HIP events on its launch stream (ffwm_prof_*),
+                      algorithmic bytes per launch / average duration vs the 8 TB/s HBM peak
+  kernels           : the same figures for every hand-written kernel seen in the timed region, and
+                      for the stand-alone operator shapes of configs[0]/[4] (cfg-1 resample2d, cfg-5
+                      block_extractor / local_attn_reshape), measured right after the timed region
+  cpu_baseline      : (N=1, rank 0) the same train step on the host CPU cores -- this repo's PyTorch
+                      modules with the oracle's C/OpenMP warp -- on a bounded sample (batch 2, 1 step)
+
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+                   --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+FP32_PEAK = 157.3e12       # FLOP/s, fp32 vector/MFMA
+TRAIN_FLOP_PER_IMG = 444e9  # ~222 GMAC per image for the full train step
+FLOWNET_FLOP_PER_IMG = 4.35e9
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="train", choices=["train", "flownet", "warp", "ops"])
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 8 train, 6 flownet)")
+    ap.add_argument("--titers", type=int, default=0, help="0 = warm-up branch (<20000), 20000 = guided-filter branch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--bucket-mb", type=int, default=64)
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    return world, rank, local
+
+
+def timed(step_fn, steps, warmup, world):
+    for _ in range(warmup):
+        step_fn()
+    from ffwm_amd import _lib
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    rows = _lib.prof_collect()
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, rows
+
+
+def kernel_rows(rows, tag):
+    out = []
+    for name, r in sorted(rows.items(), key=lambda kv: -kv[1]["total_ms"]):
+        if r["avg_ms"] <= 0:
+            continue
+        bps = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3)
+        out.append({"kernel": name, "where": tag, "launches": r["launches"], "avg_us": round(r["avg_ms"] * 1e3, 2),
+                    "total_ms": round(r["total_ms"], 3), "alg_MB": round(r["bytes_per_launch"] / 1e6, 3),
+                    "GBps": round(bps / 1e9, 1), "frac_hbm_peak": round(bps / HBM_PEAK, 4)})
+    return out
+
+
+def standalone_kernels(reps=10):
+    """cfg-1 / cfg-5 operator shapes, HIP-event timed through the library profiler."""
+    from ffwm_amd import _lib, ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    rows = []
+
+    def run(tag, fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        rows.extend(kernel_rows(_lib.prof_collect(), tag))
+
+    src = torch.rand(4, 128, 256, 256, generator=g).to(dev)
+    flow = (torch.rand(4, 2, 256, 256, generator=g) * 4 - 2).to(dev)
+    out = torch.empty(4, 128, 768, 768, device=dev)
+    run("cfg5/GPU block_extractor k=3 src[4,128,256,256] flow~U[-2,2)", lambda: ops.block_extractor_forward(src, flow, 3, out=out))
+    gs, gf = torch.zeros_like(src), torch.zeros_like(flow)
+    run("cfg5/GPU block_extractor k=3 backward", lambda: ops.block_extractor_backward(src, flow, out, 3, gs, gf))
+    del src, out, gs, gf
+    attn = torch.rand(4, 9, 256, 256, generator=g).to(dev)
+    o = torch.empty(4, 1, 768, 768, device=dev)
+    gi = torch.empty_like(attn)
+    run("cfg5/GPU local_attn_reshape k=3 [4,9,256,256]", lambda: ops.local_attn_reshape_forward(attn, 3, out=o))
+    run("cfg5/GPU local_attn_reshape k=3 backward", lambda: ops.local_attn_reshape_backward(o, 3, gi))
+    in1 = torch.rand(1, 64, 128, 128, generator=g).to(dev)
+    in2 = torch.cat((torch.rand(1, 2, 128, 128, generator=g) * 6 - 3, torch.full((1, 1, 128, 128), 2.0)), 1).to(dev)
+    o = torch.empty_like(in1)
+    go = torch.rand(1, 64, 128, 128, generator=g).to(dev)
+    g1, g2 = torch.zeros_like(in1), torch.empty_like(in2)
+    run("cfg1 resample2d ks=4 [1,64,128,128]", lambda: ops.resample2d_forward(in1, in2, 4, 1, out=o))
+    run("cfg1 resample2d ks=4 backward", lambda: ops.resample2d_backward(in1, in2, go, 4, 1, g1, g2))
+    return rows
+
+
+def cpu_train_baseline(titers):
+    """The same train step on the host cores: this repo's modules on CPU, warps through the oracle's
+    C/OpenMP restatement (test infrastructure, used here only as the CPU comparison leg)."""
+    import oracle
+    from ffwm_amd import trainer
+    oracle.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def warp(images, flow, mode="bilinear"):
+        return oracle.WarpOracleFn.apply(images, flow, False)
+
+    def warp_flipcat(feat, flow):
+        return oracle.WarpOracleFn.apply(feat, flow, True)
+
+    bs = 2
+    t = trainer.FFWMTrainer("cpu", seed=0, titers=titers, warp=warp, warp_flipcat=warp_flipcat)
+    batch = trainer.synthetic_batch(bs, "cpu", seed=1)
+    t0 = time.perf_counter()
+    t.step(batch)
+    dt = time.perf_counter() - t0
+    return {"value": round(bs / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "1 full FFWM train step, batch %d (no warm-up), %d torch/OpenMP threads, %.1f s" % (bs, cores, dt)}
+
+
+def cpu_ops_baseline():
+    import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    g = torch.Generator().manual_seed(0)
+    src = torch.rand(1, 32, 256, 256, generator=g)
+    flow = torch.rand(1, 2, 256, 256, generator=g) * 4 - 2
+    t0 = time.perf_counter()
+    oracle.block_extractor_forward(src, flow, 3)
+    dt = time.perf_counter() - t0
+    nbytes = 4.0 * (32 * 65536 + 2 * 65536 + 32 * 9 * 65536)
+    return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": "oracle block_extractor forward, src [1,32,256,256] (1/16 of cfg-5 per GPU), %.2f s" % dt}
+
+
+def main():
+    args = parse()
+    world, rank, local = init_dist(args)
+    dev = torch.device("cuda", local)
+    torch.backends.cudnn.benchmark = True      # MIOpen find mode: pick the fastest conv algorithm
+    from ffwm_amd import _lib
+    _lib.load()                                # fail loudly if the HIP library is missing
+
+    result = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+
+    if args.workload == "train":
+        from ffwm_amd import trainer
+        bs = args.batch or 8
+        t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers,
+                                bucket_bytes=args.bucket_mb << 20)
+        batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
+        dt, rows = timed(lambda: t.step(batch, batch_increment=0), args.steps, args.warmup, world)
+        imgs = bs * world * args.steps
+        result.update({"metric": "train img/s (128x128, full FFWM GAN step)", "value": round(imgs / dt, 2),
+                       "unit": "img/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                       "config": {"workload": "BASELINE configs[2]: full FFWM train step (netG+netD+flowNetF+flowNetB, "
+                                              "all losses, 3x Adam), synthetic MultiPIE-shaped 128x128",
+                                  "batch_per_gpu": bs, "global_batch": bs * world,
+                                  "parallelism": "dp%d" % world, "titers_branch": "<20000" if args.titers < 20000 else ">=20000",
+                                  "weights": "seeded random init (no pretrained VGG19/LightCNN/FlowNet offline)"},
+                       "img_per_s_per_gpu": round(imgs / dt / world, 2),
+                       "fp32_flop_frac": round(imgs / dt / world * TRAIN_FLOP_PER_IMG / FP32_PEAK, 4),
+                       "losses": {k: round(v, 5) for k, v in t.loss_values().items()}})
+        if world > 1:
+            result["config"]["grad_bytes_per_step"] = t.red_G.grad_bytes() + t.red_D.grad_bytes()
+    elif args.workload == "flownet":
+        from ffwm_amd import nets
+        bs = args.batch or 6
+        torch.manual_seed(0)
+        net = nets.FlowNet(64).to(dev).eval()
+        x = torch.rand(bs, 3, 128, 128, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+
+        def step():
+            with torch.no_grad():
+                net(x)
+        dt, rows = timed(step, args.steps, args.warmup, world)
+        imgs = bs * world * args.steps
+        result.update({"metric": "FlowNetF forward img/s (128x128)", "value": round(imgs / dt, 2), "unit": "img/s",
+                       "ms_per_step": round(dt / args.steps * 1e3, 3),
+                       "config": {"workload": "BASELINE configs[1]: FlowNetF forward-only, bs=%d" % bs,
+                                  "batch_per_gpu": bs, "parallelism": "dp%d" % world},
+                       "fp32_flop_frac": round(imgs / dt / world * FLOWNET_FLOP_PER_IMG / FP32_PEAK, 5)})
+    elif args.workload == "warp":
+        # the warp + flip + cat sub-path of netG's warp-attention, forward + backward, bs images
+        from ffwm_amd.external_function import WarpFlipCat
+        bs = args.batch or 8
+        g = torch.Generator().manual_seed(1 + rank)
+        feats = [torch.rand(bs, c, s, s, generator=g).to(dev).requires_grad_(True) for c, s in ((128, 32), (64, 64), (64, 128))]
+        flows = [(torch.rand(bs, 2, s, s, generator=g) * 2.2 - 1.1).to(dev).requires_grad_(True) for s in (32, 64, 128)]
+        gos = [torch.rand(bs, 2 * c, s, s, generator=g).to(dev) for c, s in ((128, 32), (64, 64), (64, 128))]
+        mod = WarpFlipCat()
+
+        def step():
+            for f, fl, go in zip(feats, flows, gos):
+                f.grad = fl.grad = None
+                mod(f, fl).backward(go)
+        dt, rows = timed(step, args.steps, args.warmup, world)
+        imgs = bs * world * args.steps
+        result.update({"metric": "warp+flip+cat path img/s (3 netG levels, fwd+bwd)", "value": round(imgs / dt, 2),
+                       "unit": "img/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                       "config": {"workload": "netG warp-attention warp sub-path, 3 levels, fwd+bwd", "batch_per_gpu": bs,
+                                  "parallelism": "dp%d" % world}})
+    else:   # ops: cfg-5 per GPU block_extractor forward + backward
+        from ffwm_amd import ops
+        g = torch.Generator().manual_seed(1 + rank)
+        bs = args.batch or 4
+        src = torch.rand(bs, 128, 256, 256, generator=g).to(dev)
+        flow = (torch.rand(bs, 2, 256, 256, generator=g) * 4 - 2).to(dev)
+        out = torch.empty(bs, 128, 768, 768, device=dev)
+        gs, gf = torch.zeros_like(src), torch.zeros_like(flow)
+
+        def step():
+            ops.block_extractor_forward(src, flow, 3, out=out)
+            gs.zero_()
+            gf.zero_()
+            ops.block_extractor_backward(src, flow, out, 3, gs, gf)
+        dt, rows = timed(step, args.steps, args.warmup, world)
+        imgs = bs * world * args.steps
+        result.update({"metric": "block_extractor fwd+bwd img/s (256x256, C=128, k=3)", "value": round(imgs / dt, 2),
+                       "unit": "img/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                       "config": {"workload": "BASELINE configs[4] per GPU: block_extractor fwd+bwd", "batch_per_gpu": bs,
+                                  "parallelism": "dp%d" % world}})
+
+    if rank == 0:
+        inrun = kernel_rows(rows, "timed region")
+        if inrun:
+            top = inrun[0]
+            result["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"], "peak": HBM_PEAK / 1e9,
+                                  "unit": "GB/s", "frac": top["frac_hbm_peak"], "traffic": None,
+                                  "avg_us": top["avg_us"], "alg_MB_per_launch": top["alg_MB"],
+                                  "launches": top["launches"],
+                                  "note": "hand-written HIP kernel with the largest total time in the timed region; "
+                                          "HIP events on its launch stream"}
+        else:
+            result["roofline"] = None
+        result["kernels"] = inrun
+        if not args.no_kernels:
+            result["kernels"] = inrun + standalone_kernels()
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_train_baseline(args.titers) if args.workload in ("train",) \
+                    else cpu_ops_baseline()
+            except Exception as e:      # the baseline leg must never take the measurement down
+                result["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,194 @@
+"""The FFWM GAN train step (BASELINE.json configs[2]/[3]) on synthetic MultiPIE-shaped tensors.
+
+Restates the computation of /root/reference/models/ffwm_model.py:72-160 (``forward`` ->
+``backward_D`` -> ``backward_G``, three Adam optimizers) with the losses of
+/root/reference/models/losses.py (GANLoss 'lsgan' :7-58, IdentityLoss :76-112, MSL1Loss :130-157,
+PerceptualLoss :293-320).  Every WarpNet call (image warps, part crops, the multi-scale
+illumination loss) and netG's warp-attention go through the HIP kernels; conv stacks run on
+PyTorch-ROCm.  Data parallelism: ``ffwm_amd.dp`` (one process per GPU, RCCL all-reduce of flat
+gradient buckets overlapped with backward).
+
+Deliberate, result-preserving differences from the reference:
+  * LightCNN and VGG19 are frozen (``requires_grad=False``).  The reference leaves LightCNN's weights
+    trainable although no optimizer owns them (SURVEY 3.2 "wasted weight-grads"); outputs and all
+    used gradients are identical.
+  * target-side feature extractors (VGG(y), LightCNN(gt)) run under ``no_grad``: the reference
+    detaches their results.
+  * pretrained VGG19 / LightCNN / FlowNet checkpoints cannot be fetched offline: seeded random
+    weights of the same architectures (same FLOPs and bytes; loss values differ).
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nets
+from .dp import BucketedGradReducer, broadcast_module_state
+from .external_function import WarpNet
+
+PRC_LAYERS = ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1")
+PRC_WEIGHTS = (1.0, 1.0 / 2, 1.0 / 4, 1.0 / 4, 1.0 / 8)
+
+
+def synthetic_batch(batch_size, device, seed=0, n_landmarks=1024):
+    """MultiPIE-shaped synthetic inputs: images ~ U[0,1), centred disc masks
+    r=48, integer landmarks in [16,111] (>= 580 of them, ffwm_model.py:222-224)."""
+    g = torch.Generator().manual_seed(seed)
+    img_S = torch.rand(batch_size, 3, 128, 128, generator=g)
+    img_F = torch.rand(batch_size, 3, 128, 128, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(128.), torch.arange(128.), indexing="ij")
+    disc = (((yy - 63.5) ** 2 + (xx - 63.5) ** 2) <= 48.0 ** 2).float().view(1, 1, 128, 128)
+    mask = disc.repeat(batch_size, 1, 1, 1)
+    lm_F = torch.randint(16, 112, (batch_size, n_landmarks, 2), generator=g)
+    batch = {"img_S": img_S, "img_F": img_F, "mask_S": mask.clone(), "mask_F": mask, "lm_F": lm_F}
+    return {k: v.to(device) for k, v in batch.items()}
+
+
+def build_part_grid(lm, d):
+    """Sampling grid (normalised, [B,2,d,d]) of a d x d patch centred on landmark ``lm`` [B,1,2]
+    (ffwm_model.py:236-246)."""
+    b = lm.size(0)
+    r = d // 2
+    lin = torch.linspace(-r, r, d, device=lm.device)
+    base = torch.stack((lin.view(1, d).expand(d, d), lin.view(d, 1).expand(d, d)), 0)   # [2,d,d]: x, y
+    centre = lm.float().view(b, 2, 1, 1) - 64.0
+    return (base.unsqueeze(0) + centre) / 64.0
+
+
+def part_grids(lm_F):
+    """Eye / nose / mouth centres from the landmark table (ffwm_model.py:217-234)."""
+    el, er = lm_F[:, 63:64], lm_F[:, 515:516]
+    nc = lm_F[:, 429:430]
+    mouth = torch.cat((lm_F[:, 64:128], lm_F[:, 516:580]), 1)
+    mc = (mouth.min(1, keepdim=True)[0] + mouth.max(1, keepdim=True)[0]) / 2
+    return [build_part_grid(c, 32) for c in (el, er, nc, mc)]
+
+
+class FFWMTrainer(object):
+    def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
+                 warp_flipcat=None, ngf=64):
+        self.device = torch.device(device)
+        self.titers = titers
+        torch.manual_seed(seed)
+        self.warp = warp if warp is not None else WarpNet()
+        self.flowNetF = nets.FlowNet(ngf).to(self.device)
+        self.flowNetB = nets.FlowNet(ngf).to(self.device)
+        self.netG = nets.FFWM(sn=True, warp_flipcat=warp_flipcat).to(self.device)
+        self.netD = nets.MSDiscriminator(128, sigmoid=False).to(self.device)
+        self.lightCNN = nets.LightCNN29().to(self.device).eval()
+        self.vgg = nets.VGG19("relu5_1").to(self.device).eval()
+        for p in self.lightCNN.parameters():
+            p.requires_grad = False
+        self.gf = {128: nets.GuidedFilter(32), 64: nets.GuidedFilter(16), 32: nets.GuidedFilter(8)}
+
+        broadcast_module_state([self.flowNetF, self.flowNetB, self.netG, self.netD, self.lightCNN, self.vgg])
+
+        flow_params = [p for net in (self.flowNetF, self.flowNetB) for n, p in net.named_parameters()
+                       if not n.startswith("inter_conv_occ")]
+        # Adam hyper-parameters of ffwm_model.py:46-49
+        self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999))
+        self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999))
+        self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999))
+        self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
+                                         bucket_bytes=bucket_bytes)
+        self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes)
+        self.losses = {}
+
+    # ------------------------------------------------------------------ loss pieces
+    def perceptual(self, x, y):
+        fx = self.vgg(x)
+        with torch.no_grad():
+            fy = self.vgg(y)
+        return sum(w * F.l1_loss(fx[k], fy[k]) for k, w in zip(PRC_LAYERS, PRC_WEIGHTS))
+
+    def identity(self, out, gt):
+        _, fc_o, pool_o = self.lightCNN(out.mean(1, keepdim=True))
+        with torch.no_grad():
+            _, fc_g, pool_g = self.lightCNN(gt.mean(1, keepdim=True))
+        return F.l1_loss(fc_o, fc_g) + F.l1_loss(pool_o, pool_g)
+
+    def illumination(self, flows_B, fakes, img_S, mask_S):
+        """MSL1Loss (losses.py:130-157): warp each generated scale back with flowNetB and compare
+        with the (resized) profile input."""
+        total = 0
+        for w, flow, fake in zip((1, 1, 1.5), flows_B, fakes):
+            size = flow.shape[2:]
+            tgt = F.interpolate(img_S, size, mode="bilinear", align_corners=True)
+            m = F.interpolate(mask_S, size, mode="nearest")
+            total = total + w * F.l1_loss(self.warp(fake, flow) * m, tgt * m)
+        return total
+
+    @staticmethod
+    def lsgan(pred, real):
+        return F.mse_loss(pred, torch.ones_like(pred) if real else torch.zeros_like(pred))
+
+    # ------------------------------------------------------------------ one optimisation step
+    def forward(self, b):
+        img_S, img_F = b["img_S"], b["img_F"]
+        flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
+        self.img_S_warp = self.warp(img_S, flow_F128)
+        self.flows_B = self.flowNetB(img_S)
+        self.img_S_rec = self.warp(img_F, self.flows_B[0])
+        self.fake32, self.fake64, self.fake128 = self.netG(img_S, flow=[flow_F32, flow_F64, flow_F128])
+        self.img_GF128 = self.gf[128](self.fake128, img_F)
+        self.parts = []
+        for grid in part_grids(b["lm_F"]):       # eye-l, eye-r, nose, mouth
+            self.parts.append((self.warp(self.img_GF128, grid), self.warp(img_F, grid)))
+
+    def backward_D(self, b):
+        m = b["mask_F"]
+        fake = self.netD(self.img_GF128.detach() * m)
+        real = self.netD(b["img_F"] * m)
+        self.loss_D = (self.lsgan(fake, False) + self.lsgan(real, True)) * 0.5
+        self.loss_D.backward()
+
+    def backward_G(self, b):
+        img_F, mask_F = b["img_F"], b["mask_F"]
+        img_F64 = F.interpolate(img_F, (64, 64), mode="bilinear")
+        img_F32 = F.interpolate(img_F, (32, 32), mode="bilinear")
+        mask64 = F.interpolate(mask_F, (64, 64), mode="nearest")
+        mask32 = F.interpolate(mask_F, (32, 32), mode="nearest")
+        if self.titers < 20000:        # warm-up branch (ffwm_model.py:97-101)
+            gf128, gf64, gf32 = self.fake128, self.fake64, self.fake32
+        else:
+            gf128 = self.img_GF128
+            gf64 = self.gf[64](self.fake64, img_F64)
+            gf32 = self.gf[32](self.fake32, img_F32)
+        pairs = ((gf128, img_F, mask_F, 1.0), (gf64, img_F64, mask64, 1.0), (gf32, img_F32, mask32, 1.5))
+        loss_prc = sum(w * self.perceptual(x * m, y * m) for x, y, m, w in pairs)
+        loss_l1 = sum(w * F.l1_loss(x * m, y * m) for x, y, m, w in pairs) * 5
+        loss_illu = self.illumination(self.flows_B, (self.fake128, self.fake64, self.fake32), b["img_S"],
+                                      b["mask_S"]) * 15
+        loss_iden = self.identity(self.fake128, img_F) * 0.5 + self.identity(gf128, img_F) * 1
+        loss_adv = self.lsgan(self.netD(self.img_GF128 * mask_F), True) * 0.1
+        (el, elt), (er, ert), (no, nog), (mo, mog) = self.parts
+        loss_fc = 2 * (self.perceptual(el, elt) + self.perceptual(er, ert)) + self.perceptual(mo, mog) + \
+            self.perceptual(no, nog)
+        self.loss_G = loss_iden + loss_l1 + loss_prc + loss_illu + loss_fc + loss_adv
+        self.losses = {"G": self.loss_G, "l1": loss_l1, "iden": loss_iden, "illu": loss_illu, "adv": loss_adv,
+                       "prc": loss_prc, "fc": loss_fc}
+        self.loss_G.backward()
+
+    def step(self, b, batch_increment=None):
+        """optimize_parameters (ffwm_model.py:151-160): forward, D step, G step."""
+        self.forward(b)
+        for p in self.netD.parameters():
+            p.requires_grad = True
+        self.red_D.zero_grad()
+        self.backward_D(b)
+        self.red_D.finish()
+        self.opt_D.step()
+        for p in self.netD.parameters():
+            p.requires_grad = False
+        self.red_G.zero_grad()
+        self.backward_G(b)
+        self.red_G.finish()
+        self.opt_G.step()
+        self.opt_F.step()
+        self.titers += batch_increment if batch_increment is not None else b["img_S"].size(0)
+        self.losses["D"] = self.loss_D
+        return self.losses
+
+    def loss_values(self):
+        return {k: float(v.detach()) for k, v in self.losses.items()}

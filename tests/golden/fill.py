@@ -1,0 +1,77 @@
+"""Closed-form, seed-free module state and inputs shared by the golden-fixture generator
+(tests/golden/make_golden.py, which runs the REFERENCE's modules in the build container) and the
+tests (which run this repo's modules).  Because both sides fill their own module from the same
+formula of (parameter name, element index), no weights need to be committed -- only outputs."""
+import math
+import zlib
+
+import torch
+
+
+def _phase(name):
+    return (zlib.crc32(name.encode()) % 10007) / 10007.0 * 2 * math.pi
+
+
+def wave(shape, name, amp=1.0, freq=0.6180339887, dtype=torch.float32):
+    n = 1
+    for s in shape:
+        n *= s
+    idx = torch.arange(n, dtype=torch.float64)
+    return (amp * torch.sin(idx * freq + _phase(name))).to(dtype).view(shape)
+
+
+def fill_module(mod, power_iters=3):
+    """Deterministic state for every parameter/buffer of ``mod`` (by state_dict name)."""
+    sd = mod.state_dict()
+    new = {}
+    for name, t in sd.items():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            new[name] = torch.zeros_like(t)
+        elif leaf == "running_var":
+            new[name] = 1.0 + 0.25 * wave(t.shape, name, 1.0).to(t.dtype)
+        elif leaf == "running_mean":
+            new[name] = wave(t.shape, name, 0.05).to(t.dtype)
+        elif leaf in ("weight", "weight_orig"):
+            if t.dim() >= 2:
+                fan_in = t[0].numel()
+                new[name] = wave(t.shape, name, 1.7 / math.sqrt(fan_in)).to(t.dtype)
+            else:                       # BatchNorm scale
+                new[name] = 1.0 + 0.2 * wave(t.shape, name, 1.0).to(t.dtype)
+        elif leaf == "bias":
+            new[name] = wave(t.shape, name, 0.05).to(t.dtype)
+        elif leaf in ("weight_u", "weight_v"):
+            new[name] = t.clone()       # set below from weight_orig
+        else:
+            new[name] = wave(t.shape, name, 0.1).to(t.dtype)
+    # spectral-norm vectors: a few deterministic power iterations on the filled weight_orig
+    for name in sd:
+        if name.endswith("weight_u"):
+            base = name[:-len("weight_u")]
+            w = new[base + "weight_orig"]
+            # ConvTranspose2d normalises over dim 1; the nets here only wrap Conv2d/Linear (dim 0)
+            wm = w.reshape(w.size(0), -1).double()
+            v = wave((wm.size(1),), base + "v0", 1.0, dtype=torch.float64)
+            v = v / v.norm()
+            for _ in range(power_iters):
+                u = wm @ v
+                u = u / u.norm()
+                v = wm.t() @ u
+                v = v / v.norm()
+            new[base + "weight_u"] = u.to(w.dtype)
+            new[base + "weight_v"] = v.to(w.dtype)
+    mod.load_state_dict(new)
+    return mod
+
+
+def image(b, c, h, w, name="img"):
+    """Values in [0,1]."""
+    return (wave((b, c, h, w), name, 0.5, freq=0.7548776662) + 0.5).contiguous()
+
+
+def flow_field(b, h, w, name="flow", amp=0.9):
+    """Normalised absolute sampling grid in [-1,1]: identity grid + smooth wobble."""
+    ys = torch.linspace(-1 + 1.0 / h, 1 - 1.0 / h, h).view(1, 1, h, 1).expand(b, 1, h, w)
+    xs = torch.linspace(-1 + 1.0 / w, 1 - 1.0 / w, w).view(1, 1, 1, w).expand(b, 1, h, w)
+    wob = wave((b, 2, h, w), name, 0.25, freq=0.0123)
+    return (torch.cat((xs, ys), 1) * amp + wob).clamp(-1.2, 1.2).contiguous()

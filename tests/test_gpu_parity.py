@@ -270,7 +270,12 @@ def test_resample2d_cfg1_shape_within_1e4(oracle):
             g2 = torch.empty_like(in2, device=DEV)
             ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), ks, dil, g1, g2)
             _close(g1, g1_ref, 1e-4)
-            _close(g2, g2_ref, 1e-5, relative=True)
+            # d/d(dx,dy,sigma) is a difference of two O(100) quotient-rule terms: measure the error
+            # against the fp64 oracle and allow what the fp32 oracle itself loses to cancellation
+            _, g2_64 = oracle.resample2d_backward(in1.double(), in2.double(), go.double(), ks, dil)
+            err_oracle32 = (g2_ref.double() - g2_64).abs().max().item()
+            err_hip = (g2.cpu().double() - g2_64).abs().max().item()
+            assert err_hip <= max(4 * err_oracle32, 1e-4), (err_hip, err_oracle32)
 
 
 def test_resample2d_module_appends_sigma_and_differentiates():

@@ -1,0 +1,134 @@
+"""The harness networks (ffwm_amd/nets.py) against golden outputs of the REFERENCE's modules
+(tests/golden/reference_modules.pt, produced by tests/golden/make_golden.py from
+/root/reference/models/base_networks.py, lightcnn/light_cnn.py, models/external_function.py,
+models/losses.py).  Both sides fill their own module with the closed-form state of
+tests/golden/fill.py, so agreement also proves state-dict name compatibility."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import fill  # noqa: E402
+import torch_refs  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(os.path.join(HERE, "golden", "reference_modules.pt"))
+
+
+def _sub(t, s):
+    return t[..., ::s, ::s]
+
+
+def _close(a, b, tol):
+    d = (a - b).abs().max().item()
+    assert d <= tol, "max abs diff %.3e > %.1e" % (d, tol)
+
+
+def test_state_dict_keys_match_reference(gold):
+    from ffwm_amd import nets
+    assert sorted(nets.FlowNet(64).state_dict().keys()) == gold["flownet64_keys"]
+    assert len(gold["flownet64_keys"]) == 243 and len(gold["ffwm_keys"]) == 383
+    assert sorted(nets.FFWM(sn=True, warp_flipcat=torch_refs.warp_flipcat).state_dict().keys()) == gold["ffwm_keys"]
+    assert sorted(nets.MSDiscriminator(128).state_dict().keys()) == gold["netD_keys"]
+    assert sorted(nets.LightCNN29().state_dict().keys()) == gold["lightcnn_keys"]
+
+
+def test_flownet_eval_and_train_forward(gold):
+    from ffwm_amd import nets
+    net = fill.fill_module(nets.FlowNet(4))
+    x = fill.image(2, 3, 128, 128, "flownet_in")
+    with torch.no_grad():
+        net.eval()
+        f128, f64, f32 = net(x)
+        g = gold["flownet4_eval"]
+        _close(_sub(f128, 2), g["flow128_s2"], 2e-5)
+        _close(f64, g["flow64"], 2e-5)
+        _close(f32, g["flow32"], 2e-5)
+        assert abs(f128.double().sum().item() - g["sum128"].item()) < 1e-2
+        net.train()
+        f128, f64, f32 = net(x)
+        g = gold["flownet4_train"]
+        _close(_sub(f128, 2), g["flow128_s2"], 5e-5)
+        _close(f64, g["flow64"], 5e-5)
+        _close(f32, g["flow32"], 5e-5)
+        _close(net.conv0[1].running_mean, g["bn_mean_conv0"], 1e-6)
+
+
+def test_flownet_unused_parameters_are_the_occ_branch():
+    from ffwm_amd import nets
+    net = nets.FlowNet(4)
+    x = fill.image(2, 3, 128, 128, "flownet_in").requires_grad_(False)
+    sum(f.sum() for f in net(x)).backward()
+    no_grad = sorted(n for n, p in net.named_parameters() if p.grad is None)
+    assert no_grad and all(n.startswith("inter_conv_occ") for n in no_grad)
+    assert len(net.unused_parameters()) == len(no_grad)
+
+
+def test_ffwm_generator_eval_forward(gold):
+    from ffwm_amd import nets
+    netG = fill.fill_module(nets.FFWM(sn=True, warp_flipcat=torch_refs.warp_flipcat)).eval()
+    img = fill.image(1, 3, 128, 128, "netG_in")
+    flows = [fill.flow_field(1, s, s, "netG_flow%d" % s) for s in (32, 64, 128)]
+    with torch.no_grad():
+        r32, r64, r128, att = netG(img, flow=flows, return_att=True)
+    g = gold["ffwm_eval"]
+    _close(r32, g["rec32"], 2e-5)
+    _close(r64, g["rec64"], 2e-5)
+    _close(_sub(r128, 2), g["rec128_s2"], 2e-5)
+    _close(_sub(att, 8), g["att_s8"], 2e-5)
+    assert abs(r128.double().sum().item() - g["sum128"].item()) < 5e-2
+    assert abs(att.double().sum().item() - g["att_sum"].item()) < 0.5
+
+
+def test_discriminator_and_lightcnn(gold):
+    from ffwm_amd import nets
+    netD = fill.fill_module(nets.MSDiscriminator(128, sigmoid=False)).eval()
+    with torch.no_grad():
+        _close(netD(fill.image(2, 3, 128, 128, "netD_in")), gold["netD_eval"]["score"], 2e-5)
+    lc = fill.fill_module(nets.LightCNN29()).eval()
+    with torch.no_grad():
+        _, fc, pool = lc(fill.image(2, 1, 128, 128, "lightcnn_in"))
+    g = gold["lightcnn_eval"]
+    _close(fc, g["fc"], 1e-4 * (1 + g["fc"].abs().max().item()))
+    _close(_sub(pool, 2), g["pool_s2"], 1e-4 * (1 + g["pool_s2"].abs().max().item()))
+
+
+def test_guided_filter(gold):
+    from ffwm_amd import nets
+    gx, gy = fill.image(2, 3, 64, 64, "gf_x"), fill.image(2, 3, 64, 64, "gf_y")
+    _close(nets.GuidedFilter(8)(gx, gy), gold["guided_filter_r8_64"], 1e-4)
+    _close(nets.GuidedFilter(16)(gx, gy), gold["guided_filter_r16_64"], 1e-4)
+
+
+def test_oracle_warp_matches_reference_warpnet(gold, oracle):
+    # golden vector for WarpNet (+ flip + cat) produced by the reference module itself
+    feat = fill.image(2, 6, 24, 20, "warp_feat")
+    fl = fill.flow_field(2, 24, 20, "warp_flow", amp=1.05)
+    _close(oracle.warp_forward(feat, fl, False), gold["warpnet"]["w"], 2e-6)
+    _close(oracle.warp_forward(feat, fl, True), gold["warpnet"]["flipcat"], 2e-6)
+
+
+def test_part_grids_and_identity_grid(gold):
+    from ffwm_amd import trainer
+    g = gold["part_grids"]
+    mine = trainer.part_grids(g["lm_F"])
+    for t, k in zip(mine, ("el", "er", "n", "m")):
+        _close(t, g[k].float(), 1e-6)
+
+
+def test_illumination_loss_matches_reference_msl1(gold):
+    from ffwm_amd import trainer
+    t = trainer.FFWMTrainer.__new__(trainer.FFWMTrainer)
+    t.warp = torch_refs.warp
+    fl3 = [fill.flow_field(2, s, s, "msl1_flow%d" % s) for s in (128, 64, 32)]
+    im3 = [fill.image(2, 3, s, s, "msl1_img%d" % s) for s in (128, 64, 32)]
+    img_F = fill.image(2, 3, 128, 128, "msl1_F")
+    mask = (fill.image(2, 1, 128, 128, "msl1_mask") > 0.4).float()
+    got = t.illumination(fl3, im3, img_F, mask)
+    assert abs(float(got) - float(gold["msl1"]["masked"])) < 1e-5

@@ -1,0 +1,45 @@
+"""One FFWM train step on CPU (batch 1, narrow FlowNets) with the torch stand-ins injected for the
+warp ops: checks the step's structure -- D then G update, requires_grad toggling, frozen feature
+nets, unused FlowNet branch excluded, both titers branches -- not its speed."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch_refs  # noqa: E402
+
+
+def _snapshot(mods):
+    return [p.detach().clone() for m in mods for p in m.parameters()]
+
+
+def test_train_step_updates_the_right_parameters():
+    from ffwm_amd import trainer
+    torch.set_num_threads(8)
+    t = trainer.FFWMTrainer("cpu", seed=0, titers=0, warp=torch_refs.warp, warp_flipcat=torch_refs.warp_flipcat,
+                            ngf=8)
+    batch = trainer.synthetic_batch(1, "cpu", seed=1)
+    # BatchNorm in train mode needs > 1 value per channel at FlowNet's 1x1 bottleneck: use batch 2 there
+    batch = {k: torch.cat((v, v.flip(-1) if v.dtype.is_floating_point else v), 0) for k, v in batch.items()}
+    before = {k: _snapshot([getattr(t, k)]) for k in ("flowNetF", "flowNetB", "netG", "netD", "lightCNN", "vgg")}
+    losses = t.step(batch)
+    vals = t.loss_values()
+    assert all(torch.isfinite(torch.tensor(v)) for v in vals.values()), vals
+    assert set(vals) == {"G", "D", "l1", "iden", "illu", "adv", "prc", "fc"}
+    after = {k: _snapshot([getattr(t, k)]) for k in before}
+    for k in ("flowNetF", "flowNetB", "netG", "netD"):
+        changed = sum(int(not torch.equal(a, b)) for a, b in zip(before[k], after[k]))
+        assert changed > 0, k
+    for k in ("lightCNN", "vgg"):
+        assert all(torch.equal(a, b) for a, b in zip(before[k], after[k])), k
+    # the never-used occlusion branch is neither updated nor in an optimizer
+    occ = [p for n, p in t.flowNetF.named_parameters() if n.startswith("inter_conv_occ")]
+    held = {id(p) for g in t.opt_F.param_groups for p in g["params"]}
+    assert occ and not any(id(p) in held for p in occ)
+    assert all(not p.requires_grad for p in t.netD.parameters())      # left frozen after the G step
+    assert t.titers == 2
+    # second step on the guided-filter branch (titers >= 20000, ffwm_model.py:97-105)
+    t.titers = 20000
+    t.step(batch)
+    assert all(torch.isfinite(torch.tensor(v)) for v in t.loss_values().values())
