@@ -149,13 +149,23 @@ def standalone_kernels(reps=10):
     return rows
 
 
+def host_threads():
+    """Threads for the CPU leg: the cores this process may run on, capped at 16 -- PyTorch's CPU
+    convolutions at batch 2 stop scaling (and then collapse) well before that on a many-core host."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def cpu_train_baseline(titers):
     """The same train step on the host cores: this repo's modules on CPU, warps through the oracle's
     C/OpenMP restatement (test infrastructure, used here only as the CPU comparison leg)."""
     import oracle
     from ffwm_amd import trainer
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     torch.set_num_threads(cores)
 
     def warp(images, flow, mode="bilinear"):
@@ -177,7 +187,7 @@ def cpu_train_baseline(titers):
 def cpu_ops_baseline():
     import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     g = torch.Generator().manual_seed(0)
     src = torch.rand(1, 32, 256, 256, generator=g)
@@ -194,7 +204,10 @@ def main():
     args = parse()
     world, rank, local = init_dist(args)
     dev = torch.device("cuda", local)
-    torch.backends.cudnn.benchmark = True      # MIOpen find mode: pick the fastest conv algorithm
+    # MIOpen ships no gfx950 kernel database in this image: every conv kernel is JIT-compiled on a
+    # fresh box.  Exhaustive find mode multiplies that start-up cost by the number of candidate
+    # solvers (~10 min), so it is opt-in; the default is MIOpen's heuristic ("immediate") choice.
+    torch.backends.cudnn.benchmark = os.environ.get("FFWM_MIOPEN_FIND", "0") == "1"
     from ffwm_amd import _lib
     _lib.load()                                # fail loudly if the HIP library is missing
 
