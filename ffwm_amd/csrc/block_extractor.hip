@@ -23,6 +23,11 @@
 namespace ffwm {
 namespace {
 
+template <typename T>
+__device__ __forceinline__ T fma_t(T a, T b, T c) { return __builtin_fma(a, b, c); }
+template <>
+__device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 template <typename T, int K>
 struct Taps {
     // "consistent" representation: tap (i, j) reads rows row[i], row[i+1] and columns col[j],
@@ -119,11 +124,11 @@ be_fwd_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __restri
                 ElemRow<T, K> r;
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    T s = 0;   // reference order: block_extractor_kernel.cu:73-77
-                    s += t.wxL[j] * t.wyT[i] * prev[j];
-                    s += t.wxR[j] * t.wyT[i] * prev[j + 1];
-                    s += t.wxL[j] * t.wyB[i] * cur[j];
-                    s += t.wxR[j] * t.wyB[i] * cur[j + 1];
+                    // block_extractor_kernel.cu:73-77, the += contracted to fma as nvcc does by default
+                    T s = (t.wxL[j] * t.wyT[i]) * prev[j];
+                    s = fma_t<T>(t.wxR[j] * t.wyT[i], prev[j + 1], s);
+                    s = fma_t<T>(t.wxL[j] * t.wyB[i], cur[j], s);
+                    s = fma_t<T>(t.wxR[j] * t.wyB[i], cur[j + 1], s);
                     r.v[j] = s;
                 }
                 buf_store_row<T, K>(ro, obase + i * orow, r);
@@ -145,16 +150,201 @@ be_fwd_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __restri
                 for (int j = 0; j < K; ++j) {
                     const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
                     constexpr unsigned E = sizeof(T);
-                    T s = 0;
-                    s += tx.wlo * ty.wlo * buf_ld<T>(rs, (rT + tx.lo) * E);
-                    s += tx.whi * ty.wlo * buf_ld<T>(rs, (rT + tx.hi) * E);
-                    s += tx.wlo * ty.whi * buf_ld<T>(rs, (rB + tx.lo) * E);
-                    s += tx.whi * ty.whi * buf_ld<T>(rs, (rB + tx.hi) * E);
+                    T s = (tx.wlo * ty.wlo) * buf_ld<T>(rs, (rT + tx.lo) * E);
+                    s = fma_t<T>(tx.whi * ty.wlo, buf_ld<T>(rs, (rT + tx.hi) * E), s);
+                    s = fma_t<T>(tx.wlo * ty.whi, buf_ld<T>(rs, (rB + tx.lo) * E), s);
+                    s = fma_t<T>(tx.whi * ty.whi, buf_ld<T>(rs, (rB + tx.hi) * E), s);
                     ElemRow<T, 1> r;
                     r.v[0] = s;
                     buf_store_row<T, 1>(ro, obase + i * orow + j * E, r);
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ forward, LDS-staged
+// Same decomposition, but the source window of the whole 64 x 4 pixel tile is staged in LDS:
+//   1. the block reduces the bounding box of its taps in UNCLAMPED source coordinates (wave
+//      shuffles + one LDS hop);
+//   2. if every pixel is "regular" (tap j+1 sits exactly one pixel after tap j, in x and in y) and
+//      the box fits kLdsRows x kLdsCols, each channel's box is copied global -> LDS with
+//      row-contiguous, fully coalesced loads; border clamping is applied while staging (LDS holds
+//      the clamp-extended image), so a pixel's (k+1)^2 neighbourhood is ALWAYS a dense square at
+//      one LDS base address + compile-time immediates.  The copy of channel c+1 overlaps the
+//      arithmetic of channel c (two buffers, one barrier per channel);
+//   3. the neighbourhood reads become ds_read_b32 (128 B/clk/CU) instead of 16 per-lane global
+//      gathers per 9 outputs, which is what bounds the direct kernel;
+//   otherwise (flow too wide for the tile, or an irregular pixel) the block falls back to direct
+//   gathers -- a block-uniform, data-dependent choice.
+constexpr int kLdsRows = 16;
+constexpr int kLdsCols = 128;
+
+template <typename T, int K>
+__global__ void __launch_bounds__(kBlock)
+be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __restrict__ out, int C,
+                  int Hs, int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs,
+                  int remap, int ablate) {
+    __shared__ T tile[2][kLdsRows * kLdsCols];
+    __shared__ int red[4][kBlock / kWave];
+    __shared__ int flag;
+    constexpr unsigned E = sizeof(T);
+    constexpr int NW = kBlock / kWave;
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+    const bool inb = tc.xf < Wf && tc.yf < Hf;
+    const int xf = tc.xf < Wf ? tc.xf : Wf - 1, yf = tc.yf < Hf ? tc.yf : Hf - 1;   // shadow a valid pixel
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const T* fl = flow + static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
+    const T fx0 = fl[0], fy0 = fl[fplane];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (threadIdx.x == 0) flag = 0;
+
+    // ---- per-pixel taps: the reference's arithmetic (block_extractor_kernel.cu:52-71); weights of
+    //      the four corners of every window element as the reference forms them (x-weight * y-weight)
+    T wq[K][K][4];
+    T wxl[K], wxr[K], wyt[K], wyb[K];
+    T flx0 = 0, fly0 = 0;
+    bool regular = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
+        const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
+        const T fxl = floor_t(dx), fyl = floor_t(dy);
+        if (j == 0) { flx0 = fxl; fly0 = fyl; }
+        regular = regular && (fxl == flx0 + static_cast<T>(j)) && (fyl == fly0 + static_cast<T>(j));
+        wxr[j] = dx - fxl; wxl[j] = 1 - (dx - fxl);
+        wyb[j] = dy - fyl; wyt[j] = 1 - (dy - fyl);
+    }
+    const T lim = static_cast<T>(1 << 20);
+    regular = regular && (flx0 > -lim) && (flx0 < lim) && (fly0 > -lim) && (fly0 < lim);   // also rejects NaN
+    const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            wq[i][j][0] = wxl[j] * wyt[i];   // :74-77 form the weight product first
+            wq[i][j][1] = wxr[j] * wyt[i];
+            wq[i][j][2] = wxl[j] * wyb[i];
+            wq[i][j][3] = wxr[j] * wyb[i];
+        }
+
+    // ---- block-wide bounding box (unclamped coordinates)
+    int umin = wave_min(u0), umax = wave_max(u0 + K), vmin = wave_min(v0), vmax = wave_max(v0 + K);
+    if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
+    __syncthreads();
+    if (!regular) flag = 1;            // benign race: every writer stores 1
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        umin = min(umin, red[0][w]); umax = max(umax, red[1][w]);
+        vmin = min(vmin, red[2][w]); vmax = max(vmax, red[3][w]);
+    }
+    __syncthreads();
+    const int bw = umax - umin + 1, bh = vmax - vmin + 1;
+    const bool use_lds = (flag == 0) && bw <= kLdsCols && bh <= kLdsRows;
+
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int W = K * Wf;
+    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const unsigned sbytes = static_cast<unsigned>(splane * E);
+    const unsigned obytes = static_cast<unsigned>(oplane * E);
+    const T* sp = src + (static_cast<size_t>(tc.b) * C + c0) * splane;
+    T* op = out + (static_cast<size_t>(tc.b) * C + c0) * oplane;
+    const unsigned obase = inb ? (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E
+                               : 0xFFFFFFF0u;   // out-of-tile lanes: the range check drops the store
+    const unsigned orow = static_cast<unsigned>(W) * E;
+
+    if (use_lds) {
+        // staging map: wave w copies box rows w, w+4, ...; lane l copies box columns l, l+64.
+        // LDS holds the clamp-extended image: box cell (r, cc) <- src[clamp(vmin+r)][clamp(umin+cc)].
+        constexpr int RI = kLdsRows / NW, CI = kLdsCols / kWave;
+        unsigned goff[RI][CI];
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                const int r = wave + ri * NW, cc = lane + ci * kWave;
+                const int gy = min(max(vmin + r, 0), Hs - 1), gx = min(max(umin + cc, 0), Ws - 1);
+                goff[ri][ci] = (r < bh && cc < bw && !(ablate & 1))
+                                   ? (static_cast<unsigned>(gy) * Ws + gx) * E : 0xFFFFFFF0u;   // OOB reads 0
+            }
+        T stage[RI][CI];
+        auto fetch = [&](const T* plane) {
+            const rsrc_t rs = make_rsrc(plane, sbytes);
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) stage[ri][ci] = buf_ld<T>(rs, goff[ri][ci]);
+        };
+        auto commit = [&](T* buf) {     // unconditional: cells outside the box stay inside the buffer
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci)
+                    buf[(wave + ri * NW) * kLdsCols + lane + ci * kWave] = stage[ri][ci];
+        };
+        const int lbase = (v0 - vmin) * kLdsCols + (u0 - umin);
+        fetch(sp);
+        commit(tile[0]);
+        __syncthreads();
+        int p = 0;
+        for (int c = c0; c < c1; ++c, op += oplane, p ^= 1) {
+            const bool more = c + 1 < c1;
+            if (more) fetch(sp + static_cast<size_t>(c + 1 - c0) * splane);   // in flight during the math
+            const T* nb = tile[p] + lbase;      // dense (K+1) x (K+1) neighbourhood, immediates only
+            const rsrc_t ro = make_rsrc(op, obytes);
+            T prev[K + 1], cur[K + 1];
+#pragma unroll
+            for (int j = 0; j <= K; ++j) prev[j] = nb[j];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+#pragma unroll
+                for (int j = 0; j <= K; ++j) cur[j] = nb[(i + 1) * kLdsCols + j];
+                ElemRow<T, K> r;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    T s = wq[i][j][0] * prev[j];                 // sample = 0 + w*s  (:73-74)
+                    s = fma_t<T>(wq[i][j][1], prev[j + 1], s);   // sample += w*s, contracted as nvcc
+                    s = fma_t<T>(wq[i][j][2], cur[j], s);        // contracts it (-fmad=true default)
+                    s = fma_t<T>(wq[i][j][3], cur[j + 1], s);
+                    r.v[j] = s;
+                }
+                if (ablate & 2) {      // ablation: keep the values live, skip the store
+#pragma unroll
+                    for (int j = 0; j < K; ++j) asm volatile("" ::"v"(r.v[j]));
+                } else {
+                    buf_store_row<T, K>(ro, obase + i * orow, r);
+                }
+#pragma unroll
+                for (int j = 0; j <= K; ++j) prev[j] = cur[j];
+            }
+            if (more) commit(tile[p ^ 1]);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- fallback: direct global gathers, every tap formed per element like the reference
+    if (!inb) return;
+    for (int c = c0; c < c1; ++c, sp += splane, op += oplane) {
+        const rsrc_t rs = make_rsrc(sp, sbytes);
+        const rsrc_t ro = make_rsrc(op, obytes);
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const Tap1<T> ty = make_tap<T>(fy0, i - K / 2, yf, Hs);
+            const unsigned rT = ty.lo * static_cast<unsigned>(Ws), rB = ty.hi * static_cast<unsigned>(Ws);
+            ElemRow<T, K> r;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, xf, Ws);
+                T s = (tx.wlo * ty.wlo) * buf_ld<T>(rs, (rT + tx.lo) * E);
+                s = fma_t<T>(tx.whi * ty.wlo, buf_ld<T>(rs, (rT + tx.hi) * E), s);
+                s = fma_t<T>(tx.wlo * ty.whi, buf_ld<T>(rs, (rB + tx.lo) * E), s);
+                s = fma_t<T>(tx.whi * ty.whi, buf_ld<T>(rs, (rB + tx.hi) * E), s);
+                r.v[j] = s;
+            }
+            buf_store_row<T, K>(ro, obase + i * orow, r);
         }
     }
 }
@@ -181,11 +371,10 @@ be_fwd_generic(const T* __restrict__ src, const T* __restrict__ flow, T* __restr
         const int yT = clamp_index(fly, Hs), yB = clamp_index(fly + 1, Hs);
         const T xLP = 1 - (dx - flx), xRP = dx - flx, yTP = 1 - (dy - fly), yBP = dy - fly;
         const T* sp = src + bc * static_cast<size_t>(Hs) * Ws;
-        T s = 0;
-        s += xLP * yTP * sp[static_cast<size_t>(yT) * Ws + xL];
-        s += xRP * yTP * sp[static_cast<size_t>(yT) * Ws + xR];
-        s += xLP * yBP * sp[static_cast<size_t>(yB) * Ws + xL];
-        s += xRP * yBP * sp[static_cast<size_t>(yB) * Ws + xR];
+        T s = (xLP * yTP) * sp[static_cast<size_t>(yT) * Ws + xL];
+        s = fma_t<T>(xRP * yTP, sp[static_cast<size_t>(yT) * Ws + xR], s);
+        s = fma_t<T>(xLP * yBP, sp[static_cast<size_t>(yB) * Ws + xL], s);
+        s = fma_t<T>(xRP * yBP, sp[static_cast<size_t>(yB) * Ws + xR], s);
         out[index] = s;
     }
 }
@@ -349,12 +538,21 @@ int launch_fwd(const T* src, const T* flow, T* out, int64_t B, int64_t C, int64_
     const double bytes = sizeof(T) * static_cast<double>(B) * (C * Hs * Ws + 2.0 * Hf * Wf + static_cast<double>(C) * k * k * Hf * Wf);
     const Geometry g = plan(B, C, Hf, Wf, 16);
     const int remap = options().xcd_remap;
+    // variant: 0 = auto (LDS-staged for k <= 4, direct gather above), 1 = direct gather, 2 = LDS-staged
+    const int variant = options().be_fwd_variant;
 #define FFWM_BE_FWD(KK)                                                                            \
     case KK: {                                                                                     \
-        LaunchScope ls("block_extractor_fwd", st, bytes);                                          \
-        hipLaunchKernelGGL((be_fwd_kernel<T, KK>), dim3(g.grid), dim3(kBlock), 0, st, src, flow,   \
-                           out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, g.tiles_y,  \
-                           g.cslabs, g.cs, remap);                                                 \
+        const bool lds = KK <= 4 && (variant == 2 || variant == 0);                              \
+        LaunchScope ls(lds ? "block_extractor_fwd_lds" : "block_extractor_fwd", st, bytes);        \
+        if (lds)                                                                                   \
+            hipLaunchKernelGGL((be_fwd_lds_kernel<T, (KK <= 4 ? KK : 1)>), dim3(g.grid),            \
+                               dim3(kBlock), 0, st, src, flow, out, (int)C, (int)Hs, (int)Ws,      \
+                               (int)Hf, (int)Wf, g.tiles_x, g.tiles_y, g.cslabs, g.cs, remap,      \
+                               options().ablate);                                                  \
+        else                                                                                       \
+            hipLaunchKernelGGL((be_fwd_kernel<T, KK>), dim3(g.grid), dim3(kBlock), 0, st, src,     \
+                               flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x,   \
+                               g.tiles_y, g.cslabs, g.cs, remap);                                  \
     } break;
     const bool generic = options().be_fwd_variant == 9;
     switch (generic ? 0 : k) {

@@ -172,6 +172,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "be_bwd_variant")) slot = &o.be_bwd_variant;
     else if (!strcmp(key, "channel_slab")) slot = &o.channel_slab;
     else if (!strcmp(key, "xcd_remap")) slot = &o.xcd_remap;
+    else if (!strcmp(key, "ablate")) slot = &o.ablate;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;

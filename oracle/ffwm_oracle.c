@@ -32,17 +32,21 @@
 #define real float
 #define FN(name) CAT(name, _f32)
 #define FLOOR(v) floorf(v)
+#define FMA(a, b, c) fmaf(a, b, c)
 #include "ffwm_oracle_impl.inc"
 #undef real
 #undef FN
 #undef FLOOR
+#undef FMA
 
 #define real double
 #define FN(name) CAT(name, _f64)
 #define FLOOR(v) floor(v)
+#define FMA(a, b, c) fma(a, b, c)
 #include "ffwm_oracle_impl.inc"
 #undef real
 #undef FN
 #undef FLOOR
+#undef FMA
 
 int oracle_abi_version(void) { return 1; }

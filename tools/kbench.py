@@ -58,6 +58,25 @@ def main():
     def want(n):
         return not only or n in only
 
+    if want("calib"):
+        # achievable HBM rates on this box for plain streaming (torch kernels), for calibration
+        a = torch.empty(4, 128, 768, 768, device=dev)
+        b = torch.empty_like(a)
+        for name, fn, nbytes in (("fill 1.2GB", lambda: a.fill_(1.0), a.numel() * 4),
+                                 ("copy 1.2GB->1.2GB", lambda: b.copy_(a), 2 * a.numel() * 4)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.reps
+            results.append({"case": "calibration " + name, "kernel": "torch", "avg_ms": round(ms, 4),
+                            "GBps": round(nbytes / ms / 1e6, 1), "frac_hbm_peak": round(nbytes / ms / 1e6 / 8000, 4)})
+        del a, b
     # cfg-5 per GPU: src [4,128,256,256], flow [4,2,256,256], k=3
     B = args.B
     if want("be_fwd") or want("be_bwd"):
