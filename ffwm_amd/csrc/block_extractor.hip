@@ -177,59 +177,73 @@ be_fwd_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __restri
 //      gathers per 9 outputs, which is what bounds the direct kernel;
 //   otherwise (flow too wide for the tile, or an irregular pixel) the block falls back to direct
 //   gathers -- a block-uniform, data-dependent choice.
-constexpr int kLdsRows = 16;
 constexpr int kLdsCols = 128;
 
-template <typename T, int K>
+// RPT = pixel rows per thread: the block's tile is 64 x (4*RPT) flow pixels.  A taller tile cuts the
+// halo re-read of the source ((4*RPT + k + 2*|flow|) / (4*RPT) rows are staged per tile row) and puts
+// RPT x more arithmetic and stores between two barriers.
+template <typename T, int K, int RPT>
 __global__ void __launch_bounds__(kBlock)
 be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __restrict__ out, int C,
                   int Hs, int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs,
                   int remap, int ablate) {
-    __shared__ T tile[2][kLdsRows * kLdsCols];
-    __shared__ int red[4][kBlock / kWave];
-    __shared__ int flag;
-    constexpr unsigned E = sizeof(T);
     constexpr int NW = kBlock / kWave;
-    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
-    const bool inb = tc.xf < Wf && tc.yf < Hf;
-    const int xf = tc.xf < Wf ? tc.xf : Wf - 1, yf = tc.yf < Hf ? tc.yf : Hf - 1;   // shadow a valid pixel
-    const size_t fplane = static_cast<size_t>(Hf) * Wf;
-    const T* fl = flow + static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
-    const T fx0 = fl[0], fy0 = fl[fplane];
+    constexpr int LROWS = (RPT == 1) ? 16 : 32;
+    constexpr unsigned E = sizeof(T);
+    __shared__ T tile[2][LROWS * kLdsCols];
+    __shared__ int red[4][NW];
+    __shared__ int flag;
+    // tile decode (64 x 4*RPT pixels per block)
+    unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = tid % tiles_x;
+    tid /= tiles_x;
+    const int ty = tid % tiles_y;
+    tid /= tiles_y;
+    const int slab = tid % cslabs;
+    const int b = tid / cslabs;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int xf_raw = tx * kTileX + lane;
+    const bool inx = xf_raw < Wf;
+    const int xf = inx ? xf_raw : Wf - 1;            // out-of-tile lanes shadow a valid pixel
     if (threadIdx.x == 0) flag = 0;
 
-    // ---- per-pixel taps: the reference's arithmetic (block_extractor_kernel.cu:52-71); weights of
-    //      the four corners of every window element as the reference forms them (x-weight * y-weight)
-    T wq[K][K][4];
-    T wxl[K], wxr[K], wyt[K], wyb[K];
-    T flx0 = 0, fly0 = 0;
+    // ---- per-pixel taps, the reference's arithmetic (block_extractor_kernel.cu:52-71)
+    T wxl[RPT][K], wxr[RPT][K], wyt[RPT][K], wyb[RPT][K];
+    int u0[RPT], v0[RPT], yfs[RPT];
+    bool iny[RPT];
     bool regular = true;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const T* fb = flow + static_cast<size_t>(b) * 2 * fplane;
+    int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
-        const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
-        const T fxl = floor_t(dx), fyl = floor_t(dy);
-        if (j == 0) { flx0 = fxl; fly0 = fyl; }
-        regular = regular && (fxl == flx0 + static_cast<T>(j)) && (fyl == fly0 + static_cast<T>(j));
-        wxr[j] = dx - fxl; wxl[j] = 1 - (dx - fxl);
-        wyb[j] = dy - fyl; wyt[j] = 1 - (dy - fyl);
-    }
-    const T lim = static_cast<T>(1 << 20);
-    regular = regular && (flx0 > -lim) && (flx0 < lim) && (fly0 > -lim) && (fly0 < lim);   // also rejects NaN
-    const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
-#pragma unroll
-    for (int i = 0; i < K; ++i)
+    for (int r = 0; r < RPT; ++r) {
+        const int yraw = ty * (NW * RPT) + wave + r * NW;
+        iny[r] = yraw < Hf;
+        const int yf = iny[r] ? yraw : Hf - 1;
+        yfs[r] = yf;
+        const T fx0 = fb[static_cast<size_t>(yf) * Wf + xf], fy0 = fb[fplane + static_cast<size_t>(yf) * Wf + xf];
+        T flx0 = 0, fly0 = 0;
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            wq[i][j][0] = wxl[j] * wyt[i];   // :74-77 form the weight product first
-            wq[i][j][1] = wxr[j] * wyt[i];
-            wq[i][j][2] = wxl[j] * wyb[i];
-            wq[i][j][3] = wxr[j] * wyb[i];
+            const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
+            const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
+            const T fxl = floor_t(dx), fyl = floor_t(dy);
+            if (j == 0) { flx0 = fxl; fly0 = fyl; }
+            regular = regular && (fxl == flx0 + static_cast<T>(j)) && (fyl == fly0 + static_cast<T>(j));
+            wxr[r][j] = dx - fxl; wxl[r][j] = 1 - (dx - fxl);
+            wyb[r][j] = dy - fyl; wyt[r][j] = 1 - (dy - fyl);
         }
+        const T lim = static_cast<T>(1 << 20);
+        const bool ok = (flx0 > -lim) && (flx0 < lim) && (fly0 > -lim) && (fly0 < lim);   // also rejects NaN
+        regular = regular && ok;
+        u0[r] = ok ? static_cast<int>(flx0) : 0;
+        v0[r] = ok ? static_cast<int>(fly0) : 0;
+        umin = min(umin, u0[r]); umax = max(umax, u0[r] + K);
+        vmin = min(vmin, v0[r]); vmax = max(vmax, v0[r] + K);
+    }
 
-    // ---- block-wide bounding box (unclamped coordinates)
-    int umin = wave_min(u0), umax = wave_max(u0 + K), vmin = wave_min(v0), vmax = wave_max(v0 + K);
+    // ---- block-wide bounding box of the taps, unclamped coordinates (wave shuffles + one LDS hop)
+    umin = wave_min(umin); umax = wave_max(umax); vmin = wave_min(vmin); vmax = wave_max(vmax);
     if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
     __syncthreads();
     if (!regular) flag = 1;            // benign race: every writer stores 1
@@ -240,25 +254,23 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
     }
     __syncthreads();
     const int bw = umax - umin + 1, bh = vmax - vmin + 1;
-    const bool use_lds = (flag == 0) && bw <= kLdsCols && bh <= kLdsRows;
+    const bool use_lds = (flag == 0) && bw <= kLdsCols && bh <= LROWS;
 
-    const int c0 = tc.slab * cs;
+    const int c0 = slab * cs;
     const int c1 = (c0 + cs < C) ? c0 + cs : C;
     const int W = K * Wf;
     const size_t oplane = static_cast<size_t>(K) * Hf * W;
     const size_t splane = static_cast<size_t>(Hs) * Ws;
     const unsigned sbytes = static_cast<unsigned>(splane * E);
     const unsigned obytes = static_cast<unsigned>(oplane * E);
-    const T* sp = src + (static_cast<size_t>(tc.b) * C + c0) * splane;
-    T* op = out + (static_cast<size_t>(tc.b) * C + c0) * oplane;
-    const unsigned obase = inb ? (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E
-                               : 0xFFFFFFF0u;   // out-of-tile lanes: the range check drops the store
+    const T* sp = src + (static_cast<size_t>(b) * C + c0) * splane;
+    T* op = out + (static_cast<size_t>(b) * C + c0) * oplane;
     const unsigned orow = static_cast<unsigned>(W) * E;
 
     if (use_lds) {
         // staging map: wave w copies box rows w, w+4, ...; lane l copies box columns l, l+64.
         // LDS holds the clamp-extended image: box cell (r, cc) <- src[clamp(vmin+r)][clamp(umin+cc)].
-        constexpr int RI = kLdsRows / NW, CI = kLdsCols / kWave;
+        constexpr int RI = LROWS / NW, CI = kLdsCols / kWave;
         unsigned goff[RI][CI];
 #pragma unroll
         for (int ri = 0; ri < RI; ++ri)
@@ -284,7 +296,13 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
                 for (int ci = 0; ci < CI; ++ci)
                     buf[(wave + ri * NW) * kLdsCols + lane + ci * kWave] = stage[ri][ci];
         };
-        const int lbase = (v0 - vmin) * kLdsCols + (u0 - umin);
+        int lbase[RPT];
+        unsigned obase[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            lbase[r] = (v0[r] - vmin) * kLdsCols + (u0[r] - umin);
+            obase[r] = (static_cast<unsigned>(yfs[r]) * K * W + static_cast<unsigned>(xf) * K) * E;
+        }
         fetch(sp);
         commit(tile[0]);
         __syncthreads();
@@ -292,32 +310,45 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
         for (int c = c0; c < c1; ++c, op += oplane, p ^= 1) {
             const bool more = c + 1 < c1;
             if (more) fetch(sp + static_cast<size_t>(c + 1 - c0) * splane);   // in flight during the math
-            const T* nb = tile[p] + lbase;      // dense (K+1) x (K+1) neighbourhood, immediates only
             const rsrc_t ro = make_rsrc(op, obytes);
-            T prev[K + 1], cur[K + 1];
 #pragma unroll
-            for (int j = 0; j <= K; ++j) prev[j] = nb[j];
+            for (int r = 0; r < RPT; ++r) {
+                const T* nb = tile[p] + lbase[r];   // dense (K+1) x (K+1) neighbourhood, immediates only
+                T prev[K + 1], cur[K + 1];
+                T yt[K], yb[K];
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-#pragma unroll
-                for (int j = 0; j <= K; ++j) cur[j] = nb[(i + 1) * kLdsCols + j];
-                ElemRow<T, K> r;
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    T s = wq[i][j][0] * prev[j];                 // sample = 0 + w*s  (:73-74)
-                    s = fma_t<T>(wq[i][j][1], prev[j + 1], s);   // sample += w*s, contracted as nvcc
-                    s = fma_t<T>(wq[i][j][2], cur[j], s);        // contracts it (-fmad=true default)
-                    s = fma_t<T>(wq[i][j][3], cur[j + 1], s);
-                    r.v[j] = s;
-                }
-                if (ablate & 2) {      // ablation: keep the values live, skip the store
-#pragma unroll
-                    for (int j = 0; j < K; ++j) asm volatile("" ::"v"(r.v[j]));
-                } else {
-                    buf_store_row<T, K>(ro, obase + i * orow, r);
+                for (int i = 0; i < K; ++i) {
+                    // opaque copies: stop the compiler from hoisting all 4*K*K weight products out of
+                    // the channel loop (it would hold them in 36 * RPT VGPRs and halve the occupancy)
+                    yt[i] = wyt[r][i];
+                    yb[i] = wyb[r][i];
+                    asm volatile("" : "+v"(yt[i]), "+v"(yb[i]));
                 }
 #pragma unroll
-                for (int j = 0; j <= K; ++j) prev[j] = cur[j];
+                for (int j = 0; j <= K; ++j) prev[j] = nb[j];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) cur[j] = nb[(i + 1) * kLdsCols + j];
+                    ElemRow<T, K> row;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        // :73-77 -- weight product first, `sample +=` contracted to fma as nvcc does
+                        T s = (wxl[r][j] * yt[i]) * prev[j];
+                        s = fma_t<T>(wxr[r][j] * yt[i], prev[j + 1], s);
+                        s = fma_t<T>(wxl[r][j] * yb[i], cur[j], s);
+                        s = fma_t<T>(wxr[r][j] * yb[i], cur[j + 1], s);
+                        row.v[j] = s;
+                    }
+                    if (ablate & 2) {      // ablation: keep the values live, skip the store
+#pragma unroll
+                        for (int j = 0; j < K; ++j) asm volatile("" ::"v"(row.v[j]));
+                    } else if (inx && iny[r]) {
+                        buf_store_row<T, K>(ro, obase[r] + i * orow, row);
+                    }
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) prev[j] = cur[j];
+                }
             }
             if (more) commit(tile[p ^ 1]);
             __syncthreads();
@@ -326,25 +357,32 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
     }
 
     // ---- fallback: direct global gathers, every tap formed per element like the reference
-    if (!inb) return;
+    if (!inx) return;
     for (int c = c0; c < c1; ++c, sp += splane, op += oplane) {
         const rsrc_t rs = make_rsrc(sp, sbytes);
         const rsrc_t ro = make_rsrc(op, obytes);
 #pragma unroll 1
-        for (int i = 0; i < K; ++i) {
-            const Tap1<T> ty = make_tap<T>(fy0, i - K / 2, yf, Hs);
-            const unsigned rT = ty.lo * static_cast<unsigned>(Ws), rB = ty.hi * static_cast<unsigned>(Ws);
-            ElemRow<T, K> r;
+        for (int r = 0; r < RPT; ++r) {
+            if (!iny[r]) continue;
+            const int yf = yfs[r];
+            const T fx0 = fb[static_cast<size_t>(yf) * Wf + xf], fy0 = fb[fplane + static_cast<size_t>(yf) * Wf + xf];
+            const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
+#pragma unroll 1
+            for (int i = 0; i < K; ++i) {
+                const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
+                const unsigned rT = ty1.lo * static_cast<unsigned>(Ws), rB = ty1.hi * static_cast<unsigned>(Ws);
+                ElemRow<T, K> row;
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, xf, Ws);
-                T s = (tx.wlo * ty.wlo) * buf_ld<T>(rs, (rT + tx.lo) * E);
-                s = fma_t<T>(tx.whi * ty.wlo, buf_ld<T>(rs, (rT + tx.hi) * E), s);
-                s = fma_t<T>(tx.wlo * ty.whi, buf_ld<T>(rs, (rB + tx.lo) * E), s);
-                s = fma_t<T>(tx.whi * ty.whi, buf_ld<T>(rs, (rB + tx.hi) * E), s);
-                r.v[j] = s;
+                for (int j = 0; j < K; ++j) {
+                    const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
+                    T s = (tx1.wlo * ty1.wlo) * buf_ld<T>(rs, (rT + tx1.lo) * E);
+                    s = fma_t<T>(tx1.whi * ty1.wlo, buf_ld<T>(rs, (rT + tx1.hi) * E), s);
+                    s = fma_t<T>(tx1.wlo * ty1.whi, buf_ld<T>(rs, (rB + tx1.lo) * E), s);
+                    s = fma_t<T>(tx1.whi * ty1.whi, buf_ld<T>(rs, (rB + tx1.hi) * E), s);
+                    row.v[j] = s;
+                }
+                buf_store_row<T, K>(ro, ob + i * orow, row);
             }
-            buf_store_row<T, K>(ro, obase + i * orow, r);
         }
     }
 }
@@ -544,12 +582,29 @@ int launch_fwd(const T* src, const T* flow, T* out, int64_t B, int64_t C, int64_
     case KK: {                                                                                     \
         const bool lds = KK <= 4 && (variant == 2 || variant == 0);                              \
         LaunchScope ls(lds ? "block_extractor_fwd_lds" : "block_extractor_fwd", st, bytes);        \
-        if (lds)                                                                                   \
-            hipLaunchKernelGGL((be_fwd_lds_kernel<T, (KK <= 4 ? KK : 1)>), dim3(g.grid),            \
-                               dim3(kBlock), 0, st, src, flow, out, (int)C, (int)Hs, (int)Ws,      \
-                               (int)Hf, (int)Wf, g.tiles_x, g.tiles_y, g.cslabs, g.cs, remap,      \
-                               options().ablate);                                                  \
-        else                                                                                       \
+        if (lds) {                                                                                 \
+            const int rpt = sizeof(T) == 8 ? 1 : (options().rows_per_thread > 0 ? options().rows_per_thread : (Hf >= 64 ? 4 : 1)); \
+            const int th = (kBlock / kWave) * (rpt >= 4 ? 4 : (rpt >= 2 ? 2 : 1));                  \
+            const int tyl = static_cast<int>((Hf + th - 1) / th);                                  \
+            const unsigned gridl = static_cast<unsigned>(B * g.tiles_x * tyl * g.cslabs);           \
+            if (rpt >= 4)                                                                          \
+                hipLaunchKernelGGL((be_fwd_lds_kernel<float, (KK <= 4 ? KK : 1), 4>), dim3(gridl),  \
+                                   dim3(kBlock), 0, st, (const float*)src, (const float*)flow,     \
+                                   (float*)out, (int)C, (int)Hs, (int)Ws,                          \
+                                   (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, remap,        \
+                                   options().ablate);                                              \
+            else if (rpt >= 2)                                                                     \
+                hipLaunchKernelGGL((be_fwd_lds_kernel<float, (KK <= 4 ? KK : 1), 2>), dim3(gridl),  \
+                                   dim3(kBlock), 0, st, (const float*)src, (const float*)flow,     \
+                                   (float*)out, (int)C, (int)Hs, (int)Ws,                          \
+                                   (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, remap,        \
+                                   options().ablate);                                              \
+            else                                                                                   \
+                hipLaunchKernelGGL((be_fwd_lds_kernel<T, (KK <= 4 ? KK : 1), 1>), dim3(gridl),      \
+                                   dim3(kBlock), 0, st, src, flow, out, (int)C, (int)Hs, (int)Ws,  \
+                                   (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, remap,        \
+                                   options().ablate);                                              \
+        } else                                                                                       \
             hipLaunchKernelGGL((be_fwd_kernel<T, KK>), dim3(g.grid), dim3(kBlock), 0, st, src,     \
                                flow, out, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x,   \
                                g.tiles_y, g.cslabs, g.cs, remap);                                  \

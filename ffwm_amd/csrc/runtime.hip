@@ -173,6 +173,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "channel_slab")) slot = &o.channel_slab;
     else if (!strcmp(key, "xcd_remap")) slot = &o.xcd_remap;
     else if (!strcmp(key, "ablate")) slot = &o.ablate;
+    else if (!strcmp(key, "rows_per_thread")) slot = &o.rows_per_thread;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;
