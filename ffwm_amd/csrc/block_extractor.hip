@@ -529,6 +529,56 @@ be_bwd_kernel(const T* __restrict__ src, const T* __restrict__ flow, const T* __
     }
 }
 
+// d(source) without global atomics for planes that fit LDS (Hs*Ws*sizeof(T) <= 64 KiB -- every
+// call the reference itself makes: 1-channel coordinate grids up to 128 x 128, models/losses.py:214-216).
+// A block owns `cg` whole (b, c) planes of grad_source in LDS, visits every flow pixel of image b,
+// forms each tap exactly as the reference does and accumulates with LDS atomics; the finished planes
+// are added to grad_source with plain coalesced stores.  Any kernel_size.
+constexpr int kPlaneThreads = 1024;
+
+template <typename T>
+__global__ void __launch_bounds__(kPlaneThreads)
+be_bwd_src_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gsrc, int C,
+                        int Hs, int Ws, int Hf, int Wf, int k, int cg, int groups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* acc = reinterpret_cast<T*>(smem_raw);
+    const int grp = blockIdx.x % groups;
+    const int b = blockIdx.x / groups;
+    const int c0 = grp * cg;
+    const int nc = (c0 + cg <= C) ? cg : C - c0;
+    const int ncell = Hs * Ws, npix = Hf * Wf;
+    const int W = k * Wf;
+    const size_t oplane = static_cast<size_t>(k) * Hf * W;
+    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) acc[i] = 0;
+    __syncthreads();
+    const T* fl = flow + static_cast<size_t>(b) * 2 * npix;
+    const T* g0 = gout + (static_cast<size_t>(b) * C + c0) * oplane;
+    for (int p = threadIdx.x; p < npix; p += kPlaneThreads) {
+        const int yf = p / Wf, xf = p - yf * Wf;
+        const T fx0 = fl[p], fy0 = fl[npix + p];
+        for (int i = 0; i < k; ++i) {
+            const Tap1<T> ty = make_tap<T>(fy0, i - k / 2, yf, Hs);
+            for (int j = 0; j < k; ++j) {
+                const Tap1<T> tx = make_tap<T>(fx0, j - k / 2, xf, Ws);
+                const size_t go = static_cast<size_t>(yf * k + i) * W + xf * k + j;
+                const unsigned oTL = ty.lo * Ws + tx.lo, oTR = ty.lo * Ws + tx.hi;
+                const unsigned oBL = ty.hi * Ws + tx.lo, oBR = ty.hi * Ws + tx.hi;
+                for (int c = 0; c < nc; ++c) {
+                    const T gv = g0[static_cast<size_t>(c) * oplane + go];
+                    T* a = acc + c * ncell;
+                    atomic_add(a + oTL, gv * tx.wlo * ty.wlo);   // block_extractor_kernel.cu:158-161
+                    atomic_add(a + oTR, gv * tx.whi * ty.wlo);
+                    atomic_add(a + oBL, gv * tx.wlo * ty.whi);
+                    atomic_add(a + oBR, gv * tx.whi * ty.whi);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    T* dst = gsrc + (static_cast<size_t>(b) * C + c0) * ncell;
+    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += acc[i];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 be_bwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ gout,
@@ -629,6 +679,23 @@ template <typename T>
 int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, int64_t B, int64_t C,
                int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, hipStream_t st) {
     const double bytes = sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * k * k * Hf * Wf + 2.0 * C * Hs * Ws + 4.0 * Hf * Wf);
+    const size_t plane_bytes = static_cast<size_t>(Hs) * Ws * sizeof(T);
+    if (gsrc && plane_bytes <= 65536 && options().scatter_variant != 1 && options().be_bwd_variant != 9) {
+        int cg = static_cast<int>(65536 / plane_bytes);
+        if (cg > C) cg = static_cast<int>(C);
+        while (cg > 1 && B * ((C + cg - 1) / cg) < 512) cg = (cg + 1) / 2;
+        const int groups = static_cast<int>((C + cg - 1) / cg);
+        {
+            LaunchScope ls("block_extractor_bwd_src_plane", st,
+                           sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * k * k * Hf * Wf + 2.0 * C * Hs * Ws + 2.0 * Hf * Wf));
+            hipLaunchKernelGGL((be_bwd_src_plane_kernel<T>), dim3(static_cast<unsigned>(B * groups)), dim3(kPlaneThreads),
+                               static_cast<size_t>(cg) * plane_bytes, st, flow, gout, gsrc, (int)C, (int)Hs, (int)Ws,
+                               (int)Hf, (int)Wf, k, cg, groups);
+        }
+        if (int rc = check_launch("ffwm_block_extractor_backward(source, plane)")) return rc;
+        if (!gflow) return FFWM_OK;
+        gsrc = nullptr;    // the pixel-major kernel below now only produces d(flow)
+    }
     const Geometry g = plan(B, C, Hf, Wf, 32);
     const int remap = options().xcd_remap;
 #define FFWM_BE_BWD(KK)                                                                            \

@@ -169,6 +169,56 @@ rs_bwd1_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* __restr
     }
 }
 
+// K2 without global atomics: a block owns `cg` whole (b, c) planes of grad_input1 in LDS
+// (cg = how many fit 64 KiB), visits every pixel of image b once -- taps and normalised weights
+// are formed once per pixel and reused for the cg channels -- accumulates with LDS atomics and
+// adds the finished planes to grad_input1 with plain coalesced stores.
+constexpr int kPlaneThreads = 1024;
+
+template <typename T, int HALF>
+__global__ void __launch_bounds__(kPlaneThreads)
+rs_bwd1_plane_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* __restrict__ gin1, int C,
+                     int Hi, int Wi, int H, int W, int dil, int quirk, int cg, int groups) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* acc = reinterpret_cast<T*>(smem_raw);
+    const int grp = blockIdx.x % groups;
+    const int b = blockIdx.x / groups;
+    const int c0 = grp * cg;
+    const int nc = (c0 + cg <= C) ? cg : C - c0;
+    const int ncell = Hi * Wi, npix = H * W;
+    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) acc[i] = 0;
+    __syncthreads();
+    const T* f = in2 + static_cast<size_t>(b) * 3 * npix;
+    const T* g0 = gout + (static_cast<size_t>(b) * C + c0) * npix;
+    for (int p = threadIdx.x; p < npix; p += kPlaneThreads) {
+        const int y = p / W, x = p - y * W;
+        RsTaps<T, HALF> t;
+        make_rs_taps<T, HALF>(t, f[p], f[npix + p], f[2 * npix + p], x, y, Hi, Wi, dil, quirk != 0);
+        constexpr unsigned E = sizeof(T);
+#pragma unroll
+        for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < HALF; ++fx) {
+                const T yT = t.wy[2 * fy], yB = t.wy[2 * fy + 1], xL = t.wx[2 * fx], xR = t.wx[2 * fx + 1];
+                const T w0 = static_cast<T>(safe_div<T>(yT * xL, t.sum)), w1 = static_cast<T>(safe_div<T>(yT * xR, t.sum));
+                const T w2 = static_cast<T>(safe_div<T>(yB * xL, t.sum)), w3 = static_cast<T>(safe_div<T>(yB * xR, t.sum));
+                const unsigned o0 = (t.row[2 * fy] + t.col[2 * fx]) / E, o1 = (t.row[2 * fy] + t.col[2 * fx + 1]) / E;
+                const unsigned o2 = (t.row[2 * fy + 1] + t.col[2 * fx]) / E, o3 = (t.row[2 * fy + 1] + t.col[2 * fx + 1]) / E;
+                for (int c = 0; c < nc; ++c) {
+                    const T g = g0[static_cast<size_t>(c) * npix + p];
+                    T* a = acc + c * ncell;
+                    atomic_add(a + o0, w0 * g);
+                    atomic_add(a + o1, w1 * g);
+                    atomic_add(a + o2, w2 * g);
+                    atomic_add(a + o3, w3 * g);
+                }
+            }
+    }
+    __syncthreads();
+    T* dst = gin1 + (static_cast<size_t>(b) * C + c0) * ncell;
+    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += acc[i];
+}
+
 // ------------------------------------------------------------------------------------ K3
 // Block = 64 consecutive x of one row (one lane per pixel) x 4 waves that split the channels.
 template <typename T, int HALF>
@@ -484,6 +534,31 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                int64_t Hi, int64_t Wi, int64_t H, int64_t W, int ks, int dil, int quirk,
                hipStream_t st) {
     const int remap = options().xcd_remap;
+    const size_t plane_bytes = static_cast<size_t>(Hi) * Wi * sizeof(T);
+    const int half = ks / 2;
+    if (gin1 && plane_bytes <= 65536 && half >= 1 && half <= 3 && options().scatter_variant != 1) {
+        const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
+        int cg = static_cast<int>(65536 / plane_bytes);
+        if (cg > C) cg = static_cast<int>(C);
+        while (cg > 1 && B * ((C + cg - 1) / cg) < 512) cg = (cg + 1) / 2;   // keep >= 2 blocks per CU
+        const int groups = static_cast<int>((C + cg - 1) / cg);
+        const unsigned grid = static_cast<unsigned>(B * groups);
+        const size_t lds = static_cast<size_t>(cg) * plane_bytes;
+        {
+            LaunchScope ls("resample2d_bwd_input1_plane", st, bytes);
+            if (half == 1)
+                hipLaunchKernelGGL((rs_bwd1_plane_kernel<T, 1>), dim3(grid), dim3(kPlaneThreads), lds, st, in2, gout, gin1,
+                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups);
+            else if (half == 2)
+                hipLaunchKernelGGL((rs_bwd1_plane_kernel<T, 2>), dim3(grid), dim3(kPlaneThreads), lds, st, in2, gout, gin1,
+                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups);
+            else
+                hipLaunchKernelGGL((rs_bwd1_plane_kernel<T, 3>), dim3(grid), dim3(kPlaneThreads), lds, st, in2, gout, gin1,
+                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups);
+        }
+        if (int rc = check_launch("ffwm_resample2d_backward(input1, plane)")) return rc;
+        gin1 = nullptr;
+    }
     if (gin1) {
         const double bytes = sizeof(T) * static_cast<double>(B) * H * W * (2.0 * C + 3.0);
         const Geometry g = plan(B, C, H, W, 32);

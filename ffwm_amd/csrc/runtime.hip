@@ -174,6 +174,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "xcd_remap")) slot = &o.xcd_remap;
     else if (!strcmp(key, "ablate")) slot = &o.ablate;
     else if (!strcmp(key, "rows_per_thread")) slot = &o.rows_per_thread;
+    else if (!strcmp(key, "scatter_variant")) slot = &o.scatter_variant;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;

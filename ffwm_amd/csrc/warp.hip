@@ -162,6 +162,46 @@ warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T*
     }
 }
 
+// d(feat) without global atomics: one block owns one (b, c) plane of grad_feat and keeps it in LDS.
+// Every output pixel of image b is visited by the block (coalesced reads of grad_output), its four
+// corner contributions are added with LDS atomics (ds_add_f32 -- contention is resolved inside
+// the CU, not at the memory-side atomic unit that a device-scope global atomic needs on a
+// multi-XCD part), then the finished plane is added to grad_feat with plain coalesced stores.
+// Used whenever the plane fits LDS (Hi*Wi*sizeof(T) <= 64 KiB: every warp in FFWM, <= 128 x 128).
+constexpr int kPlaneThreads = 1024;
+
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kPlaneThreads)
+warp_bwd_feat_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gfeat,
+                           int C, int Hi, int Wi, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* acc = reinterpret_cast<T*>(smem_raw);
+    const int c = blockIdx.x % C;
+    const int b = blockIdx.x / C;
+    const int ncell = Hi * Wi, npix = H * W;
+    for (int i = threadIdx.x; i < ncell; i += kPlaneThreads) acc[i] = 0;
+    __syncthreads();
+    const int Co = FLIP ? 2 * C : C;
+    const T* fl = flow + static_cast<size_t>(b) * 2 * npix;
+    const T* g0 = gout + (static_cast<size_t>(b) * Co + c) * npix;
+    const T* g1 = g0 + static_cast<size_t>(C) * npix;
+    for (int p = threadIdx.x; p < npix; p += kPlaneThreads) {
+        Corners<T> cn;
+        make_corners<T>(cn, fl[p], fl[npix + p], Hi, Wi);
+        T g = g0[p];
+        if (FLIP) {
+            const int y = p / W, x = p - y * W;
+            g += g1[y * W + (W - 1 - x)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (cn.valid[q]) atomic_add(acc + cn.off[q] / static_cast<unsigned>(sizeof(T)), cn.w[q] * g);
+    }
+    __syncthreads();
+    T* dst = gfeat + (static_cast<size_t>(b) * C + c) * ncell;
+    for (int i = threadIdx.x; i < ncell; i += kPlaneThreads) dst[i] += acc[i];
+}
+
 int check_dims(const char* fn, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
                int dtype) {
     FFWM_REQUIRE(dtype_ok(dtype), FFWM_ERR_DTYPE, "%s: dtype %d is not FFWM_F32/FFWM_F64", fn, dtype);
@@ -197,9 +237,27 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
                int64_t Hi, int64_t Wi, int64_t H, int64_t W, int flip, hipStream_t st) {
     const double bytes = sizeof(T) * static_cast<double>(B) *
                          (2.0 * C * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W);
-    const Geometry g = plan(B, C, H, W, 32);
     const int remap = options().xcd_remap;
-    LaunchScope ls(flip ? "warp_flipcat_bwd" : "warp_bwd", st, bytes);
+    const size_t plane_bytes = static_cast<size_t>(Hi) * Wi * sizeof(T);
+    if (gfeat && plane_bytes <= 65536 && options().scatter_variant != 1) {
+        {   // d(feat): LDS-resident plane per (b, c), no global atomics
+            LaunchScope ls(flip ? "warp_flipcat_bwd_feat" : "warp_bwd_feat", st,
+                           sizeof(T) * static_cast<double>(B) * (2.0 * C * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
+            const unsigned grid = static_cast<unsigned>(B * C);
+            if (flip)
+                hipLaunchKernelGGL((warp_bwd_feat_plane_kernel<T, true>), dim3(grid), dim3(kPlaneThreads), plane_bytes,
+                                   st, flow, gout, gfeat, (int)C, (int)Hi, (int)Wi, (int)H, (int)W);
+            else
+                hipLaunchKernelGGL((warp_bwd_feat_plane_kernel<T, false>), dim3(grid), dim3(kPlaneThreads), plane_bytes,
+                                   st, flow, gout, gfeat, (int)C, (int)Hi, (int)Wi, (int)H, (int)W);
+        }
+        if (int rc = check_launch("ffwm_warp_backward(feat)")) return rc;
+        if (!gflow) return FFWM_OK;
+        gfeat = nullptr;   // the pixel-major kernel below now only produces d(flow)
+    }
+    const Geometry g = plan(B, C, H, W, 32);
+    LaunchScope ls(gfeat ? (flip ? "warp_flipcat_bwd" : "warp_bwd") : (flip ? "warp_flipcat_bwd_flow" : "warp_bwd_flow"), st,
+                   gfeat ? bytes : sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
     if (flip)
         hipLaunchKernelGGL((warp_bwd_kernel<T, true>), dim3(g.grid), dim3(kBlock), 0, st, feat, flow, gout,
                            gfeat, gflow, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, g.tiles_x, g.tiles_y,

@@ -129,7 +129,8 @@ int ffwm_prof_reset(void);
 
 /* Tuning/ablation switches (bench and tests only): returns the previous value, or
  * FFWM_ERR_ARG for an unknown key.  Keys: "be_fwd_variant", "be_bwd_variant",
- * "channel_slab", "xcd_remap", "ablate", "rows_per_thread". */
+ * "channel_slab", "xcd_remap", "ablate", "rows_per_thread",
+ * "scatter_variant". */
 int ffwm_set_option(const char* key, int value);
 
 #ifdef __cplusplus
