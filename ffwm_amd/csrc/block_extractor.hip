@@ -579,6 +579,357 @@ be_bwd_src_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, 
     for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += acc[i];
 }
 
+// ------------------------------------------------------------------------------ backward, owned tiles
+// d(source) + d(flow) for planes too large for LDS, without device-scope atomics on grad_source
+// (a global float atomic on a multi-XCD part executes at the memory side: the all-atomic kernel
+// above runs at ~40 G atomics/s = 114 GB/s on cfg-5).
+//
+// The source plane is cut into TW x TH tiles (TW = 64 - 2h, TH = RH - 2h).  A block OWNS one tile of
+// grad_source for a slab of channels and keeps it in LDS.  It visits the 64 x RH flow pixels of the
+// tile grown by a halo of h pixels -- every pixel whose taps can land in the tile when |tap offset|
+// <= h -- recomputes their taps, and adds the contributions that fall inside its own tile with LDS
+// atomics (ds_add_f32); what falls outside is the neighbouring block's job (it revisits the same
+// pixel as part of ITS halo).  The finished tile is added to grad_source with plain coalesced
+// read-modify-write rows.  d(flow) of the tile's own pixels accumulates in registers over the channel
+// slab (the clamp-extended source box is staged in LDS next to the accumulator, so the (k+1)^2
+// neighbourhood is a dense square at one LDS address + immediates, as in the forward kernel).
+//
+// Exactness for ANY flow: a contribution pixel p -> cell q is taken by the tile kernel iff p lies in
+// the 64 x RH region of q's tile; be_bwd_far_kernel (launched first) takes exactly the complement
+// with global atomics.  For |flow| < h - 1 the complement is empty and that kernel only reads the
+// flow field.
+constexpr int kTileRW = 64;
+
+struct TileGeo {
+    int TW, TH, h, RH;
+};
+
+// Is flow pixel (xf, yf) inside the region of the tile that owns clamped source cell (cu, cv)?
+__device__ __forceinline__ bool near_x(int cu, int xf, const TileGeo& g) {
+    const int r0 = (cu / g.TW) * g.TW - g.h;
+    return xf >= r0 && xf < r0 + kTileRW;
+}
+__device__ __forceinline__ bool near_y(int cv, int yf, const TileGeo& g) {
+    const int r0 = (cv / g.TH) * g.TH - g.h;
+    return yf >= r0 && yf < r0 + g.RH;
+}
+
+template <int K, int RH>
+__global__ void __launch_bounds__(kBlock)
+be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
+                   float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
+                   int ntx, int nty, int cslabs, int cs, int h, int remap) {
+    using T = float;
+    constexpr int RW = kTileRW, NW = kBlock / kWave, PPT = RH / NW;
+    constexpr unsigned E = sizeof(T);
+    __shared__ T S[RH * RW];      // clamp-extended source box of the current channel
+    // grad_source accumulator in box coordinates (the central TW x TH cells are owned).  DOUBLE on
+    // purpose: on gfx950 ds_add_f64 retires a wave in ~9 clk, ds_add_f32 needs ~190 (measured,
+    // tools/ubench/atomics.hip) -- and the sum is rounded to float once, at the flush.
+    __shared__ double A[RH * RW];
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int TW = RW - 2 * h, TH = RH - 2 * h;
+    const int x0 = tx * TW - h, y0 = ty * TH - h;          // box / region origin (source == flow coordinates)
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int xf = x0 + lane;
+    const bool xin = xf >= 0 && xf < Wf;
+    const bool xown = lane >= h && lane < h + TW;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int W = K * Wf;
+    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const unsigned sbytes = static_cast<unsigned>(splane * E);
+    const unsigned obytes = static_cast<unsigned>(oplane * E);
+    const unsigned orow = static_cast<unsigned>(W) * E;
+    const T* sp = src + (static_cast<size_t>(b) * C + c0) * splane;
+    T* gp = gsrc + (static_cast<size_t>(b) * C + c0) * splane;
+    const T* op = gout + (static_cast<size_t>(b) * C + c0) * oplane;
+    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, static_cast<unsigned>(2 * fplane * E));
+
+    // staging / flush column of this lane
+    const int gxs = min(max(x0 + lane, 0), Ws - 1);
+    const bool xcell = xown && (x0 + lane) >= 0 && (x0 + lane) < Ws;
+    // stage one channel's clamp-extended source box (the other resident blocks of the CU cover its
+    // latency).  y0w is laundered through an empty asm so the row offsets are recomputed -- one clamp
+    // + one multiply-add each -- instead of being hoisted into loop-invariant VGPRs.
+    auto stage = [&](const T* plane) {
+        const rsrc_t rs = make_rsrc(plane, sbytes);
+        int y0w = y0 + wave;
+        asm volatile("" : "+v"(y0w));
+#pragma unroll 1
+        for (int r8 = 0; r8 < PPT; r8 += 8) {
+            T st[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int gy = min(max(y0w + (r8 + q) * NW, 0), Hs - 1);
+                st[q] = buf_ld<T>(rs, (static_cast<unsigned>(gy) * Ws + gxs) * E);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) S[(wave + (r8 + q) * NW) * RW + lane] = st[q];
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) A[(wave + r * NW) * RW + lane] = 0;
+    stage(sp);
+    __syncthreads();
+
+    T gxa[PPT], gya[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) gxa[r] = gya[r] = 0;
+
+    for (int c = c0; c < c1; ++c, op += oplane) {
+        const bool more = c + 1 < c1;
+        const rsrc_t rg = make_rsrc(op, obytes);
+        const rsrc_t rs = make_rsrc(sp + static_cast<size_t>(c - c0) * splane, sbytes);
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r) {
+            const int row = wave + r * NW;
+            const int yf = y0 + row;
+            T gx = 0, gy = 0;
+            if (xin && yf >= 0 && yf < Hf) {
+                const bool owned = xown && row >= h && row < h + TH && gflow != nullptr;
+                const unsigned fo = (static_cast<unsigned>(yf) * Wf + xf) * E;
+                const T fx0 = buf_ld<T>(rfl, fo), fy0 = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
+                // taps, the reference's arithmetic (block_extractor_kernel.cu:117-135)
+                T wxr[K], wyb[K];
+                T flx0 = 0, fly0 = 0;
+                bool regular = true;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
+                    const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
+                    const T fxl = floor_t(dx), fyl = floor_t(dy);
+                    if (j == 0) { flx0 = fxl; fly0 = fyl; }
+                    regular = regular && (fxl == flx0 + static_cast<T>(j)) && (fyl == fly0 + static_cast<T>(j));
+                    wxr[j] = dx - fxl;
+                    wyb[j] = dy - fyl;
+                }
+                const T lim = static_cast<T>(1 << 20);
+                regular = regular && (flx0 > -lim) && (flx0 < lim) && (fly0 > -lim) && (fly0 < lim);   // rejects NaN too
+                const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
+                if (regular) {
+                    const int u0 = static_cast<int>(flx0), v0 = static_cast<int>(fly0);
+                    int ax[K + 1], ay[K + 1];          // accumulator column / row*RW of each neighbourhood cell, -1 = not mine
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) {
+                        const int bx = min(max(u0 + j, 0), Ws - 1) - x0;
+                        const int by = min(max(v0 + j, 0), Hs - 1) - y0;
+                        ax[j] = (static_cast<unsigned>(bx - h) < static_cast<unsigned>(TW)) ? bx : -1;
+                        ay[j] = (static_cast<unsigned>(by - h) < static_cast<unsigned>(TH)) ? by * RW : -1;
+                    }
+                    const int sx = u0 - x0, sy = v0 - y0;
+                    const bool inbox = sx >= 0 && sx + K < RW && sy >= 0 && sy + K < RH;
+                    const bool lds_nb = owned && inbox;
+                    const bool glb_nb = owned && !inbox;          // flow wider than the halo: gather from global
+                    const T* nb = S + (inbox ? sy * RW + sx : 0);
+                    unsigned gcol[K + 1];
+                    if (glb_nb) {
+#pragma unroll
+                        for (int j = 0; j <= K; ++j) gcol[j] = static_cast<unsigned>(min(max(u0 + j, 0), Ws - 1)) * E;
+                    }
+                    auto nb_row = [&](int i, T* dst) {
+                        if (lds_nb) {
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) dst[j] = nb[i * RW + j];
+                        } else if (glb_nb) {
+                            const unsigned ro = static_cast<unsigned>(min(max(v0 + i, 0), Hs - 1)) * Ws * E;
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) dst[j] = buf_ld<T>(rs, ro + gcol[j]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) dst[j] = 0;
+                        }
+                    };
+                    T sprev[K + 1], scur[K + 1], aprev[K + 1], acur[K + 1];
+                    nb_row(0, sprev);
+#pragma unroll
+                    for (int j = 0; j <= K; ++j) aprev[j] = 0;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        ElemRow<T, K> g;
+                        buf_load_row<T, K>(rg, ob + i * orow, g);
+                        nb_row(i + 1, scur);
+#pragma unroll
+                        for (int j = 0; j <= K; ++j) acur[j] = 0;
+                        const T yb = wyb[i], yt = 1 - wyb[i];
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            const T gv = g.v[j];
+                            const T xr = wxr[j], xl = 1 - wxr[j];
+                            const T gl = gv * xl, gr = gv * xr;
+                            aprev[j] += gl * yt;              // block_extractor_kernel.cu:158-161
+                            aprev[j + 1] += gr * yt;
+                            acur[j] += gl * yb;
+                            acur[j + 1] += gr * yb;
+                            // :163-164 with the four products regrouped into source differences
+                            gy += gl * (scur[j] - sprev[j]) + gr * (scur[j + 1] - sprev[j + 1]);
+                            gx += gv * (yt * (sprev[j + 1] - sprev[j]) + yb * (scur[j + 1] - scur[j]));
+                        }
+                        if (ay[i] >= 0) {
+#pragma unroll
+                            for (int j = 0; j <= K; ++j)
+                                if (ax[j] >= 0)
+                                    __hip_atomic_fetch_add(&A[ay[i] + ax[j]], static_cast<double>(aprev[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+#pragma unroll
+                        for (int j = 0; j <= K; ++j) {
+                            sprev[j] = scur[j];
+                            aprev[j] = acur[j];
+                        }
+                    }
+                    if (ay[K] >= 0) {
+#pragma unroll
+                        for (int j = 0; j <= K; ++j)
+                            if (ax[j] >= 0)
+                                __hip_atomic_fetch_add(&A[ay[K] + ax[j]], static_cast<double>(aprev[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+                    // a floor disagrees between neighbouring taps (fp rounding on an integer boundary),
+                    // NaN or huge flow: every tap on its own, like the reference
+#pragma unroll 1
+                    for (int i = 0; i < K; ++i) {
+                        const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
+#pragma unroll 1
+                        for (int j = 0; j < K; ++j) {
+                            const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
+                            const T gv = buf_ld<T>(rg, ob + i * orow + j * E);
+                            const int cxs[2] = {static_cast<int>(tx1.lo), static_cast<int>(tx1.hi)};
+                            const int cys[2] = {static_cast<int>(ty1.lo), static_cast<int>(ty1.hi)};
+                            const T wxs[2] = {tx1.wlo, tx1.whi}, wys[2] = {ty1.wlo, ty1.whi};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int bx = cxs[q & 1] - x0, by = cys[q >> 1] - y0;
+                                if (static_cast<unsigned>(bx - h) < static_cast<unsigned>(TW) &&
+                                    static_cast<unsigned>(by - h) < static_cast<unsigned>(TH))
+                                    __hip_atomic_fetch_add(&A[by * RW + bx], static_cast<double>(gv * wxs[q & 1] * wys[q >> 1]), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            if (owned) {
+                                const unsigned rT = ty1.lo * static_cast<unsigned>(Ws) * E, rB = ty1.hi * static_cast<unsigned>(Ws) * E;
+                                const T sTL = buf_ld<T>(rs, rT + tx1.lo * E), sTR = buf_ld<T>(rs, rT + tx1.hi * E);
+                                const T sBL = buf_ld<T>(rs, rB + tx1.lo * E), sBR = buf_ld<T>(rs, rB + tx1.hi * E);
+                                gy += gv * (-tx1.wlo * sTL - tx1.whi * sTR + tx1.wlo * sBL + tx1.whi * sBR);
+                                gx += gv * (-ty1.wlo * sTL - ty1.whi * sBL + ty1.wlo * sTR + ty1.whi * sBR);
+                            }
+                        }
+                    }
+                }
+            }
+            gxa[r] += gx;       // r is wave-uniform: indexed VGPR access (s_set_gpr_idx), no scratch
+            gya[r] += gy;
+        }
+        __syncthreads();                       // every contribution of channel c is in A
+        {
+            const rsrc_t rq = make_rsrc(gp + static_cast<size_t>(c - c0) * splane, sbytes);
+            int y0w = y0 + wave;
+            asm volatile("" : "+v"(y0w));
+            // rows in groups of 4: four read-modify-writes in flight per lane, few live registers
+#pragma unroll 1
+            for (int r4 = 0; r4 < PPT; r4 += 4) {
+                T old[4];
+                unsigned off[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = wave + (r4 + q) * NW;
+                    const int cy = y0w + (r4 + q) * NW;
+                    const bool mine = xcell && row >= h && row < h + TH && cy >= 0 && cy < Hs;
+                    off[q] = mine ? (static_cast<unsigned>(cy) * Ws + static_cast<unsigned>(x0 + lane)) * E : 0xFFFFFFF0u;
+                    old[q] = buf_ld<T>(rq, off[q]);                 // out of range: reads 0
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = (wave + (r4 + q) * NW) * RW + lane;
+                    ElemRow<T, 1> v;
+                    v.v[0] = old[q] + static_cast<T>(A[idx]);
+                    buf_store_row<T, 1>(rq, off[q], v);             // out of range: dropped
+                    A[idx] = 0;
+                }
+            }
+        }
+        if (more) stage(sp + static_cast<size_t>(c + 1 - c0) * splane);
+        __syncthreads();
+    }
+    if (gflow) {
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            const int row = wave + r * NW;
+            const int yf = y0 + row;
+            if (xin && xown && row >= h && row < h + TH && yf >= 0 && yf < Hf) {
+                const size_t fo = static_cast<size_t>(b) * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
+                atomic_add(gflow + fo, gxa[r]);
+                atomic_add(gflow + fo + fplane, gya[r]);
+            }
+        }
+    }
+}
+
+// The complement of the tile kernel: contributions whose flow pixel lies outside the region of the
+// destination cell's tile (flow wider than the halo).  One thread per flow pixel; a pixel with no
+// such tap leaves after reading its flow vector.
+template <typename T, int K>
+__global__ void __launch_bounds__(kBlock)
+be_bwd_far_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gsrc, int C, int Hs,
+                  int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs, TileGeo geo) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, 0);
+    if (tc.xf >= Wf || tc.yf >= Hf) return;
+    constexpr unsigned E = sizeof(T);
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const size_t foff = static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(tc.yf) * Wf + tc.xf;
+    const T fx0 = flow[foff], fy0 = flow[foff + fplane];
+    // per tap: clamped lo/hi cells; a cell is "far" when this pixel is outside its tile's region
+    unsigned farx = 0, fary = 0;       // bit 2j = lo cell of tap j, bit 2j+1 = hi cell
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
+        const Tap1<T> ty = make_tap<T>(fy0, j - K / 2, tc.yf, Hs);
+        farx |= (near_x(static_cast<int>(tx.lo), tc.xf, geo) ? 0u : 1u) << (2 * j);
+        farx |= (near_x(static_cast<int>(tx.hi), tc.xf, geo) ? 0u : 1u) << (2 * j + 1);
+        fary |= (near_y(static_cast<int>(ty.lo), tc.yf, geo) ? 0u : 1u) << (2 * j);
+        fary |= (near_y(static_cast<int>(ty.hi), tc.yf, geo) ? 0u : 1u) << (2 * j + 1);
+    }
+    if ((farx | fary) == 0) return;
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int W = K * Wf;
+    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const unsigned obytes = static_cast<unsigned>(oplane * E);
+    T* gp = gsrc + (static_cast<size_t>(tc.b) * C + c0) * splane;
+    const T* op = gout + (static_cast<size_t>(tc.b) * C + c0) * oplane;
+    const unsigned obase = (static_cast<unsigned>(tc.yf) * K * W + static_cast<unsigned>(tc.xf) * K) * E;
+    const unsigned orow = static_cast<unsigned>(W) * E;
+    for (int c = c0; c < c1; ++c, op += oplane, gp += splane) {
+        const rsrc_t rg = make_rsrc(op, obytes);
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const Tap1<T> ty = make_tap<T>(fy0, i - K / 2, tc.yf, Hs);
+            const unsigned fy2 = (fary >> (2 * i)) & 3u;
+#pragma unroll 1
+            for (int j = 0; j < K; ++j) {
+                const unsigned fx2 = (farx >> (2 * j)) & 3u;
+                if ((fx2 | fy2) == 0) continue;
+                const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
+                const T gv = buf_ld<T>(rg, obase + i * orow + j * E);
+                const unsigned rT = ty.lo * static_cast<unsigned>(Ws) * E, rB = ty.hi * static_cast<unsigned>(Ws) * E;
+                const unsigned cL = tx.lo * E, cR = tx.hi * E;
+                if ((fx2 & 1u) | (fy2 & 1u)) atomic_add_off(gp, rT + cL, gv * tx.wlo * ty.wlo);
+                if ((fx2 & 2u) | (fy2 & 1u)) atomic_add_off(gp, rT + cR, gv * tx.whi * ty.wlo);
+                if ((fx2 & 1u) | (fy2 & 2u)) atomic_add_off(gp, rB + cL, gv * tx.wlo * ty.whi);
+                if ((fx2 & 2u) | (fy2 & 2u)) atomic_add_off(gp, rB + cR, gv * tx.whi * ty.whi);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 be_bwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ gout,
@@ -696,8 +1047,55 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
         if (!gflow) return FFWM_OK;
         gsrc = nullptr;    // the pixel-major kernel below now only produces d(flow)
     }
-    const Geometry g = plan(B, C, Hf, Wf, 32);
     const int remap = options().xcd_remap;
+    // owned-tile path: float, k <= 4, grad_source wanted, plane too large for the LDS-plane kernel
+    // be_bwd_variant: 0 = auto, 1 = all-atomic pixel kernel, 2 = owned tiles, 9 = generic
+    if constexpr (sizeof(T) == 4) {
+        const int variant = options().be_bwd_variant;
+        if (gsrc && k >= 1 && k <= 4 && (variant == 0 || variant == 2)) {
+            int h = options().be_bwd_halo > 0 ? options().be_bwd_halo : 4;
+            h = h < 2 ? 2 : (h > 12 ? 12 : h);
+            constexpr int RH = 64;
+            const TileGeo geo{kTileRW - 2 * h, RH - 2 * h, h, RH};
+            const int ntx = static_cast<int>(((Ws > Wf ? Ws : Wf) + geo.TW - 1) / geo.TW);
+            const int nty = static_cast<int>(((Hs > Hf ? Hs : Hf) + geo.TH - 1) / geo.TH);
+            int cs = options().channel_slab > 0 ? options().channel_slab : 16;
+            if (cs > C) cs = static_cast<int>(C);
+            while (cs > 4 && B * ntx * nty * ((C + cs - 1) / cs) < 1536) cs = (cs + 1) / 2;   // >= 6 blocks per CU
+            const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            const Geometry gf = plan(B, C, Hf, Wf, 32);
+            {
+                LaunchScope ls("block_extractor_bwd_far", st, sizeof(T) * 2.0 * B * Hf * Wf);
+                switch (k) {
+#define FFWM_BE_FAR(KK)                                                                                       \
+    case KK:                                                                                                  \
+        hipLaunchKernelGGL((be_bwd_far_kernel<float, KK>), dim3(gf.grid), dim3(kBlock), 0, st, (const float*)flow, \
+                           (const float*)gout, (float*)gsrc, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf,      \
+                           gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs, geo);                                    \
+        break;
+                    FFWM_BE_FAR(1) FFWM_BE_FAR(2) FFWM_BE_FAR(3) FFWM_BE_FAR(4)
+#undef FFWM_BE_FAR
+                }
+            }
+            if (int rc = check_launch("ffwm_block_extractor_backward(far)")) return rc;
+            {
+                LaunchScope ls("block_extractor_bwd_tile", st, bytes);
+                const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
+                switch (k) {
+#define FFWM_BE_TILE(KK)                                                                                      \
+    case KK:                                                                                                  \
+        hipLaunchKernelGGL((be_bwd_tile_kernel<KK, RH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,  \
+                           (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C,       \
+                           (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, h, remap);               \
+        break;
+                    FFWM_BE_TILE(1) FFWM_BE_TILE(2) FFWM_BE_TILE(3) FFWM_BE_TILE(4)
+#undef FFWM_BE_TILE
+                }
+            }
+            return check_launch("ffwm_block_extractor_backward(tile)");
+        }
+    }
+    const Geometry g = plan(B, C, Hf, Wf, 32);
 #define FFWM_BE_BWD(KK)                                                                            \
     case KK: {                                                                                     \
         LaunchScope ls("block_extractor_bwd", st, bytes);                                          \

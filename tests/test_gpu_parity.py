@@ -111,6 +111,85 @@ def test_block_extractor_integer_boundary_flows(oracle):
     _close(gf, gf_ref, BWD_TOL[torch.float32], relative=True)
 
 
+BE_TILE_CASES = [
+    # planes above 64 KiB take the owned-tile backward (be_bwd_far_kernel + be_bwd_tile_kernel)
+    # (B, C, Hs, Ws, Hf, Wf, k, flow_scale, seed)
+    (2, 5, 140, 150, 140, 150, 3, 2.0, 20),     # bounded flow: every contribution inside the halo
+    (1, 3, 130, 131, 130, 131, 3, 9.0, 21),     # flow wider than the halo: tile + far kernels share the work
+    (1, 2, 129, 140, 129, 140, 3, 300.0, 22),   # flow leaves the image: everything clamps onto the border
+    (1, 3, 140, 150, 100, 171, 3, 3.0, 23),     # flow grid != source grid (wider and shorter)
+    (1, 2, 150, 129, 150, 129, 2, 2.5, 24),     # even k
+    (1, 2, 129, 129, 129, 129, 4, 2.5, 25),
+    (1, 20, 129, 129, 129, 129, 1, 2.5, 26),    # several channel slabs
+]
+
+
+@pytest.mark.parametrize("halo", [0, 2, 7])
+@pytest.mark.parametrize("case", BE_TILE_CASES)
+def test_block_extractor_backward_owned_tiles(oracle, case, halo):
+    from ffwm_amd import ops, _lib
+    src, flow, go, k = _be_inputs(case, torch.float32)
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, k)
+    gs = torch.zeros_like(src, device=DEV)
+    gf = torch.zeros_like(flow, device=DEV)
+    _lib.set_option("be_bwd_halo", halo)
+    try:
+        ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), k, gs, gf)
+    finally:
+        _lib.set_option("be_bwd_halo", 0)
+    # case 2 collapses ~18k pixels x 9 taps onto the border cells through float atomics in arbitrary
+    # order (as the reference does): the fp32 summation-order noise alone is ~1e-5 relative there
+    tol = 1e-4 if case[7] >= 100 else BWD_TOL[torch.float32]
+    _close(gs, gs_ref, tol, relative=True)
+    _close(gf, gf_ref, tol, relative=True)
+
+
+@pytest.mark.parametrize("case", BE_CASES[:7])
+def test_block_extractor_backward_owned_tiles_small_planes(oracle, case):
+    """The same kernels forced onto planes that would normally take the LDS-plane path."""
+    from ffwm_amd import ops, _lib
+    src, flow, go, k = _be_inputs(case, torch.float32)
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, k)
+    gs = torch.zeros_like(src, device=DEV)
+    gf = torch.zeros_like(flow, device=DEV)
+    _lib.set_option("scatter_variant", 1)
+    try:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), k, gs, gf)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        rows = _lib.prof_collect()
+    finally:
+        _lib.set_option("scatter_variant", 0)
+    assert "block_extractor_bwd_tile" in rows
+    _close(gs, gs_ref, BWD_TOL[torch.float32], relative=True)
+    _close(gf, gf_ref, BWD_TOL[torch.float32], relative=True)
+
+
+def test_block_extractor_backward_owned_tiles_accumulates_and_handles_irregular_flow(oracle):
+    """grad buffers are accumulated into (+=), and irregular pixels (integer-boundary, NaN, huge
+    flows) take the per-tap path of both kernels."""
+    from ffwm_amd import ops
+    g = _gen(27)
+    src = torch.rand(1, 2, 130, 140, generator=g)
+    base = torch.randint(-3, 4, (1, 2, 130, 140), generator=g).float()
+    eps = torch.tensor([0.0, 1e-7, -1e-7, 5e-7, -5e-7])[torch.randint(0, 5, (1, 2, 130, 140), generator=g)]
+    flow = base + eps * (1 + torch.arange(140.).view(1, 1, 1, 140))
+    flow[0, 0, 5, 5] = 1e30
+    flow[0, 1, 6, 6] = -1e30
+    go = torch.rand(1, 2, 390, 420, generator=g)
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, 3)
+    gs0 = torch.rand(1, 2, 130, 140, generator=g)
+    gs = gs0.clone().to(DEV)
+    gf = torch.zeros_like(flow, device=DEV)
+    ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), 3, gs, gf)
+    _close(gs, gs_ref + gs0, BWD_TOL[torch.float32], relative=True)
+    ok = torch.isfinite(gf_ref)
+    assert torch.equal(torch.isfinite(gf.cpu()), ok)
+    assert (gf.cpu()[ok] - gf_ref[ok]).abs().max().item() <= BWD_TOL[torch.float32] * (1 + gf_ref[ok].abs().max().item())
+
+
 def test_block_extractor_generic_kernel_matches_tiled(oracle):
     from ffwm_amd import ops, _lib
     src, flow, go, k = _be_inputs(BE_CASES[1], torch.float32)
