@@ -614,19 +614,25 @@ __device__ __forceinline__ bool near_y(int cv, int yf, const TileGeo& g) {
     return yf >= r0 && yf < r0 + g.RH;
 }
 
-template <int K, int RH>
-__global__ void __launch_bounds__(kBlock)
+template <int K, int RH, int H>
+__global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 ? 4 : 2))
 be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
                    float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
-                   int ntx, int nty, int cslabs, int cs, int h, int remap) {
+                   int ntx, int nty, int cslabs, int cs, int remap, int ablate) {
     using T = float;
     constexpr int RW = kTileRW, NW = kBlock / kWave, PPT = RH / NW;
+    constexpr int TW = RW - 2 * H, TH = RH - 2 * H;       // owned tile
+    constexpr int AP = RW + 2 * H, AH = RH + 2 * H;       // accumulator box = region grown by H again
+    constexpr int NA = AP * AH;
     constexpr unsigned E = sizeof(T);
-    __shared__ T S[RH * RW];      // clamp-extended source box of the current channel
-    // grad_source accumulator in box coordinates (the central TW x TH cells are owned).  DOUBLE on
-    // purpose: on gfx950 ds_add_f64 retires a wave in ~9 clk, ds_add_f32 needs ~190 (measured,
-    // tools/ubench/atomics.hip) -- and the sum is rounded to float once, at the flush.
-    __shared__ double A[RH * RW];
+    __shared__ T S[RH * RW];      // clamp-extended source box of the current channel (region coordinates)
+    // grad_source accumulator, UNCLAMPED coordinates, origin (x0 - H, y0 - H): every tap of a region
+    // pixel whose offset is within +-H lands inside it, so the hot path needs no ownership masks and
+    // no clamps -- cells outside the owned TW x TH centre are simply never flushed (the neighbouring
+    // block computes them), and cells outside the image are folded onto the border before the flush.
+    // DOUBLE on purpose: on gfx950 ds_add_f64 retires a wave in ~9 clk, ds_add_f32 needs ~190
+    // (measured, tools/ubench/atomics.hip) -- and the sum is rounded to float once, at the flush.
+    __shared__ double A[NA];
     unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
     const int tx = t % ntx;
     t /= ntx;
@@ -634,12 +640,12 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
     t /= nty;
     const int slab = t % cslabs;
     const int b = t / cslabs;
-    const int TW = RW - 2 * h, TH = RH - 2 * h;
-    const int x0 = tx * TW - h, y0 = ty * TH - h;          // box / region origin (source == flow coordinates)
+    const int x0 = tx * TW - H, y0 = ty * TH - H;          // region / S-box origin (source == flow coordinates)
+    const int ax0 = x0 - H, ay0 = y0 - H;                  // A-box origin
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int xf = x0 + lane;
     const bool xin = xf >= 0 && xf < Wf;
-    const bool xown = lane >= h && lane < h + TW;
+    const bool xown = lane >= H && lane < H + TW;
 
     const int c0 = slab * cs;
     const int c1 = (c0 + cs < C) ? c0 + cs : C;
@@ -655,30 +661,28 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
     const T* op = gout + (static_cast<size_t>(b) * C + c0) * oplane;
     const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, static_cast<unsigned>(2 * fplane * E));
 
-    // staging / flush column of this lane
-    const int gxs = min(max(x0 + lane, 0), Ws - 1);
-    const bool xcell = xown && (x0 + lane) >= 0 && (x0 + lane) < Ws;
+    // out-of-image accumulator cells fold onto the border cell they clamp to (block-uniform)
+    const bool foldL = tx == 0, foldR = tx == (Ws - 1) / TW && Ws - ax0 < AP;
+    const bool foldT = ty == 0, foldB = ty == (Hs - 1) / TH && Hs - ay0 < AH;
+
     // stage one channel's clamp-extended source box (the other resident blocks of the CU cover its
     // latency).  y0w is laundered through an empty asm so the row offsets are recomputed -- one clamp
     // + one multiply-add each -- instead of being hoisted into loop-invariant VGPRs.
+    const int gxs = min(max(x0 + lane, 0), Ws - 1);
     auto stage = [&](const T* plane) {
         const rsrc_t rs = make_rsrc(plane, sbytes);
         int y0w = y0 + wave;
         asm volatile("" : "+v"(y0w));
-#pragma unroll 1
-        for (int r8 = 0; r8 < PPT; r8 += 8) {
-            T st[8];
+        T st[PPT];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int gy = min(max(y0w + (r8 + q) * NW, 0), Hs - 1);
-                st[q] = buf_ld<T>(rs, (static_cast<unsigned>(gy) * Ws + gxs) * E);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) S[(wave + (r8 + q) * NW) * RW + lane] = st[q];
+        for (int q = 0; q < PPT; ++q) {
+            const int gy = min(max(y0w + q * NW, 0), Hs - 1);
+            st[q] = buf_ld<T>(rs, (static_cast<unsigned>(gy) * Ws + gxs) * E);
         }
-    };
 #pragma unroll
-    for (int r = 0; r < PPT; ++r) A[(wave + r * NW) * RW + lane] = 0;
+        for (int q = 0; q < PPT; ++q) S[(wave + q * NW) * RW + lane] = st[q];
+    };
+    for (int i = threadIdx.x; i < NA; i += kBlock) A[i] = 0;
     stage(sp);
     __syncthreads();
 
@@ -690,15 +694,36 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
         const bool more = c + 1 < c1;
         const rsrc_t rg = make_rsrc(op, obytes);
         const rsrc_t rs = make_rsrc(sp + static_cast<size_t>(c - c0) * splane, sbytes);
+        // software pipeline: the flow vector and the k x k grad_output window of pixel row r+1 are
+        // requested before row r is processed (their addresses do not depend on the flow), so the
+        // ~300 instructions of one row cover the latency of the next one's loads
+        struct PixLoad {
+            T fx, fy;
+            ElemRow<T, K> g[K];
+        };
+        const int xfc = min(max(xf, 0), Wf - 1);
+        auto request = [&](int r, PixLoad& d) {
+            int yfc = y0 + wave + r * NW;
+            yfc = min(max(yfc, 0), Hf - 1);                    // rows outside the flow image shadow a valid one
+            const unsigned fo = (static_cast<unsigned>(yfc) * Wf + xfc) * E;
+            d.fx = buf_ld<T>(rfl, fo);
+            d.fy = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
+            const unsigned ob = (static_cast<unsigned>(yfc) * K * W + static_cast<unsigned>(xfc) * K) * E;
+#pragma unroll
+            for (int i = 0; i < K; ++i) buf_load_row<T, K>(rg, ob + i * orow, d.g[i]);
+        };
+        PixLoad nxt;
+        request(0, nxt);
 #pragma unroll 1
         for (int r = 0; r < PPT; ++r) {
             const int row = wave + r * NW;
             const int yf = y0 + row;
+            const PixLoad cur = nxt;
+            if (r + 1 < PPT) request(r + 1, nxt);
             T gx = 0, gy = 0;
             if (xin && yf >= 0 && yf < Hf) {
-                const bool owned = xown && row >= h && row < h + TH && gflow != nullptr;
-                const unsigned fo = (static_cast<unsigned>(yf) * Wf + xf) * E;
-                const T fx0 = buf_ld<T>(rfl, fo), fy0 = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
+                const bool owned = xown && row >= H && row < H + TH && gflow != nullptr;
+                const T fx0 = cur.fx, fy0 = cur.fy;
                 // taps, the reference's arithmetic (block_extractor_kernel.cu:117-135)
                 T wxr[K], wyb[K];
                 T flx0 = 0, fly0 = 0;
@@ -709,92 +734,71 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
                     const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
                     const T fxl = floor_t(dx), fyl = floor_t(dy);
                     if (j == 0) { flx0 = fxl; fly0 = fyl; }
-                    regular = regular && (fxl == flx0 + static_cast<T>(j)) && (fyl == fly0 + static_cast<T>(j));
+                    regular = regular & (fxl == flx0 + static_cast<T>(j)) & (fyl == fly0 + static_cast<T>(j));
                     wxr[j] = dx - fxl;
                     wyb[j] = dy - fyl;
                 }
                 const T lim = static_cast<T>(1 << 20);
-                regular = regular && (flx0 > -lim) && (flx0 < lim) && (fly0 > -lim) && (fly0 < lim);   // rejects NaN too
+                regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);   // rejects NaN too
+                const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
+                const int au = u0 - ax0, av = v0 - ay0;          // neighbourhood origin in the accumulator box
+                const int su = u0 - x0, sv = v0 - y0;            // ... and in the source box
+                const bool fit = regular & (static_cast<unsigned>(au) <= static_cast<unsigned>(AP - 1 - K)) &
+                                 (static_cast<unsigned>(av) <= static_cast<unsigned>(AH - 1 - K));
+                const bool sfit = (static_cast<unsigned>(su) <= static_cast<unsigned>(RW - 1 - K)) &
+                                  (static_cast<unsigned>(sv) <= static_cast<unsigned>(RH - 1 - K));
                 const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
-                if (regular) {
-                    const int u0 = static_cast<int>(flx0), v0 = static_cast<int>(fly0);
-                    int ax[K + 1], ay[K + 1];          // accumulator column / row*RW of each neighbourhood cell, -1 = not mine
+                if (fit & (!owned | sfit)) {
+                    // hot path: dense (K+1)^2 neighbourhood at one LDS address + immediates, no masks.
+                    // A pixel that is not owned reads an arbitrary valid source neighbourhood: its d(flow)
+                    // is never written.
+                    double* ap = A + av * AP + au;
+                    const T* nb = S + (owned ? sv * RW + su : 0);
+                    T sprev[K + 1], scur[K + 1], aprev[K + 1], acur[K + 1];
 #pragma unroll
                     for (int j = 0; j <= K; ++j) {
-                        const int bx = min(max(u0 + j, 0), Ws - 1) - x0;
-                        const int by = min(max(v0 + j, 0), Hs - 1) - y0;
-                        ax[j] = (static_cast<unsigned>(bx - h) < static_cast<unsigned>(TW)) ? bx : -1;
-                        ay[j] = (static_cast<unsigned>(by - h) < static_cast<unsigned>(TH)) ? by * RW : -1;
+                        sprev[j] = nb[j];
+                        aprev[j] = 0;
                     }
-                    const int sx = u0 - x0, sy = v0 - y0;
-                    const bool inbox = sx >= 0 && sx + K < RW && sy >= 0 && sy + K < RH;
-                    const bool lds_nb = owned && inbox;
-                    const bool glb_nb = owned && !inbox;          // flow wider than the halo: gather from global
-                    const T* nb = S + (inbox ? sy * RW + sx : 0);
-                    unsigned gcol[K + 1];
-                    if (glb_nb) {
-#pragma unroll
-                        for (int j = 0; j <= K; ++j) gcol[j] = static_cast<unsigned>(min(max(u0 + j, 0), Ws - 1)) * E;
-                    }
-                    auto nb_row = [&](int i, T* dst) {
-                        if (lds_nb) {
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) dst[j] = nb[i * RW + j];
-                        } else if (glb_nb) {
-                            const unsigned ro = static_cast<unsigned>(min(max(v0 + i, 0), Hs - 1)) * Ws * E;
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) dst[j] = buf_ld<T>(rs, ro + gcol[j]);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) dst[j] = 0;
-                        }
-                    };
-                    T sprev[K + 1], scur[K + 1], aprev[K + 1], acur[K + 1];
-                    nb_row(0, sprev);
-#pragma unroll
-                    for (int j = 0; j <= K; ++j) aprev[j] = 0;
 #pragma unroll
                     for (int i = 0; i < K; ++i) {
-                        ElemRow<T, K> g;
-                        buf_load_row<T, K>(rg, ob + i * orow, g);
-                        nb_row(i + 1, scur);
 #pragma unroll
-                        for (int j = 0; j <= K; ++j) acur[j] = 0;
+                        for (int j = 0; j <= K; ++j) {
+                            scur[j] = nb[(i + 1) * RW + j];
+                            acur[j] = 0;
+                        }
                         const T yb = wyb[i], yt = 1 - wyb[i];
 #pragma unroll
                         for (int j = 0; j < K; ++j) {
-                            const T gv = g.v[j];
+                            const T gv = cur.g[i].v[j];
                             const T xr = wxr[j], xl = 1 - wxr[j];
                             const T gl = gv * xl, gr = gv * xr;
-                            aprev[j] += gl * yt;              // block_extractor_kernel.cu:158-161
-                            aprev[j + 1] += gr * yt;
-                            acur[j] += gl * yb;
-                            acur[j + 1] += gr * yb;
+                            aprev[j] = fma_t<T>(gl, yt, aprev[j]);              // block_extractor_kernel.cu:158-161
+                            aprev[j + 1] = fma_t<T>(gr, yt, aprev[j + 1]);
+                            acur[j] = fma_t<T>(gl, yb, acur[j]);
+                            acur[j + 1] = fma_t<T>(gr, yb, acur[j + 1]);
                             // :163-164 with the four products regrouped into source differences
-                            gy += gl * (scur[j] - sprev[j]) + gr * (scur[j + 1] - sprev[j + 1]);
-                            gx += gv * (yt * (sprev[j + 1] - sprev[j]) + yb * (scur[j + 1] - scur[j]));
+                            gy = fma_t<T>(gl, scur[j] - sprev[j], fma_t<T>(gr, scur[j + 1] - sprev[j + 1], gy));
+                            gx = fma_t<T>(gv * yt, sprev[j + 1] - sprev[j], fma_t<T>(gv * yb, scur[j + 1] - scur[j], gx));
                         }
-                        if (ay[i] >= 0) {
 #pragma unroll
-                            for (int j = 0; j <= K; ++j)
-                                if (ax[j] >= 0)
-                                    __hip_atomic_fetch_add(&A[ay[i] + ax[j]], static_cast<double>(aprev[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
+                        for (int j = 0; j <= K; ++j)
+                            __hip_atomic_fetch_add(ap + i * AP + j, static_cast<double>(aprev[j]), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                         for (int j = 0; j <= K; ++j) {
                             sprev[j] = scur[j];
                             aprev[j] = acur[j];
                         }
                     }
-                    if (ay[K] >= 0) {
 #pragma unroll
-                        for (int j = 0; j <= K; ++j)
-                            if (ax[j] >= 0)
-                                __hip_atomic_fetch_add(&A[ay[K] + ax[j]], static_cast<double>(aprev[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                    for (int j = 0; j <= K; ++j)
+                        __hip_atomic_fetch_add(ap + K * AP + j, static_cast<double>(aprev[j]), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    // a floor disagrees between neighbouring taps (fp rounding on an integer boundary),
-                    // NaN or huge flow: every tap on its own, like the reference
+                    // a tap outside the accumulator box (flow wider than the halo), a floor that disagrees
+                    // between neighbouring taps (fp rounding on an integer boundary), NaN or huge flow:
+                    // every tap on its own like the reference, clamped cells, ownership tested per cell
 #pragma unroll 1
                     for (int i = 0; i < K; ++i) {
                         const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
@@ -807,10 +811,11 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
                             const T wxs[2] = {tx1.wlo, tx1.whi}, wys[2] = {ty1.wlo, ty1.whi};
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const int bx = cxs[q & 1] - x0, by = cys[q >> 1] - y0;
-                                if (static_cast<unsigned>(bx - h) < static_cast<unsigned>(TW) &&
-                                    static_cast<unsigned>(by - h) < static_cast<unsigned>(TH))
-                                    __hip_atomic_fetch_add(&A[by * RW + bx], static_cast<double>(gv * wxs[q & 1] * wys[q >> 1]), __ATOMIC_RELAXED,
+                                const int cx = cxs[q & 1], cy = cys[q >> 1];
+                                if (static_cast<unsigned>(cx - tx * TW) < static_cast<unsigned>(TW) &&
+                                    static_cast<unsigned>(cy - ty * TH) < static_cast<unsigned>(TH))
+                                    __hip_atomic_fetch_add(&A[(cy - ay0) * AP + (cx - ax0)],
+                                                           static_cast<double>(gv * wxs[q & 1] * wys[q >> 1]), __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                             if (owned) {
@@ -828,30 +833,69 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
             gya[r] += gy;
         }
         __syncthreads();                       // every contribution of channel c is in A
+        // border tiles: fold the out-of-image cells onto the border cell they clamp to -- columns
+        // first (one thread per accumulator row), then rows (one thread per column)
+        if (foldL || foldR) {
+            if (threadIdx.x < AH) {
+                double* arow = A + threadIdx.x * AP;
+                if (foldL) {
+                    double s = 0;
+                    for (int u = 0; u < -ax0; ++u) s += arow[u];
+                    arow[-ax0] += s;
+                }
+                if (foldR) {
+                    double s = 0;
+                    for (int u = Ws - ax0; u < AP; ++u) s += arow[u];
+                    arow[Ws - 1 - ax0] += s;
+                }
+            }
+            __syncthreads();
+        }
+        if (foldT || foldB) {
+            if (threadIdx.x < AP) {
+                double* acol = A + threadIdx.x;
+                if (foldT) {
+                    double s = 0;
+                    for (int v = 0; v < -ay0; ++v) s += acol[v * AP];
+                    acol[-ay0 * AP] += s;
+                }
+                if (foldB) {
+                    double s = 0;
+                    for (int v = Hs - ay0; v < AH; ++v) s += acol[v * AP];
+                    acol[(Hs - 1 - ay0) * AP] += s;
+                }
+            }
+            __syncthreads();
+        }
         {
+            // flush the owned in-image cells (read-modify-write rows of grad_source) and clear the box
             const rsrc_t rq = make_rsrc(gp + static_cast<size_t>(c - c0) * splane, sbytes);
-            int y0w = y0 + wave;
-            asm volatile("" : "+v"(y0w));
-            // rows in groups of 4: four read-modify-writes in flight per lane, few live registers
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
 #pragma unroll 1
-            for (int r4 = 0; r4 < PPT; r4 += 4) {
+            for (int i0 = 0; i0 < NA; i0 += 4 * kBlock) {
                 T old[4];
                 unsigned off[4];
+                int idx[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int row = wave + (r4 + q) * NW;
-                    const int cy = y0w + (r4 + q) * NW;
-                    const bool mine = xcell && row >= h && row < h + TH && cy >= 0 && cy < Hs;
-                    off[q] = mine ? (static_cast<unsigned>(cy) * Ws + static_cast<unsigned>(x0 + lane)) * E : 0xFFFFFFF0u;
+                    idx[q] = i0 + q * kBlock + tid;
+                    const int arow = idx[q] / AP, acol = idx[q] - arow * AP;
+                    const int cx = ax0 + acol, cy = ay0 + arow;
+                    const bool mine = idx[q] < NA && static_cast<unsigned>(acol - 2 * H) < static_cast<unsigned>(TW) &&
+                                      static_cast<unsigned>(arow - 2 * H) < static_cast<unsigned>(TH) && cx >= 0 && cx < Ws &&
+                                      cy >= 0 && cy < Hs;
+                    off[q] = mine ? (static_cast<unsigned>(cy) * Ws + static_cast<unsigned>(cx)) * E : 0xFFFFFFF0u;
                     old[q] = buf_ld<T>(rq, off[q]);                 // out of range: reads 0
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int idx = (wave + (r4 + q) * NW) * RW + lane;
-                    ElemRow<T, 1> v;
-                    v.v[0] = old[q] + static_cast<T>(A[idx]);
-                    buf_store_row<T, 1>(rq, off[q], v);             // out of range: dropped
-                    A[idx] = 0;
+                    if (idx[q] < NA) {
+                        ElemRow<T, 1> v;
+                        v.v[0] = old[q] + static_cast<T>(A[idx[q]]);
+                        buf_store_row<T, 1>(rq, off[q], v);         // out of range: dropped
+                        A[idx[q]] = 0;
+                    }
                 }
             }
         }
@@ -863,7 +907,7 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
         for (int r = 0; r < PPT; ++r) {
             const int row = wave + r * NW;
             const int yf = y0 + row;
-            if (xin && xown && row >= h && row < h + TH && yf >= 0 && yf < Hf) {
+            if (xin && xown && row >= H && row < H + TH && yf >= 0 && yf < Hf) {
                 const size_t fo = static_cast<size_t>(b) * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
                 atomic_add(gflow + fo, gxa[r]);
                 atomic_add(gflow + fo + fplane, gya[r]);
@@ -1053,13 +1097,13 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
     if constexpr (sizeof(T) == 4) {
         const int variant = options().be_bwd_variant;
         if (gsrc && k >= 1 && k <= 4 && (variant == 0 || variant == 2)) {
-            int h = options().be_bwd_halo > 0 ? options().be_bwd_halo : 4;
-            h = h < 2 ? 2 : (h > 12 ? 12 : h);
-            constexpr int RH = 64;
+            // halo 4 (|tap offset| <= 4 stays on the fast path) or 8; region height 32 or 64 rows
+            const int h = options().be_bwd_halo > 4 ? 8 : 4;
+            const int RH = (h == 4 && k == 3 && options().be_bwd_rows == 64) ? 64 : 32;
             const TileGeo geo{kTileRW - 2 * h, RH - 2 * h, h, RH};
             const int ntx = static_cast<int>(((Ws > Wf ? Ws : Wf) + geo.TW - 1) / geo.TW);
             const int nty = static_cast<int>(((Hs > Hf ? Hs : Hf) + geo.TH - 1) / geo.TH);
-            int cs = options().channel_slab > 0 ? options().channel_slab : 16;
+            int cs = options().channel_slab > 0 ? options().channel_slab : 8;
             if (cs > C) cs = static_cast<int>(C);
             while (cs > 4 && B * ntx * nty * ((C + cs - 1) / cs) < 1536) cs = (cs + 1) / 2;   // >= 6 blocks per CU
             const int cslabs = static_cast<int>((C + cs - 1) / cs);
@@ -1081,16 +1125,22 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
             {
                 LaunchScope ls("block_extractor_bwd_tile", st, bytes);
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-                switch (k) {
-#define FFWM_BE_TILE(KK)                                                                                      \
+#define FFWM_BE_TILE(KK, RR, HH)                                                                              \
+    hipLaunchKernelGGL((be_bwd_tile_kernel<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,  \
+                       (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
+                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, options().ablate)
+#define FFWM_BE_TILE_K(KK)                                                                                    \
     case KK:                                                                                                  \
-        hipLaunchKernelGGL((be_bwd_tile_kernel<KK, RH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,  \
-                           (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C,       \
-                           (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, h, remap);               \
+        if (h == 8) FFWM_BE_TILE(KK, 32, 8);                                                                  \
+        else FFWM_BE_TILE(KK, 32, 4);                                                                         \
         break;
-                    FFWM_BE_TILE(1) FFWM_BE_TILE(2) FFWM_BE_TILE(3) FFWM_BE_TILE(4)
-#undef FFWM_BE_TILE
+                if (RH == 64) {
+                    FFWM_BE_TILE(3, 64, 4);
+                } else {
+                    switch (k) { FFWM_BE_TILE_K(1) FFWM_BE_TILE_K(2) FFWM_BE_TILE_K(3) FFWM_BE_TILE_K(4) }
                 }
+#undef FFWM_BE_TILE_K
+#undef FFWM_BE_TILE
             }
             return check_launch("ffwm_block_extractor_backward(tile)");
         }

@@ -124,19 +124,21 @@ BE_TILE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("halo", [0, 2, 7])
+@pytest.mark.parametrize("halo,rows", [(0, 0), (8, 0), (4, 64)])
 @pytest.mark.parametrize("case", BE_TILE_CASES)
-def test_block_extractor_backward_owned_tiles(oracle, case, halo):
+def test_block_extractor_backward_owned_tiles(oracle, case, halo, rows):
     from ffwm_amd import ops, _lib
     src, flow, go, k = _be_inputs(case, torch.float32)
     gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, k)
     gs = torch.zeros_like(src, device=DEV)
     gf = torch.zeros_like(flow, device=DEV)
     _lib.set_option("be_bwd_halo", halo)
+    _lib.set_option("be_bwd_rows", rows)
     try:
         ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), k, gs, gf)
     finally:
         _lib.set_option("be_bwd_halo", 0)
+        _lib.set_option("be_bwd_rows", 0)
     # case 2 collapses ~18k pixels x 9 taps onto the border cells through float atomics in arbitrary
     # order (as the reference does): the fp32 summation-order noise alone is ~1e-5 relative there
     tol = 1e-4 if case[7] >= 100 else BWD_TOL[torch.float32]
