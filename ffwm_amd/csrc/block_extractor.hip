@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(kPlaneThreads)
 be_bwd_src_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gsrc, int C,
                         int Hs, int Ws, int Hf, int Wf, int k, int cg, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* acc = reinterpret_cast<T*>(smem_raw);
+    double* acc = reinterpret_cast<double*>(smem_raw);
     const int grp = blockIdx.x % groups;
     const int b = blockIdx.x / groups;
     const int c0 = grp * cg;
@@ -565,18 +565,18 @@ be_bwd_src_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, 
                 const unsigned oBL = ty.hi * Ws + tx.lo, oBR = ty.hi * Ws + tx.hi;
                 for (int c = 0; c < nc; ++c) {
                     const T gv = g0[static_cast<size_t>(c) * oplane + go];
-                    T* a = acc + c * ncell;
-                    atomic_add(a + oTL, gv * tx.wlo * ty.wlo);   // block_extractor_kernel.cu:158-161
-                    atomic_add(a + oTR, gv * tx.whi * ty.wlo);
-                    atomic_add(a + oBL, gv * tx.wlo * ty.whi);
-                    atomic_add(a + oBR, gv * tx.whi * ty.whi);
+                    double* a = acc + c * ncell;
+                    lds_add(a + oTL, gv * tx.wlo * ty.wlo);   // block_extractor_kernel.cu:158-161
+                    lds_add(a + oTR, gv * tx.whi * ty.wlo);
+                    lds_add(a + oBL, gv * tx.wlo * ty.whi);
+                    lds_add(a + oBR, gv * tx.whi * ty.whi);
                 }
             }
         }
     }
     __syncthreads();
     T* dst = gsrc + (static_cast<size_t>(b) * C + c0) * ncell;
-    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += acc[i];
+    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += static_cast<T>(acc[i]);
 }
 
 // ------------------------------------------------------------------------------ backward, owned tiles
@@ -1074,17 +1074,18 @@ template <typename T>
 int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, int64_t B, int64_t C,
                int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, hipStream_t st) {
     const double bytes = sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * k * k * Hf * Wf + 2.0 * C * Hs * Ws + 4.0 * Hf * Wf);
-    const size_t plane_bytes = static_cast<size_t>(Hs) * Ws * sizeof(T);
-    if (gsrc && plane_bytes <= 65536 && options().scatter_variant != 1 && options().be_bwd_variant != 9) {
-        int cg = static_cast<int>(65536 / plane_bytes);
+    const size_t plane_lds = static_cast<size_t>(Hs) * Ws * sizeof(double);     // the LDS accumulator is double
+    if (gsrc && plane_lds <= 131072 && options().scatter_variant != 1 && options().be_bwd_variant != 9) {
+        int cg = static_cast<int>(131072 / plane_lds);
         if (cg > C) cg = static_cast<int>(C);
         while (cg > 1 && B * ((C + cg - 1) / cg) < 512) cg = (cg + 1) / 2;
         const int groups = static_cast<int>((C + cg - 1) / cg);
         {
             LaunchScope ls("block_extractor_bwd_src_plane", st,
                            sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * k * k * Hf * Wf + 2.0 * C * Hs * Ws + 2.0 * Hf * Wf));
+            allow_large_lds(reinterpret_cast<const void*>(be_bwd_src_plane_kernel<T>));
             hipLaunchKernelGGL((be_bwd_src_plane_kernel<T>), dim3(static_cast<unsigned>(B * groups)), dim3(kPlaneThreads),
-                               static_cast<size_t>(cg) * plane_bytes, st, flow, gout, gsrc, (int)C, (int)Hs, (int)Ws,
+                               static_cast<size_t>(cg) * plane_lds, st, flow, gout, gsrc, (int)C, (int)Hs, (int)Ws,
                                (int)Hf, (int)Wf, k, cg, groups);
         }
         if (int rc = check_launch("ffwm_block_extractor_backward(source, plane)")) return rc;

@@ -15,6 +15,9 @@ constexpr int kTileY = kBlock / kTileX;
 // ---------------------------------------------------------------- host side
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// Kernels that ask for more than 64 KiB of dynamic LDS need their limit raised once (160 KiB per CU on gfx950).
+void allow_large_lds(const void* kernel);
+constexpr int kMaxLdsBytes = 160 * 1024;
 
 struct Options {
     int be_fwd_variant = 0;   // 0 = auto
@@ -107,6 +110,12 @@ __device__ __forceinline__ double safe_div(T a, T b) {
 
 __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// LDS accumulation goes through DOUBLE cells: ds_add_f64 ~9 clk per wave, ds_add_f32 ~190 on gfx950.
+template <typename T>
+__device__ __forceinline__ void lds_add(double* cell, T v) {
+    __hip_atomic_fetch_add(cell, static_cast<double>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // ---- buffer addressing -------------------------------------------------------------------
 // A tensor plane is addressed as (wave-uniform 128-bit buffer resource in SGPRs) + (32-bit

@@ -169,10 +169,11 @@ rs_bwd1_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* __restr
     }
 }
 
-// K2 without global atomics: a block owns `cg` whole (b, c) planes of grad_input1 in LDS
-// (cg = how many fit 64 KiB), visits every pixel of image b once -- taps and normalised weights
-// are formed once per pixel and reused for the cg channels -- accumulates with LDS atomics and
-// adds the finished planes to grad_input1 with plain coalesced stores.
+// K2 without global atomics: a block owns `cg` whole (b, c) planes of grad_input1 in LDS, visits
+// every pixel of image b once -- taps and normalised weights are formed once per pixel and reused for
+// the cg channels -- accumulates with LDS atomics and adds the finished planes to grad_input1 with
+// plain coalesced stores.  The LDS accumulator is DOUBLE whatever T is: on gfx950 ds_add_f64 retires a
+// wave in ~9 clk where ds_add_f32 needs ~190 (tools/ubench/atomics.hip); rounded to T once, at the end.
 constexpr int kPlaneThreads = 1024;
 
 template <typename T, int HALF>
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(kPlaneThreads)
 rs_bwd1_plane_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* __restrict__ gin1, int C,
                      int Hi, int Wi, int H, int W, int dil, int quirk, int cg, int groups) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* acc = reinterpret_cast<T*>(smem_raw);
+    double* acc = reinterpret_cast<double*>(smem_raw);
     const int grp = blockIdx.x % groups;
     const int b = blockIdx.x / groups;
     const int c0 = grp * cg;
@@ -206,17 +207,17 @@ rs_bwd1_plane_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* _
                 const unsigned o2 = (t.row[2 * fy + 1] + t.col[2 * fx]) / E, o3 = (t.row[2 * fy + 1] + t.col[2 * fx + 1]) / E;
                 for (int c = 0; c < nc; ++c) {
                     const T g = g0[static_cast<size_t>(c) * npix + p];
-                    T* a = acc + c * ncell;
-                    atomic_add(a + o0, w0 * g);
-                    atomic_add(a + o1, w1 * g);
-                    atomic_add(a + o2, w2 * g);
-                    atomic_add(a + o3, w3 * g);
+                    double* a = acc + c * ncell;
+                    lds_add(a + o0, w0 * g);
+                    lds_add(a + o1, w1 * g);
+                    lds_add(a + o2, w2 * g);
+                    lds_add(a + o3, w3 * g);
                 }
             }
     }
     __syncthreads();
     T* dst = gin1 + (static_cast<size_t>(b) * C + c0) * ncell;
-    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += acc[i];
+    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += static_cast<T>(acc[i]);
 }
 
 // ------------------------------------------------------------------------------------ K3
@@ -534,16 +535,19 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                int64_t Hi, int64_t Wi, int64_t H, int64_t W, int ks, int dil, int quirk,
                hipStream_t st) {
     const int remap = options().xcd_remap;
-    const size_t plane_bytes = static_cast<size_t>(Hi) * Wi * sizeof(T);
+    const size_t plane_lds = static_cast<size_t>(Hi) * Wi * sizeof(double);     // the LDS accumulator is double
     const int half = ks / 2;
-    if (gin1 && plane_bytes <= 65536 && half >= 1 && half <= 3 && options().scatter_variant != 1) {
+    if (gin1 && plane_lds <= 131072 && half >= 1 && half <= 3 && options().scatter_variant != 1) {
         const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
-        int cg = static_cast<int>(65536 / plane_bytes);
+        int cg = static_cast<int>(131072 / plane_lds);
         if (cg > C) cg = static_cast<int>(C);
         while (cg > 1 && B * ((C + cg - 1) / cg) < 512) cg = (cg + 1) / 2;   // keep >= 2 blocks per CU
         const int groups = static_cast<int>((C + cg - 1) / cg);
         const unsigned grid = static_cast<unsigned>(B * groups);
-        const size_t lds = static_cast<size_t>(cg) * plane_bytes;
+        const size_t lds = static_cast<size_t>(cg) * plane_lds;
+        allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_plane_kernel<T, 1>));
+        allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_plane_kernel<T, 2>));
+        allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_plane_kernel<T, 3>));
         {
             LaunchScope ls("resample2d_bwd_input1_plane", st, bytes);
             if (half == 1)

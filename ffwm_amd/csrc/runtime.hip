@@ -4,6 +4,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,14 @@ int check_launch(const char* what) {
         return FFWM_ERR_LAUNCH;
     }
     return FFWM_OK;
+}
+
+void allow_large_lds(const void* kernel) {
+    static std::mutex mu;
+    static std::set<const void*> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.insert(kernel).second)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
 }
 
 Options& options() {

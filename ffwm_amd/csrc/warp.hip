@@ -162,44 +162,112 @@ warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T*
     }
 }
 
-// d(feat) without global atomics: one block owns one (b, c) plane of grad_feat and keeps it in LDS.
-// Every output pixel of image b is visited by the block (coalesced reads of grad_output), its four
-// corner contributions are added with LDS atomics (ds_add_f32 -- contention is resolved inside
-// the CU, not at the memory-side atomic unit that a device-scope global atomic needs on a
-// multi-XCD part), then the finished plane is added to grad_feat with plain coalesced stores.
-// Used whenever the plane fits LDS (Hi*Wi*sizeof(T) <= 64 KiB: every warp in FFWM, <= 128 x 128).
+// d(feat) without contended global atomics: a block owns `cg` whole (b, c) planes of grad_feat in LDS.
+// It visits the output pixels of image b (all of them, or one of `nsplit` interleaved row groups when
+// there are too few planes to fill the chip), forms the four corners ONCE per pixel and adds the
+// contributions of its cg channels with LDS atomics; the finished planes are added to grad_feat with
+// plain coalesced read-modify-write rows (nsplit == 1) or one global atomic per non-zero cell.
+//   * The LDS accumulator is DOUBLE: on gfx950 ds_add_f64 retires a wave in ~9 clk where ds_add_f32
+//     needs ~190 (tools/ubench/atomics.hip); the sum is rounded to float once, at the flush.
+//   * Robust to the degenerate flows of an untrained FlowNet (every pixel samples the same cell):
+//     the collisions are resolved inside the CU instead of at the memory-side atomic unit.
+// Used whenever one double plane fits LDS (Hi*Wi <= 20480 cells: every warp in FFWM, <= 128 x 128).
 constexpr int kPlaneThreads = 1024;
+constexpr int kPlaneLdsBytes = kMaxLdsBytes;
+constexpr int kPlaneUnroll = 4;
 
-template <typename T, bool FLIP>
+template <typename T, bool FLIP, int CG>
 __global__ void __launch_bounds__(kPlaneThreads)
 warp_bwd_feat_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gfeat,
-                           int C, int Hi, int Wi, int H, int W) {
+                           int C, int Hi, int Wi, int H, int W, int groups, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* acc = reinterpret_cast<T*>(smem_raw);
-    const int c = blockIdx.x % C;
-    const int b = blockIdx.x / C;
+    double* acc = reinterpret_cast<double*>(smem_raw);
+    unsigned t = blockIdx.x;
+    const int split = t % nsplit;
+    t /= nsplit;
+    const int grp = t % groups;
+    const int b = t / groups;
+    const int c0 = grp * CG;
+    const int nc = (c0 + CG <= C) ? CG : C - c0;
     const int ncell = Hi * Wi, npix = H * W;
-    for (int i = threadIdx.x; i < ncell; i += kPlaneThreads) acc[i] = 0;
+    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) acc[i] = 0;
     __syncthreads();
     const int Co = FLIP ? 2 * C : C;
     const T* fl = flow + static_cast<size_t>(b) * 2 * npix;
-    const T* g0 = gout + (static_cast<size_t>(b) * Co + c) * npix;
+    const T* g0 = gout + (static_cast<size_t>(b) * Co + c0) * npix;
     const T* g1 = g0 + static_cast<size_t>(C) * npix;
-    for (int p = threadIdx.x; p < npix; p += kPlaneThreads) {
-        Corners<T> cn;
-        make_corners<T>(cn, fl[p], fl[npix + p], Hi, Wi);
-        T g = g0[p];
-        if (FLIP) {
-            const int y = p / W, x = p - y * W;
-            g += g1[y * W + (W - 1 - x)];
+    // pixel p = (it * nsplit + split) * kPlaneThreads + tid: kPlaneUnroll pixels per trip so that all
+    // their loads are in flight together
+    const int stride = kPlaneThreads * nsplit;
+    for (int p0 = split * kPlaneThreads + threadIdx.x; p0 < npix; p0 += stride * kPlaneUnroll) {
+        T fx[kPlaneUnroll], fy[kPlaneUnroll], g[kPlaneUnroll][CG];
+        int mir[kPlaneUnroll];
+#pragma unroll
+        for (int u = 0; u < kPlaneUnroll; ++u) {
+            const int p = p0 + u * stride;
+            const int pc = p < npix ? p : npix - 1;
+            fx[u] = fl[pc];
+            fy[u] = fl[npix + pc];
+            const int y = pc / W, x = pc - y * W;
+            mir[u] = y * W + (W - 1 - x);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const int cc = c < nc ? c : 0;
+                g[u][c] = g0[static_cast<size_t>(cc) * npix + pc];
+                if (FLIP) g[u][c] += g1[static_cast<size_t>(cc) * npix + mir[u]];
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (cn.valid[q]) atomic_add(acc + cn.off[q] / static_cast<unsigned>(sizeof(T)), cn.w[q] * g);
+        for (int u = 0; u < kPlaneUnroll; ++u) {
+            if (p0 + u * stride >= npix) break;
+            Corners<T> cn;
+            make_corners<T>(cn, fx[u], fy[u], Hi, Wi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!cn.valid[q]) continue;
+                double* cell = acc + cn.off[q] / static_cast<unsigned>(sizeof(T));
+#pragma unroll
+                for (int c = 0; c < CG; ++c)
+                    if (c < nc)
+                        __hip_atomic_fetch_add(cell + c * ncell, static_cast<double>(cn.w[q] * g[u][c]), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
     __syncthreads();
-    T* dst = gfeat + (static_cast<size_t>(b) * C + c) * ncell;
-    for (int i = threadIdx.x; i < ncell; i += kPlaneThreads) dst[i] += acc[i];
+    T* dst = gfeat + (static_cast<size_t>(b) * C + c0) * ncell;
+    if (nsplit == 1) {
+        for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += static_cast<T>(acc[i]);
+    } else {
+        for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) {
+            const T v = static_cast<T>(acc[i]);
+            if (v != 0) atomic_add(dst + i, v);
+        }
+    }
+}
+
+// Geometry of a plane launch: channels per block (cg in {1,2,4,8}) and pixel split.
+struct PlanePlan {
+    int cg, groups, nsplit;
+    size_t lds;
+    bool ok;
+};
+inline PlanePlan plan_planes(int64_t B, int64_t C, int64_t cells, int64_t npix, int max_cg) {
+    PlanePlan p{1, 0, 1, 0, false};
+    const size_t plane = static_cast<size_t>(cells) * sizeof(double);
+    if (plane > static_cast<size_t>(kPlaneLdsBytes)) return p;
+    p.ok = true;
+    int cg = max_cg;
+    // as many channels per block as LDS holds twice over (2 blocks per CU), but keep >= 512 blocks
+    while (cg > 1 && (cg * plane * 2 > static_cast<size_t>(kPlaneLdsBytes) || cg > C || B * ((C + cg - 1) / cg) < 512)) cg >>= 1;
+    p.cg = cg;
+    p.groups = static_cast<int>((C + cg - 1) / cg);
+    p.lds = cg * plane;
+    int ns = 1;
+    const int64_t trips = (npix + kPlaneThreads * kPlaneUnroll - 1) / (kPlaneThreads * kPlaneUnroll);
+    while (B * p.groups * ns < 256 && ns * 2 <= trips) ns *= 2;   // too few planes: split the pixels
+    p.nsplit = ns;
+    return p;
 }
 
 int check_dims(const char* fn, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W,
@@ -238,18 +306,33 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
     const double bytes = sizeof(T) * static_cast<double>(B) *
                          (2.0 * C * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W);
     const int remap = options().xcd_remap;
-    const size_t plane_bytes = static_cast<size_t>(Hi) * Wi * sizeof(T);
-    if (gfeat && plane_bytes <= 65536 && options().scatter_variant != 1) {
-        {   // d(feat): LDS-resident plane per (b, c), no global atomics
+    const PlanePlan pp = plan_planes(B, C, Hi * Wi, H * W, sizeof(T) == 8 ? 2 : 8);
+    if (gfeat && pp.ok && options().scatter_variant != 1) {
+        {   // d(feat): LDS-resident planes, no contended global atomics
             LaunchScope ls(flip ? "warp_flipcat_bwd_feat" : "warp_bwd_feat", st,
                            sizeof(T) * static_cast<double>(B) * (2.0 * C * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
-            const unsigned grid = static_cast<unsigned>(B * C);
-            if (flip)
-                hipLaunchKernelGGL((warp_bwd_feat_plane_kernel<T, true>), dim3(grid), dim3(kPlaneThreads), plane_bytes,
-                                   st, flow, gout, gfeat, (int)C, (int)Hi, (int)Wi, (int)H, (int)W);
-            else
-                hipLaunchKernelGGL((warp_bwd_feat_plane_kernel<T, false>), dim3(grid), dim3(kPlaneThreads), plane_bytes,
-                                   st, flow, gout, gfeat, (int)C, (int)Hi, (int)Wi, (int)H, (int)W);
+            const unsigned grid = static_cast<unsigned>(B * pp.groups * pp.nsplit);
+#define FFWM_WARP_PLANE(FL, CG)                                                                              \
+    do {                                                                                                     \
+        auto kfn = warp_bwd_feat_plane_kernel<T, FL, CG>;                                                    \
+        allow_large_lds(reinterpret_cast<const void*>(kfn));                                                 \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kPlaneThreads), pp.lds, st, flow, gout, gfeat, (int)C,      \
+                           (int)Hi, (int)Wi, (int)H, (int)W, pp.groups, pp.nsplit);                          \
+    } while (0)
+#define FFWM_WARP_PLANE_CG(FL)                                                                               \
+    switch (pp.cg) {                                                                                         \
+        case 8: FFWM_WARP_PLANE(FL, 8); break;                                                               \
+        case 4: FFWM_WARP_PLANE(FL, 4); break;                                                               \
+        case 2: FFWM_WARP_PLANE(FL, 2); break;                                                               \
+        default: FFWM_WARP_PLANE(FL, 1); break;                                                              \
+    }
+            if (flip) {
+                FFWM_WARP_PLANE_CG(true)
+            } else {
+                FFWM_WARP_PLANE_CG(false)
+            }
+#undef FFWM_WARP_PLANE_CG
+#undef FFWM_WARP_PLANE
         }
         if (int rc = check_launch("ffwm_warp_backward(feat)")) return rc;
         if (!gflow) return FFWM_OK;
