@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--graph", default="off", choices=["on", "off"],
+                    help="train workload: replay the step from captured hipGraphs, or run it eagerly (default: measured faster on ROCm 7.2)")
     return ap.parse_args()
 
 
@@ -220,14 +222,23 @@ def main():
         t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers,
                                 bucket_bytes=args.bucket_mb << 20)
         batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
+        graphed = args.graph == "on"
+        if graphed:
+            t.capture(batch, warmup=max(2, args.warmup))
         dt, rows = timed(lambda: t.step(batch, batch_increment=0), args.steps, args.warmup, world)
+        if graphed:
+            # HIP events cannot bracket kernels inside a replayed graph: time the hand-written kernels
+            # in two EAGER steps of the same trainer right after the timed region
+            t.release_graphs()
+            _, rows = timed(lambda: t.step(batch, batch_increment=0), 2, 1, world)
         imgs = bs * world * args.steps
         result.update({"metric": "train img/s (128x128, full FFWM GAN step)", "value": round(imgs / dt, 2),
                        "unit": "img/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
                        "config": {"workload": "BASELINE configs[2]: full FFWM train step (netG+netD+flowNetF+flowNetB, "
                                               "all losses, 3x Adam), synthetic MultiPIE-shaped 128x128",
                                   "batch_per_gpu": bs, "global_batch": bs * world,
-                                  "parallelism": "dp%d" % world, "titers_branch": "<20000" if args.titers < 20000 else ">=20000",
+                                  "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed else "eager",
+                                  "titers_branch": "<20000" if args.titers < 20000 else ">=20000",
                                   "weights": "seeded random init (no pretrained VGG19/LightCNN/FlowNet offline)"},
                        "img_per_s_per_gpu": round(imgs / dt / world, 2),
                        "fp32_flop_frac": round(imgs / dt / world * TRAIN_FLOP_PER_IMG / FP32_PEAK, 4),
@@ -300,8 +311,9 @@ def main():
                                   "unit": "GB/s", "frac": top["frac_hbm_peak"], "traffic": None,
                                   "avg_us": top["avg_us"], "alg_MB_per_launch": top["alg_MB"],
                                   "launches": top["launches"],
-                                  "note": "hand-written HIP kernel with the largest total time in the timed region; "
-                                          "HIP events on its launch stream"}
+                                  "note": "hand-written HIP kernel with the largest total time in one step; HIP events "
+                                          "on its launch stream" + (" (eager steps run right after the graph-replayed "
+                                          "timed region)" if args.workload == "train" and args.graph == "on" else "")}
         else:
             result["roofline"] = None
         result["kernels"] = inrun

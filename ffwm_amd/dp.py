@@ -39,6 +39,7 @@ class BucketedGradReducer(object):
             cur_bytes += nbytes
         if cur:
             self._seal(cur)
+        self.overlap = True
         self._hooks = []
         if self.world > 1:
             for p in params:
@@ -72,7 +73,15 @@ class BucketedGradReducer(object):
         b["launched"] = True
         b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def set_overlap(self, on):
+        """on: buckets are reduced from the autograd hooks, overlapping with backward (default).
+        off: nothing is launched from the hooks; finish() reduces every bucket (used when backward is
+        replayed from a captured hipGraph, where no Python hook runs)."""
+        self.overlap = bool(on)
+
     def _on_grad(self, p):
+        if not self.overlap:
+            return
         b = self._bucket_of[p]
         view = self._view[p]
         if p.grad is not view and (p.grad is None or p.grad.data_ptr() != view.data_ptr()):
@@ -89,7 +98,7 @@ class BucketedGradReducer(object):
         if self.world == 1:
             return
         for b in self.buckets:
-            if not b["launched"]:
+            if not b["launched"] or not self.overlap:
                 self._launch(b)       # parameters without a gradient this step still take part
         for b in self.buckets:
             b["handle"].wait()

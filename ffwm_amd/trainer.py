@@ -86,10 +86,15 @@ class FFWMTrainer(object):
 
         flow_params = [p for net in (self.flowNetF, self.flowNetB) for n, p in net.named_parameters()
                        if not n.startswith("inter_conv_occ")]
-        # Adam hyper-parameters of ffwm_model.py:46-49
-        self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999))
-        self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999))
-        self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999))
+        # Adam hyper-parameters of ffwm_model.py:46-49 (capturable: the step counter lives on the
+        # device, so an optimizer step can be part of a captured hipGraph)
+        cap = self.device.type == "cuda"
+        self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999), capturable=cap)
+        self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
+        self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
+        self.world_size = world_size
+        self._graphs = None
+        self._static = None
         self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
                                          bucket_bytes=bucket_bytes)
         self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes)
@@ -170,25 +175,110 @@ class FFWMTrainer(object):
                        "prc": loss_prc, "fc": loss_fc}
         self.loss_G.backward()
 
-    def step(self, b, batch_increment=None):
-        """optimize_parameters (ffwm_model.py:151-160): forward, D step, G step."""
+    # optimize_parameters (ffwm_model.py:151-160) in three segments, cut where data parallelism has its
+    # exchange steps (gradient all-reduce of the D set, then of the G set)
+    def _seg_forward_and_D(self, b):
         self.forward(b)
         for p in self.netD.parameters():
             p.requires_grad = True
         self.red_D.zero_grad()
         self.backward_D(b)
-        self.red_D.finish()
+
+    def _seg_stepD_and_G(self, b):
         self.opt_D.step()
         for p in self.netD.parameters():
             p.requires_grad = False
         self.red_G.zero_grad()
         self.backward_G(b)
-        self.red_G.finish()
+
+    def _seg_stepG(self):
         self.opt_G.step()
         self.opt_F.step()
+
+    def step(self, b, batch_increment=None):
+        """optimize_parameters (ffwm_model.py:151-160): forward, D step, G step."""
+        if self._graphs is not None:
+            return self._step_graphed(b, batch_increment)
+        self._seg_forward_and_D(b)
+        self.red_D.finish()
+        self._seg_stepD_and_G(b)
+        self.red_G.finish()
+        self._seg_stepG()
         self.titers += batch_increment if batch_increment is not None else b["img_S"].size(0)
         self.losses["D"] = self.loss_D
         return self.losses
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def capture(self, b, warmup=3):
+        """Capture the train step into hipGraphs (HIP graphs through torch.cuda.CUDAGraph): the eager
+        step issues ~4600 small launches and is launch-bound (SURVEY 7 'hard parts'); a replay submits
+        them as pre-built graphs.  Single GPU: ONE graph for the whole step.  Data parallel: three
+        graphs with the two gradient all-reduces issued between them (RCCL stays outside the capture;
+        the buckets are reduced in one shot instead of overlapping with backward).
+        The batch is copied into static device buffers before every replay; the `titers` branch
+        (< 20000 / >= 20000) is frozen at capture time -- re-capture when it flips."""
+        assert self.device.type == "cuda" and self._graphs is None
+        self._static = {k: v.clone() for k, v in b.items()}
+        sb = self._static
+        self.red_D.set_overlap(False)
+        self.red_G.set_overlap(False)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # MIOpen solver selection, allocator warm-up, Adam state
+                self._seg_forward_and_D(sb)
+                self.red_D.finish()
+                self._seg_stepD_and_G(sb)
+                self.red_G.finish()
+                self._seg_stepG()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graphs = []
+        if self.world_size == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._seg_forward_and_D(sb)
+                self._seg_stepD_and_G(sb)
+                self._seg_stepG()
+            graphs = [g]
+        else:
+            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._seg_forward_and_D(sb)
+            self.red_D.finish()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._seg_stepD_and_G(sb)
+            self.red_G.finish()
+            with torch.cuda.graph(g3, pool=g1.pool()):
+                self._seg_stepG()
+            graphs = [g1, g2, g3]
+        self.losses["D"] = self.loss_D
+        self._graphs = graphs
+        self._frozen_branch = self.titers < 20000
+        return self
+
+    def _step_graphed(self, b, batch_increment):
+        if (self.titers < 20000) != self._frozen_branch:
+            raise RuntimeError("the titers branch flipped: call release_graphs() and capture() again")
+        for k, v in self._static.items():
+            if b[k] is not v:
+                v.copy_(b[k], non_blocking=True)
+        if len(self._graphs) == 1:
+            self._graphs[0].replay()
+        else:
+            self._graphs[0].replay()
+            self.red_D.finish()
+            self._graphs[1].replay()
+            self.red_G.finish()
+            self._graphs[2].replay()
+        self.titers += batch_increment if batch_increment is not None else b["img_S"].size(0)
+        return self.losses
+
+    def release_graphs(self):
+        self._graphs = None
+        self._static = None
+        self.red_D.set_overlap(True)
+        self.red_G.set_overlap(True)
 
     def loss_values(self):
         return {k: float(v.detach()) for k, v in self.losses.items()}
