@@ -220,7 +220,7 @@ def main():
         from ffwm_amd import trainer
         bs = args.batch or 8
         t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers,
-                                bucket_bytes=args.bucket_mb << 20)
+                                bucket_bytes=args.bucket_mb << 20, capturable=args.graph == "on")
         batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
         graphed = args.graph == "on"
         if graphed:

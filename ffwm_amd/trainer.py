@@ -67,7 +67,7 @@ def part_grids(lm_F):
 
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
-                 warp_flipcat=None, ngf=64):
+                 warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None):
         self.device = torch.device(device)
         self.titers = titers
         torch.manual_seed(seed)
@@ -82,13 +82,23 @@ class FFWMTrainer(object):
             p.requires_grad = False
         self.gf = {128: nets.GuidedFilter(32), 64: nets.GuidedFilter(16), 32: nets.GuidedFilter(8)}
 
+        # spectral norm of netG's 52 and netD's 9 convs: one batched launch per forward call instead
+        # of ~12 tiny kernels per layer (GPU only -- the CPU baseline keeps PyTorch's per-layer hooks)
+        if fused_spectral_norm is None:
+            fused_spectral_norm = self.device.type == "cuda"
+        if fused_spectral_norm:
+            from .spectral_norm import fuse_spectral_norm
+            fuse_spectral_norm(self.netG)
+            fuse_spectral_norm(self.netD)
+
         broadcast_module_state([self.flowNetF, self.flowNetB, self.netG, self.netD, self.lightCNN, self.vgg])
 
         flow_params = [p for net in (self.flowNetF, self.flowNetB) for n, p in net.named_parameters()
                        if not n.startswith("inter_conv_occ")]
-        # Adam hyper-parameters of ffwm_model.py:46-49 (capturable: the step counter lives on the
-        # device, so an optimizer step can be part of a captured hipGraph)
-        cap = self.device.type == "cuda"
+        # Adam hyper-parameters of ffwm_model.py:46-49 (capturable=True keeps the step counter on the
+        # device so that an optimizer step can sit inside a captured hipGraph; it costs ~10 ms per
+        # eager step, so it is only switched on for capture())
+        cap = bool(capturable) and self.device.type == "cuda"
         self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999), capturable=cap)
         self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
         self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
@@ -218,6 +228,8 @@ class FFWMTrainer(object):
         The batch is copied into static device buffers before every replay; the `titers` branch
         (< 20000 / >= 20000) is frozen at capture time -- re-capture when it flips."""
         assert self.device.type == "cuda" and self._graphs is None
+        if not all(g.get("capturable", False) for o in (self.opt_F, self.opt_G, self.opt_D) for g in o.param_groups):
+            raise RuntimeError("capture() needs FFWMTrainer(..., capturable=True)")
         self._static = {k: v.clone() for k, v in b.items()}
         sb = self._static
         self.red_D.set_overlap(False)

@@ -116,6 +116,49 @@ int ffwm_warp_backward(const void* feat, const void* flow, const void* grad_outp
                        void* grad_feat, void* grad_flow, int64_t B, int64_t C, int64_t Hi,
                        int64_t Wi, int64_t H, int64_t W, int flipcat, int dtype, void* stream);
 
+/* ---- batched spectral normalisation of conv weights (netG / netD) -----------------------------
+ * Replaces the per-layer hook of torch.nn.utils.spectral_norm that the reference wraps around every
+ * convolution of FFWM and MSDiscriminator (models/base_networks.py:5,218-264,381-413):
+ *     power_iterations x { v = normalize(W^T u); u = normalize(W v) };  sigma = u . (W v);
+ *     weight_sn = W / sigma                         with W = weight.view(rows = Cout, cols = -1)
+ * Three launches handle FFWM_SN_MAX_LAYERS layers (grids over (layer, chunk) pairs).  power_iterations
+ * is 0 or 1 (the hook's default).  u[rows] and v[cols] are
+ * updated IN PLACE (as the hook does in training mode) and copied to u_saved / v_saved, because a
+ * later forward call may overwrite them before this call's backward runs (the hook clones them for
+ * the same reason); power_iterations = 0 is the eval-mode behaviour (stored u, v).  wv[rows] is caller-provided scratch, sigma[1] receives sigma (needed by
+ * the backward).  The `layers` array lives in HOST memory; all pointers inside are device pointers. */
+#define FFWM_SN_MAX_LAYERS 32
+typedef struct {
+    const void* weight;   /* [rows, cols] */
+    void* u;              /* [rows]  in/out */
+    void* v;              /* [cols]  in/out */
+    void* wv;             /* [rows]  scratch */
+    void* weight_sn;      /* [rows, cols] out */
+    void* sigma;          /* [1] out */
+    void* u_saved;        /* [rows] out: the u this call normalised with (for its backward); may be NULL */
+    void* v_saved;        /* [cols] out: likewise */
+    int rows, cols;
+} ffwm_sn_layer;
+
+int ffwm_spectral_norm_forward(const ffwm_sn_layer* layers, int n_layers, int power_iterations,
+                               double eps, int dtype, void* stream);
+
+/* grad_weight = grad_weight_sn / sigma - (<grad_weight_sn, weight> / sigma^2) u v^T   (OVERWRITTEN;
+ * u, v are constants, exactly as in the hook, where the power iteration runs under no_grad). */
+typedef struct {
+    const void* weight;          /* [rows, cols] */
+    const void* u;               /* [rows] */
+    const void* v;               /* [cols] */
+    const void* sigma;           /* [1] */
+    const void* grad_weight_sn;  /* [rows, cols] */
+    void* grad_weight;           /* [rows, cols] out */
+    void* partials;              /* scratch, ceil(rows*cols / 8192) elements */
+    int rows, cols;
+} ffwm_sn_grad_layer;
+
+int ffwm_spectral_norm_backward(const ffwm_sn_grad_layer* layers, int n_layers, int dtype,
+                                void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded

@@ -529,7 +529,7 @@ def test_train_step_graph_replay_matches_eager(split):
     torch.backends.cudnn.benchmark = False
     batch = trainer.synthetic_batch(2, DEV, seed=3)
     te = trainer.FFWMTrainer(DEV, seed=0, ngf=16)
-    tg = trainer.FFWMTrainer(DEV, seed=0, ngf=16)
+    tg = trainer.FFWMTrainer(DEV, seed=0, ngf=16, capturable=True)
     if split:
         tg.world_size = 2          # take the DP capture path (the reducers are world-size-1 no-ops here)
     for _ in range(2):             # capture() runs 2 eager warm-up steps; the capture itself executes nothing
@@ -547,3 +547,45 @@ def test_train_step_graph_replay_matches_eager(split):
     pe = torch.cat([p.detach().flatten() for p in te.netG.parameters()])
     pg = torch.cat([p.detach().flatten() for p in tg.netG.parameters()])
     assert (pe - pg).abs().max().item() <= 5e-3
+
+
+# ------------------------------------------------------------------------- batched spectral norm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fused_spectral_norm_matches_torch_hooks(dtype):
+    """netD-like stack with torch.nn.utils.spectral_norm vs the same stack with the hooks replaced by
+    the batched HIP kernels: outputs, the in-place u / v updates and the weight_orig gradients, over
+    two training-mode calls followed by their backward (u, v of call 1 are overwritten by call 2
+    before call 1's backward runs) and an eval-mode call."""
+    import copy
+    import torch.nn as nn
+    from torch.nn.utils import spectral_norm
+    from ffwm_amd.spectral_norm import fuse_spectral_norm
+    torch.manual_seed(0)
+    ref = nn.Sequential(spectral_norm(nn.Conv2d(3, 16, 3, 2, 1)), nn.LeakyReLU(0.2),
+                        spectral_norm(nn.Conv2d(16, 40, 3, 1, 1)), nn.LeakyReLU(0.2),
+                        spectral_norm(nn.Conv2d(40, 70, 1)), nn.LeakyReLU(0.2),
+                        spectral_norm(nn.Conv2d(70, 5, 4, 2, 1))).to(DEV).to(dtype)
+    fus = copy.deepcopy(ref)
+    group = fuse_spectral_norm(fus)
+    assert len(group.layers) == 4
+    assert sorted(ref.state_dict().keys()) == sorted(fus.state_dict().keys())
+    x1 = torch.rand(2, 3, 16, 16, device=DEV, dtype=dtype)
+    x2 = torch.rand(2, 3, 16, 16, device=DEV, dtype=dtype)
+    tol = 2e-5 if dtype == torch.float32 else 1e-11
+    outs = []
+    for net in (ref, fus):
+        net.train()
+        y1 = net(x1)
+        y2 = net(x2)
+        (y1.square().mean() + 3 * y2.mean()).backward()
+        net.eval()
+        with torch.no_grad():
+            y3 = net(x1)
+        outs.append((y1, y2, y3))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= tol * (1 + a.abs().max().item())
+    sr, sf = ref.state_dict(), fus.state_dict()
+    for k in sr:
+        assert (sr[k] - sf[k]).abs().max().item() <= tol, k
+    for (n, p), (_, q) in zip(ref.named_parameters(), fus.named_parameters()):
+        assert (p.grad - q.grad).abs().max().item() <= tol * (1 + p.grad.abs().max().item()), n
