@@ -67,7 +67,7 @@ def part_grids(lm_F):
 
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
-                 warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None):
+                 warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True):
         self.device = torch.device(device)
         self.titers = titers
         torch.manual_seed(seed)
@@ -103,6 +103,7 @@ class FFWMTrainer(object):
         self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
         self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
         self.world_size = world_size
+        self.batched_losses = batched_losses
         self._graphs = None
         self._static = None
         self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
@@ -117,11 +118,47 @@ class FFWMTrainer(object):
             fy = self.vgg(y)
         return sum(w * F.l1_loss(fx[k], fy[k]) for k, w in zip(PRC_LAYERS, PRC_WEIGHTS))
 
+    def perceptual_many(self, pairs):
+        """[perceptual(x_i, y_i) for i] for pairs that share one shape, with ONE VGG pass over the
+        concatenated x's and one over the y's.  VGG19 has no batch statistics, so every sample's
+        features are those of a separate call; only the number of launches changes."""
+        n = len(pairs)
+        fx = self.vgg(torch.cat([p[0] for p in pairs], 0))
+        with torch.no_grad():
+            fy = self.vgg(torch.cat([p[1] for p in pairs], 0))
+        total = 0
+        for k, w in zip(PRC_LAYERS, PRC_WEIGHTS):
+            total = total + w * (fx[k] - fy[k]).abs().reshape(n, -1).mean(1)      # the L1 mean of each pair
+        return total
+
     def identity(self, out, gt):
         _, fc_o, pool_o = self.lightCNN(out.mean(1, keepdim=True))
         with torch.no_grad():
             _, fc_g, pool_g = self.lightCNN(gt.mean(1, keepdim=True))
         return F.l1_loss(fc_o, fc_g) + F.l1_loss(pool_o, pool_g)
+
+    def identity_many(self, outs, gt, weights):
+        """sum_i weight_i * identity(out_i, gt): the ground-truth features are extracted once, and an
+        output that appears several times (warm-up branch: the guided-filter output IS fake128) is run
+        through LightCNN once.  LightCNN has no batch statistics either."""
+        uniq, wsum = [], []
+        for o, w in zip(outs, weights):
+            for i, u in enumerate(uniq):
+                if u is o:
+                    wsum[i] += w
+                    break
+            else:
+                uniq.append(o)
+                wsum.append(w)
+        with torch.no_grad():
+            _, fc_g, pool_g = self.lightCNN(gt.mean(1, keepdim=True))
+        n, b = len(uniq), gt.size(0)
+        _, fc_o, pool_o = self.lightCNN(torch.cat([u.mean(1, keepdim=True) for u in uniq], 0))
+        total = 0
+        for i, w in enumerate(wsum):
+            sl = slice(i * b, (i + 1) * b)
+            total = total + w * (F.l1_loss(fc_o[sl], fc_g) + F.l1_loss(pool_o[sl], pool_g))
+        return total
 
     def illumination(self, flows_B, fakes, img_S, mask_S):
         """MSL1Loss (losses.py:130-157): warp each generated scale back with flowNetB and compare
@@ -171,15 +208,26 @@ class FFWMTrainer(object):
             gf64 = self.gf[64](self.fake64, img_F64)
             gf32 = self.gf[32](self.fake32, img_F32)
         pairs = ((gf128, img_F, mask_F, 1.0), (gf64, img_F64, mask64, 1.0), (gf32, img_F32, mask32, 1.5))
-        loss_prc = sum(w * self.perceptual(x * m, y * m) for x, y, m, w in pairs)
+        (el, elt), (er, ert), (no, nog), (mo, mog) = self.parts
+        if self.batched_losses and el.shape == gf32.shape:
+            # result-preserving launch diet: the 32 x 32 scale and the four 32 x 32 part crops share
+            # one VGG pass (five pairs per call instead of five calls)
+            p32 = self.perceptual_many([(gf32 * mask32, img_F32 * mask32), (el, elt), (er, ert), (mo, mog), (no, nog)])
+            loss_prc = self.perceptual(gf128 * mask_F, img_F * mask_F) + self.perceptual(gf64 * mask64, img_F64 * mask64) + \
+                1.5 * p32[0]
+            loss_fc = 2 * (p32[1] + p32[2]) + p32[3] + p32[4]
+        else:
+            loss_prc = sum(w * self.perceptual(x * m, y * m) for x, y, m, w in pairs)
+            loss_fc = 2 * (self.perceptual(el, elt) + self.perceptual(er, ert)) + self.perceptual(mo, mog) + \
+                self.perceptual(no, nog)
         loss_l1 = sum(w * F.l1_loss(x * m, y * m) for x, y, m, w in pairs) * 5
         loss_illu = self.illumination(self.flows_B, (self.fake128, self.fake64, self.fake32), b["img_S"],
                                       b["mask_S"]) * 15
-        loss_iden = self.identity(self.fake128, img_F) * 0.5 + self.identity(gf128, img_F) * 1
+        if self.batched_losses:
+            loss_iden = self.identity_many((self.fake128, gf128), img_F, (0.5, 1.0))
+        else:
+            loss_iden = self.identity(self.fake128, img_F) * 0.5 + self.identity(gf128, img_F) * 1
         loss_adv = self.lsgan(self.netD(self.img_GF128 * mask_F), True) * 0.1
-        (el, elt), (er, ert), (no, nog), (mo, mog) = self.parts
-        loss_fc = 2 * (self.perceptual(el, elt) + self.perceptual(er, ert)) + self.perceptual(mo, mog) + \
-            self.perceptual(no, nog)
         self.loss_G = loss_iden + loss_l1 + loss_prc + loss_illu + loss_fc + loss_adv
         self.losses = {"G": self.loss_G, "l1": loss_l1, "iden": loss_iden, "illu": loss_illu, "adv": loss_adv,
                        "prc": loss_prc, "fc": loss_fc}

@@ -43,3 +43,24 @@ def test_train_step_updates_the_right_parameters():
     t.titers = 20000
     t.step(batch)
     assert all(torch.isfinite(torch.tensor(v)) for v in t.loss_values().values())
+
+
+def test_batched_loss_passes_are_result_preserving():
+    """One VGG pass over the five 32 x 32 pairs / one LightCNN pass over the distinct outputs must give
+    the losses of the separate calls (no batch statistics in either net)."""
+    from ffwm_amd import trainer
+    torch.set_num_threads(8)
+    vals = []
+    for batched in (False, True):
+        t = trainer.FFWMTrainer("cpu", seed=0, titers=0, warp=torch_refs.warp, warp_flipcat=torch_refs.warp_flipcat,
+                                ngf=8, batched_losses=batched)
+        batch = trainer.synthetic_batch(1, "cpu", seed=1)
+        batch = {k: torch.cat((v, v.flip(-1) if v.dtype.is_floating_point else v), 0) for k, v in batch.items()}
+        t.step(batch)
+        vals.append(t.loss_values())
+        t.titers = 20000
+        t.step(batch)
+        vals.append(t.loss_values())
+    for a, b in ((vals[0], vals[2]), (vals[1], vals[3])):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-4 * (1 + abs(a[k])), (k, a[k], b[k])
