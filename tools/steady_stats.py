@@ -1,0 +1,50 @@
+"""Aggregate a rocprofv3 kernel trace over its steady-state tail.
+
+    python tools/steady_stats.py <kernel_trace.csv> <out.csv> [--window-ms 300] [--header "text"]
+
+MIOpen's find pass, JIT compiles and warm-up pollute whole-run statistics; this keeps only the
+dispatches that START inside the last `window` milliseconds of the trace and writes per-kernel
+calls / total / average (the same columns as rocprofv3's *_kernel_stats.csv) plus VGPR and LDS use."""
+import argparse
+import csv
+import collections
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("out")
+    ap.add_argument("--window-ms", type=float, default=300.0)
+    ap.add_argument("--header", default="")
+    a = ap.parse_args()
+    rows = []
+    with open(a.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                         r.get("VGPR_Count", r.get("Arch_VGPR_Count", "")), r.get("LDS_Block_Size", "")))
+    t_end = max(r[1] for r in rows)
+    t0 = t_end - int(a.window_ms * 1e6)
+    sel = [r for r in rows if r[0] >= t0]
+    agg = collections.OrderedDict()
+    busy = 0
+    for s, e, name, vg, lds in sel:
+        d = agg.setdefault(name, [0, 0, vg, lds])
+        d[0] += 1
+        d[1] += e - s
+        busy += e - s
+    short = sum(1 for s, e, *_ in sel if e - s < 10000)
+    total = sum(v[1] for v in agg.values())
+    with open(a.out, "w") as f:
+        if a.header:
+            f.write("# %s\n" % a.header)
+        f.write("# steady-state window = last %.0f ms of the trace: %d dispatches, GPU busy %.1f ms (%.0f%% of the window), "
+                "%d dispatches shorter than 10 us\n" % (a.window_ms, len(sel), busy / 1e6, 100.0 * busy / (a.window_ms * 1e6), short))
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "VGPR", "LDS"])
+        for name, (calls, ns, vg, lds) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([name[:160], calls, ns, ns // calls, "%.2f" % (100.0 * ns / total), vg, lds])
+    print("window %.0f ms: %d dispatches, busy %.1f ms" % (a.window_ms, len(sel), busy / 1e6))
+
+
+if __name__ == "__main__":
+    main()
