@@ -98,6 +98,18 @@ def timed(step_fn, steps, warmup, world):
     return dt, rows
 
 
+def pmc_traffic():
+    """HBM-side bytes per dispatch measured with rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
+    runs of this same command, FETCH_SIZE doubled per the gfx950 calibration) -- profiles/r01_pmc_traffic.json.
+    PMC counters cannot be read from inside the process, so the committed measurement is attached."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+    except (OSError, ValueError):
+        return {}
+
+
 def kernel_rows(rows, tag):
     out = []
     for name, r in sorted(rows.items(), key=lambda kv: -kv[1]["total_ms"]):
@@ -307,8 +319,13 @@ def main():
         inrun = kernel_rows(rows, "timed region")
         if inrun:
             top = inrun[0]
+            pmc = pmc_traffic().get(top["kernel"])
             result["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"], "peak": HBM_PEAK / 1e9,
-                                  "unit": "GB/s", "frac": top["frac_hbm_peak"], "traffic": None,
+                                  "unit": "GB/s", "frac": top["frac_hbm_peak"],
+                                  "traffic": pmc["traffic_bytes"] if pmc else None,
+                                  "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                                    "of this command; bytes per launch, FETCH_SIZE x2 per the gfx950 calibration)"
+                                  if pmc else None,
                                   "avg_us": top["avg_us"], "alg_MB_per_launch": top["alg_MB"],
                                   "launches": top["launches"],
                                   "note": "hand-written HIP kernel with the largest total time in one step; HIP events "
@@ -319,6 +336,10 @@ def main():
         result["kernels"] = inrun
         if not args.no_kernels:
             result["kernels"] = inrun + standalone_kernels()
+        traffic = pmc_traffic()
+        for row in result["kernels"]:
+            if row["kernel"] in traffic and (row["where"] == "timed region" or not row["kernel"].startswith("warp")):
+                row["pmc_traffic_MB"] = round(traffic[row["kernel"]]["traffic_bytes"] / 1e6, 3)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_train_baseline(args.titers) if args.workload in ("train",) \
