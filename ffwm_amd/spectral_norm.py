@@ -35,15 +35,7 @@ class _SnGradLayer(ctypes.Structure):
 
 
 def _bind():
-    lib = _lib.load()
-    if not getattr(lib, "_sn_bound", False):
-        lib.ffwm_spectral_norm_forward.argtypes = [ctypes.POINTER(_SnLayer), ctypes.c_int, ctypes.c_int, ctypes.c_double,
-                                                   ctypes.c_int, ctypes.c_void_p]
-        lib.ffwm_spectral_norm_forward.restype = ctypes.c_int
-        lib.ffwm_spectral_norm_backward.argtypes = [ctypes.POINTER(_SnGradLayer), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        lib.ffwm_spectral_norm_backward.restype = ctypes.c_int
-        lib._sn_bound = True
-    return lib
+    return _lib.load()
 
 
 _DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
@@ -69,7 +61,7 @@ class _SnGroupFunction(Function):
             a.v_saved = base + group.v_off[i] * esz
             a.sigma = base + (group.uv_total + i) * esz
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.ffwm_spectral_norm_forward(arr, n, group.n_power_iterations if training else 0, group.eps,
+        _lib.check(lib.ffwm_spectral_norm_forward(ctypes.cast(arr, ctypes.c_void_p), n, group.n_power_iterations if training else 0, group.eps,
                                                   _DT[dt], stream), "ffwm_spectral_norm_forward")
         ctx.save_for_backward(*weights)
         ctx.group, ctx.saved = group, saved
@@ -106,7 +98,7 @@ class _SnGroupFunction(Function):
             k += 1
         if k:
             stream = torch.cuda.current_stream(saved.device).cuda_stream
-            _lib.check(lib.ffwm_spectral_norm_backward(arr, k, _DT[saved.dtype], stream), "ffwm_spectral_norm_backward")
+            _lib.check(lib.ffwm_spectral_norm_backward(ctypes.cast(arr, ctypes.c_void_p), k, _DT[saved.dtype], stream), "ffwm_spectral_norm_backward")
         return (None, None) + tuple(gws)
 
 

@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--flow", type=float, default=2.0, help="block_extractor flow ~ U[-f, f) px")
     ap.add_argument("--B", type=int, default=4)
+    ap.add_argument("--warp-flow", default="random", choices=["random", "smooth", "const"],
+                    help="warp sampling grid: random = U[-1.1,1.1) per pixel (worst case: every lane its own cache line), "
+                         "smooth = identity grid + a few pixels of low-frequency displacement (a trained FlowNet), "
+                         "const = every pixel samples the image centre (an untrained FlowNet, tanh(~0))")
     args = ap.parse_args()
     for kv in args.opt:
         k, v = kv.split("=")
@@ -114,19 +118,31 @@ def main():
         o = torch.empty_like(in1)
         results += run("big resample2d fwd ks=4 [8,64,512,512]", lambda: ops.resample2d_forward(in1, in2, 4, 1, out=o), args.reps)
         del in1, in2, o
+    def make_flow(b, size):
+        if args.warp_flow == "random":
+            return (torch.rand(b, 2, size, size, generator=g) * 2.2 - 1.1).to(dev)
+        if args.warp_flow == "const":
+            return torch.zeros(b, 2, size, size, device=dev) + 1e-3
+        lin = (torch.arange(size, dtype=torch.float32) + 0.5) / size * 2 - 1
+        yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+        amp = 6.0 / size                                          # ~3 pixels of displacement
+        fx = xx + amp * torch.sin(3.1 * yy + 0.3) * torch.cos(2.3 * xx)
+        fy = yy + amp * torch.cos(2.7 * xx - 0.2) * torch.sin(1.9 * yy)
+        return torch.stack((fx, fy), 0).unsqueeze(0).repeat(b, 1, 1, 1).contiguous().to(dev)
+
     if want("warp"):
         for (C, S) in ((128, 32), (64, 64), (64, 128)):
             feat = torch.rand(8, C, S, S, generator=g).to(dev)
-            fl = (torch.rand(8, 2, S, S, generator=g) * 2.2 - 1.1).to(dev)
+            fl = make_flow(8, S)
             o = torch.empty(8, 2 * C, S, S, device=dev)
             go = torch.rand(8, 2 * C, S, S, device=dev)
             gfe, gfl = torch.zeros_like(feat), torch.zeros_like(fl)
-            results += run("netG warp+flip+cat fwd [8,%d,%d,%d]" % (C, S, S), lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
+            results += run("netG warp+flip+cat fwd [8,%d,%d,%d] flow=%s" % (C, S, S, args.warp_flow), lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
             results += run("netG warp+flip+cat bwd [8,%d,%d,%d]" % (C, S, S), lambda: ops.warp_backward(feat, fl, go, True, gfe, gfl), args.reps)
         feat = torch.rand(32, 64, 256, 256, generator=g).to(dev)
-        fl = (torch.rand(32, 2, 256, 256, generator=g) * 2.2 - 1.1).to(dev)
+        fl = make_flow(32, 256)
         o = torch.empty(32, 128, 256, 256, device=dev)
-        results += run("big warp+flip+cat fwd [32,64,256,256]", lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
+        results += run("big warp+flip+cat fwd [32,64,256,256] flow=%s" % args.warp_flow, lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
         del feat, fl, o
     for r in results:
         print(json.dumps(r))
