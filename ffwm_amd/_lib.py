@@ -31,6 +31,8 @@ _SIGNATURES = {
     # (host array of ffwm_sn_layer / ffwm_sn_grad_layer structs, see ffwm_amd/spectral_norm.py)
     "ffwm_spectral_norm_forward": [_p, _i, _i, ctypes.c_double, _i, _p],
     "ffwm_spectral_norm_backward": [_p, _i, _i, _p],
+    "ffwm_guided_filter_forward": [_p, _p, _p, _p, _i64, _i64, _i64, _i, ctypes.c_double, _i, _p],
+    "ffwm_guided_filter_backward": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
     "ffwm_prof_enable": [_i],
     "ffwm_prof_collect": [],
     "ffwm_prof_get": [_i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),

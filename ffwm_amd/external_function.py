@@ -178,3 +178,47 @@ class WarpFlipCat(nn.Module):
 
     def forward(self, feat, flow):
         return WarpFunction.apply(feat, flow, True)
+
+
+class GuidedFilterFunction(Function):
+    """apply(x[B,C,H,W], y[B,C,H,W], r, eps) -> GuidedFilter(r, eps)(x, y) of the reference
+    (models/external_function.py:239-277), one launch forward and one backward.  y is data (FFWM filters
+    the generated image against the ground truth, models/ffwm_model.py:81): it gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, y, r, eps):
+        _require_cuda(x)
+        x = x.contiguous()
+        y = y.contiguous()
+        out, saved = ops.guided_filter_forward(x, y, r, eps)
+        ctx.save_for_backward(x, y, saved)
+        ctx.r = r
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("GuidedFilterFunction: no gradient for y (the guidance target is data)")
+        x, y, saved = ctx.saved_tensors
+        gx = ops.guided_filter_backward(x, y, saved, grad_output.contiguous(), ctx.r) if ctx.needs_input_grad[0] else None
+        return gx, None, None, None
+
+
+class GuidedFilter(nn.Module):
+    """Same constructor and call as the reference's GuidedFilter(r, eps=1e-8)(x, y)
+    (models/external_function.py:239-277) for c_x == c_y, H, W <= 128."""
+
+    def __init__(self, r, eps=1e-8):
+        super().__init__()
+        self.r = r
+        self.eps = eps
+
+    def forward(self, x, y):
+        n_x, c_x, h_x, w_x = x.size()
+        n_y, c_y, h_y, w_y = y.size()
+        assert n_x == n_y
+        assert h_x == h_y and w_x == w_y
+        assert h_x > 2 * self.r + 1 and w_x > 2 * self.r + 1
+        if c_x != c_y:
+            raise NotImplementedError("GuidedFilter: the HIP kernel needs c_x == c_y (FFWM's only usage)")
+        return GuidedFilterFunction.apply(x, y, self.r, self.eps)

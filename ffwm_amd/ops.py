@@ -225,3 +225,36 @@ def warp_backward(feat, flow, grad_output, flipcat=False, grad_feat=None, grad_f
             _ptr(feat), _ptr(flow), _ptr(grad_output), _ptr(grad_feat), _ptr(grad_flow), B, C, Hi, Wi, H, W,
             1 if flipcat else 0, _dtype_code(feat), stream), "ffwm_warp_backward")
     return grad_feat, grad_flow
+
+
+# ---------------------------------------------------------------- guided filter
+def guided_filter_forward(x, y, r, eps=1e-8):
+    """-> (out, saved); GuidedFilter(r, eps)(x, y), reference external_function.py:239-277."""
+    _check("guided_filter_forward", x, y)
+    if x.shape != y.shape:
+        raise ValueError("guided_filter_forward: x and y must have the same shape (c_x == c_y), got %s vs %s"
+                         % (tuple(x.shape), tuple(y.shape)))
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    saved = x.new_empty((5, B, C, H, W))
+    if out.numel() == 0:
+        return out, saved
+    with _on_device(x) as stream:
+        _lib.check(_lib.load().ffwm_guided_filter_forward(
+            _ptr(x), _ptr(y), _ptr(out), _ptr(saved), B * C, H, W, int(r), float(eps), _dtype_code(x), stream),
+            "ffwm_guided_filter_forward")
+    return out, saved
+
+
+def guided_filter_backward(x, y, saved, grad_output, r):
+    """-> grad_x (y is data and gets no gradient)."""
+    _check("guided_filter_backward", x, y, grad_output)
+    B, C, H, W = x.shape
+    gx = torch.empty_like(x)
+    if gx.numel() == 0:
+        return gx
+    with _on_device(x) as stream:
+        _lib.check(_lib.load().ffwm_guided_filter_backward(
+            _ptr(x), _ptr(y), _ptr(saved), _ptr(grad_output), _ptr(gx), B * C, H, W, int(r), _dtype_code(x), stream),
+            "ffwm_guided_filter_backward")
+    return gx

@@ -159,6 +159,21 @@ typedef struct {
 int ffwm_spectral_norm_backward(const ffwm_sn_grad_layer* layers, int n_layers, int dtype,
                                 void* stream);
 
+/* ---- guided filter (illumination-adaption path) ------------------------------------------------
+ * out = GuidedFilter(r, eps)(x, y) of models/external_function.py:239-277 (box filters as cumsum
+ * differences, :164-193), per [H, W] plane; x, y, out are [planes = B*C, H, W] contiguous with
+ * c_x == c_y (the only way FFWM calls it: models/ffwm_model.py:57-59,81,104-105).  H, W <= 128,
+ * H > 2r+1, W > 2r+1.  `saved` [5, planes, H, W] receives mean_x, mean_y, A, var_x+eps, mean_A for the
+ * backward.  One launch (the PyTorch module issues ~100). */
+int ffwm_guided_filter_forward(const void* x, const void* y, void* output, void* saved,
+                               int64_t planes, int64_t H, int64_t W, int r, double eps, int dtype,
+                               void* stream);
+
+/* grad_x (OVERWRITTEN) of the above; y is data (the ground-truth image) and gets no gradient. */
+int ffwm_guided_filter_backward(const void* x, const void* y, const void* saved,
+                                const void* grad_output, void* grad_x, int64_t planes, int64_t H,
+                                int64_t W, int r, int dtype, void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded

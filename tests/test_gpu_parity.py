@@ -589,3 +589,49 @@ def test_fused_spectral_norm_matches_torch_hooks(dtype):
         assert (sr[k] - sf[k]).abs().max().item() <= tol, k
     for (n, p), (_, q) in zip(ref.named_parameters(), fus.named_parameters()):
         assert (p.grad - q.grad).abs().max().item() <= tol * (1 + p.grad.abs().max().item()), n
+
+
+# ------------------------------------------------------------------------- guided filter
+GF_CASES = [
+    # (B, C, H, W, r, seed)
+    (2, 3, 128, 128, 32, 0),     # gf128 of FFWMModel (ffwm_model.py:57,81)
+    (2, 3, 64, 64, 16, 1),       # gf64
+    (1, 3, 32, 32, 8, 2),        # gf32
+    (1, 2, 37, 61, 5, 3),        # ragged, non-square
+    (1, 1, 9, 12, 3, 4),         # the smallest planes the reference accepts for r = 3 (H > 2r+1)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", GF_CASES)
+def test_guided_filter_matches_torch_restatement(case, dtype):
+    """HIP guided filter vs ffwm_amd.nets.GuidedFilter -- the PyTorch restatement of the reference module that
+    tests/test_nets_golden.py pins to the reference's own output -- evaluated on the CPU in float64.
+    fp32 tolerance: E[xy] - E[x]E[y] cancels ~2 digits and A = cov / (var + 1e-8) amplifies it."""
+    from ffwm_amd import nets
+    from ffwm_amd.external_function import GuidedFilter
+    B, C, H, W, r, seed = case
+    if dtype == torch.float64 and 2 * H * (W + 1) * 8 > 160 * 1024:
+        pytest.skip("a float64 plane pair of this size does not fit LDS")
+    g = _gen(seed)
+    x = torch.rand(B, C, H, W, generator=g, dtype=torch.float64)
+    y = torch.rand(B, C, H, W, generator=g, dtype=torch.float64)
+    go = torch.rand(B, C, H, W, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    ref = nets.GuidedFilter(r)(xr, y)
+    ref.backward(go)
+    xd = x.to(DEV, dtype).requires_grad_(True)
+    out = GuidedFilter(r)(xd, y.to(DEV, dtype))
+    out.backward(go.to(DEV, dtype))
+    tol = 2e-4 if dtype == torch.float32 else 1e-9
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= tol * (1 + ref.abs().max().item())
+    assert (xd.grad.cpu().double() - xr.grad).abs().max().item() <= tol * (1 + xr.grad.abs().max().item())
+
+
+def test_guided_filter_rejects_what_the_reference_rejects():
+    from ffwm_amd import ops
+    x = torch.rand(1, 1, 8, 8, device=DEV)
+    with pytest.raises(Exception):
+        ops.guided_filter_forward(x, x, 4)          # H > 2r+1 violated
+    with pytest.raises(NotImplementedError):
+        ops.guided_filter_forward(x.cpu(), x.cpu(), 1)
