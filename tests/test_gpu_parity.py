@@ -635,3 +635,63 @@ def test_guided_filter_rejects_what_the_reference_rejects():
         ops.guided_filter_forward(x, x, 4)          # H > 2r+1 violated
     with pytest.raises(NotImplementedError):
         ops.guided_filter_forward(x.cpu(), x.cpu(), 1)
+
+
+# ------------------------------------------------------------------------- the reference's real caller of a3-a5
+def test_affine_regularization_loss_matches_reference_golden():
+    """AffineRegularizationLoss / MultiAffineRegularizationLoss on the HIP ops against the value the
+    reference's own classes produced (tests/golden/make_golden.py: the imported reference module with the
+    CUDA ops replaced by their proven CPU identities).  The loss is a sum of squared residuals of grids of
+    magnitude ~128 evaluated in fp32 -- by the reference too -- hence the relative 2e-3."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fill
+    from ffwm_amd.losses import AffineRegularizationLoss, MultiAffineRegularizationLoss
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules.pt"))["affine_reg"]
+    for kz, s in ((3, 32), (5, 64), (7, 128)):
+        m = AffineRegularizationLoss(kz)
+        assert torch.equal(m.kernel, gold["kz%d" % kz]["kernel"])
+        flow = fill.flow_field(2, s, s, "reg_flow%d" % s).to(DEV).requires_grad_(True)
+        loss = m(flow)
+        ref = float(gold["kz%d" % kz]["loss"])
+        assert abs(float(loss) - ref) <= 2e-3 * (1 + abs(ref)), (kz, float(loss), ref)
+        loss.backward()                                   # the ops' backward kernels at the reference's real sizes
+        assert torch.isfinite(flow.grad).all() and float(flow.grad.abs().max()) > 0
+    multi = MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3})
+    assert multi.layers == gold["multi_layers"].tolist()
+    flows = [fill.flow_field(2, s, s, "reg_flow%d" % s).to(DEV) for s in (128, 64, 32)]
+    ref = float(gold["multi"])
+    got = float(multi(flows[::-1]))
+    assert abs(got - ref) <= 2e-3 * (1 + abs(ref)), (got, ref)
+
+
+def test_affine_regularization_gradient_matches_identity_ops():
+    """d(loss)/d(flow) through the HIP backward kernels == through pixel_shuffle / unfold autograd."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fill
+    from ffwm_amd.losses import AffineRegularizationLoss
+
+    class _Reshape(torch.nn.Module):
+        def forward(self, x, k):
+            return F.pixel_shuffle(x, k)
+
+    class _Extract(torch.nn.Module):
+        def __init__(self, k):
+            super().__init__()
+            self.k = k
+
+        def forward(self, grid, f):
+            k = self.k
+            b, _, h, w = f.shape
+            return F.unfold(grid, k).view(b, k, k, h, w).permute(0, 3, 1, 4, 2).reshape(b, 1, h * k, w * k)
+
+    for kz, s in ((3, 32), (5, 64)):
+        flow0 = fill.flow_field(2, s, s, "reg_flow%d" % s).double()
+        a = flow0.to(DEV).requires_grad_(True)
+        AffineRegularizationLoss(kz)(a).backward()
+        ref_m = AffineRegularizationLoss(kz)
+        ref_m.reshape, ref_m.extractor = _Reshape(), _Extract(kz)
+        b = flow0.clone().requires_grad_(True)
+        ref_m(b).backward()
+        assert (a.grad.cpu() - b.grad).abs().max().item() <= 1e-9 * (1 + b.grad.abs().max().item())
