@@ -107,6 +107,6 @@ def prof_collect():
 
 def set_option(key, value):
     rc = load().ffwm_set_option(key.encode(), int(value))
-    if rc < 0 and key not in ("be_fwd_variant", "be_bwd_variant", "channel_slab", "xcd_remap", "ablate", "rows_per_thread", "scatter_variant", "be_bwd_halo", "be_bwd_rows"):
+    if rc < 0 and key not in ("be_fwd_variant", "be_bwd_variant", "channel_slab", "xcd_remap", "ablate", "rows_per_thread", "scatter_variant", "be_bwd_halo", "be_bwd_rows", "warp_fwd_variant"):
         check(rc, "ffwm_set_option")
     return rc

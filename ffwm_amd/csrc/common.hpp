@@ -26,6 +26,7 @@ struct Options {
     int xcd_remap = 1;
     int scatter_variant = 0;  // backward scatters: 0 = auto (LDS-resident plane when it fits), 1 = global atomics
     int rows_per_thread = 0;  // block_extractor LDS kernels: 0 = auto, 1 / 2 / 4
+    int warp_fwd_variant = 0; // warp forward: 0 = auto, 1 = direct gathers, 2 = LDS-staged tiles
     int be_bwd_halo = 0;      // block_extractor owned-tile backward: halo in pixels (<= 4 -> 4 (default), else 8)
     int be_bwd_rows = 0;      // ... region height: 32 (default) or 64 rows
     int ablate = 0;           // bench-only ablation bits (1 = skip source fetch, 2 = skip stores)

@@ -185,6 +185,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "rows_per_thread")) slot = &o.rows_per_thread;
     else if (!strcmp(key, "scatter_variant")) slot = &o.scatter_variant;
     else if (!strcmp(key, "be_bwd_halo")) slot = &o.be_bwd_halo;
+    else if (!strcmp(key, "warp_fwd_variant")) slot = &o.warp_fwd_variant;
     else if (!strcmp(key, "be_bwd_rows")) slot = &o.be_bwd_rows;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);

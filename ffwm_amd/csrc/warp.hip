@@ -104,6 +104,210 @@ warp_fwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, T* __res
     }
 }
 
+// ------------------------------------------------------------------------------ forward, LDS-staged
+// The direct kernel above issues 4 dword gathers + 1-2 dword stores per pixel and channel: with 4 bytes per
+// lane every memory instruction costs a full address-processing slot, so it is instruction-rate-bound
+// (3.4 TB/s on a smooth flow, 1.2 TB/s on a random one) long before HBM is.  Here a block owns a 64 x 16
+// output tile; it reduces the bounding box of the tile's sampling positions (wave shuffles + one LDS hop),
+// and if the box fits 128 x 32 source cells it copies the ZERO-PADDED box of each channel global -> LDS with
+// 16-byte row-contiguous loads (the copy of channel c+1 overlaps the arithmetic of channel c), reads the
+// four corners from LDS (one address + immediates), and stores 4 consecutive pixels per lane as one
+// dwordx4 (direct) + one dwordx4 (mirrored, for the fused flip + cat).  A tile whose box is too large
+// (flow zooming out by more than ~2x, or random) falls back to direct gathers -- a block-uniform choice.
+constexpr int kWlTileX = 64, kWlTileY = 16, kWlPix = 4, kWlRows = 32, kWlCols = 128;
+
+template <bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_fwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ flow, float* __restrict__ out, int C,
+                    int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+    using T = float;
+    constexpr int NW = kBlock / kWave;
+    constexpr unsigned E = sizeof(T);
+    __shared__ __attribute__((aligned(16))) T tile[2][kWlRows * kWlCols];
+    __shared__ int red[4][NW];
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    t /= tiles_y;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int y = ty * kWlTileY + (threadIdx.x >> 4);
+    const int xb = tx * kWlTileX + (threadIdx.x & 15) * kWlPix;
+    const bool yin = y < H;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * plane, static_cast<unsigned>(2 * plane * E));
+
+    // ---- per-pixel corners (ATen grid_sampler_2d, bilinear / zeros / align_corners=False)
+    int x0[kWlPix], y0[kWlPix];
+    T w[kWlPix][4];
+    bool live[kWlPix];
+    int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < kWlPix; ++k) {
+        const int x = xb + k;
+        const bool pin = yin && x < W;
+        const unsigned fo = pin ? (static_cast<unsigned>(y) * W + x) * E : kOob;
+        const T gx = buf_ld<T>(rfl, fo), gy = buf_ld<T>(rfl, pin ? fo + static_cast<unsigned>(plane * E) : kOob);
+        Corners<T> cn;
+        make_corners<T>(cn, gx, gy, Hi, Wi);
+        const bool any = pin && (cn.valid[0] || cn.valid[1] || cn.valid[2] || cn.valid[3]);
+        live[k] = any;
+        // a pixel with a valid corner has floor(ix) in [-1, Wi-1], floor(iy) in [-1, Hi-1]
+        const T ix = ((gx + 1) * static_cast<T>(Wi) - 1) / 2, iy = ((gy + 1) * static_cast<T>(Hi) - 1) / 2;
+        x0[k] = any ? static_cast<int>(floor_t(ix)) : 0;
+        y0[k] = any ? static_cast<int>(floor_t(iy)) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[k][q] = any ? ((q & 1) ? cn.dxw[1] : cn.dxw[0]) * ((q >> 1) ? cn.dyw[1] : cn.dyw[0]) : static_cast<T>(0);
+        if (any) {
+            umin = min(umin, x0[k]); umax = max(umax, x0[k] + 1);
+            vmin = min(vmin, y0[k]); vmax = max(vmax, y0[k] + 1);
+        }
+    }
+    umin = wave_min(umin); umax = wave_max(umax); vmin = wave_min(vmin); vmax = wave_max(vmax);
+    if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        umin = min(umin, red[0][k]); umax = max(umax, red[1][k]);
+        vmin = min(vmin, red[2][k]); vmax = max(vmax, red[3][k]);
+    }
+    const bool empty = umin > umax;                    // no pixel of the tile samples inside the image
+    const int bx0 = empty ? 0 : (umin & ~3), by0 = empty ? 0 : vmin;          // 16-byte aligned box origin
+    const int bw = empty ? 0 : umax - bx0 + 1, bh = empty ? 0 : vmax - by0 + 1;
+    const bool use_lds = bw <= kWlCols && bh <= kWlRows;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int Co = FLIP ? 2 * C : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * E);
+    const unsigned obytes = static_cast<unsigned>(plane * E);
+    const T* fp = feat + (static_cast<size_t>(b) * C + c0) * iplane;
+    T* op = out + (static_cast<size_t>(b) * Co + c0) * plane;
+    const size_t flip_planes = static_cast<size_t>(C) * plane;
+    const bool full = yin && xb + kWlPix <= W;         // all 4 pixels inside the row: one dwordx4 store
+    const unsigned o_direct = (static_cast<unsigned>(y) * W + xb) * E;
+    const unsigned o_flip = (static_cast<unsigned>(y) * W + (W - kWlPix - xb)) * E;
+
+    auto store4 = [&](T* plane_out, const T (&v)[kWlPix]) {
+        const rsrc_t ro = make_rsrc(plane_out, obytes);
+        if (full) {
+            ElemRow<T, kWlPix> r;
+#pragma unroll
+            for (int k = 0; k < kWlPix; ++k) r.v[k] = v[k];
+            buf_store_row<T, kWlPix>(ro, o_direct, r);
+            if (FLIP) {
+                ElemRow<T, kWlPix> m;
+#pragma unroll
+                for (int k = 0; k < kWlPix; ++k) m.v[k] = v[kWlPix - 1 - k];
+                buf_store_row<T, kWlPix>(make_rsrc(plane_out + flip_planes, obytes), o_flip, m);
+            }
+        } else if (yin) {
+#pragma unroll
+            for (int k = 0; k < kWlPix; ++k) {
+                if (xb + k < W) {
+                    ElemRow<T, 1> r;
+                    r.v[0] = v[k];
+                    buf_store_row<T, 1>(ro, (static_cast<unsigned>(y) * W + xb + k) * E, r);
+                    if (FLIP)
+                        buf_store_row<T, 1>(make_rsrc(plane_out + flip_planes, obytes),
+                                            (static_cast<unsigned>(y) * W + (W - 1 - xb - k)) * E, r);
+                }
+            }
+        }
+    };
+
+    if (use_lds) {
+        // staging map: chunk = 4 consecutive columns; thread handles box row (tid >> 5) + 8 i, columns (tid & 31) * 4
+        constexpr int NCH = kWlRows * kWlCols / 4 / kBlock;       // 4 chunks per thread
+        unsigned goff[NCH];
+        unsigned keep[NCH];                                       // per-element validity bits of the chunk
+        const int col4 = (threadIdx.x & 31) * 4;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int r = (threadIdx.x >> 5) + 8 * i;
+            const int gy = by0 + r, gx = bx0 + col4;
+            const bool rowok = r < bh && col4 < bw && gy >= 0 && gy < Hi && gx >= 0;     // gx is a multiple of 4
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m |= (rowok && gx + e < Wi) ? (1u << e) : 0u;
+            keep[i] = m;
+            goff[i] = m ? (static_cast<unsigned>(gy) * Wi + gx) * E : kOob;
+        }
+        u32x4 stage[NCH];
+        auto fetch = [&](const T* pl) {
+            const rsrc_t rs = make_rsrc(pl, ibytes);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], 0, 0);
+        };
+        auto commit = [&](T* buf) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                u32x4 v = stage[i];
+                v.x = (keep[i] & 1u) ? v.x : 0u;      // zero padding lives in LDS: the corner loop needs no masks
+                v.y = (keep[i] & 2u) ? v.y : 0u;
+                v.z = (keep[i] & 4u) ? v.z : 0u;
+                v.w = (keep[i] & 8u) ? v.w : 0u;
+                *reinterpret_cast<u32x4*>(buf + ((threadIdx.x >> 5) + 8 * i) * kWlCols + col4) = v;
+            }
+        };
+        int lbase[kWlPix];
+#pragma unroll
+        for (int k = 0; k < kWlPix; ++k) lbase[k] = live[k] ? (y0[k] - by0) * kWlCols + (x0[k] - bx0) : 0;
+        fetch(fp);
+        commit(tile[0]);
+        __syncthreads();
+        int p = 0;
+        for (int c = c0; c < c1; ++c, op += plane, p ^= 1) {
+            const bool more = c + 1 < c1;
+            if (more) fetch(fp + static_cast<size_t>(c + 1 - c0) * iplane);      // in flight during the math
+            T v[kWlPix];
+#pragma unroll
+            for (int k = 0; k < kWlPix; ++k) {
+                const T* nb = tile[p] + lbase[k];
+                T s = 0;                                // same summation order as the direct kernel / the oracle
+                s += nb[0] * w[k][0];
+                s += nb[1] * w[k][1];
+                s += nb[kWlCols] * w[k][2];
+                s += nb[kWlCols + 1] * w[k][3];
+                v[k] = s;
+            }
+            store4(op, v);
+            if (more) commit(tile[p ^ 1]);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- fallback: direct gathers with hardware zero padding (kOob offsets), 4 pixels per thread
+    unsigned off[kWlPix][4];
+    T wm[kWlPix][4];
+#pragma unroll
+    for (int k = 0; k < kWlPix; ++k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cx = x0[k] + (q & 1), cy = y0[k] + (q >> 1);
+            const bool ok = live[k] && cx >= 0 && cx < Wi && cy >= 0 && cy < Hi;
+            off[k][q] = ok ? (static_cast<unsigned>(cy) * Wi + cx) * E : kOob;
+            wm[k][q] = ok ? w[k][q] : static_cast<T>(0);
+        }
+    }
+    for (int c = c0; c < c1; ++c, fp += iplane, op += plane) {
+        const rsrc_t rf = make_rsrc(fp, ibytes);
+        T v[kWlPix];
+#pragma unroll
+        for (int k = 0; k < kWlPix; ++k) {
+            T s = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s += buf_ld<T>(rf, off[k][q]) * wm[k][q];
+            v[k] = s;
+        }
+        store4(op, v);
+    }
+}
+
 template <typename T, bool FLIP>
 __global__ void __launch_bounds__(kBlock)
 warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T* __restrict__ gout,
@@ -291,6 +495,29 @@ int launch_fwd(const T* feat, const T* flow, T* out, int64_t B, int64_t C, int64
     const Geometry g = plan(B, C, H, W, 16);
     const int remap = options().xcd_remap;
     LaunchScope ls(flip ? "warp_flipcat_fwd" : "warp_fwd", st, bytes);
+    // warp_fwd_variant: 0 = auto (LDS-staged tiles for large float outputs), 1 = direct gathers, 2 = LDS-staged
+    if constexpr (sizeof(T) == 4) {
+        const int variant = options().warp_fwd_variant;
+        // (measured: the tile kernel wins once the output no longer sits in L2 -- 4.6 vs 3.4 TB/s on [32,64,256,256];
+        //  on the <= 34 MB tensors of netG the direct kernel is as fast or faster)
+        if (variant == 2 || (variant == 0 && H >= 64 && W >= 64 && B * C * H * W >= (1LL << 24))) {
+            const int txs = static_cast<int>((W + kWlTileX - 1) / kWlTileX), tys = static_cast<int>((H + kWlTileY - 1) / kWlTileY);
+            int cs = options().channel_slab > 0 ? options().channel_slab : 16;
+            if (cs > C) cs = static_cast<int>(C);
+            while (cs > 2 && B * txs * tys * ((C + cs - 1) / cs) < 2048) cs = (cs + 1) / 2;
+            const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            const unsigned grid = static_cast<unsigned>(B * txs * tys * cslabs);
+            if (flip)
+                hipLaunchKernelGGL((warp_fwd_lds_kernel<true>), dim3(grid), dim3(kBlock), 0, st, (const float*)feat,
+                                   (const float*)flow, (float*)out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, txs, tys, cslabs,
+                                   cs, remap);
+            else
+                hipLaunchKernelGGL((warp_fwd_lds_kernel<false>), dim3(grid), dim3(kBlock), 0, st, (const float*)feat,
+                                   (const float*)flow, (float*)out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, txs, tys, cslabs,
+                                   cs, remap);
+            return check_launch("ffwm_warp_forward(lds)");
+        }
+    }
     if (flip)
         hipLaunchKernelGGL((warp_fwd_kernel<T, true>), dim3(g.grid), dim3(kBlock), 0, st, feat, flow, out,
                            (int)C, (int)Hi, (int)Wi, (int)H, (int)W, g.tiles_x, g.tiles_y, g.cslabs, g.cs, remap);

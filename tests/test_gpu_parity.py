@@ -405,6 +405,65 @@ def test_warp_forward_backward(oracle, case, dtype, flipcat):
     _close(gfl, gfl_ref, BWD_TOL[dtype], relative=True)
 
 
+def _smooth_flow(B, H, W, scale, shift, amp, seed):
+    """Normalised sampling grid: identity * scale + shift + a few pixels of low-frequency wobble."""
+    ys = (torch.arange(H, dtype=torch.float32) + 0.5) / H * 2 - 1
+    xs = (torch.arange(W, dtype=torch.float32) + 0.5) / W * 2 - 1
+    yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+    ph = 0.37 * seed
+    fx = xx * scale + shift + amp * torch.sin(3.1 * yy + ph) * torch.cos(2.3 * xx)
+    fy = yy * scale - shift + amp * torch.cos(2.7 * xx - ph) * torch.sin(1.9 * yy)
+    return torch.stack((fx, fy), 0).unsqueeze(0).repeat(B, 1, 1, 1).contiguous()
+
+
+WARP_LDS_CASES = [
+    # (B, C, Hi, Wi, H, W, scale, shift, amp, seed): sampling boxes that fit the LDS tile -> staged path
+    (2, 5, 64, 64, 64, 64, 1.0, 0.0, 0.05, 0),       # identity + 1.6 px wobble
+    (1, 6, 70, 67, 70, 67, 1.0, 0.0, 0.08, 1),       # ragged: W not a multiple of 4, partial tiles
+    (1, 3, 96, 130, 80, 129, 1.05, 0.3, 0.04, 2),    # shifted: a band of the grid leaves the image (zero padding)
+    (1, 4, 128, 128, 64, 64, 0.45, -0.2, 0.02, 3),   # zoom-in crop from a larger source
+    (1, 3, 64, 64, 128, 128, 1.0, 0.0, 0.03, 4),     # upsampling
+    (1, 2, 66, 66, 66, 66, 1.8, 0.0, 0.0, 5),        # zoom-out 1.8x: most tiles exceed the box -> mixed staged / fallback
+]
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("flipcat", [False, True])
+@pytest.mark.parametrize("case", WARP_LDS_CASES)
+def test_warp_forward_lds_staged(oracle, case, flipcat, variant):
+    from ffwm_amd import ops, _lib
+    B, C, Hi, Wi, H, W, scale, shift, amp, seed = case
+    feat = torch.rand(B, C, Hi, Wi, generator=_gen(seed))
+    flow = _smooth_flow(B, H, W, scale, shift, amp, seed)
+    ref = oracle.warp_forward(feat, flow, flipcat)
+    _lib.set_option("warp_fwd_variant", variant)
+    try:
+        out = ops.warp_forward(feat.to(DEV), flow.to(DEV), flipcat)
+    finally:
+        _lib.set_option("warp_fwd_variant", 0)
+    _close(out, ref, FWD_TOL[torch.float32])
+
+
+@pytest.mark.parametrize("case", WARP_CASES[:4])
+def test_warp_forward_lds_kernel_on_random_and_small_inputs(oracle, case):
+    """The tile kernel forced onto small images and per-pixel random flows (its direct-gather fallback)."""
+    from ffwm_amd import ops, _lib
+    B, C, Hi, Wi, H, W, seed = case
+    g = _gen(seed)
+    feat = torch.rand(B, C, Hi, Wi, generator=g)
+    flow = torch.rand(B, 2, H, W, generator=g) * 2.4 - 1.2
+    flow[0, 0, 0, 0] = float("nan")
+    flow[0, 1, -1, -1] = 1e30
+    ref = oracle.warp_forward(feat, flow, True)
+    _lib.set_option("warp_fwd_variant", 2)
+    try:
+        out = ops.warp_forward(feat.to(DEV), flow.to(DEV), True)
+    finally:
+        _lib.set_option("warp_fwd_variant", 0)
+    assert torch.isfinite(out).all()
+    _close(out, ref, FWD_TOL[torch.float32])
+
+
 def test_warpnet_matches_torch_grid_sample_on_gpu():
     """The reference's WarpNet is F.grid_sample: compare against ATen's own GPU kernel too."""
     from ffwm_amd.external_function import WarpNet, WarpFlipCat
