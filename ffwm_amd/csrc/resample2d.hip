@@ -179,11 +179,14 @@ constexpr int kPlaneThreads = 1024;
 template <typename T, int HALF>
 __global__ void __launch_bounds__(kPlaneThreads)
 rs_bwd1_plane_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* __restrict__ gin1, int C,
-                     int Hi, int Wi, int H, int W, int dil, int quirk, int cg, int groups) {
+                     int Hi, int Wi, int H, int W, int dil, int quirk, int cg, int groups, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* acc = reinterpret_cast<double*>(smem_raw);
-    const int grp = blockIdx.x % groups;
-    const int b = blockIdx.x / groups;
+    unsigned bid = blockIdx.x;
+    const int split = bid % nsplit;          // with few planes the pixels are split over nsplit blocks per plane group
+    bid /= nsplit;
+    const int grp = bid % groups;
+    const int b = bid / groups;
     const int c0 = grp * cg;
     const int nc = (c0 + cg <= C) ? cg : C - c0;
     const int ncell = Hi * Wi, npix = H * W;
@@ -191,7 +194,7 @@ rs_bwd1_plane_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* _
     __syncthreads();
     const T* f = in2 + static_cast<size_t>(b) * 3 * npix;
     const T* g0 = gout + (static_cast<size_t>(b) * C + c0) * npix;
-    for (int p = threadIdx.x; p < npix; p += kPlaneThreads) {
+    for (int p = split * kPlaneThreads + threadIdx.x; p < npix; p += kPlaneThreads * nsplit) {
         const int y = p / W, x = p - y * W;
         RsTaps<T, HALF> t;
         make_rs_taps<T, HALF>(t, f[p], f[npix + p], f[2 * npix + p], x, y, Hi, Wi, dil, quirk != 0);
@@ -217,7 +220,14 @@ rs_bwd1_plane_kernel(const T* __restrict__ in2, const T* __restrict__ gout, T* _
     }
     __syncthreads();
     T* dst = gin1 + (static_cast<size_t>(b) * C + c0) * ncell;
-    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += static_cast<T>(acc[i]);
+    if (nsplit == 1) {
+        for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += static_cast<T>(acc[i]);
+    } else {                                 // several blocks share the planes: one global atomic per non-zero cell
+        for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) {
+            const T v = static_cast<T>(acc[i]);
+            if (v != 0) atomic_add(dst + i, v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------ K3
@@ -543,7 +553,9 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
         if (cg > C) cg = static_cast<int>(C);
         while (cg > 1 && B * ((C + cg - 1) / cg) < 512) cg = (cg + 1) / 2;   // keep >= 2 blocks per CU
         const int groups = static_cast<int>((C + cg - 1) / cg);
-        const unsigned grid = static_cast<unsigned>(B * groups);
+        int nsplit = 1;                      // the per-pixel Gaussian weights (double exp) dominate: fill the chip
+        while (B * groups * nsplit < 256 && nsplit * 2 * kPlaneThreads <= H * W) nsplit *= 2;
+        const unsigned grid = static_cast<unsigned>(B * groups * nsplit);
         const size_t lds = static_cast<size_t>(cg) * plane_lds;
         allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_plane_kernel<T, 1>));
         allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_plane_kernel<T, 2>));
@@ -552,13 +564,13 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             LaunchScope ls("resample2d_bwd_input1_plane", st, bytes);
             if (half == 1)
                 hipLaunchKernelGGL((rs_bwd1_plane_kernel<T, 1>), dim3(grid), dim3(kPlaneThreads), lds, st, in2, gout, gin1,
-                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups);
+                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups, nsplit);
             else if (half == 2)
                 hipLaunchKernelGGL((rs_bwd1_plane_kernel<T, 2>), dim3(grid), dim3(kPlaneThreads), lds, st, in2, gout, gin1,
-                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups);
+                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups, nsplit);
             else
                 hipLaunchKernelGGL((rs_bwd1_plane_kernel<T, 3>), dim3(grid), dim3(kPlaneThreads), lds, st, in2, gout, gin1,
-                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups);
+                                   (int)C, (int)Hi, (int)Wi, (int)H, (int)W, dil, quirk, cg, groups, nsplit);
         }
         if (int rc = check_launch("ffwm_resample2d_backward(input1, plane)")) return rc;
         gin1 = nullptr;
