@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--flow-init", default="fit-identity", choices=["fit-identity", "random"],
+                    help="train workload: stand-in for the reference's PRETRAINED flow nets -- fit flowNetF/B to the identity "
+                         "sampling grid for 80 untimed Adam steps (default), or leave them randomly initialised")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="train workload: replay the step from captured hipGraphs, or run it eagerly (default: measured faster on ROCm 7.2)")
     return ap.parse_args()
@@ -235,6 +238,7 @@ def main():
         t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers,
                                 bucket_bytes=args.bucket_mb << 20, capturable=args.graph == "on")
         batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
+        flow_fit = t.pretrain_flow_identity(batch) if args.flow_init == "fit-identity" else None
         graphed = args.graph == "on"
         if graphed:
             t.capture(batch, warmup=max(2, args.warmup))
@@ -252,7 +256,10 @@ def main():
                                   "batch_per_gpu": bs, "global_batch": bs * world,
                                   "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed else "eager",
                                   "titers_branch": "<20000" if args.titers < 20000 else ">=20000",
-                                  "weights": "seeded random init (no pretrained VGG19/LightCNN/FlowNet offline)"},
+                                  "weights": "seeded random init (no pretrained VGG19/LightCNN/FlowNet offline)",
+                                  "flow_nets": ("fitted to the identity grid for 80 untimed steps (stand-in for the reference's "
+                                                "pretrained flowNetF/B checkpoints), final L1 %s" % [round(v, 3) for v in flow_fit])
+                                  if flow_fit else "randomly initialised"},
                        "img_per_s_per_gpu": round(imgs / dt / world, 2),
                        "fp32_flop_frac": round(imgs / dt / world * TRAIN_FLOP_PER_IMG / FP32_PEAK, 4),
                        "losses": {k: round(v, 5) for k, v in t.loss_values().items()}})

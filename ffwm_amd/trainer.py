@@ -115,6 +115,38 @@ class FFWMTrainer(object):
         self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes)
         self.losses = {}
 
+    # ------------------------------------------------------------------ stand-in for the pretrained flow nets
+    def pretrain_flow_identity(self, b, steps=80, lr=2e-3):
+        """The reference never trains FFWM from randomly initialised flow nets: train_ffwm.py loads
+        pretrained flowNetF / flowNetB checkpoints (README, models/ffwm_model.py:30-35), whose fields
+        are smooth near-identity sampling grids.  Those checkpoints cannot be fetched offline, and an
+        untrained FlowNet outputs tanh(~0): every pixel samples the image centre -- an access pattern
+        (all lanes on one cache line, all scatter-adds on four cells) that real training never sees.
+        This fits both nets to the identity grid for a few Adam steps (own throw-away optimizer;
+        the step's optimizers and their state are untouched) so the timed step runs on realistic flows."""
+        def grid(s):
+            lin = (torch.arange(s, dtype=torch.float32, device=self.device) + 0.5) / s * 2 - 1
+            yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+            return torch.stack((xx, yy), 0).unsqueeze(0)
+        targets = [grid(128), grid(64), grid(32)]
+        last = []
+        for net in (self.flowNetF, self.flowNetB):
+            params = [p for n, p in net.named_parameters() if not n.startswith("inter_conv_occ")]
+            grads_before = [p.grad for p in params]          # views into the reducer's buckets: keep them
+            opt = torch.optim.Adam(params, lr=lr)
+            for _ in range(steps):
+                flows = net(b["img_S"])
+                loss = sum((f - g).abs().mean() for f, g in zip(flows, targets))
+                for p in params:
+                    p.grad = None
+                loss.backward()
+                opt.step()
+            for p, g in zip(params, grads_before):
+                p.grad = g
+            last.append(float(loss.detach()))
+        broadcast_module_state([self.flowNetF, self.flowNetB])
+        return last
+
     # ------------------------------------------------------------------ loss pieces
     def perceptual(self, x, y):
         fx = self.vgg(x)
