@@ -720,9 +720,10 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
             const int yf = y0 + row;
             const PixLoad cur = nxt;
             if (r + 1 < PPT) request(r + 1, nxt);
+            const bool row_owned = row >= H && row < H + TH && gflow != nullptr;      // wave-uniform
             T gx = 0, gy = 0;
             if (xin && yf >= 0 && yf < Hf) {
-                const bool owned = xown && row >= H && row < H + TH && gflow != nullptr;
+                const bool owned = xown && row_owned;
                 const T fx0 = cur.fx, fy0 = cur.fy;
                 // taps, the reference's arithmetic (block_extractor_kernel.cu:117-135)
                 T wxr[K], wyb[K];
@@ -753,48 +754,62 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
                     // A pixel that is not owned reads an arbitrary valid source neighbourhood: its d(flow)
                     // is never written.
                     double* ap = A + av * AP + au;
-                    const T* nb = S + (owned ? sv * RW + su : 0);
-                    T sprev[K + 1], scur[K + 1], aprev[K + 1], acur[K + 1];
+                    // d(source): the (K+1)^2 contributions are the separable product Wy^T G Wx of the K x K window
+                    // (block_extractor_kernel.cu:158-161 summed over the window): columns first (tx[i][c]),
+                    // then rows, one accumulator row at a time -> 4K(K+1)/... fmas instead of 6 K^2 operations
+                    T xl[K], yt[K];
 #pragma unroll
-                    for (int j = 0; j <= K; ++j) {
-                        sprev[j] = nb[j];
-                        aprev[j] = 0;
+                    for (int j = 0; j < K; ++j) {
+                        xl[j] = 1 - wxr[j];
+                        yt[j] = 1 - wyb[j];
                     }
+                    T tx[K][K + 1];
 #pragma unroll
                     for (int i = 0; i < K; ++i) {
 #pragma unroll
-                        for (int j = 0; j <= K; ++j) {
-                            scur[j] = nb[(i + 1) * RW + j];
-                            acur[j] = 0;
-                        }
-                        const T yb = wyb[i], yt = 1 - wyb[i];
-#pragma unroll
-                        for (int j = 0; j < K; ++j) {
-                            const T gv = cur.g[i].v[j];
-                            const T xr = wxr[j], xl = 1 - wxr[j];
-                            const T gl = gv * xl, gr = gv * xr;
-                            aprev[j] = fma_t<T>(gl, yt, aprev[j]);              // block_extractor_kernel.cu:158-161
-                            aprev[j + 1] = fma_t<T>(gr, yt, aprev[j + 1]);
-                            acur[j] = fma_t<T>(gl, yb, acur[j]);
-                            acur[j + 1] = fma_t<T>(gr, yb, acur[j + 1]);
-                            // :163-164 with the four products regrouped into source differences
-                            gy = fma_t<T>(gl, scur[j] - sprev[j], fma_t<T>(gr, scur[j + 1] - sprev[j + 1], gy));
-                            gx = fma_t<T>(gv * yt, sprev[j + 1] - sprev[j], fma_t<T>(gv * yb, scur[j + 1] - scur[j], gx));
-                        }
-#pragma unroll
-                        for (int j = 0; j <= K; ++j)
-                            __hip_atomic_fetch_add(ap + i * AP + j, static_cast<double>(aprev[j]), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                        for (int j = 0; j <= K; ++j) {
-                            sprev[j] = scur[j];
-                            aprev[j] = acur[j];
+                        for (int c2 = 0; c2 <= K; ++c2) {
+                            T v = 0;
+                            if (c2 < K) v = cur.g[i].v[c2] * xl[c2];
+                            if (c2 > 0) v = (c2 < K) ? fma_t<T>(cur.g[i].v[c2 - 1], wxr[c2 - 1], v) : cur.g[i].v[c2 - 1] * wxr[c2 - 1];
+                            tx[i][c2] = v;
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j <= K; ++j)
-                        __hip_atomic_fetch_add(ap + K * AP + j, static_cast<double>(aprev[j]), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int r2 = 0; r2 <= K; ++r2) {
+#pragma unroll
+                        for (int c2 = 0; c2 <= K; ++c2) {
+                            T v = 0;
+                            if (r2 < K) v = tx[r2][c2] * yt[r2];
+                            if (r2 > 0) v = (r2 < K) ? fma_t<T>(tx[r2 - 1][c2], wyb[r2 - 1], v) : tx[r2 - 1][c2] * wyb[r2 - 1];
+                            __hip_atomic_fetch_add(ap + r2 * AP + c2, static_cast<double>(v), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    // d(flow) (:163-164), only where this wave's row belongs to the tile (wave-uniform) and for
+                    // the lanes that own their pixel: products regrouped into source differences, summed along
+                    // the rows (gx) / columns (gy) of the window first
+                    if (row_owned) {
+                        const T* nb = S + (owned ? sv * RW + su : 0);
+                        T sp[K + 1], sc[K + 1];
+#pragma unroll
+                        for (int j = 0; j <= K; ++j) sp[j] = nb[j];
+#pragma unroll
+                        for (int i = 0; i < K; ++i) {
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) sc[j] = nb[(i + 1) * RW + j];
+                            T hx = 0, hy = 0;             // sum_j g_ij * (horizontal difference on the top / bottom row)
+#pragma unroll
+                            for (int j = 0; j < K; ++j) {
+                                hx = fma_t<T>(cur.g[i].v[j], sp[j + 1] - sp[j], hx);
+                                hy = fma_t<T>(cur.g[i].v[j], sc[j + 1] - sc[j], hy);
+                            }
+                            gx = fma_t<T>(yt[i], hx, fma_t<T>(wyb[i], hy, gx));
+#pragma unroll
+                            for (int c2 = 0; c2 <= K; ++c2) gy = fma_t<T>(tx[i][c2], sc[c2] - sp[c2], gy);   // vertical differences
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) sp[j] = sc[j];
+                        }
+                    }
                 } else {
                     // a tap outside the accumulator box (flow wider than the halo), a floor that disagrees
                     // between neighbouring taps (fp rounding on an integer boundary), NaN or huge flow:
@@ -1104,7 +1119,7 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
             const TileGeo geo{kTileRW - 2 * h, RH - 2 * h, h, RH};
             const int ntx = static_cast<int>(((Ws > Wf ? Ws : Wf) + geo.TW - 1) / geo.TW);
             const int nty = static_cast<int>(((Hs > Hf ? Hs : Hf) + geo.TH - 1) / geo.TH);
-            int cs = options().channel_slab > 0 ? options().channel_slab : 8;
+            int cs = options().channel_slab > 0 ? options().channel_slab : 4;
             if (cs > C) cs = static_cast<int>(C);
             while (cs > 4 && B * ntx * nty * ((C + cs - 1) / cs) < 1536) cs = (cs + 1) / 2;   // >= 6 blocks per CU
             const int cslabs = static_cast<int>((C + cs - 1) / cs);
