@@ -931,6 +931,370 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
     }
 }
 
+template <int K, int RH, int H>
+__global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 && H <= 4 ? 4 : 2))
+be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
+                   float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
+                   int ntx, int nty, int cslabs, int cs, int remap, int ablate) {
+    using T = float;
+    constexpr int RW = kTileRW, NW = kBlock / kWave, PPT = RH / NW;
+    constexpr int TW = RW, TH = RH;                       // the block's flow pixels: no overlap with its neighbours
+    constexpr int AP = RW + 2 * H, AH = RH + 2 * H;       // accumulator / source box = tile grown by H
+    constexpr int NA = AP * AH;
+    constexpr unsigned E = sizeof(T);
+    __shared__ T S[NA];           // clamp-extended source box of the current channel (same box as A)
+    // grad_source accumulator, UNCLAMPED coordinates, origin (x0 - H, y0 - H): every tap of a tile pixel
+    // whose offset is within +-H lands inside it (no masks, no clamps in the hot path); after the channel's
+    // pixels are done the out-of-image cells are folded onto the border and every non-zero cell is added
+    // to grad_source with ONE global atomic (neighbouring blocks' boxes overlap: their sums meet in memory).
+    // Compared with the owned-tile kernel no pixel is visited twice (x1.0 instead of x1.52 pixel visits),
+    // at the price of ~1.4 coalesced global atomics per pixel and channel.
+    // DOUBLE on purpose: ds_add_f64 ~9 clk per wave, ds_add_f32 ~190 on gfx950 (tools/ubench/atomics.hip).
+    __shared__ double A[NA];
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int x0 = tx * TW, y0 = ty * TH;                  // tile origin (source == flow coordinates)
+    const int ax0 = x0 - H, ay0 = y0 - H;                  // box origin
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int xf = x0 + lane;
+    const bool xin = xf >= 0 && xf < Wf;
+    const bool xown = true;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int W = K * Wf;
+    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const unsigned sbytes = static_cast<unsigned>(splane * E);
+    const unsigned obytes = static_cast<unsigned>(oplane * E);
+    const unsigned orow = static_cast<unsigned>(W) * E;
+    const T* sp = src + (static_cast<size_t>(b) * C + c0) * splane;
+    T* gp = gsrc + (static_cast<size_t>(b) * C + c0) * splane;
+    const T* op = gout + (static_cast<size_t>(b) * C + c0) * oplane;
+    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, static_cast<unsigned>(2 * fplane * E));
+
+    // out-of-image accumulator cells fold onto the border cell they clamp to (block-uniform)
+    const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;   // the box meets the image (else: be_bwd_far2_kernel's job)
+    const bool foldL = ax0 < 0, foldR = Ws - ax0 < AP;
+    const bool foldT = ay0 < 0, foldB = Hs - ay0 < AH;
+
+    // stage one channel's clamp-extended source box (the other resident blocks of the CU cover its
+    // latency).  y0w is laundered through an empty asm so the row offsets are recomputed -- one clamp
+    // + one multiply-add each -- instead of being hoisted into loop-invariant VGPRs.
+    auto stage = [&](const T* plane) {
+        const rsrc_t rs = make_rsrc(plane, sbytes);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+#pragma unroll 1
+        for (int i0 = 0; i0 < NA; i0 += 4 * kBlock) {
+            T st[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = i0 + q * kBlock + tid;
+                const int arow = idx / AP, acol = idx - arow * AP;
+                const int gy = min(max(ay0 + arow, 0), Hs - 1), gx = min(max(ax0 + acol, 0), Ws - 1);
+                st[q] = buf_ld<T>(rs, idx < NA ? (static_cast<unsigned>(gy) * Ws + gx) * E : 0xFFFFFFF0u);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = i0 + q * kBlock + tid;
+                if (idx < NA) S[idx] = st[q];
+            }
+        }
+    };
+    for (int i = threadIdx.x; i < NA; i += kBlock) A[i] = 0;
+    stage(sp);
+    __syncthreads();
+
+    T gxa[PPT], gya[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) gxa[r] = gya[r] = 0;
+
+    for (int c = c0; c < c1; ++c, op += oplane) {
+        const bool more = c + 1 < c1;
+        const rsrc_t rg = make_rsrc(op, obytes);
+        const rsrc_t rs = make_rsrc(sp + static_cast<size_t>(c - c0) * splane, sbytes);
+        // software pipeline: the flow vector and the k x k grad_output window of pixel row r+1 are
+        // requested before row r is processed (their addresses do not depend on the flow), so the
+        // ~300 instructions of one row cover the latency of the next one's loads
+        struct PixLoad {
+            T fx, fy;
+            ElemRow<T, K> g[K];
+        };
+        const int xfc = min(max(xf, 0), Wf - 1);
+        auto request = [&](int r, PixLoad& d) {
+            int yfc = y0 + wave + r * NW;
+            yfc = min(max(yfc, 0), Hf - 1);                    // rows outside the flow image shadow a valid one
+            const unsigned fo = (static_cast<unsigned>(yfc) * Wf + xfc) * E;
+            d.fx = buf_ld<T>(rfl, fo);
+            d.fy = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
+            const unsigned ob = (static_cast<unsigned>(yfc) * K * W + static_cast<unsigned>(xfc) * K) * E;
+#pragma unroll
+            for (int i = 0; i < K; ++i) buf_load_row<T, K>(rg, ob + i * orow, d.g[i]);
+        };
+        PixLoad nxt;
+        request(0, nxt);
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r) {
+            const int row = wave + r * NW;
+            const int yf = y0 + row;
+            const PixLoad cur = nxt;
+            if (r + 1 < PPT) request(r + 1, nxt);
+            const bool row_owned = gflow != nullptr;
+            T gx = 0, gy = 0;
+            if (xin && yf >= 0 && yf < Hf) {
+                const bool owned = xown && row_owned;
+                const T fx0 = cur.fx, fy0 = cur.fy;
+                // taps, the reference's arithmetic (block_extractor_kernel.cu:117-135)
+                T wxr[K], wyb[K];
+                T flx0 = 0, fly0 = 0;
+                bool regular = true;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
+                    const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
+                    const T fxl = floor_t(dx), fyl = floor_t(dy);
+                    if (j == 0) { flx0 = fxl; fly0 = fyl; }
+                    regular = regular & (fxl == flx0 + static_cast<T>(j)) & (fyl == fly0 + static_cast<T>(j));
+                    wxr[j] = dx - fxl;
+                    wyb[j] = dy - fyl;
+                }
+                const T lim = static_cast<T>(1 << 20);
+                regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);   // rejects NaN too
+                const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
+                const int au = u0 - ax0, av = v0 - ay0;          // neighbourhood origin in the accumulator box
+                const int su = au, sv = av;                      // ... which is also the source box
+                const bool fit = inside & regular & (static_cast<unsigned>(au) <= static_cast<unsigned>(AP - 1 - K)) &
+                                 (static_cast<unsigned>(av) <= static_cast<unsigned>(AH - 1 - K));
+                const bool sfit = fit;
+                const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
+                if (fit & (!owned | sfit)) {
+                    // hot path: dense (K+1)^2 neighbourhood at one LDS address + immediates, no masks.
+                    // A pixel that is not owned reads an arbitrary valid source neighbourhood: its d(flow)
+                    // is never written.
+                    double* ap = A + av * AP + au;
+                    // d(source): the (K+1)^2 contributions are the separable product Wy^T G Wx of the K x K window
+                    // (block_extractor_kernel.cu:158-161 summed over the window): columns first (tx[i][c]),
+                    // then rows, one accumulator row at a time -> 4K(K+1)/... fmas instead of 6 K^2 operations
+                    T xl[K], yt[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        xl[j] = 1 - wxr[j];
+                        yt[j] = 1 - wyb[j];
+                    }
+                    T tx[K][K + 1];
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+#pragma unroll
+                        for (int c2 = 0; c2 <= K; ++c2) {
+                            T v = 0;
+                            if (c2 < K) v = cur.g[i].v[c2] * xl[c2];
+                            if (c2 > 0) v = (c2 < K) ? fma_t<T>(cur.g[i].v[c2 - 1], wxr[c2 - 1], v) : cur.g[i].v[c2 - 1] * wxr[c2 - 1];
+                            tx[i][c2] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int r2 = 0; r2 <= K; ++r2) {
+#pragma unroll
+                        for (int c2 = 0; c2 <= K; ++c2) {
+                            T v = 0;
+                            if (r2 < K) v = tx[r2][c2] * yt[r2];
+                            if (r2 > 0) v = (r2 < K) ? fma_t<T>(tx[r2 - 1][c2], wyb[r2 - 1], v) : tx[r2 - 1][c2] * wyb[r2 - 1];
+                            __hip_atomic_fetch_add(ap + r2 * AP + c2, static_cast<double>(v), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    // d(flow) (:163-164), only where this wave's row belongs to the tile (wave-uniform) and for
+                    // the lanes that own their pixel: products regrouped into source differences, summed along
+                    // the rows (gx) / columns (gy) of the window first
+                    if (row_owned) {
+                        const T* nb = S + (owned ? sv * AP + su : 0);
+                        T sp[K + 1], sc[K + 1];
+#pragma unroll
+                        for (int j = 0; j <= K; ++j) sp[j] = nb[j];
+#pragma unroll
+                        for (int i = 0; i < K; ++i) {
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) sc[j] = nb[(i + 1) * AP + j];
+                            T hx = 0, hy = 0;             // sum_j g_ij * (horizontal difference on the top / bottom row)
+#pragma unroll
+                            for (int j = 0; j < K; ++j) {
+                                hx = fma_t<T>(cur.g[i].v[j], sp[j + 1] - sp[j], hx);
+                                hy = fma_t<T>(cur.g[i].v[j], sc[j + 1] - sc[j], hy);
+                            }
+                            gx = fma_t<T>(yt[i], hx, fma_t<T>(wyb[i], hy, gx));
+#pragma unroll
+                            for (int c2 = 0; c2 <= K; ++c2) gy = fma_t<T>(tx[i][c2], sc[c2] - sp[c2], gy);   // vertical differences
+#pragma unroll
+                            for (int j = 0; j <= K; ++j) sp[j] = sc[j];
+                        }
+                    }
+                } else {
+                    // a tap outside the accumulator box (flow wider than the halo), a floor that disagrees
+                    // between neighbouring taps (fp rounding on an integer boundary), NaN or huge flow:
+                    // every tap on its own like the reference, clamped cells, ownership tested per cell
+#pragma unroll 1
+                    for (int i = 0; i < K; ++i) {
+                        const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
+#pragma unroll 1
+                        for (int j = 0; j < K; ++j) {
+                            const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
+                            const T gv = buf_ld<T>(rg, ob + i * orow + j * E);
+                            const int cxs[2] = {static_cast<int>(tx1.lo), static_cast<int>(tx1.hi)};
+                            const int cys[2] = {static_cast<int>(ty1.lo), static_cast<int>(ty1.hi)};
+                            const T wxs[2] = {tx1.wlo, tx1.whi}, wys[2] = {ty1.wlo, ty1.whi};
+                            (void)cxs; (void)cys; (void)wxs; (void)wys;      // scattered by be_bwd_far2_kernel
+                            if (owned) {
+                                const unsigned rT = ty1.lo * static_cast<unsigned>(Ws) * E, rB = ty1.hi * static_cast<unsigned>(Ws) * E;
+                                const T sTL = buf_ld<T>(rs, rT + tx1.lo * E), sTR = buf_ld<T>(rs, rT + tx1.hi * E);
+                                const T sBL = buf_ld<T>(rs, rB + tx1.lo * E), sBR = buf_ld<T>(rs, rB + tx1.hi * E);
+                                gy += gv * (-tx1.wlo * sTL - tx1.whi * sTR + tx1.wlo * sBL + tx1.whi * sBR);
+                                gx += gv * (-ty1.wlo * sTL - ty1.whi * sBL + ty1.wlo * sTR + ty1.whi * sBR);
+                            }
+                        }
+                    }
+                }
+            }
+            gxa[r] += gx;       // r is wave-uniform: indexed VGPR access (s_set_gpr_idx), no scratch
+            gya[r] += gy;
+        }
+        __syncthreads();                       // every contribution of channel c is in A
+        // border tiles: fold the out-of-image cells onto the border cell they clamp to -- columns
+        // first (one thread per accumulator row), then rows (one thread per column)
+        if (foldL || foldR) {
+            if (threadIdx.x < AH) {
+                double* arow = A + threadIdx.x * AP;
+                if (foldL) {
+                    double s = 0;
+                    for (int u = 0; u < -ax0; ++u) s += arow[u];
+                    arow[-ax0] += s;
+                }
+                if (foldR) {
+                    double s = 0;
+                    for (int u = Ws - ax0; u < AP; ++u) s += arow[u];
+                    arow[Ws - 1 - ax0] += s;
+                }
+            }
+            __syncthreads();
+        }
+        if (foldT || foldB) {
+            if (threadIdx.x < AP) {
+                double* acol = A + threadIdx.x;
+                if (foldT) {
+                    double s = 0;
+                    for (int v = 0; v < -ay0; ++v) s += acol[v * AP];
+                    acol[-ay0 * AP] += s;
+                }
+                if (foldB) {
+                    double s = 0;
+                    for (int v = Hs - ay0; v < AH; ++v) s += acol[v * AP];
+                    acol[(Hs - 1 - ay0) * AP] += s;
+                }
+            }
+            __syncthreads();
+        }
+        {
+            // flush: one global atomic per non-zero in-image cell, then clear the box
+            T* gplane = gp + static_cast<size_t>(c - c0) * splane;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+#pragma unroll 1
+            for (int i0 = 0; i0 < NA; i0 += kBlock) {
+                const int idx = i0 + tid;
+                if (idx < NA) {
+                    const int arow = idx / AP, acol = idx - arow * AP;
+                    const int cx = ax0 + acol, cy = ay0 + arow;
+                    const T v = static_cast<T>(A[idx]);
+                    A[idx] = 0;
+                    if (v != 0 && cx >= 0 && cx < Ws && cy >= 0 && cy < Hs) atomic_add(gplane + static_cast<size_t>(cy) * Ws + cx, v);
+                }
+            }
+        }
+        if (more) stage(sp + static_cast<size_t>(c + 1 - c0) * splane);
+        __syncthreads();
+    }
+    if (gflow) {
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            const int row = wave + r * NW;
+            const int yf = y0 + row;
+            if (xin && yf >= 0 && yf < Hf) {
+                const size_t fo = static_cast<size_t>(b) * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
+                atomic_add(gflow + fo, gxa[r]);
+                atomic_add(gflow + fo + fplane, gya[r]);
+            }
+        }
+    }
+}
+
+// Complement of be_bwd_tile2_kernel: flow pixels with a tap outside their own tile's box (flow wider than
+// the halo, integer-boundary rounding, NaN / huge flow) scatter ALL their taps with global atomics here.
+template <typename T, int K>
+__global__ void __launch_bounds__(kBlock)
+be_bwd_far2_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gsrc, int C, int Hs,
+                   int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs, TileGeo geo) {
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, 0);
+    if (tc.xf >= Wf || tc.yf >= Hf) return;
+    constexpr unsigned E = sizeof(T);
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const size_t foff = static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(tc.yf) * Wf + tc.xf;
+    const T fx0 = flow[foff], fy0 = flow[foff + fplane];
+    // the tile kernel's `fit` predicate, same arithmetic
+    T flx0 = 0, fly0 = 0;
+    bool regular = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(tc.xf);
+        const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(tc.yf);
+        const T fxl = floor_t(dx), fyl = floor_t(dy);
+        if (j == 0) { flx0 = fxl; fly0 = fyl; }
+        regular = regular & (fxl == flx0 + static_cast<T>(j)) & (fyl == fly0 + static_cast<T>(j));
+    }
+    const T lim = static_cast<T>(1 << 20);
+    regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);
+    const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
+    const int ax0 = (tc.xf / geo.TW) * geo.TW - geo.h, ay0 = (tc.yf / geo.TH) * geo.TH - geo.h;
+    const int AP = geo.TW + 2 * geo.h, AH = geo.TH + 2 * geo.h;
+    const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;
+    const bool fit = inside & regular & (static_cast<unsigned>(u0 - ax0) <= static_cast<unsigned>(AP - 1 - K)) &
+                     (static_cast<unsigned>(v0 - ay0) <= static_cast<unsigned>(AH - 1 - K));
+    if (fit) return;
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int W = K * Wf;
+    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const unsigned obytes = static_cast<unsigned>(oplane * E);
+    T* gp = gsrc + (static_cast<size_t>(tc.b) * C + c0) * splane;
+    const T* op = gout + (static_cast<size_t>(tc.b) * C + c0) * oplane;
+    const unsigned obase = (static_cast<unsigned>(tc.yf) * K * W + static_cast<unsigned>(tc.xf) * K) * E;
+    const unsigned orow = static_cast<unsigned>(W) * E;
+    for (int c = c0; c < c1; ++c, op += oplane, gp += splane) {
+        const rsrc_t rg = make_rsrc(op, obytes);
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const Tap1<T> ty = make_tap<T>(fy0, i - K / 2, tc.yf, Hs);
+#pragma unroll 1
+            for (int j = 0; j < K; ++j) {
+                const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
+                const T gv = buf_ld<T>(rg, obase + i * orow + j * E);
+                const unsigned rT = ty.lo * static_cast<unsigned>(Ws) * E, rB = ty.hi * static_cast<unsigned>(Ws) * E;
+                const unsigned cL = tx.lo * E, cR = tx.hi * E;
+                atomic_add_off(gp, rT + cL, gv * tx.wlo * ty.wlo);
+                atomic_add_off(gp, rT + cR, gv * tx.whi * ty.wlo);
+                atomic_add_off(gp, rB + cL, gv * tx.wlo * ty.whi);
+                atomic_add_off(gp, rB + cR, gv * tx.whi * ty.whi);
+            }
+        }
+    }
+}
+
 // The complement of the tile kernel: contributions whose flow pixel lies outside the region of the
 // destination cell's tile (flow wider than the halo).  One thread per flow pixel; a pixel with no
 // such tap leaves after reading its flow vector.
@@ -1109,14 +1473,16 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
     }
     const int remap = options().xcd_remap;
     // owned-tile path: float, k <= 4, grad_source wanted, plane too large for the LDS-plane kernel
-    // be_bwd_variant: 0 = auto, 1 = all-atomic pixel kernel, 2 = owned tiles, 9 = generic
+    // be_bwd_variant: 0 = auto (3), 1 = all-atomic pixel kernel, 2 = owned tiles (halo revisits, plain stores),
+    //                 3 = shared-cell tiles (no revisits, atomic flush), 9 = generic
     if constexpr (sizeof(T) == 4) {
         const int variant = options().be_bwd_variant;
-        if (gsrc && k >= 1 && k <= 4 && (variant == 0 || variant == 2)) {
+        if (gsrc && k >= 1 && k <= 4 && (variant == 0 || variant == 2 || variant == 3)) {
             // halo 4 (|tap offset| <= 4 stays on the fast path) or 8; region height 32 or 64 rows
             const int h = options().be_bwd_halo > 4 ? 8 : 4;
-            const int RH = (h == 4 && k == 3 && options().be_bwd_rows == 64) ? 64 : 32;
-            const TileGeo geo{kTileRW - 2 * h, RH - 2 * h, h, RH};
+            const bool shared_cells = variant == 0 || variant == 3;      // tiles without halo revisits + atomic flush
+            const int RH = (!shared_cells && h == 4 && k == 3 && options().be_bwd_rows == 64) ? 64 : 32;
+            const TileGeo geo = shared_cells ? TileGeo{kTileRW, RH, h, RH} : TileGeo{kTileRW - 2 * h, RH - 2 * h, h, RH};
             const int ntx = static_cast<int>(((Ws > Wf ? Ws : Wf) + geo.TW - 1) / geo.TW);
             const int nty = static_cast<int>(((Hs > Hf ? Hs : Hf) + geo.TH - 1) / geo.TH);
             int cs = options().channel_slab > 0 ? options().channel_slab : 4;
@@ -1129,9 +1495,14 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
                 switch (k) {
 #define FFWM_BE_FAR(KK)                                                                                       \
     case KK:                                                                                                  \
-        hipLaunchKernelGGL((be_bwd_far_kernel<float, KK>), dim3(gf.grid), dim3(kBlock), 0, st, (const float*)flow, \
-                           (const float*)gout, (float*)gsrc, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf,      \
-                           gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs, geo);                                    \
+        if (shared_cells)                                                                                     \
+            hipLaunchKernelGGL((be_bwd_far2_kernel<float, KK>), dim3(gf.grid), dim3(kBlock), 0, st, (const float*)flow, \
+                               (const float*)gout, (float*)gsrc, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf,  \
+                               gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs, geo);                                \
+        else                                                                                                  \
+            hipLaunchKernelGGL((be_bwd_far_kernel<float, KK>), dim3(gf.grid), dim3(kBlock), 0, st, (const float*)flow, \
+                               (const float*)gout, (float*)gsrc, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf,  \
+                               gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs, geo);                                \
         break;
                     FFWM_BE_FAR(1) FFWM_BE_FAR(2) FFWM_BE_FAR(3) FFWM_BE_FAR(4)
 #undef FFWM_BE_FAR
@@ -1139,19 +1510,24 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
             }
             if (int rc = check_launch("ffwm_block_extractor_backward(far)")) return rc;
             {
-                LaunchScope ls("block_extractor_bwd_tile", st, bytes);
+                LaunchScope ls(shared_cells ? "block_extractor_bwd_tile2" : "block_extractor_bwd_tile", st, bytes);
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-#define FFWM_BE_TILE(KK, RR, HH)                                                                              \
-    hipLaunchKernelGGL((be_bwd_tile_kernel<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,  \
+#define FFWM_BE_TILE(KERNEL, KK, RR, HH)                                                                      \
+    hipLaunchKernelGGL((KERNEL<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,              \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
                        (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, options().ablate)
 #define FFWM_BE_TILE_K(KK)                                                                                    \
     case KK:                                                                                                  \
-        if (h == 8) FFWM_BE_TILE(KK, 32, 8);                                                                  \
-        else FFWM_BE_TILE(KK, 32, 4);                                                                         \
+        if (shared_cells) {                                                                                   \
+            if (h == 8) FFWM_BE_TILE(be_bwd_tile2_kernel, KK, 32, 8);                                         \
+            else FFWM_BE_TILE(be_bwd_tile2_kernel, KK, 32, 4);                                                \
+        } else {                                                                                              \
+            if (h == 8) FFWM_BE_TILE(be_bwd_tile_kernel, KK, 32, 8);                                          \
+            else FFWM_BE_TILE(be_bwd_tile_kernel, KK, 32, 4);                                                 \
+        }                                                                                                     \
         break;
                 if (RH == 64) {
-                    FFWM_BE_TILE(3, 64, 4);
+                    FFWM_BE_TILE(be_bwd_tile_kernel, 3, 64, 4);
                 } else {
                     switch (k) { FFWM_BE_TILE_K(1) FFWM_BE_TILE_K(2) FFWM_BE_TILE_K(3) FFWM_BE_TILE_K(4) }
                 }

@@ -124,9 +124,9 @@ BE_TILE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("halo,rows", [(0, 0), (8, 0), (4, 64)])
+@pytest.mark.parametrize("halo,rows,variant", [(0, 0, 0), (8, 0, 3), (0, 0, 2), (8, 0, 2), (4, 64, 2)])
 @pytest.mark.parametrize("case", BE_TILE_CASES)
-def test_block_extractor_backward_owned_tiles(oracle, case, halo, rows):
+def test_block_extractor_backward_owned_tiles(oracle, case, halo, rows, variant):
     from ffwm_amd import ops, _lib
     src, flow, go, k = _be_inputs(case, torch.float32)
     gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, k)
@@ -134,11 +134,13 @@ def test_block_extractor_backward_owned_tiles(oracle, case, halo, rows):
     gf = torch.zeros_like(flow, device=DEV)
     _lib.set_option("be_bwd_halo", halo)
     _lib.set_option("be_bwd_rows", rows)
+    _lib.set_option("be_bwd_variant", variant)       # 0 = auto (shared-cell tiles), 2 = owned tiles, 3 = shared-cell tiles
     try:
         ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), k, gs, gf)
     finally:
         _lib.set_option("be_bwd_halo", 0)
         _lib.set_option("be_bwd_rows", 0)
+        _lib.set_option("be_bwd_variant", 0)
     # case 2 collapses ~18k pixels x 9 taps onto the border cells through float atomics in arbitrary
     # order (as the reference does): the fp32 summation-order noise alone is ~1e-5 relative there
     tol = 1e-4 if case[7] >= 100 else BWD_TOL[torch.float32]
@@ -164,7 +166,7 @@ def test_block_extractor_backward_owned_tiles_small_planes(oracle, case):
         rows = _lib.prof_collect()
     finally:
         _lib.set_option("scatter_variant", 0)
-    assert "block_extractor_bwd_tile" in rows
+    assert "block_extractor_bwd_tile2" in rows
     _close(gs, gs_ref, BWD_TOL[torch.float32], relative=True)
     _close(gf, gf_ref, BWD_TOL[torch.float32], relative=True)
 
