@@ -103,9 +103,13 @@ class FFWMTrainer(object):
         # device so that an optimizer step can sit inside a captured hipGraph; it costs ~10 ms per
         # eager step, so it is only switched on for capture())
         cap = bool(capturable) and self.device.type == "cuda"
-        self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999), capturable=cap)
-        self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
-        self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999), capturable=cap)
+        # fused (one multi-tensor kernel per optimizer instead of ~10 foreach launches) on the GPU; its
+        # capturable form keeps the step counter on the device without the per-parameter kernels of the
+        # foreach implementation (1275 extra launches per step, measured)
+        kw = {"fused": True, "capturable": cap} if self.device.type == "cuda" else {}
+        self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999), **kw)
+        self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), **kw)
+        self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999), **kw)
         self.world_size = world_size
         self.batched_losses = batched_losses
         self._graphs = None

@@ -16,15 +16,16 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--window-ms", type=float, default=300.0)
     ap.add_argument("--header", default="")
+    ap.add_argument("--end-offset-ms", type=float, default=0.0, help="end the window this long before the end of the trace")
     a = ap.parse_args()
     rows = []
     with open(a.trace) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                          r.get("VGPR_Count", r.get("Arch_VGPR_Count", "")), r.get("LDS_Block_Size", "")))
-    t_end = max(r[1] for r in rows)
+    t_end = max(r[1] for r in rows) - int(a.end_offset_ms * 1e6)
     t0 = t_end - int(a.window_ms * 1e6)
-    sel = [r for r in rows if r[0] >= t0]
+    sel = [r for r in rows if t0 <= r[0] < t_end]
     agg = collections.OrderedDict()
     busy = 0
     for s, e, name, vg, lds in sel:
