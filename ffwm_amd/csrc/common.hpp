@@ -144,36 +144,38 @@ __device__ __forceinline__ T buf_ld(rsrc_t r, unsigned boff) {
 }
 
 // N consecutive dwords starting at dword `POS` of w[], as the widest instructions available.
-template <int N, int POS = 0>
+// AUX = cache-policy bits (0 = default, 2 = nt: a stream that is read once).
+template <int N, int POS = 0, int AUX = 0>
 __device__ __forceinline__ void buf_load_dwords(rsrc_t r, unsigned boff, unsigned* w) {
     if constexpr (N - POS >= 4) {
-        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, boff + 4u * POS, 0, 0);
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, boff + 4u * POS, 0, AUX);
         w[POS] = v.x; w[POS + 1] = v.y; w[POS + 2] = v.z; w[POS + 3] = v.w;
-        buf_load_dwords<N, POS + 4>(r, boff, w);
+        buf_load_dwords<N, POS + 4, AUX>(r, boff, w);
     } else if constexpr (N - POS == 3) {
-        u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, boff + 4u * POS, 0, 0);
+        u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, boff + 4u * POS, 0, AUX);
         w[POS] = v.x; w[POS + 1] = v.y; w[POS + 2] = v.z;
     } else if constexpr (N - POS == 2) {
-        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, boff + 4u * POS, 0, 0);
+        u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, boff + 4u * POS, 0, AUX);
         w[POS] = v.x; w[POS + 1] = v.y;
     } else if constexpr (N - POS == 1) {
-        w[POS] = __builtin_amdgcn_raw_buffer_load_b32(r, boff + 4u * POS, 0, 0);
+        w[POS] = __builtin_amdgcn_raw_buffer_load_b32(r, boff + 4u * POS, 0, AUX);
     }
 }
-template <int N, int POS = 0>
+// AUX = cache-policy bits of the instruction (0 = default, 2 = nt: streaming store that is not kept in L2)
+template <int N, int POS = 0, int AUX = 0>
 __device__ __forceinline__ void buf_store_dwords(rsrc_t r, unsigned boff, const unsigned* w) {
     if constexpr (N - POS >= 4) {
         u32x4 v = {w[POS], w[POS + 1], w[POS + 2], w[POS + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(v, r, boff + 4u * POS, 0, 0);
-        buf_store_dwords<N, POS + 4>(r, boff, w);
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, boff + 4u * POS, 0, AUX);
+        buf_store_dwords<N, POS + 4, AUX>(r, boff, w);
     } else if constexpr (N - POS == 3) {
         u32x3 v = {w[POS], w[POS + 1], w[POS + 2]};
-        __builtin_amdgcn_raw_buffer_store_b96(v, r, boff + 4u * POS, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(v, r, boff + 4u * POS, 0, AUX);
     } else if constexpr (N - POS == 2) {
         u32x2 v = {w[POS], w[POS + 1]};
-        __builtin_amdgcn_raw_buffer_store_b64(v, r, boff + 4u * POS, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, r, boff + 4u * POS, 0, AUX);
     } else if constexpr (N - POS == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(w[POS], r, boff + 4u * POS, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(w[POS], r, boff + 4u * POS, 0, AUX);
     }
 }
 
@@ -190,8 +192,16 @@ __device__ __forceinline__ void buf_load_row(rsrc_t r, unsigned boff, ElemRow<T,
     buf_load_dwords<K * sizeof(T) / 4>(r, boff, row.w);
 }
 template <typename T, int K>
+__device__ __forceinline__ void buf_load_row_nt(rsrc_t r, unsigned boff, ElemRow<T, K>& row) {
+    buf_load_dwords<K * sizeof(T) / 4, 0, 2>(r, boff, row.w);
+}
+template <typename T, int K>
 __device__ __forceinline__ void buf_store_row(rsrc_t r, unsigned boff, const ElemRow<T, K>& row) {
     buf_store_dwords<K * sizeof(T) / 4>(r, boff, row.w);
+}
+template <typename T, int K>
+__device__ __forceinline__ void buf_store_row_nt(rsrc_t r, unsigned boff, const ElemRow<T, K>& row) {
+    buf_store_dwords<K * sizeof(T) / 4, 0, 2>(r, boff, row.w);
 }
 
 struct TileCoord {

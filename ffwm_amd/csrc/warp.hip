@@ -119,7 +119,7 @@ constexpr int kWlTileX = 64, kWlTileY = 16, kWlPix = 4, kWlRows = 32, kWlCols = 
 template <bool FLIP>
 __global__ void __launch_bounds__(kBlock)
 warp_fwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ flow, float* __restrict__ out, int C,
-                    int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+                    int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int nt) {
     using T = float;
     constexpr int NW = kBlock / kWave;
     constexpr unsigned E = sizeof(T);
@@ -197,12 +197,14 @@ warp_fwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ fl
             ElemRow<T, kWlPix> r;
 #pragma unroll
             for (int k = 0; k < kWlPix; ++k) r.v[k] = v[k];
-            buf_store_row<T, kWlPix>(ro, o_direct, r);
+            if (nt) buf_store_row_nt<T, kWlPix>(ro, o_direct, r);
+            else buf_store_row<T, kWlPix>(ro, o_direct, r);
             if (FLIP) {
                 ElemRow<T, kWlPix> m;
 #pragma unroll
                 for (int k = 0; k < kWlPix; ++k) m.v[k] = v[kWlPix - 1 - k];
-                buf_store_row<T, kWlPix>(make_rsrc(plane_out + flip_planes, obytes), o_flip, m);
+                if (nt) buf_store_row_nt<T, kWlPix>(make_rsrc(plane_out + flip_planes, obytes), o_flip, m);
+                else buf_store_row<T, kWlPix>(make_rsrc(plane_out + flip_planes, obytes), o_flip, m);
             }
         } else if (yin) {
 #pragma unroll
@@ -507,14 +509,15 @@ int launch_fwd(const T* feat, const T* flow, T* out, int64_t B, int64_t C, int64
             while (cs > 2 && B * txs * tys * ((C + cs - 1) / cs) < 2048) cs = (cs + 1) / 2;
             const int cslabs = static_cast<int>((C + cs - 1) / cs);
             const unsigned grid = static_cast<unsigned>(B * txs * tys * cslabs);
+            const int nt = sizeof(T) * static_cast<double>(B) * C * H * W * (flip ? 2 : 1) >= 64.0 * 1024 * 1024 ? 1 : 0;   // streaming stores
             if (flip)
                 hipLaunchKernelGGL((warp_fwd_lds_kernel<true>), dim3(grid), dim3(kBlock), 0, st, (const float*)feat,
                                    (const float*)flow, (float*)out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, txs, tys, cslabs,
-                                   cs, remap);
+                                   cs, remap, nt);
             else
                 hipLaunchKernelGGL((warp_fwd_lds_kernel<false>), dim3(grid), dim3(kBlock), 0, st, (const float*)feat,
                                    (const float*)flow, (float*)out, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, txs, tys, cslabs,
-                                   cs, remap);
+                                   cs, remap, nt);
             return check_launch("ffwm_warp_forward(lds)");
         }
     }
