@@ -1201,23 +1201,39 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
             __syncthreads();
         }
         {
-            // flush: one global atomic per non-zero in-image cell, then clear the box
+            // flush + restage in one sweep over the box: one global atomic per non-zero in-image cell of
+            // channel c (then the cell is cleared), and the same cell of channel c+1's clamp-extended
+            // source goes into S -- an in-image cell has the same plane offset in both
             T* gplane = gp + static_cast<size_t>(c - c0) * splane;
+            const rsrc_t rn = make_rsrc(sp + static_cast<size_t>(more ? c + 1 - c0 : c - c0) * splane, more ? sbytes : 0u);
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
 #pragma unroll 1
-            for (int i0 = 0; i0 < NA; i0 += kBlock) {
-                const int idx = i0 + tid;
-                if (idx < NA) {
+            for (int i0 = 0; i0 < NA; i0 += 4 * kBlock) {
+                T st[4];
+                unsigned off[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = i0 + q * kBlock + tid;
                     const int arow = idx / AP, acol = idx - arow * AP;
                     const int cx = ax0 + acol, cy = ay0 + arow;
-                    const T v = static_cast<T>(A[idx]);
-                    A[idx] = 0;
-                    if (v != 0 && cx >= 0 && cx < Ws && cy >= 0 && cy < Hs) atomic_add(gplane + static_cast<size_t>(cy) * Ws + cx, v);
+                    const int gy = min(max(cy, 0), Hs - 1), gx = min(max(cx, 0), Ws - 1);
+                    off[q] = static_cast<unsigned>(gy) * Ws + gx;
+                    st[q] = buf_ld<T>(rn, idx < NA ? off[q] * E : 0xFFFFFFF0u);
+                    if (gy != cy || gx != cx) off[q] = 0xFFFFFFFFu;          // outside the image: nothing to flush
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = i0 + q * kBlock + tid;
+                    if (idx < NA) {
+                        const T v = static_cast<T>(A[idx]);
+                        A[idx] = 0;
+                        if (v != 0 && off[q] != 0xFFFFFFFFu) atomic_add(gplane + off[q], v);
+                        if (more) S[idx] = st[q];
+                    }
                 }
             }
         }
-        if (more) stage(sp + static_cast<size_t>(c + 1 - c0) * splane);
         __syncthreads();
     }
     if (gflow) {
