@@ -540,11 +540,14 @@ constexpr int kPlaneThreads = 1024;
 template <typename T>
 __global__ void __launch_bounds__(kPlaneThreads)
 be_bwd_src_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gsrc, int C,
-                        int Hs, int Ws, int Hf, int Wf, int k, int cg, int groups) {
+                        int Hs, int Ws, int Hf, int Wf, int k, int cg, int groups, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* acc = reinterpret_cast<double*>(smem_raw);
-    const int grp = blockIdx.x % groups;
-    const int b = blockIdx.x / groups;
+    unsigned bid = blockIdx.x;
+    const int split = bid % nsplit;          // few planes (the reference's 1-channel grids): the pixels are split over nsplit blocks
+    bid /= nsplit;
+    const int grp = bid % groups;
+    const int b = bid / groups;
     const int c0 = grp * cg;
     const int nc = (c0 + cg <= C) ? cg : C - c0;
     const int ncell = Hs * Ws, npix = Hf * Wf;
@@ -554,7 +557,7 @@ be_bwd_src_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, 
     __syncthreads();
     const T* fl = flow + static_cast<size_t>(b) * 2 * npix;
     const T* g0 = gout + (static_cast<size_t>(b) * C + c0) * oplane;
-    for (int p = threadIdx.x; p < npix; p += kPlaneThreads) {
+    for (int p = split * kPlaneThreads + threadIdx.x; p < npix; p += kPlaneThreads * nsplit) {
         const int yf = p / Wf, xf = p - yf * Wf;
         const T fx0 = fl[p], fy0 = fl[npix + p];
         for (int i = 0; i < k; ++i) {
@@ -577,7 +580,14 @@ be_bwd_src_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, 
     }
     __syncthreads();
     T* dst = gsrc + (static_cast<size_t>(b) * C + c0) * ncell;
-    for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += static_cast<T>(acc[i]);
+    if (nsplit == 1) {
+        for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) dst[i] += static_cast<T>(acc[i]);
+    } else {                                 // several blocks share the planes: one global atomic per non-zero cell
+        for (int i = threadIdx.x; i < nc * ncell; i += kPlaneThreads) {
+            const T v = static_cast<T>(acc[i]);
+            if (v != 0) atomic_add(dst + i, v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------ backward, owned tiles
@@ -1478,13 +1488,15 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
         if (cg > C) cg = static_cast<int>(C);
         while (cg > 1 && B * ((C + cg - 1) / cg) < 512) cg = (cg + 1) / 2;
         const int groups = static_cast<int>((C + cg - 1) / cg);
+        int nsplit = 1;
+        while (B * groups * nsplit < 256 && nsplit * 2 * kPlaneThreads <= Hf * Wf) nsplit *= 2;
         {
             LaunchScope ls("block_extractor_bwd_src_plane", st,
                            sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * k * k * Hf * Wf + 2.0 * C * Hs * Ws + 2.0 * Hf * Wf));
             allow_large_lds(reinterpret_cast<const void*>(be_bwd_src_plane_kernel<T>));
-            hipLaunchKernelGGL((be_bwd_src_plane_kernel<T>), dim3(static_cast<unsigned>(B * groups)), dim3(kPlaneThreads),
+            hipLaunchKernelGGL((be_bwd_src_plane_kernel<T>), dim3(static_cast<unsigned>(B * groups * nsplit)), dim3(kPlaneThreads),
                                static_cast<size_t>(cg) * plane_lds, st, flow, gout, gsrc, (int)C, (int)Hs, (int)Ws,
-                               (int)Hf, (int)Wf, k, cg, groups);
+                               (int)Hf, (int)Wf, k, cg, groups, nsplit);
         }
         if (int rc = check_launch("ffwm_block_extractor_backward(source, plane)")) return rc;
         if (!gflow) return FFWM_OK;

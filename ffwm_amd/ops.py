@@ -258,3 +258,27 @@ def guided_filter_backward(x, y, saved, grad_output, r):
             _ptr(x), _ptr(y), _ptr(saved), _ptr(grad_output), _ptr(gx), B * C, H, W, int(r), _dtype_code(x), stream),
             "ffwm_guided_filter_backward")
     return gx
+
+
+# ---------------------------------------------------------------- fused affine regularisation
+def affine_regularization(flow, ktk, kernel_size, want_grad=True):
+    """-> (loss, grad_flow or None): AffineRegularizationLoss(kz)(flow) of the reference (losses.py:200-219)
+    and its gradient, one launch.  ktk = the module's K^T K matrix [kz^2, kz^2] in flow's dtype."""
+    if flow.dim() != 4 or flow.size(1) != 2:
+        raise ValueError("affine_regularization: flow must be [B,2,h,w]")
+    if not flow.is_cuda:
+        raise NotImplementedError("affine_regularization: ffwm_amd ops run on the GPU only (got a %s tensor)" % flow.device)
+    flow = flow.contiguous()
+    ktk = ktk.to(device=flow.device, dtype=flow.dtype).contiguous()
+    B, _, h, w = flow.shape
+    k = int(kernel_size)
+    if ktk.numel() != k ** 4:
+        raise ValueError("affine_regularization: ktk must hold kz^2 x kz^2 values")
+    loss = torch.zeros((), device=flow.device, dtype=flow.dtype)
+    grad = torch.zeros_like(flow) if want_grad else None
+    scale = 1.0 / (B * (h - k + 1) * (w - k + 1))
+    with _on_device(flow) as stream:
+        _lib.check(_lib.load().ffwm_affine_regularization(
+            _ptr(flow), _ptr(ktk), _ptr(loss), _ptr(grad), B, h, w, k, scale, _dtype_code(flow), stream),
+            "ffwm_affine_regularization")
+    return loss * scale, grad

@@ -174,6 +174,19 @@ int ffwm_guided_filter_backward(const void* x, const void* y, const void* saved,
                                 const void* grad_output, void* grad_x, int64_t planes, int64_t H,
                                 int64_t W, int r, int dtype, void* stream);
 
+/* ---- fused affine regularisation (FlowNet pre-training) -----------------------------------------
+ * AffineRegularizationLoss.__call__ of models/losses.py:200-219 for one flow scale in ONE launch:
+ *   loss_sum[0] += sum over b, both coordinate grids g = (flow + 1) / 2 * 128 and every kz x kz window p
+ *                  of g of  p^T (K^T K) p            (the caller multiplies by loss_scale = 1 / (B h' w'))
+ *   grad_flow  += d(loss_scale * that sum) / d flow   (may be NULL)
+ * flow[B,2,h,w]; ktk[kz^2, kz^2] = the reference's `self.kernel` (K^T K, losses.py:192-198) in the
+ * tensors' dtype; kernel_size in {3, 5, 7} (models/flownet_model.py:31).  The reference reaches the same
+ * numbers through conv2d -> local_attn_reshape -> block_extractor -> avg_pool2d (those entry points remain;
+ * ffwm_amd/losses.py composes them like the reference when `fused=False`). */
+int ffwm_affine_regularization(const void* flow, const void* ktk, void* loss_sum, void* grad_flow,
+                               int64_t B, int64_t h, int64_t w, int kernel_size, double loss_scale,
+                               int dtype, void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded

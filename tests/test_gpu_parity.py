@@ -756,3 +756,33 @@ def test_affine_regularization_gradient_matches_identity_ops():
         b = flow0.clone().requires_grad_(True)
         ref_m(b).backward()
         assert (a.grad.cpu() - b.grad).abs().max().item() <= 1e-9 * (1 + b.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_fused_affine_regularization_matches_the_op_composition(dtype):
+    """One kernel per scale (fused=True) vs conv2d -> local_attn_reshape -> block_extractor -> avg_pool2d
+    (fused=False, the reference's own composition on the HIP ops): loss value, gradient, and the golden."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fill
+    from ffwm_amd.losses import AffineRegularizationLoss, MultiAffineRegularizationLoss
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules.pt"))["affine_reg"]
+    tol = 2e-3 if dtype == torch.float32 else 1e-9
+    for kz, s in ((3, 32), (5, 64), (7, 128), (5, 37)):
+        flow0 = (fill.flow_field(2, s, s, "reg_flow%d" % s) if s != 37 else
+                 torch.rand(3, 2, 37, 41, generator=_gen(kz)) * 2 - 1).to(dtype)
+        a = flow0.to(DEV).requires_grad_(True)
+        b = flow0.to(DEV).requires_grad_(True)
+        la = AffineRegularizationLoss(kz, fused=True)(a)
+        lb = AffineRegularizationLoss(kz, fused=False)(b)
+        assert abs(float(la) - float(lb)) <= tol * (1 + abs(float(lb))), (kz, float(la), float(lb))
+        if s != 37:
+            ref = float(gold["kz%d" % kz]["loss"])
+            assert abs(float(la) - ref) <= 2e-3 * (1 + abs(ref)), (kz, float(la), ref)
+        (3 * la).backward()
+        (3 * lb).backward()
+        assert (a.grad - b.grad).abs().max().item() <= tol * (1 + b.grad.abs().max().item()), kz
+    multi = MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3}, fused=True)
+    flows = [fill.flow_field(2, s, s, "reg_flow%d" % s).to(DEV, dtype) for s in (128, 64, 32)]
+    ref = float(gold["multi"])
+    assert abs(float(multi(flows[::-1])) - ref) <= 2e-3 * (1 + abs(ref))

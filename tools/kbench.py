@@ -144,6 +144,29 @@ def main():
         o = torch.empty(32, 128, 256, 256, device=dev)
         results += run("big warp+flip+cat fwd [32,64,256,256] flow=%s" % args.warp_flow, lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
         del feat, fl, o
+    if want("affine"):
+        # MultiAffineRegularizationLoss at the reference's FlowNet pre-training sizes (bs 6, kz 7/5/3 on 128/64/32 px):
+        # the reference's op composition on the HIP kernels vs the fused kernel, forward + backward, wall time
+        import time
+        from ffwm_amd.losses import MultiAffineRegularizationLoss
+        flows = [(torch.rand(6, 2, sz, sz, generator=g) * 2 - 1).to(dev).requires_grad_(True) for sz in (32, 64, 128)]
+        for fused in (False, True):
+            m = MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3}, fused=fused)
+
+            def step():
+                for f in flows:
+                    f.grad = None
+                m(flows).backward()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / args.reps * 1e3
+            results.append({"case": "MultiAffineRegularizationLoss fwd+bwd bs=6 (3 scales), %s" % ("fused kernel" if fused else "op composition"),
+                            "kernel": "wall", "avg_ms": round(ms, 4)})
     for r in results:
         print(json.dumps(r))
 
