@@ -67,8 +67,15 @@ def init_dist(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # FFWM_DIST_BACKEND=gloo lets the launch path be exercised on a box with fewer GPUs than ranks
+        # (ranks then share devices; RCCL refuses that).  The driver's runs use the default: nccl = RCCL.
+        backend = os.environ.get("FFWM_DIST_BACKEND", "nccl")
+        local = local % torch.cuda.device_count() if backend != "nccl" else local
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
