@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- FFWM flow-warp hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|flownet|warp|ops]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|flownet|flowtrain|warp|ops]
 
 Default workload = BASELINE.json configs[2]: the full FFWM train step (netG + netD + flowNetF +
 flowNetB, all losses, three Adam optimizers) on synthetic MultiPIE-shaped 128x128 tensors, batch 8
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=["train", "flownet", "warp", "ops"])
+    ap.add_argument("--workload", default="train", choices=["train", "flownet", "flowtrain", "warp", "ops"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 8 train, 6 flownet)")
     ap.add_argument("--titers", type=int, default=0, help="0 = warm-up branch (<20000), 20000 = guided-filter branch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -292,6 +292,21 @@ def main():
                        "config": {"workload": "BASELINE configs[1]: FlowNetF forward-only, bs=%d" % bs,
                                   "batch_per_gpu": bs, "parallelism": "dp%d" % world},
                        "fp32_flop_frac": round(imgs / dt / world * FLOWNET_FLOP_PER_IMG / FP32_PEAK, 5)})
+    elif args.workload == "flowtrain":
+        # FlowNet pre-training step (train_flow.py / models/flownet_model.py:57-78): the only trainer of the
+        # reference that runs the custom ops; README.md:105,116 trains it with batch 6
+        from ffwm_amd import trainer
+        bs = args.batch or 6
+        t = trainer.FlowNetTrainer(dev, world_size=world, seed=0, bucket_bytes=args.bucket_mb << 20)
+        batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
+        dt, rows = timed(lambda: t.step(batch), args.steps, args.warmup, world)
+        imgs = bs * world * args.steps
+        result.update({"metric": "FlowNet pre-training img/s (128x128)", "value": round(imgs / dt, 2), "unit": "img/s",
+                       "ms_per_step": round(dt / args.steps * 1e3, 3),
+                       "config": {"workload": "FlowNetModel train step (correctness + affine regularisation + landmark "
+                                              "losses, Adam), synthetic 128x128", "batch_per_gpu": bs,
+                                  "parallelism": "dp%d" % world, "weights": "seeded random init"},
+                       "losses": {k: round(v, 5) for k, v in t.loss_values().items()}})
     elif args.workload == "warp":
         # the warp + flip + cat sub-path of netG's warp-attention, forward + backward, bs images
         from ffwm_amd.external_function import WarpFlipCat
@@ -340,7 +355,7 @@ def main():
             # algorithmic bytes in a step (launch-latency-bound helpers on a few hundred KB -- guided filter
             # on 24 planes, spectral norm on 61 small matrices -- are listed in `kernels` with the rest)
             top = max(inrun, key=lambda r: r["alg_MB"] * r["launches"])
-            pmc = pmc_traffic().get(top["kernel"])
+            pmc = pmc_traffic().get(top["kernel"]) if args.workload == "train" else None     # measured on the train workload
             result["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"], "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": top["frac_hbm_peak"],
                                   "traffic": pmc["traffic_bytes"] if pmc else None,
@@ -357,7 +372,7 @@ def main():
         result["kernels"] = inrun
         if not args.no_kernels:
             result["kernels"] = inrun + standalone_kernels()
-        traffic = pmc_traffic()
+        traffic = pmc_traffic() if args.workload == "train" else {}
         for row in result["kernels"]:
             if row["kernel"] in traffic and (row["where"] == "timed region" or not row["kernel"].startswith("warp")):
                 row["pmc_traffic_MB"] = round(traffic[row["kernel"]]["traffic_bytes"] / 1e6, 3)

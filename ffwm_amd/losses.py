@@ -101,3 +101,88 @@ class MultiAffineRegularizationLoss(nn.Module):
         for i in range(len(flow_fields)):
             loss = loss + self.method_dic[self.layers[i]](flow_fields[i])
         return loss
+
+
+# ------------------------------------------------------------------------------------------------
+# The other two losses of FlowNet pre-training (models/flownet_model.py:64-72)
+class LandmarkLoss(nn.Module):
+    """MSE between the flow sampled at the frontal landmarks and the (normalised) profile landmarks
+    (losses.py:61-74).  flow [B,2,s,s]; lm_S / lm_F integer pixel coordinates [B,L,2]; gate [B,L,2]."""
+
+    def forward(self, flow, lm_S, lm_F, gate):
+        b, _, s, _ = flow.size()
+        flow_view = flow.transpose(1, 2).transpose(2, 3).reshape(b, -1, 2)
+        index = lm_F[:, :, 0:1] + lm_F[:, :, 1:2] * s
+        index = torch.cat((index, index), 2)
+        flow_points = torch.gather(flow_view, 1, index)
+        gt_points = lm_S.float() / (s / 2.0) - 1
+        return F.mse_loss(flow_points * gate, gt_points * gate)
+
+
+class MultiScaleLDLoss(nn.Module):
+    """losses.py:114-126: LandmarkLoss on the 128 / 64 / 32 px flows, weights 1000 / 1000 / 1500.  The integer
+    landmarks are divided by the scale with INTEGER division: that is what ``lm.div(scale)`` did for integer
+    tensors in the reference's pinned PyTorch 1.5.0 (README.md:14); from 1.6 on ``div`` is true division and
+    the reference's own ``torch.gather`` call rejects the float index."""
+
+    def __init__(self):
+        super().__init__()
+        self.criterionLD = LandmarkLoss()
+        self.weights = [1000, 1000, 1500]
+        self.img_size = 128
+
+    def forward(self, flows, lm_S, lm_F, gate):
+        ld_loss = 0
+        for i, flow in enumerate(flows):
+            scale = self.img_size // flow.size(3)
+            lms = torch.div(lm_S, scale, rounding_mode="floor") if scale > 1 else lm_S
+            lmf = torch.div(lm_F, scale, rounding_mode="floor") if scale > 1 else lm_F
+            ld_loss = ld_loss + self.weights[i] * self.criterionLD(flow, lms, lmf, gate)
+        return ld_loss
+
+
+class PerceptualCorrectness(nn.Module):
+    """losses.py:322-396 (the sampling-correctness loss of Global-Flow-Local-Attention) on the bilinear
+    path the reference really takes (``use_bilinear_sampling=True``): for every flow scale,
+    exp(-cos(warp(source_vgg, flow), target_vgg) / max_j cos(source_vgg_j, target_vgg)) averaged under the
+    mask.  ``vgg`` maps an image to {'relu1_1': ..., ...}; ``warp`` is WarpNet (HIP) or a stand-in.
+
+    Result-preserving difference: the VGG features and the N^2 x N^2 correlation maximum do not depend on
+    the flow, and neither the images nor VGG are trained, so they are evaluated under no_grad -- the
+    reference back-propagates through a [B, N^2, N^2] matrix (1 GiB per sample at relu1_1) for nothing."""
+
+    def __init__(self, vgg, warp, layer=("relu1_1", "relu2_1", "relu3_1", "relu4_1")):
+        super().__init__()
+        self.vgg = vgg
+        self.warp = warp
+        self.layer = list(layer)
+        self.eps = 1e-8
+
+    def forward(self, target, source, flow_list, used_layers, norm_mask=None):
+        used_layers = sorted(used_layers, reverse=True)
+        with torch.no_grad():
+            self.target_vgg, self.source_vgg = self.vgg(target), self.vgg(source)
+        loss = 0
+        for i in range(len(flow_list)):
+            loss = loss + self.calculate_loss(flow_list[i], self.layer[used_layers[i]], norm_mask)
+        return loss
+
+    def calculate_loss(self, flow, layer, norm_mask=None):
+        target_vgg = self.target_vgg[layer]
+        source_vgg = self.source_vgg[layer]
+        b, c, h, w = target_vgg.shape
+        flow = F.interpolate(flow, [h, w])
+        target_all = target_vgg.reshape(b, c, -1)                       # [b, C, N2]
+        with torch.no_grad():
+            source_all = source_vgg.reshape(b, c, -1).transpose(1, 2)   # [b, N2, C]
+            source_norm = source_all / (source_all.norm(dim=2, keepdim=True) + self.eps)
+            target_norm = target_all / (target_all.norm(dim=1, keepdim=True) + self.eps)
+            correction_max = torch.bmm(source_norm, target_norm).max(dim=1)[0]      # [b, N2]
+        input_sample = self.warp(source_vgg, flow).reshape(b, c, -1)
+        correction_sample = F.cosine_similarity(input_sample, target_all)          # [b, N2]
+        loss_map = torch.exp(-correction_sample / (correction_max + self.eps))
+        e1 = torch.exp(torch.tensor(-1.0, dtype=loss_map.dtype, device=loss_map.device))
+        if norm_mask is None:
+            return torch.mean(loss_map) - e1
+        norm_mask = F.interpolate(norm_mask, size=(h, w)).reshape(-1, h * w)
+        return (torch.sum(norm_mask * loss_map) - e1) / (torch.sum(norm_mask) + self.eps)

@@ -41,7 +41,10 @@ def synthetic_batch(batch_size, device, seed=0, n_landmarks=1024):
     disc = (((yy - 63.5) ** 2 + (xx - 63.5) ** 2) <= 48.0 ** 2).float().view(1, 1, 128, 128)
     mask = disc.repeat(batch_size, 1, 1, 1)
     lm_F = torch.randint(16, 112, (batch_size, n_landmarks, 2), generator=g)
-    batch = {"img_S": img_S, "img_F": img_F, "mask_S": mask.clone(), "mask_F": mask, "lm_F": lm_F}
+    lm_S = torch.randint(16, 112, (batch_size, n_landmarks, 2), generator=g)
+    gate = (torch.rand(batch_size, n_landmarks, 1, generator=g) > 0.2).float()     # landmark visibility (flownet_model.py:53-54)
+    batch = {"img_S": img_S, "img_F": img_F, "mask_S": mask.clone(), "mask_F": mask, "lm_F": lm_F, "lm_S": lm_S,
+             "gate": gate}
     return {k: v.to(device) for k, v in batch.items()}
 
 
@@ -379,6 +382,57 @@ class FFWMTrainer(object):
         self._static = None
         self.red_D.set_overlap(True)
         self.red_G.set_overlap(True)
+
+    def loss_values(self):
+        return {k: float(v.detach()) for k, v in self.losses.items()}
+
+
+class FlowNetTrainer(object):
+    """FlowNet pre-training, the other trainer of the reference (train_flow.py -> models/flownet_model.py:57-78):
+        flows = flowNet(img_S); fake_F = WarpNet(img_S, flow128)
+        loss  = 20 * PerceptualCorrectness(img_F, img_S, flows[::-1], [2, 1, 0], mask)
+              + 0.01 * MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3})(flows[::-1])
+              + MultiScaleLDLoss(flows, lm_S, lm_F, gate)
+        Adam(lr 4e-4, betas (0.5, 0.999)) on flowNet
+    This is the only training path of the reference that runs the custom ops.  Here the warp of
+    the VGG features and of the image go through the HIP warp kernels and the regulariser is the fused
+    affine-regularisation kernel.  VGG19 is seeded random (no pretrained weights offline), frozen."""
+
+    def __init__(self, device, world_size=1, seed=0, ngf=64, warp=None, fused_regularization=None, bucket_bytes=64 << 20):
+        from .losses import MultiAffineRegularizationLoss, MultiScaleLDLoss, PerceptualCorrectness
+        self.device = torch.device(device)
+        torch.manual_seed(seed)
+        self.warp = warp if warp is not None else WarpNet()
+        self.flowNet = nets.FlowNet(ngf).to(self.device)
+        self.vgg = nets.VGG19("relu3_1").to(self.device).eval()
+        broadcast_module_state([self.flowNet, self.vgg])
+        if fused_regularization is None:
+            fused_regularization = self.device.type == "cuda"
+        self.Regularization = MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3}, fused=fused_regularization)
+        self.Correctness = PerceptualCorrectness(self.vgg, self.warp)
+        self.criterionLD = MultiScaleLDLoss()
+        params = [p for n, p in self.flowNet.named_parameters() if not n.startswith("inter_conv_occ")]
+        kw = {"fused": True} if self.device.type == "cuda" else {}
+        self.optimizer = torch.optim.Adam(params, lr=0.0004, betas=(0.5, 0.999), **kw)
+        self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes)
+        self.losses = {}
+
+    def step(self, b):
+        """optimize_parameters (flownet_model.py:74-78)."""
+        gate = torch.cat((b["gate"], b["gate"]), 2)
+        flow, flow64, flow32 = self.flowNet(b["img_S"])
+        self.fake_F = self.warp(b["img_S"], flow)
+        flows = [flow, flow64, flow32]
+        loss_cor = self.Correctness(b["img_F"], b["img_S"], flows[::-1], [2, 1, 0], norm_mask=b["mask_F"]) * 20
+        loss_reg = self.Regularization(flows[::-1]) * 0.01
+        loss_lm = self.criterionLD(flows, b["lm_S"], b["lm_F"], gate)
+        loss = loss_cor + loss_lm + loss_reg
+        self.reducer.zero_grad()
+        loss.backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        self.losses = {"loss": loss, "cor": loss_cor, "reg": loss_reg, "lm": loss_lm}
+        return self.losses
 
     def loss_values(self):
         return {k: float(v.detach()) for k, v in self.losses.items()}

@@ -136,6 +136,40 @@ with torch.no_grad():
     reg["multi_layers"] = torch.tensor(multi.layers)
 out["affine_reg"] = reg
 
+# ---- MultiScaleLDLoss (losses.py:61-74,114-126) and PerceptualCorrectness.calculate_loss (:342-371, bilinear
+#      path).  The reference's VGG19 needs torchvision's pretrained weights: the loss is fed closed-form
+#      "features" directly (the class is instantiated without __init__).
+g = torch.Generator().manual_seed(1234)
+lm_S = torch.randint(16, 112, (2, 40, 2), generator=g)
+lm_F = torch.randint(16, 112, (2, 40, 2), generator=g)
+gate = (torch.rand(2, 40, 1, generator=g) > 0.3).float()
+gate2 = torch.cat((gate, gate), 2)
+ld_flows = [fill.flow_field(2, s, s, "ld_flow%d" % s) for s in (128, 64, 32)]
+with torch.no_grad():
+    try:
+        ld = losses.MultiScaleLDLoss()(ld_flows, lm_S, lm_F, gate2)
+        out["ld_loss"] = {"lm_S": lm_S, "lm_F": lm_F, "gate": gate, "loss": ld.double(), "mode": "reference"}
+    except Exception as e:      # torch >= 1.6: lm_F.div(scale) is float and torch.gather refuses it; the reference
+        # (PyTorch 1.5) floor-divides integer tensors.  Pin the per-scale LandmarkLoss instead, with the division
+        # done the 1.5 way, and the weighted sum the class would have formed.
+        crit = losses.LandmarkLoss()
+        tot = 0
+        for i, fl in enumerate(ld_flows):
+            sc = 128 // fl.size(3)
+            tot = tot + [1000, 1000, 1500][i] * crit(fl, lm_S // sc if sc > 1 else lm_S, lm_F // sc if sc > 1 else lm_F, gate2)
+        out["ld_loss"] = {"lm_S": lm_S, "lm_F": lm_F, "gate": gate, "loss": tot.double(), "mode": "per-scale (torch>=1.6: %s)" % type(e).__name__}
+
+    pc = object.__new__(losses.PerceptualCorrectness)
+    torch.nn.Module.__init__(pc)
+    pc.eps = 1e-8
+    pc.l1_loss = torch.nn.L1Loss()
+    tv_, sv_ = fill.image(2, 8, 16, 16, "pc_target") + 0.1, fill.image(2, 8, 16, 16, "pc_source") + 0.1
+    pc.target_vgg, pc.source_vgg = {"relu1_1": tv_}, {"relu1_1": sv_}
+    pflow = fill.flow_field(2, 32, 32, "pc_flow")
+    pmask = (fill.image(2, 1, 32, 32, "pc_mask") > 0.4).float()
+    out["correctness"] = {"masked": pc.calculate_loss(pflow, "relu1_1", pmask, True).double(),
+                          "unmasked": pc.calculate_loss(pflow, "relu1_1", None, True).double()}
+
 torch.save(out, os.path.join(HERE, "reference_modules.pt"))
 tot = os.path.getsize(os.path.join(HERE, "reference_modules.pt"))
 print("wrote reference_modules.pt  %.1f KiB" % (tot / 1024.0))

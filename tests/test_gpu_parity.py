@@ -786,3 +786,24 @@ def test_fused_affine_regularization_matches_the_op_composition(dtype):
     flows = [fill.flow_field(2, s, s, "reg_flow%d" % s).to(DEV, dtype) for s in (128, 64, 32)]
     ref = float(gold["multi"])
     assert abs(float(multi(flows[::-1])) - ref) <= 2e-3 * (1 + abs(ref))
+
+
+def test_flownet_pretraining_step_on_gpu_fused_vs_composed_regulariser():
+    """One FlowNetModel train step (flownet_model.py:57-78) with the HIP warp and (a) the fused affine
+    regulariser, (b) the reference's op composition: same losses, finite, and the used FlowNet parameters move."""
+    from ffwm_amd import trainer
+    torch.backends.cudnn.benchmark = False
+    batch = trainer.synthetic_batch(2, DEV, seed=5)
+    vals = []
+    for fused in (True, False):
+        t = trainer.FlowNetTrainer(DEV, seed=0, ngf=16, fused_regularization=fused)
+        before = torch.cat([p.detach().flatten() for p in t.flowNet.parameters()])
+        t.step(batch)
+        torch.cuda.synchronize()
+        v = t.loss_values()
+        assert all(torch.isfinite(torch.tensor(x)) for x in v.values()), v
+        after = torch.cat([p.detach().flatten() for p in t.flowNet.parameters()])
+        assert float((after - before).abs().max()) > 0
+        vals.append(v)
+    for k in vals[0]:
+        assert abs(vals[0][k] - vals[1][k]) <= 2e-3 * (1 + abs(vals[1][k])), (k, vals[0][k], vals[1][k])

@@ -132,3 +132,20 @@ def test_illumination_loss_matches_reference_msl1(gold):
     mask = (fill.image(2, 1, 128, 128, "msl1_mask") > 0.4).float()
     got = t.illumination(fl3, im3, img_F, mask)
     assert abs(float(got) - float(gold["msl1"]["masked"])) < 1e-5
+
+
+def test_flownet_pretraining_losses_match_reference(gold):
+    """MultiScaleLDLoss / LandmarkLoss (losses.py:61-74,114-126) and PerceptualCorrectness.calculate_loss
+    (:342-371, bilinear path) against the imported reference classes (tests/golden/make_golden.py)."""
+    from ffwm_amd.losses import MultiScaleLDLoss, PerceptualCorrectness
+    ld = gold["ld_loss"]
+    flows = [fill.flow_field(2, s, s, "ld_flow%d" % s) for s in (128, 64, 32)]
+    got = MultiScaleLDLoss()(flows, ld["lm_S"], ld["lm_F"], torch.cat((ld["gate"], ld["gate"]), 2))
+    assert abs(float(got) - float(ld["loss"])) <= 1e-4 * (1 + abs(float(ld["loss"])))
+    pc = PerceptualCorrectness(vgg=None, warp=torch_refs.warp)
+    pc.target_vgg = {"relu1_1": fill.image(2, 8, 16, 16, "pc_target") + 0.1}
+    pc.source_vgg = {"relu1_1": fill.image(2, 8, 16, 16, "pc_source") + 0.1}
+    pflow = fill.flow_field(2, 32, 32, "pc_flow")
+    pmask = (fill.image(2, 1, 32, 32, "pc_mask") > 0.4).float()
+    assert abs(float(pc.calculate_loss(pflow, "relu1_1", pmask)) - float(gold["correctness"]["masked"])) <= 1e-5
+    assert abs(float(pc.calculate_loss(pflow, "relu1_1", None)) - float(gold["correctness"]["unmasked"])) <= 1e-5

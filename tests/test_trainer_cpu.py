@@ -64,3 +64,23 @@ def test_batched_loss_passes_are_result_preserving():
     for a, b in ((vals[0], vals[2]), (vals[1], vals[3])):
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-4 * (1 + abs(a[k])), (k, a[k], b[k])
+
+
+def test_flownet_pretraining_step_on_cpu():
+    """FlowNetModel.optimize_parameters (flownet_model.py:57-78) on CPU with the torch stand-in warp and the
+    op-composition regulariser replaced by its fused form being GPU-only: here fused_regularization=False is
+    not available either (the composed ops are GPU kernels), so the regulariser is stubbed; what is checked is
+    the structure: three flows, the three loss terms, one Adam step on the used FlowNet parameters only."""
+    from ffwm_amd import trainer
+    torch.set_num_threads(8)
+    t = trainer.FlowNetTrainer("cpu", seed=0, ngf=8, warp=torch_refs.warp, fused_regularization=False)
+    t.Regularization = lambda flows: sum((f[:, :, 1:] - f[:, :, :-1]).abs().mean() for f in flows)   # CPU stand-in
+    batch = trainer.synthetic_batch(2, "cpu", seed=2)
+    before = [p.detach().clone() for p in t.flowNet.parameters()]
+    t.step(batch)
+    vals = t.loss_values()
+    assert set(vals) == {"loss", "cor", "reg", "lm"}
+    assert all(torch.isfinite(torch.tensor(v)) for v in vals.values()), vals
+    after = list(t.flowNet.parameters())
+    changed = {n for (n, _), a, b in zip(t.flowNet.named_parameters(), before, after) if not torch.equal(a, b)}
+    assert changed and not any(n.startswith("inter_conv_occ") for n in changed)
