@@ -33,6 +33,7 @@ _SIGNATURES = {
     "ffwm_spectral_norm_backward": [_p, _i, _i, _p],
     "ffwm_guided_filter_forward": [_p, _p, _p, _p, _i64, _i64, _i64, _i, ctypes.c_double, _i, _p],
     "ffwm_affine_regularization": [_p, _p, _p, _p, _i64, _i64, _i64, _i, ctypes.c_double, _i, _p],
+    "ffwm_correlation_colmax": [_p, _p, _p, _i64, _i64, _i64, _i, _p],
     "ffwm_guided_filter_backward": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
     "ffwm_prof_enable": [_i],
     "ffwm_prof_collect": [],

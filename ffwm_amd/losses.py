@@ -177,7 +177,11 @@ class PerceptualCorrectness(nn.Module):
             source_all = source_vgg.reshape(b, c, -1).transpose(1, 2)   # [b, N2, C]
             source_norm = source_all / (source_all.norm(dim=2, keepdim=True) + self.eps)
             target_norm = target_all / (target_all.norm(dim=1, keepdim=True) + self.eps)
-            correction_max = torch.bmm(source_norm, target_norm).max(dim=1)[0]      # [b, N2]
+            # (the MFMA kernel wants >= 192 workgroups of 128 columns; below that rocBLAS + max is as fast)
+            if source_norm.is_cuda and source_norm.dtype == torch.float32 and c in (64, 128, 256) and b * ((h * w + 127) // 128) >= 192:
+                correction_max = ops.correlation_colmax(source_norm, target_norm)   # MFMA, no [b, N2, N2] matrix
+            else:
+                correction_max = torch.bmm(source_norm, target_norm).max(dim=1)[0]  # [b, N2]
         input_sample = self.warp(source_vgg, flow).reshape(b, c, -1)
         correction_sample = F.cosine_similarity(input_sample, target_all)          # [b, N2]
         loss_map = torch.exp(-correction_sample / (correction_max + self.eps))

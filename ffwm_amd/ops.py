@@ -282,3 +282,22 @@ def affine_regularization(flow, ktk, kernel_size, want_grad=True):
             _ptr(flow), _ptr(ktk), _ptr(loss), _ptr(grad), B, h, w, k, scale, _dtype_code(flow), stream),
             "ffwm_affine_regularization")
     return loss * scale, grad
+
+
+# ---------------------------------------------------------------- correlation column maximum (MFMA)
+def correlation_colmax(source, target):
+    """torch.bmm(source[B,N,C], target[B,C,N]).max(dim=1)[0] without the [B,N,N] matrix (losses.py:347-353)."""
+    if source.dim() != 3 or target.dim() != 3 or source.size(0) != target.size(0) or source.size(1) != target.size(2) \
+            or source.size(2) != target.size(1):
+        raise ValueError("correlation_colmax: need source [B,N,C] and target [B,C,N]")
+    if not source.is_cuda:
+        raise NotImplementedError("correlation_colmax: ffwm_amd ops run on the GPU only (got a %s tensor)" % source.device)
+    if source.dtype != torch.float32 or target.dtype != torch.float32:
+        raise TypeError("correlation_colmax: float32 only")
+    source, target = source.contiguous(), target.contiguous()
+    B, N, C = source.shape
+    out = source.new_empty((B, N))
+    with _on_device(source) as stream:
+        _lib.check(_lib.load().ffwm_correlation_colmax(_ptr(source), _ptr(target), _ptr(out), B, N, C, _lib.F32, stream),
+                   "ffwm_correlation_colmax")
+    return out

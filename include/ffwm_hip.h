@@ -187,6 +187,14 @@ int ffwm_affine_regularization(const void* flow, const void* ktk, void* loss_sum
                                int64_t B, int64_t h, int64_t w, int kernel_size, double loss_scale,
                                int dtype, void* stream);
 
+/* ---- correlation column maximum (correctness loss of FlowNet pre-training) ----------------------
+ * out[b, j] = max_i sum_k source[b, i, k] * target[b, k, j]   -- torch.max(torch.bmm(source_norm,
+ * target_norm), dim=1)[0] of PerceptualCorrectness.calculate_loss (models/losses.py:347-353) without
+ * the [B, N, N] matrix (1 GiB per sample at relu1_1), on fp32-in / fp32-accumulate MFMA.
+ * source[B,N,C], target[B,C,N] contiguous float32, C in {64, 128, 256}, out[B,N]. */
+int ffwm_correlation_colmax(const void* source, const void* target, void* out, int64_t B, int64_t N,
+                            int64_t C, int dtype, void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded

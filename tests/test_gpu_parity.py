@@ -807,3 +807,21 @@ def test_flownet_pretraining_step_on_gpu_fused_vs_composed_regulariser():
         vals.append(v)
     for k in vals[0]:
         assert abs(vals[0][k] - vals[1][k]) <= 2e-3 * (1 + abs(vals[1][k])), (k, vals[0][k], vals[1][k])
+
+
+# ------------------------------------------------------------------------- correlation column maximum (MFMA)
+@pytest.mark.parametrize("shape", [(2, 1024, 64), (1, 4096, 128), (2, 1024, 256), (1, 1000, 64), (3, 160, 64)])
+def test_correlation_colmax_matches_bmm_max(shape):
+    """max_i <source_i, target_j> on fp32 MFMA vs torch.bmm(...).max(dim=1) in float64 on the CPU, with an
+    ASYMMETRIC target so that a transposed accumulator read-out cannot pass; N = 1000 / 160 exercise the
+    ragged last row tile and partial column tiles."""
+    from ffwm_amd import ops
+    B, N, C = shape
+    g = _gen(N + C)
+    src = torch.randn(B, N, C, generator=g)
+    tgt = torch.randn(B, C, N, generator=g) * (1 + torch.arange(N, dtype=torch.float32) / N).view(1, 1, N)
+    src = src / (src.norm(dim=2, keepdim=True) + 1e-8)
+    tgt = tgt / (tgt.norm(dim=1, keepdim=True) + 1e-8)
+    ref = torch.bmm(src.double(), tgt.double()).max(dim=1)[0]
+    out = ops.correlation_colmax(src.to(DEV), tgt.to(DEV)).cpu().double()
+    assert (out - ref).abs().max().item() <= 2e-6

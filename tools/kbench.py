@@ -144,6 +144,30 @@ def main():
         o = torch.empty(32, 128, 256, 256, device=dev)
         results += run("big warp+flip+cat fwd [32,64,256,256] flow=%s" % args.warp_flow, lambda: ops.warp_forward(feat, fl, True, out=o), args.reps)
         del feat, fl, o
+    if want("corr"):
+        # correlation column maximum of the correctness loss at relu1_1 of 128 x 128 images, batch 6 (flownet_model.py:67):
+        # fp32 MFMA kernel vs torch.bmm + max (which materialises 6 x 1 GiB)
+        import time
+        for (N, C) in ((16384, 64), (4096, 128), (1024, 256)):
+            s_ = torch.randn(6, N, C, generator=g).to(dev)
+            t_ = torch.randn(6, C, N, generator=g).to(dev)
+            s_ = s_ / (s_.norm(dim=2, keepdim=True) + 1e-8)
+            t_ = t_ / (t_.norm(dim=1, keepdim=True) + 1e-8)
+            rows = run("correlation colmax B=6 N=%d C=%d" % (N, C), lambda: ops.correlation_colmax(s_, t_), args.reps)
+            for r in rows:
+                r["TFLOPs"] = round(2.0 * 6 * N * N * C / (r["avg_ms"] * 1e-3) / 1e12, 1)
+                r["frac_fp32_mfma_peak"] = round(r["TFLOPs"] / 157.3, 3)
+            results += rows
+            for _ in range(3):
+                torch.bmm(s_, t_).max(dim=1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                torch.bmm(s_, t_).max(dim=1)
+            torch.cuda.synchronize()
+            results.append({"case": "torch.bmm + max B=6 N=%d C=%d" % (N, C), "kernel": "wall",
+                            "avg_ms": round((time.perf_counter() - t0) / args.reps * 1e3, 4)})
+            del s_, t_
     if want("affine"):
         # MultiAffineRegularizationLoss at the reference's FlowNet pre-training sizes (bs 6, kz 7/5/3 on 128/64/32 px):
         # the reference's op composition on the HIP kernels vs the fused kernel, forward + backward, wall time
