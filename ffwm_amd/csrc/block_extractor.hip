@@ -629,7 +629,7 @@ template <int K, int RH, int H>
 __global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 ? 4 : 2))
 be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
                    float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
-                   int ntx, int nty, int cslabs, int cs, int remap, int ablate) {
+                   int ntx, int nty, int cslabs, int cs, int remap) {
     using T = float;
     constexpr int RW = kTileRW, NW = kBlock / kWave, PPT = RH / NW;
     constexpr int TW = RW - 2 * H, TH = RH - 2 * H;       // owned tile
@@ -946,7 +946,7 @@ template <int K, int RH, int H>
 __global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 && H <= 4 ? 4 : 2))
 be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
                    float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
-                   int ntx, int nty, int cslabs, int cs, int remap, int ablate) {
+                   int ntx, int nty, int cslabs, int cs, int remap) {
     using T = float;
     constexpr int RW = kTileRW, NW = kBlock / kWave, PPT = RH / NW;
     constexpr int TW = RW, TH = RH;                       // the block's flow pixels: no overlap with its neighbours
@@ -1546,7 +1546,7 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
 #define FFWM_BE_TILE(KERNEL, KK, RR, HH)                                                                      \
     hipLaunchKernelGGL((KERNEL<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,              \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
-                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, options().ablate)
+                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap)
 #define FFWM_BE_TILE_K(KK)                                                                                    \
     case KK:                                                                                                  \
         if (shared_cells) {                                                                                   \
