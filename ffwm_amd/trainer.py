@@ -386,6 +386,46 @@ class FFWMTrainer(object):
     def loss_values(self):
         return {k: float(v.detach()) for k, v in self.losses.items()}
 
+    # ------------------------------------------------------------------ checkpoint interchange / evaluation forward
+    MODEL_NAMES = ("netG", "netD", "flowNetF", "flowNetB")      # ffwm_model.py:20-24
+
+    def save_networks(self, save_dir, epoch):
+        """BaseModel.save_networks (models/base_model.py:172-191): one '<epoch>_net_<name>.pth' state dict per
+        network, CPU tensors, the reference's key names (weight_orig / weight_u / weight_v of the spectral-norm
+        convs included -- the fused spectral norm keeps them), so either code base can load the other's files.
+        Like the reference, optimizer state is not saved."""
+        import os
+        os.makedirs(save_dir, exist_ok=True)
+        for name in self.MODEL_NAMES:
+            sd = {k: v.detach().cpu() for k, v in getattr(self, name).state_dict().items()}
+            torch.save(sd, os.path.join(save_dir, "%s_net_%s.pth" % (epoch, name)))
+
+    def load_networks(self, load_dir, epoch, names=None):
+        """BaseModel.load_networks (models/base_model.py:207-229)."""
+        import os
+        for name in (names or self.MODEL_NAMES):
+            sd = torch.load(os.path.join(load_dir, "%s_net_%s.pth" % (epoch, name)), map_location=str(self.device))
+            if hasattr(sd, "_metadata"):
+                del sd._metadata
+            getattr(self, name).load_state_dict(sd)
+
+    @torch.no_grad()
+    def test_forward(self, b):
+        """FFWMModel.test_forward (models/ffwm_model.py:183-189): flowNetF -> warped profile, netG -> frontal view and
+        attention map, guided-filtered output.  Returns (fake_F128, img_GF128, img_S_warp, att)."""
+        flow_F128, flow_F64, flow_F32 = self.flowNetF(b["img_S"])
+        img_S_warp = self.warp(b["img_S"], flow_F128)
+        _, _, fake_F128, att = self.netG(b["img_S"], flow=[flow_F32, flow_F64, flow_F128], return_att=True)
+        att = torch.mean(att[:, :64, :, :], (1,), keepdim=True)
+        img_GF128 = self.gf[128](fake_F128, b["img_F"])
+        return fake_F128, img_GF128, img_S_warp, att
+
+    @torch.no_grad()
+    def identity_feature(self, fake_F128):
+        """FFWMModel.test (ffwm_model.py:191-202, crop=False): the LightCNN feature used for rank-1 matching."""
+        _, fea, _ = self.lightCNN(torch.mean(fake_F128, dim=(1,), keepdim=True))
+        return fea
+
 
 class FlowNetTrainer(object):
     """FlowNet pre-training, the other trainer of the reference (train_flow.py -> models/flownet_model.py:57-78):

@@ -84,3 +84,34 @@ def test_flownet_pretraining_step_on_cpu():
     after = list(t.flowNet.parameters())
     changed = {n for (n, _), a, b in zip(t.flowNet.named_parameters(), before, after) if not torch.equal(a, b)}
     assert changed and not any(n.startswith("inter_conv_occ") for n in changed)
+
+
+def test_checkpoint_interchange_roundtrip_and_reference_key_names(tmp_path):
+    """save_networks / load_networks use the reference's file naming ('<epoch>_net_<name>.pth', base_model.py:172-229)
+    and key names (the goldens hold the reference modules' own state-dict keys); test_forward runs the evaluation path
+    (ffwm_model.py:183-202)."""
+    import os
+    from ffwm_amd import trainer
+    torch.set_num_threads(8)
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules.pt"))
+    a = trainer.FFWMTrainer("cpu", seed=1, warp=torch_refs.warp, warp_flipcat=torch_refs.warp_flipcat)
+    a.save_networks(str(tmp_path), "latest")
+    assert sorted(os.listdir(str(tmp_path))) == ["latest_net_flowNetB.pth", "latest_net_flowNetF.pth", "latest_net_netD.pth",
+                                                 "latest_net_netG.pth"]
+    assert sorted(torch.load(os.path.join(str(tmp_path), "latest_net_netG.pth")).keys()) == gold["ffwm_keys"]
+    assert sorted(torch.load(os.path.join(str(tmp_path), "latest_net_flowNetF.pth")).keys()) == gold["flownet64_keys"]
+    assert sorted(torch.load(os.path.join(str(tmp_path), "latest_net_netD.pth")).keys()) == gold["netD_keys"]
+    b = trainer.FFWMTrainer("cpu", seed=2, warp=torch_refs.warp, warp_flipcat=torch_refs.warp_flipcat)
+    b.load_networks(str(tmp_path), "latest")
+    for name in a.MODEL_NAMES:
+        for (k, v), (_, w) in zip(getattr(a, name).state_dict().items(), getattr(b, name).state_dict().items()):
+            assert torch.equal(v, w), (name, k)
+    batch = trainer.synthetic_batch(1, "cpu", seed=3)
+    for t in (a, b):
+        for n in t.MODEL_NAMES:
+            getattr(t, n).eval()
+    fa, fb = a.test_forward(batch), b.test_forward(batch)
+    # (a randomly initialised netG overflows in eval mode -- running statistics of an untrained net: NaNs compare equal)
+    assert all(torch.allclose(x, y, atol=1e-5, equal_nan=True) for x, y in zip(fa, fb))
+    assert fa[0].shape == (1, 3, 128, 128) and fa[3].shape == (1, 1, 128, 128)
+    assert a.identity_feature(fa[0]).shape[0] == 1
