@@ -313,7 +313,14 @@ def main():
         bs = args.batch or 8
         g = torch.Generator().manual_seed(1 + rank)
         feats = [torch.rand(bs, c, s, s, generator=g).to(dev).requires_grad_(True) for c, s in ((128, 32), (64, 64), (64, 128))]
-        flows = [(torch.rand(bs, 2, s, s, generator=g) * 2.2 - 1.1).to(dev).requires_grad_(True) for s in (32, 64, 128)]
+        def smooth(s):      # identity grid + ~3 px of low-frequency displacement: what a trained FlowNet produces
+            lin = (torch.arange(s, dtype=torch.float32) + 0.5) / s * 2 - 1
+            yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+            amp = 6.0 / s
+            fx = xx + amp * torch.sin(3.1 * yy + 0.3) * torch.cos(2.3 * xx)
+            fy = yy + amp * torch.cos(2.7 * xx - 0.2) * torch.sin(1.9 * yy)
+            return torch.stack((fx, fy), 0).unsqueeze(0).repeat(bs, 1, 1, 1).contiguous()
+        flows = [smooth(s).to(dev).requires_grad_(True) for s in (32, 64, 128)]
         gos = [torch.rand(bs, 2 * c, s, s, generator=g).to(dev) for c, s in ((128, 32), (64, 64), (64, 128))]
         mod = WarpFlipCat()
 
@@ -325,7 +332,7 @@ def main():
         imgs = bs * world * args.steps
         result.update({"metric": "warp+flip+cat path img/s (3 netG levels, fwd+bwd)", "value": round(imgs / dt, 2),
                        "unit": "img/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
-                       "config": {"workload": "netG warp-attention warp sub-path, 3 levels, fwd+bwd", "batch_per_gpu": bs,
+                       "config": {"workload": "netG warp-attention warp sub-path (warp + flip + cat), 3 levels, fwd+bwd, smooth flows", "batch_per_gpu": bs,
                                   "parallelism": "dp%d" % world}})
     else:   # ops: cfg-5 per GPU block_extractor forward + backward
         from ffwm_amd import ops
