@@ -28,6 +28,12 @@ __device__ __forceinline__ T fma_t(T a, T b, T c) { return __builtin_fma(a, b, c
 template <>
 __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// separately rounded product / sum (what two ATen kernels in a row compute): never contracted to an fma
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
 template <typename T, int K>
 struct Taps {
     // "consistent" representation: tap (i, j) reads rows row[i], row[i+1] and columns col[j],
@@ -182,11 +188,17 @@ constexpr int kLdsCols = 128;
 // RPT = pixel rows per thread: the block's tile is 64 x (4*RPT) flow pixels.  A taller tile cuts the
 // halo re-read of the source ((4*RPT + k + 2*|flow|) / (4*RPT) rows are staged per tile row) and puts
 // RPT x more arithmetic and stores between two barriers.
-template <typename T, int K, int RPT>
+//
+// MODE selects what happens to the k x k bilinear samples s_ij of a pixel and channel (the fused
+// extractor + attention consumer; see the "block attention" section below):
+//   0  block_extractor: the samples are the output                      out [B, C, k Hf, k Wf]
+//   1  attention forward: out = (sum_ij s_ij * w_ij) / k^2              out [B, C, Hf, Wf], aux = w [B, k^2, Hf, Wf]
+//   2  attention weight gradient: gw_ij += sum_c s_ij * (g_c / k^2)     out = gw [B, k^2, Hf, Wf] (atomic), aux = g [B, C, Hf, Wf]
+template <typename T, int K, int RPT, int MODE = 0>
 __global__ void __launch_bounds__(kBlock)
 be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __restrict__ out, int C,
                   int Hs, int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs,
-                  int remap, int ablate, int nt) {
+                  int remap, int ablate, int nt, const T* __restrict__ aux = nullptr) {
     constexpr int NW = kBlock / kWave;
     constexpr int LROWS = (RPT == 1) ? 16 : 32;
     constexpr unsigned E = sizeof(T);
@@ -259,13 +271,17 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
     const int c0 = slab * cs;
     const int c1 = (c0 + cs < C) ? c0 + cs : C;
     const int W = K * Wf;
-    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t oplane = MODE == 0 ? static_cast<size_t>(K) * Hf * W : fplane;
     const size_t splane = static_cast<size_t>(Hs) * Ws;
     const unsigned sbytes = static_cast<unsigned>(splane * E);
     const unsigned obytes = static_cast<unsigned>(oplane * E);
     const T* sp = src + (static_cast<size_t>(b) * C + c0) * splane;
-    T* op = out + (static_cast<size_t>(b) * C + c0) * oplane;
+    T* op = MODE == 2 ? out + static_cast<size_t>(b) * K * K * fplane : out + (static_cast<size_t>(b) * C + c0) * oplane;
     const unsigned orow = static_cast<unsigned>(W) * E;
+    // fused modes: per-pixel attention weights (1) / upstream gradient of the current channel (2)
+    const T* wb = MODE == 1 ? aux + static_cast<size_t>(b) * K * K * fplane : nullptr;
+    const T* gb = MODE == 2 ? aux + (static_cast<size_t>(b) * C + c0) * fplane : nullptr;
+    constexpr T kK2 = static_cast<T>(K * K);
 
     if (use_lds) {
         // staging map: wave w copies box rows w, w+4, ...; lane l copies box columns l, l+64.
@@ -301,7 +317,110 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             lbase[r] = (v0[r] - vmin) * kLdsCols + (u0[r] - umin);
-            obase[r] = (static_cast<unsigned>(yfs[r]) * K * W + static_cast<unsigned>(xf) * K) * E;
+            obase[r] = MODE == 0 ? (static_cast<unsigned>(yfs[r]) * K * W + static_cast<unsigned>(xf) * K) * E
+                                 : (static_cast<unsigned>(yfs[r]) * Wf + static_cast<unsigned>(xf)) * E;
+        }
+        if constexpr (MODE != 0) {
+            // Fused consumers: the k x k samples are linear in the (k+1)^2 neighbourhood cells n_ab, so
+            //   MODE 1  out = sum_ab coef_ab n_ab,  coef_ab = sum_ij (w_ij / k^2) [bilinear weight of cell ab in sample ij]
+            //           -- formed ONCE per pixel, then (k+1)^2 LDS reads + fmas per channel instead of 4 k^2 + k^2;
+            //   MODE 2  T_ab += (g_c / k^2) n_ab per channel, and gw_ij = sum_ab [weight of ab in ij] T_ab once at the end.
+            // (Same sums as the composition, re-associated: ~1e-7 relative.)
+            constexpr int NC = (K + 1) * (K + 1);
+            T coef[RPT][NC];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) coef[r][q] = 0;
+            T gcur[RPT], gnxt[RPT];        // MODE 2: g / k^2 of the current / next channel
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) gcur[r] = gnxt[r] = 0;
+            const size_t pixr0 = static_cast<size_t>(xf);
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                    for (int i = 0; i < K; ++i)
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            const T wij = wb[(i * K + j) * fplane + static_cast<size_t>(yfs[r]) * Wf + pixr0] / kK2;
+                            const T wt = wij * wyt[r][i], wbm = wij * wyb[r][i];
+                            coef[r][i * (K + 1) + j] = fma_t<T>(wt, wxl[r][j], coef[r][i * (K + 1) + j]);
+                            coef[r][i * (K + 1) + j + 1] = fma_t<T>(wt, wxr[r][j], coef[r][i * (K + 1) + j + 1]);
+                            coef[r][(i + 1) * (K + 1) + j] = fma_t<T>(wbm, wxl[r][j], coef[r][(i + 1) * (K + 1) + j]);
+                            coef[r][(i + 1) * (K + 1) + j + 1] = fma_t<T>(wbm, wxr[r][j], coef[r][(i + 1) * (K + 1) + j + 1]);
+                        }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) gcur[r] = gb[static_cast<size_t>(yfs[r]) * Wf + pixr0] / kK2;
+            }
+            fetch(sp);
+            commit(tile[0]);
+            __syncthreads();
+            int p = 0;
+            for (int c = c0; c < c1; ++c, op += (MODE == 2 ? 0 : oplane), p ^= 1) {
+                const bool more = c + 1 < c1;
+                if constexpr (MODE == 2) {
+                    if (more) {
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r)
+                            gnxt[r] = gb[static_cast<size_t>(c + 1 - c0) * fplane + static_cast<size_t>(yfs[r]) * Wf + pixr0] / kK2;
+                    }
+                }
+                if (more) fetch(sp + static_cast<size_t>(c + 1 - c0) * splane);   // in flight during the math
+                const rsrc_t ro = make_rsrc(op, obytes);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const T* nb = tile[p] + lbase[r];
+                    if constexpr (MODE == 1) {
+                        T orow[K + 1];
+#pragma unroll
+                        for (int a = 0; a <= K; ++a) {
+                            orow[a] = coef[r][a * (K + 1)] * nb[a * kLdsCols];
+#pragma unroll
+                            for (int bq = 1; bq <= K; ++bq) orow[a] = fma_t<T>(coef[r][a * (K + 1) + bq], nb[a * kLdsCols + bq], orow[a]);
+                        }
+                        T o = orow[0];
+#pragma unroll
+                        for (int a = 1; a <= K; ++a) o += orow[a];
+                        if (inx && iny[r]) {
+                            ElemRow<T, 1> ov;
+                            ov.v[0] = o;
+                            buf_store_row<T, 1>(ro, obase[r], ov);
+                        }
+                    } else {
+#pragma unroll
+                        for (int a = 0; a <= K; ++a)
+#pragma unroll
+                            for (int bq = 0; bq <= K; ++bq)
+                                coef[r][a * (K + 1) + bq] = fma_t<T>(gcur[r], nb[a * kLdsCols + bq], coef[r][a * (K + 1) + bq]);
+                    }
+                }
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) gcur[r] = gnxt[r];
+                }
+                if (more) commit(tile[p ^ 1]);
+                __syncthreads();
+            }
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (inx && iny[r]) {
+#pragma unroll
+                        for (int i = 0; i < K; ++i)
+#pragma unroll
+                            for (int j = 0; j < K; ++j) {
+                                const T* t0 = &coef[r][i * (K + 1) + j];
+                                T v = (wxl[r][j] * wyt[r][i]) * t0[0];
+                                v = fma_t<T>(wxr[r][j] * wyt[r][i], t0[1], v);
+                                v = fma_t<T>(wxl[r][j] * wyb[r][i], t0[K + 1], v);
+                                v = fma_t<T>(wxr[r][j] * wyb[r][i], t0[K + 2], v);
+                                atomic_add(op + (i * K + j) * fplane + static_cast<size_t>(yfs[r]) * Wf + pixr0, v);
+                            }
+                    }
+            }
+            return;
         }
         fetch(sp);
         commit(tile[0]);
@@ -359,15 +478,19 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
 
     // ---- fallback: direct global gathers, every tap formed per element like the reference
     if (!inx) return;
-    for (int c = c0; c < c1; ++c, sp += splane, op += oplane) {
+    for (int c = c0; c < c1; ++c, sp += splane, op += (MODE == 2 ? 0 : oplane)) {
         const rsrc_t rs = make_rsrc(sp, sbytes);
         const rsrc_t ro = make_rsrc(op, obytes);
 #pragma unroll 1
         for (int r = 0; r < RPT; ++r) {
             if (!iny[r]) continue;
             const int yf = yfs[r];
-            const T fx0 = fb[static_cast<size_t>(yf) * Wf + xf], fy0 = fb[fplane + static_cast<size_t>(yf) * Wf + xf];
+            const size_t pix = static_cast<size_t>(yf) * Wf + xf;
+            const T fx0 = fb[pix], fy0 = fb[fplane + pix];
             const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
+            T osum = 0;
+            T gd = 0;
+            if constexpr (MODE == 2) gd = gb[static_cast<size_t>(c - c0) * fplane + pix] / kK2;
 #pragma unroll 1
             for (int i = 0; i < K; ++i) {
                 const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
@@ -381,8 +504,15 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
                     s = fma_t<T>(tx1.wlo * ty1.whi, buf_ld<T>(rs, (rB + tx1.lo) * E), s);
                     s = fma_t<T>(tx1.whi * ty1.whi, buf_ld<T>(rs, (rB + tx1.hi) * E), s);
                     row.v[j] = s;
+                    if constexpr (MODE == 1) osum = add_rn(osum, mul_rn(s, wb[(i * K + j) * fplane + pix]));
+                    if constexpr (MODE == 2) atomic_add(op + (i * K + j) * fplane + pix, gd * s);
                 }
-                buf_store_row<T, K>(ro, ob + i * orow, row);
+                if constexpr (MODE == 0) buf_store_row<T, K>(ro, ob + i * orow, row);
+            }
+            if constexpr (MODE == 1) {
+                ElemRow<T, 1> o;
+                o.v[0] = osum / kK2;
+                buf_store_row<T, 1>(ro, static_cast<unsigned>(pix) * E, o);
             }
         }
     }
@@ -942,11 +1072,14 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
     }
 }
 
-template <int K, int RH, int H>
+// FUSED (block attention backward): gout is the gradient of the attention output, [B, C, Hf, Wf], and the
+// k x k grad_output window of a pixel is (g / k^2) * w_ij with the attention weights w [B, k^2, Hf, Wf]
+// (what avg_pool2d's and the product's backward hand to the extractor) -- formed in registers, never stored.
+template <int K, int RH, int H, bool FUSED = false>
 __global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 && H <= 4 ? 4 : 2))
 be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
                    float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
-                   int ntx, int nty, int cslabs, int cs, int remap) {
+                   int ntx, int nty, int cslabs, int cs, int remap, const float* __restrict__ attn = nullptr) {
     using T = float;
     constexpr int RW = kTileRW, NW = kBlock / kWave, PPT = RH / NW;
     constexpr int TW = RW, TH = RH;                       // the block's flow pixels: no overlap with its neighbours
@@ -979,9 +1112,9 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
     const int c0 = slab * cs;
     const int c1 = (c0 + cs < C) ? c0 + cs : C;
     const int W = K * Wf;
-    const size_t oplane = static_cast<size_t>(K) * Hf * W;
     const size_t splane = static_cast<size_t>(Hs) * Ws;
     const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const size_t oplane = FUSED ? fplane : static_cast<size_t>(K) * Hf * W;
     const unsigned sbytes = static_cast<unsigned>(splane * E);
     const unsigned obytes = static_cast<unsigned>(oplane * E);
     const unsigned orow = static_cast<unsigned>(W) * E;
@@ -989,6 +1122,8 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
     T* gp = gsrc + (static_cast<size_t>(b) * C + c0) * splane;
     const T* op = gout + (static_cast<size_t>(b) * C + c0) * oplane;
     const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, static_cast<unsigned>(2 * fplane * E));
+    const rsrc_t ratt = make_rsrc(FUSED ? attn + static_cast<size_t>(b) * K * K * fplane : src,
+                                  FUSED ? static_cast<unsigned>(K * K * fplane * E) : 0u);
 
     // out-of-image accumulator cells fold onto the border cell they clamp to (block-uniform)
     const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;   // the box meets the image (else: be_bwd_far2_kernel's job)
@@ -1035,8 +1170,8 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
         // requested before row r is processed (their addresses do not depend on the flow), so the
         // ~300 instructions of one row cover the latency of the next one's loads
         struct PixLoad {
-            T fx, fy;
-            ElemRow<T, K> g[K];
+            T fx, fy, gs;              // gs: FUSED only, the pixel's upstream gradient
+            ElemRow<T, K> g[K];        // grad_output window (FUSED: the attention weights until `cur` is formed)
         };
         const int xfc = min(max(xf, 0), Wf - 1);
         auto request = [&](int r, PixLoad& d) {
@@ -1045,9 +1180,21 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
             const unsigned fo = (static_cast<unsigned>(yfc) * Wf + xfc) * E;
             d.fx = buf_ld<T>(rfl, fo);
             d.fy = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
-            const unsigned ob = (static_cast<unsigned>(yfc) * K * W + static_cast<unsigned>(xfc) * K) * E;
+            if constexpr (FUSED) {
+                ElemRow<T, 1> gv;
+                buf_load_row_nt<T, 1>(rg, fo, gv);
+                d.gs = gv.v[0];
 #pragma unroll
-            for (int i = 0; i < K; ++i) buf_load_row_nt<T, K>(rg, ob + i * orow, d.g[i]);   // read exactly once: streaming (nt) loads, -3 %
+                for (int i = 0; i < K; ++i)
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+                        d.g[i].v[j] = buf_ld<T>(ratt, fo + static_cast<unsigned>((i * K + j) * fplane * E));   // L2-resident
+            } else {
+                d.gs = 0;
+                const unsigned ob = (static_cast<unsigned>(yfc) * K * W + static_cast<unsigned>(xfc) * K) * E;
+#pragma unroll
+                for (int i = 0; i < K; ++i) buf_load_row_nt<T, K>(rg, ob + i * orow, d.g[i]);   // read exactly once: streaming (nt) loads, -3 %
+            }
         };
         PixLoad nxt;
         request(0, nxt);
@@ -1055,8 +1202,15 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
         for (int r = 0; r < PPT; ++r) {
             const int row = wave + r * NW;
             const int yf = y0 + row;
-            const PixLoad cur = nxt;
+            PixLoad cur = nxt;
             if (r + 1 < PPT) request(r + 1, nxt);
+            if constexpr (FUSED) {
+                const T gd = cur.gs / static_cast<T>(K * K);
+#pragma unroll
+                for (int i = 0; i < K; ++i)
+#pragma unroll
+                    for (int j = 0; j < K; ++j) cur.g[i].v[j] = gd * cur.g[i].v[j];
+            }
             const bool row_owned = gflow != nullptr;
             T gx = 0, gy = 0;
             if (xin && yf >= 0 && yf < Hf) {
@@ -1156,7 +1310,10 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
 #pragma unroll 1
                         for (int j = 0; j < K; ++j) {
                             const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
-                            const T gv = buf_ld<T>(rg, ob + i * orow + j * E);
+                            const T gv = FUSED ? (cur.gs / static_cast<T>(K * K)) *
+                                                     buf_ld<T>(ratt, (static_cast<unsigned>(yf) * Wf + xf) * E +
+                                                                         static_cast<unsigned>((i * K + j) * fplane * E))
+                                               : buf_ld<T>(rg, ob + i * orow + j * E);
                             const int cxs[2] = {static_cast<int>(tx1.lo), static_cast<int>(tx1.hi)};
                             const int cys[2] = {static_cast<int>(ty1.lo), static_cast<int>(ty1.hi)};
                             const T wxs[2] = {tx1.wlo, tx1.whi}, wys[2] = {ty1.wlo, ty1.whi};
@@ -1262,10 +1419,11 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
 
 // Complement of be_bwd_tile2_kernel: flow pixels with a tap outside their own tile's box (flow wider than
 // the halo, integer-boundary rounding, NaN / huge flow) scatter ALL their taps with global atomics here.
-template <typename T, int K>
+template <typename T, int K, bool FUSED = false>
 __global__ void __launch_bounds__(kBlock)
 be_bwd_far2_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gsrc, int C, int Hs,
-                   int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs, TileGeo geo) {
+                   int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs, TileGeo geo,
+                   const T* __restrict__ attn = nullptr) {
     const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, 0);
     if (tc.xf >= Wf || tc.yf >= Hf) return;
     constexpr unsigned E = sizeof(T);
@@ -1295,7 +1453,7 @@ be_bwd_far2_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __
     const int c0 = tc.slab * cs;
     const int c1 = (c0 + cs < C) ? c0 + cs : C;
     const int W = K * Wf;
-    const size_t oplane = static_cast<size_t>(K) * Hf * W;
+    const size_t oplane = FUSED ? fplane : static_cast<size_t>(K) * Hf * W;
     const size_t splane = static_cast<size_t>(Hs) * Ws;
     const unsigned obytes = static_cast<unsigned>(oplane * E);
     T* gp = gsrc + (static_cast<size_t>(tc.b) * C + c0) * splane;
@@ -1310,7 +1468,10 @@ be_bwd_far2_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __
 #pragma unroll 1
             for (int j = 0; j < K; ++j) {
                 const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
-                const T gv = buf_ld<T>(rg, obase + i * orow + j * E);
+                const unsigned pix = (static_cast<unsigned>(tc.yf) * Wf + tc.xf) * E;
+                const T gv = FUSED ? (buf_ld<T>(rg, pix) / static_cast<T>(K * K)) *
+                                         attn[(static_cast<size_t>(tc.b) * K * K + i * K + j) * fplane + pix / E]
+                                   : buf_ld<T>(rg, obase + i * orow + j * E);
                 const unsigned rT = ty.lo * static_cast<unsigned>(Ws) * E, rB = ty.hi * static_cast<unsigned>(Ws) * E;
                 const unsigned cL = tx.lo * E, cR = tx.hi * E;
                 atomic_add_off(gp, rT + cL, gv * tx.wlo * ty.wlo);
@@ -1605,6 +1766,192 @@ int check_dims(const char* fn, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int
     return FFWM_OK;
 }
 
+
+// ------------------------------------------------------------------------------ block attention
+// The fused extractor + attention consumer: for the GFLA-style local attention the
+// cfg-5 shape models,
+//     out = avg_pool2d(BlockExtractor(source, flow, k) * LocalAttnReshape(weights, k), k, k)
+// never needs the k^2-fold expanded tensors: out[b,c,y,x] = (sum_ij s_ij(c) * w_ij) / k^2 with the k x k
+// bilinear samples s_ij of pixel (y, x) and its k^2 attention weights w[b, i k + j, y, x].
+//   forward            be_fwd_lds_kernel<.., MODE 1>: same LDS-staged sampling, one store per pixel and channel
+//   d(source), d(flow) be_bwd_far2_kernel / be_bwd_tile2_kernel<.., FUSED>: grad_output window (g / k^2) w_ij in registers
+//   d(weights)         be_fwd_lds_kernel<.., MODE 2>: the samples again, reduced over the channel slab in
+//                      registers, one atomic per (pixel, ij, slab)
+// Everything else (float64, k > 4, no d(source) wanted) runs the literal per-pixel kernels below.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+ba_fwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ wts, T* __restrict__ out,
+               int64_t n, int C, int Hs, int Ws, int Hf, int Wf, int k) {
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
+         index += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int xf = static_cast<int>(index % Wf);
+        const int yf = static_cast<int>((index / Wf) % Hf);
+        const int64_t bc = index / static_cast<int64_t>(fplane);
+        const int64_t b = bc / C;
+        const size_t pix = static_cast<size_t>(yf) * Wf + xf;
+        const T fx0 = flow[b * 2 * fplane + pix], fy0 = flow[b * 2 * fplane + fplane + pix];
+        const T* sp = src + bc * static_cast<size_t>(Hs) * Ws;
+        const T* wp = wts + b * k * k * fplane + pix;
+        T osum = 0;
+        for (int i = 0; i < k; ++i) {
+            const Tap1<T> ty = make_tap<T>(fy0, i - k / 2, yf, Hs);
+            const size_t rT = static_cast<size_t>(ty.lo) * Ws, rB = static_cast<size_t>(ty.hi) * Ws;
+            for (int j = 0; j < k; ++j) {
+                const Tap1<T> tx = make_tap<T>(fx0, j - k / 2, xf, Ws);
+                T s = (tx.wlo * ty.wlo) * sp[rT + tx.lo];
+                s = fma_t<T>(tx.whi * ty.wlo, sp[rT + tx.hi], s);
+                s = fma_t<T>(tx.wlo * ty.whi, sp[rB + tx.lo], s);
+                s = fma_t<T>(tx.whi * ty.whi, sp[rB + tx.hi], s);
+                osum = add_rn(osum, mul_rn(s, wp[(i * k + j) * fplane]));
+            }
+        }
+        out[index] = osum / static_cast<T>(k * k);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+ba_bwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ wts,
+               const T* __restrict__ gout, T* __restrict__ gsrc, T* __restrict__ gflow, T* __restrict__ gw, int64_t n,
+               int C, int Hs, int Ws, int Hf, int Wf, int k) {
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
+         index += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int xf = static_cast<int>(index % Wf);
+        const int yf = static_cast<int>((index / Wf) % Hf);
+        const int64_t bc = index / static_cast<int64_t>(fplane);
+        const int64_t b = bc / C;
+        const size_t pix = static_cast<size_t>(yf) * Wf + xf;
+        const size_t foff = b * 2 * fplane + pix;
+        const T fx0 = flow[foff], fy0 = flow[foff + fplane];
+        const size_t soff = bc * static_cast<size_t>(Hs) * Ws;
+        const T* sp = src + soff;
+        const T* wp = wts + b * k * k * fplane + pix;
+        const T gd = gout[index] / static_cast<T>(k * k);
+        T gx = 0, gy = 0;
+        for (int i = 0; i < k; ++i) {
+            const Tap1<T> ty = make_tap<T>(fy0, i - k / 2, yf, Hs);
+            const size_t rT = static_cast<size_t>(ty.lo) * Ws, rB = static_cast<size_t>(ty.hi) * Ws;
+            for (int j = 0; j < k; ++j) {
+                const Tap1<T> tx = make_tap<T>(fx0, j - k / 2, xf, Ws);
+                const T sTL = sp[rT + tx.lo], sTR = sp[rT + tx.hi], sBL = sp[rB + tx.lo], sBR = sp[rB + tx.hi];
+                const T g = gd * wp[(i * k + j) * fplane];
+                if (gsrc) {
+                    T* gp = gsrc + soff;
+                    atomic_add(gp + rT + tx.lo, g * tx.wlo * ty.wlo);
+                    atomic_add(gp + rT + tx.hi, g * tx.whi * ty.wlo);
+                    atomic_add(gp + rB + tx.lo, g * tx.wlo * ty.whi);
+                    atomic_add(gp + rB + tx.hi, g * tx.whi * ty.whi);
+                }
+                gy += g * (-tx.wlo * sTL - tx.whi * sTR + tx.wlo * sBL + tx.whi * sBR);
+                gx += g * (-ty.wlo * sTL - ty.whi * sBL + ty.wlo * sTR + ty.whi * sBR);
+                if (gw) {
+                    T s = (tx.wlo * ty.wlo) * sTL;
+                    s = fma_t<T>(tx.whi * ty.wlo, sTR, s);
+                    s = fma_t<T>(tx.wlo * ty.whi, sBL, s);
+                    s = fma_t<T>(tx.whi * ty.whi, sBR, s);
+                    atomic_add(gw + b * k * k * fplane + (i * k + j) * fplane + pix, gd * s);
+                }
+            }
+        }
+        if (gflow) {
+            atomic_add(gflow + foff, gx);
+            atomic_add(gflow + foff + fplane, gy);
+        }
+    }
+}
+
+template <typename T>
+int launch_attn_fwd(const T* src, const T* flow, const T* wts, T* out, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                    int64_t Hf, int64_t Wf, int k, hipStream_t st) {
+    const double bytes = sizeof(T) * static_cast<double>(B) * (C * Hs * Ws + (2.0 + k * k) * Hf * Wf + static_cast<double>(C) * Hf * Wf);
+    if constexpr (sizeof(T) == 4) {
+        if (k == 3 && options().be_fwd_variant != 9) {
+            const Geometry g = plan(B, C, Hf, Wf, 16);
+            const int rpt = Hf >= 64 ? 4 : 1;
+            const int th = (kBlock / kWave) * rpt;
+            const int tyl = static_cast<int>((Hf + th - 1) / th);
+            const unsigned gridl = static_cast<unsigned>(B * g.tiles_x * tyl * g.cslabs);
+            LaunchScope ls("block_attention_fwd_lds", st, bytes);
+            if (rpt == 4)
+                hipLaunchKernelGGL((be_fwd_lds_kernel<float, 3, 4, 1>), dim3(gridl), dim3(kBlock), 0, st, src, flow, out, (int)C,
+                                   (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, options().xcd_remap, 0, 0, wts);
+            else
+                hipLaunchKernelGGL((be_fwd_lds_kernel<float, 3, 1, 1>), dim3(gridl), dim3(kBlock), 0, st, src, flow, out, (int)C,
+                                   (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, options().xcd_remap, 0, 0, wts);
+            return check_launch("ffwm_block_attention_forward");
+        }
+    }
+    const int64_t n = B * C * Hf * Wf;
+    const unsigned grid = static_cast<unsigned>(n / kBlock + 1 < 65536 ? n / kBlock + 1 : 65536);
+    LaunchScope ls("block_attention_fwd_generic", st, bytes);
+    hipLaunchKernelGGL((ba_fwd_generic<T>), dim3(grid), dim3(kBlock), 0, st, src, flow, wts, out, n, (int)C, (int)Hs, (int)Ws,
+                       (int)Hf, (int)Wf, k);
+    return check_launch("ffwm_block_attention_forward");
+}
+
+template <typename T>
+int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T* gsrc, T* gflow, T* gw, int64_t B,
+                    int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, hipStream_t st) {
+    const double bytes = sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hf * Wf + 2.0 * C * Hs * Ws + (4.0 + k * k) * Hf * Wf);
+    if constexpr (sizeof(T) == 4) {
+        if (k == 3 && gsrc && options().be_bwd_variant != 9) {
+            const int h = options().be_bwd_halo > 4 ? 8 : 4;
+            const TileGeo geo{kTileRW, 32, h, 32};
+            const int ntx = static_cast<int>(((Ws > Wf ? Ws : Wf) + geo.TW - 1) / geo.TW);
+            const int nty = static_cast<int>(((Hs > Hf ? Hs : Hf) + geo.TH - 1) / geo.TH);
+            int cs = options().channel_slab > 0 ? options().channel_slab : 4;
+            if (cs > C) cs = static_cast<int>(C);
+            const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            const Geometry gf = plan(B, C, Hf, Wf, 32);
+            {
+                LaunchScope ls("block_attention_bwd_far", st, sizeof(T) * 2.0 * B * Hf * Wf);
+                hipLaunchKernelGGL((be_bwd_far2_kernel<float, 3, true>), dim3(gf.grid), dim3(kBlock), 0, st, flow, gout, gsrc,
+                                   (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs, geo, wts);
+            }
+            if (int rc = check_launch("ffwm_block_attention_backward(far)")) return rc;
+            {
+                LaunchScope ls("block_attention_bwd_tile2", st, bytes);
+                const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
+                if (h == 8)
+                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 8, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
+                                       gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
+                                       options().xcd_remap, wts);
+                else
+                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
+                                       gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
+                                       options().xcd_remap, wts);
+            }
+            if (int rc = check_launch("ffwm_block_attention_backward(tile)")) return rc;
+            if (gw) {
+                // the samples once more, reduced over the channels: same traffic as the forward minus its output
+                const Geometry g = plan(B, C, Hf, Wf, 16);
+                const int rpt = Hf >= 64 ? 4 : 1;
+                const int th = (kBlock / kWave) * rpt;
+                const int tyl = static_cast<int>((Hf + th - 1) / th);
+                const unsigned gridl = static_cast<unsigned>(B * g.tiles_x * tyl * g.cslabs);
+                LaunchScope ls("block_attention_bwd_weights", st,
+                               sizeof(T) * static_cast<double>(B) * (C * Hs * Ws + (2.0 + k * k) * Hf * Wf + static_cast<double>(C) * Hf * Wf));
+                if (rpt == 4)
+                    hipLaunchKernelGGL((be_fwd_lds_kernel<float, 3, 4, 2>), dim3(gridl), dim3(kBlock), 0, st, src, flow, gw, (int)C,
+                                       (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, options().xcd_remap, 0, 0, gout);
+                else
+                    hipLaunchKernelGGL((be_fwd_lds_kernel<float, 3, 1, 2>), dim3(gridl), dim3(kBlock), 0, st, src, flow, gw, (int)C,
+                                       (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, options().xcd_remap, 0, 0, gout);
+                return check_launch("ffwm_block_attention_backward(weights)");
+            }
+            return FFWM_OK;
+        }
+    }
+    const int64_t n = B * C * Hf * Wf;
+    const unsigned grid = static_cast<unsigned>(n / kBlock + 1 < 65536 ? n / kBlock + 1 : 65536);
+    LaunchScope ls("block_attention_bwd_generic", st, bytes);
+    hipLaunchKernelGGL((ba_bwd_generic<T>), dim3(grid), dim3(kBlock), 0, st, src, flow, wts, gout, gsrc, gflow, gw, n, (int)C,
+                       (int)Hs, (int)Ws, (int)Hf, (int)Wf, k);
+    return check_launch("ffwm_block_attention_backward");
+}
+
 }  // namespace
 }  // namespace ffwm
 
@@ -1641,4 +1988,36 @@ extern "C" int ffwm_block_extractor_backward(const void* source, const void* flo
     return launch_bwd<double>((const double*)source, (const double*)flow_field, (const double*)grad_output,
                               (double*)grad_source, (double*)grad_flow_field, B, C, Hs, Ws, Hf, Wf,
                               kernel_size, st);
+}
+
+extern "C" int ffwm_block_attention_forward(const void* source, const void* flow_field, const void* weights, void* output,
+                                            int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+                                            int kernel_size, int dtype, void* stream) {
+    const char* fn = "ffwm_block_attention_forward";
+    FFWM_REQUIRE(source && flow_field && weights && output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hs, Ws, Hf, Wf, kernel_size, dtype)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_attn_fwd<float>((const float*)source, (const float*)flow_field, (const float*)weights, (float*)output,
+                                      B, C, Hs, Ws, Hf, Wf, kernel_size, st);
+    return launch_attn_fwd<double>((const double*)source, (const double*)flow_field, (const double*)weights,
+                                   (double*)output, B, C, Hs, Ws, Hf, Wf, kernel_size, st);
+}
+
+extern "C" int ffwm_block_attention_backward(const void* source, const void* flow_field, const void* weights,
+                                             const void* grad_output, void* grad_source, void* grad_flow_field,
+                                             void* grad_weights, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                                             int64_t Hf, int64_t Wf, int kernel_size, int dtype, void* stream) {
+    const char* fn = "ffwm_block_attention_backward";
+    FFWM_REQUIRE(source && flow_field && weights && grad_output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hs, Ws, Hf, Wf, kernel_size, dtype)) return rc;
+    if (!grad_source && !grad_flow_field && !grad_weights) return FFWM_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_attn_bwd<float>((const float*)source, (const float*)flow_field, (const float*)weights,
+                                      (const float*)grad_output, (float*)grad_source, (float*)grad_flow_field,
+                                      (float*)grad_weights, B, C, Hs, Ws, Hf, Wf, kernel_size, st);
+    return launch_attn_bwd<double>((const double*)source, (const double*)flow_field, (const double*)weights,
+                                   (const double*)grad_output, (double*)grad_source, (double*)grad_flow_field,
+                                   (double*)grad_weights, B, C, Hs, Ws, Hf, Wf, kernel_size, st);
 }

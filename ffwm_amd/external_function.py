@@ -64,6 +64,53 @@ class BlockExtractor(nn.Module):
         return BlockExtractorFunction.apply(source.contiguous(), flow_field.contiguous(), self.kernel_size)
 
 
+class BlockAttentionFunction(Function):
+    """apply(source[B,C,Hs,Ws], flow_field[B,2,Hf,Wf], weights[B,k*k,Hf,Wf], kernel_size) -> [B,C,Hf,Wf]
+
+    The fused extractor + attention consumer: equal to
+    ``F.avg_pool2d(BlockExtractor(k)(source, flow) * LocalAttnReshape()(weights, k), k, k)`` -- the composition
+    of the reference's ops a GFLA-style local attention runs -- without materialising the k^2-fold tensors."""
+
+    @staticmethod
+    def forward(ctx, source, flow_field, weights, kernel_size):
+        assert source.is_contiguous() and flow_field.is_contiguous() and weights.is_contiguous()
+        assert flow_field.size(1) == 2
+        assert weights.size(1) == kernel_size * kernel_size
+        _require_cuda(source)
+        ctx.save_for_backward(source, flow_field, weights)
+        ctx.kernel_size = kernel_size
+        return ops.block_attention_forward(source, flow_field, weights, kernel_size)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        source, flow_field, weights = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        grad_source = torch.zeros_like(source) if need[0] else None
+        grad_flow = torch.zeros_like(flow_field) if need[1] else None
+        grad_weights = torch.zeros_like(weights) if need[2] else None
+        if need[0] or need[1] or need[2]:
+            # the fast path produces d(source) and d(flow) in one pass: ask for d(source) whenever d(flow) is wanted
+            gs = grad_source if grad_source is not None or not need[1] else torch.zeros_like(source)
+            ops.block_attention_backward(source, flow_field, weights, grad_output.contiguous(), ctx.kernel_size,
+                                         gs, grad_flow, grad_weights)
+        return grad_source, grad_flow, grad_weights, None
+
+
+class BlockAttention(nn.Module):
+    """``softmax=True`` normalises the k*k attention logits over dim 1 first (a [B,k*k,H,W] torch op: 1/C-th of
+    the data the fused kernels move)."""
+
+    def __init__(self, kernel_size=3, softmax=False):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.softmax = softmax
+
+    def forward(self, source, flow_field, attn):
+        weights = torch.softmax(attn, 1) if self.softmax else attn
+        return BlockAttentionFunction.apply(source.contiguous(), flow_field.contiguous(), weights.contiguous(),
+                                            self.kernel_size)
+
+
 class LocalAttnReshapeFunction(Function):
     """apply(inputs[B,k*k,H,W], kernel_size) -> [B,1,k*H,k*W]"""
 

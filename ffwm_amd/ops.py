@@ -104,6 +104,51 @@ def block_extractor_backward(source, flow_field, grad_output, kernel_size, grad_
     return grad_source, grad_flow_field
 
 
+# ---------------------------------------------------------------- block attention (fused consumer)
+def block_attention_forward(source, flow_field, weights, kernel_size, out=None):
+    """out[B,C,Hf,Wf] = avg_pool2d(block_extractor(source, flow) * local_attn_reshape(weights), k) without the
+    k^2-fold expanded tensors; weights[B,k*k,Hf,Wf]."""
+    _check("block_attention_forward", source, flow_field, weights, out)
+    B, C, Hs, Ws = source.shape
+    Bf, two, Hf, Wf = flow_field.shape
+    k = int(kernel_size)
+    if two != 2 or Bf < B:
+        raise ValueError("block_attention_forward: flow_field must be [>=B, 2, Hf, Wf]")
+    if tuple(weights.shape) != (B, k * k, Hf, Wf):
+        raise ValueError("block_attention_forward: weights must be [B, k*k, Hf, Wf], got %s" % (tuple(weights.shape),))
+    if out is None:
+        out = source.new_empty((B, C, Hf, Wf))
+    elif tuple(out.shape) != (B, C, Hf, Wf):
+        raise ValueError("block_attention_forward: output has the wrong shape")
+    if out.numel() == 0:
+        return out
+    with _on_device(source) as stream:
+        _lib.check(_lib.load().ffwm_block_attention_forward(
+            _ptr(source), _ptr(flow_field), _ptr(weights), _ptr(out), B, C, Hs, Ws, Hf, Wf, k, _dtype_code(source),
+            stream), "ffwm_block_attention_forward")
+    return out
+
+
+def block_attention_backward(source, flow_field, weights, grad_output, kernel_size, grad_source=None,
+                             grad_flow_field=None, grad_weights=None):
+    """Accumulates (+=) into the given, zero-filled gradient buffers; None skips one."""
+    _check("block_attention_backward", source, flow_field, weights, grad_output, grad_source, grad_flow_field,
+           grad_weights)
+    B, C, Hs, Ws = source.shape
+    _, _, Hf, Wf = flow_field.shape
+    k = int(kernel_size)
+    if tuple(grad_output.shape) != (B, C, Hf, Wf) or tuple(weights.shape) != (B, k * k, Hf, Wf):
+        raise ValueError("block_attention_backward: grad_output / weights have the wrong shape")
+    if grad_output.numel() == 0:
+        return grad_source, grad_flow_field, grad_weights
+    with _on_device(source) as stream:
+        _lib.check(_lib.load().ffwm_block_attention_backward(
+            _ptr(source), _ptr(flow_field), _ptr(weights), _ptr(grad_output), _ptr(grad_source),
+            _ptr(grad_flow_field), _ptr(grad_weights), B, C, Hs, Ws, Hf, Wf, k, _dtype_code(source), stream),
+            "ffwm_block_attention_backward")
+    return grad_source, grad_flow_field, grad_weights
+
+
 # ---------------------------------------------------------------- local_attn_reshape
 def local_attn_reshape_forward(inputs, kernel_size, out=None):
     """-> out[B,1,k*H,k*W]; reference local_attn_reshape_kernel.cu:21-61."""

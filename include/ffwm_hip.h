@@ -195,6 +195,27 @@ int ffwm_affine_regularization(const void* flow, const void* ktk, void* loss_sum
 int ffwm_correlation_colmax(const void* source, const void* target, void* out, int64_t B, int64_t N,
                             int64_t C, int dtype, void* stream);
 
+/* Fused extractor + attention consumer (the GFLA-style local attention the cfg-5 shape
+ * models): what the reference API can only express as
+ *     avg_pool2d(BlockExtractor(source, flow, k) * LocalAttnReshape(weights, k), k, k)
+ * (models/external_function.py:14-101 + F.avg_pool2d, the same composition models/losses.py:211-219 uses),
+ * without the k^2-fold expanded tensors:
+ *     out[b,c,y,x] = (sum_ij sample_ij(b,c,y,x) * weights[b, i*k + j, y, x]) / k^2,
+ * sample_ij = the block_extractor value at (y*k + i, x*k + j).  Products and the row-major sum are rounded
+ * separately and divided once, like the three ATen/extension kernels of the composition.
+ * source[B,C,Hs,Ws], flow_field[>=B,2,Hf,Wf], weights[B,k*k,Hf,Wf], output[B,C,Hf,Wf] (overwritten). */
+int ffwm_block_attention_forward(const void* source, const void* flow_field, const void* weights, void* output,
+                                 int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+                                 int kernel_size, int dtype, void* stream);
+
+/* grad_source[B,C,Hs,Ws] +=, grad_flow_field[B,2,Hf,Wf] +=, grad_weights[B,k*k,Hf,Wf] += for
+ * grad_output[B,C,Hf,Wf]; any of the three may be NULL.  The extractor's grad_output window is
+ * (grad_output / k^2) * weights_ij, formed in registers. */
+int ffwm_block_attention_backward(const void* source, const void* flow_field, const void* weights,
+                                  const void* grad_output, void* grad_source, void* grad_flow_field,
+                                  void* grad_weights, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
+                                  int64_t Wf, int kernel_size, int dtype, void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded

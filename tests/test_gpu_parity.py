@@ -148,6 +148,97 @@ def test_block_extractor_backward_owned_tiles(oracle, case, halo, rows, variant)
     _close(gf, gf_ref, tol, relative=True)
 
 
+# ------------------------------------------------------------------------- block attention (fused consumer)
+def _attention_reference(oracle, src, flow, w, k, go=None):
+    """The composition of the reference's ops the fused kernels replace:
+    avg_pool2d(BlockExtractor(source, flow) * LocalAttnReshape(weights), k, k), forward and backward, from the
+    oracle's extractor / reshape and ATen's CPU product and pooling."""
+    import torch.nn.functional as F
+    ext = oracle.block_extractor_forward(src, flow, k)
+    wr = oracle.local_attn_reshape_forward(w, k)
+    out = F.avg_pool2d(ext * wr, k, k)
+    if go is None:
+        return out
+    gpool = (go / (k * k)).repeat_interleave(k, 2).repeat_interleave(k, 3)       # avg_pool2d backward
+    gs, gf = oracle.block_extractor_backward(src, flow, (gpool * wr).contiguous(), k)
+    gw = oracle.local_attn_reshape_backward((gpool * ext).sum(1, keepdim=True), k)
+    return out, gs, gf, gw
+
+
+ATTN_CASES = BE_CASES[:7] + BE_CASES[9:] + BE_TILE_CASES[:4] + [
+    (2, 13, 70, 130, 70, 130, 3, 1.5, 30),      # rows-per-thread 2 forward path, several channel slabs
+    (1, 4, 64, 64, 64, 64, 3, 0.0, 31),         # constant flow k // 2: the unfold identity
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_block_attention_matches_the_composition(oracle, case, dtype):
+    from ffwm_amd import ops
+    if dtype == torch.float64 and case[2] * case[3] > 64 * 64:
+        pytest.skip("float64 runs the per-pixel kernels: small cases are enough")
+    src, flow, _, k = _be_inputs(case, dtype)
+    B, C, Hf, Wf = src.shape[0], src.shape[1], flow.shape[2], flow.shape[3]
+    g = _gen(100 + case[8])
+    w = torch.rand(B, k * k, Hf, Wf, generator=g, dtype=dtype)
+    go = torch.rand(B, C, Hf, Wf, generator=g, dtype=dtype)
+    out_ref, gs_ref, gf_ref, gw_ref = _attention_reference(oracle, src, flow, w, k, go)
+    out = ops.block_attention_forward(src.to(DEV), flow.to(DEV), w.to(DEV), k)
+    _close(out, out_ref, FWD_TOL[dtype])
+    gs, gf, gw = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV), torch.zeros_like(w, device=DEV)
+    ops.block_attention_backward(src.to(DEV), flow.to(DEV), w.to(DEV), go.to(DEV), k, gs, gf, gw)
+    tol = 1e-4 if case[7] >= 100 else BWD_TOL[dtype]
+    _close(gs, gs_ref, tol, relative=True)
+    _close(gf, gf_ref, tol, relative=True)
+    _close(gw, gw_ref, tol, relative=True)
+
+
+def test_block_attention_module_softmax_and_partial_grads(oracle):
+    """BlockAttention(softmax=True) through autograd, including the d(flow)-only and d(weights)-only calls."""
+    import torch.nn.functional as F
+    from ffwm_amd.external_function import BlockAttention, BlockExtractor, LocalAttnReshape
+    g = _gen(41)
+    src = torch.rand(2, 6, 40, 72, generator=g)
+    flow = torch.rand(2, 2, 40, 72, generator=g) * 4 - 2
+    attn = torch.randn(2, 9, 40, 72, generator=g)
+    go = torch.rand(2, 6, 40, 72, generator=g)
+
+    def run(fused, need):
+        s, f, a = (t.to(DEV).requires_grad_(n) for t, n in zip((src, flow, attn), need))
+        if fused:
+            out = BlockAttention(3, softmax=True)(s, f, a)
+        else:
+            out = F.avg_pool2d(BlockExtractor(3)(s, f) * LocalAttnReshape()(torch.softmax(a, 1), 3), 3, 3)
+        out.backward(go.to(DEV))
+        return out.detach(), [t.grad for t in (s, f, a)]
+
+    for need in [(True, True, True), (False, True, False), (False, False, True), (True, False, False)]:
+        out, grads = run(True, need)
+        out_ref, grads_ref = run(False, need)
+        _close(out, out_ref.cpu(), FWD_TOL[torch.float32])
+        for gr, gr_ref, n in zip(grads, grads_ref, need):
+            assert (gr is not None) == n
+            if n:
+                _close(gr, gr_ref.cpu(), BWD_TOL[torch.float32], relative=True)
+
+
+def test_block_attention_cfg5_shape_is_the_unfold_identity():
+    """BASELINE configs[4] per-GPU shape with the constant flow k // 2: the fused forward must equal
+    avg-pooling of unfold(source) * weights (no oracle needed at this size), and it must be deterministic."""
+    import torch.nn.functional as F
+    from ffwm_amd import ops
+    g = _gen(42)
+    B, C, H, W, k = 1, 32, 256, 256, 3
+    src = torch.rand(B, C, H, W, generator=g).to(DEV)
+    w = torch.rand(B, 9, H - 2, W - 2, generator=g).to(DEV)
+    flow = torch.full((B, 2, H - 2, W - 2), 1.0, device=DEV)
+    out = ops.block_attention_forward(src, flow, w, k)
+    patches = F.unfold(src, k).view(B, C, 9, H - 2, W - 2)
+    ref = (patches * w.unsqueeze(1)).sum(2) / 9
+    _close(out, ref.cpu(), 2e-6)
+    assert torch.equal(out, ops.block_attention_forward(src, flow, w, k))
+
+
 @pytest.mark.parametrize("case", BE_CASES[:7])
 def test_block_extractor_backward_owned_tiles_small_planes(oracle, case):
     """The same kernels forced onto planes that would normally take the LDS-plane path."""

@@ -25,12 +25,15 @@ def run(name, fn, reps, warmup=3):
     torch.cuda.synchronize()
     _lib.prof_reset()
     _lib.prof_enable(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(reps):
         fn()
+    e1.record()
     torch.cuda.synchronize()
     rows = _lib.prof_collect()
     _lib.prof_enable(False)
-    out = []
+    out = [{"case": name, "kernel": "(whole call, stream time incl. torch kernels)", "avg_ms": round(e0.elapsed_time(e1) / reps, 5)}]
     for k, r in rows.items():
         gbs = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9 if r["avg_ms"] > 0 else 0.0
         out.append({"case": name, "kernel": k, "avg_ms": round(r["avg_ms"], 5), "GBps": round(gbs, 1),
@@ -97,6 +100,24 @@ def main():
             results += run("cfg5 block_extractor bwd", lambda: ops.block_extractor_backward(src, flow, go, 3, gs, gf), args.reps)
             del go, gs, gf
         del src, flow, out
+    if want("attn"):
+        # the fused extractor + attention consumer on the cfg-5 shape, next to the composition it replaces
+        import torch.nn.functional as F
+        src = torch.rand(B, 128, 256, 256, generator=g).to(dev)
+        flow = ((torch.rand(B, 2, 256, 256, generator=g) * 2 - 1) * args.flow).to(dev)
+        w = torch.softmax(torch.randn(B, 9, 256, 256, generator=g), 1).to(dev)
+        out = torch.empty(B, 128, 256, 256, device=dev)
+        go = torch.rand(B, 128, 256, 256, device=dev)
+        gs, gf, gw = torch.zeros_like(src), torch.zeros_like(flow), torch.zeros_like(w)
+        results += run("cfg5 block_attention fwd", lambda: ops.block_attention_forward(src, flow, w, 3, out=out), args.reps)
+        results += run("cfg5 block_attention bwd",
+                       lambda: ops.block_attention_backward(src, flow, w, go, 3, gs, gf, gw), args.reps)
+
+        def composition():
+            ext = ops.block_extractor_forward(src, flow, 3)
+            return F.avg_pool2d(ext * ops.local_attn_reshape_forward(w, 3), 3, 3)
+        results += run("cfg5 composition fwd (extract, reshape, mul, avg_pool)", composition, max(3, args.reps // 4))
+        del src, flow, w, out, go, gs, gf, gw
     if want("lar"):
         attn = torch.rand(B, 9, 256, 256, generator=g).to(dev)
         o = torch.empty(B, 1, 768, 768, device=dev)
