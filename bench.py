@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--flow-init", default="fit-identity", choices=["fit-identity", "random"],
                     help="train workload: stand-in for the reference's PRETRAINED flow nets -- fit flowNetF/B to the identity "
                          "sampling grid for 80 untimed Adam steps (default), or leave them randomly initialised")
+    ap.add_argument("--mfma-wgrad", default="on", choices=["on", "off"],
+                    help="weight gradients of netG's large 3x3 convs on the hand-written MFMA kernel (off: vendor library)")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="train workload: replay the step from captured hipGraphs, or run it eagerly (default: measured faster on ROCm 7.2)")
     return ap.parse_args()
@@ -246,7 +248,8 @@ def main():
         from ffwm_amd import trainer
         bs = args.batch or 8
         t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers,
-                                bucket_bytes=args.bucket_mb << 20, capturable=args.graph == "on")
+                                bucket_bytes=args.bucket_mb << 20, capturable=args.graph == "on",
+                                mfma_wgrad=args.mfma_wgrad == "on")
         batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
         flow_fit = t.pretrain_flow_identity(batch) if args.flow_init == "fit-identity" else None
         graphed = args.graph == "on"
@@ -265,6 +268,8 @@ def main():
                                               "all losses, 3x Adam), synthetic MultiPIE-shaped 128x128",
                                   "batch_per_gpu": bs, "global_batch": bs * world,
                                   "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed else "eager",
+                                  "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))
+                                  if args.mfma_wgrad == "on" else "vendor library",
                                   "titers_branch": "<20000" if args.titers < 20000 else ">=20000",
                                   "weights": "seeded random init (no pretrained VGG19/LightCNN/FlowNet offline)",
                                   "flow_nets": ("fitted to the identity grid for 80 untimed steps (stand-in for the reference's "

@@ -354,11 +354,31 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) gcur[r] = gb[static_cast<size_t>(yfs[r]) * Wf + pixr0] / kK2;
             }
-            fetch(sp);
-            commit(tile[0]);
+            // Two channels ahead: the box of channel c+2 is requested (into the register set that channel c
+            // just left) before channel c is processed, so a fetch has two iterations to land -- one block
+            // iteration is only ~(k+1)^2 fmas per pixel, far shorter than the memory latency.
+            T stage2[RI][CI];
+            auto fetch_to = [&](const T* plane, T (&st)[RI][CI]) {
+                const rsrc_t rs = make_rsrc(plane, sbytes);
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci) st[ri][ci] = buf_ld<T>(rs, goff[ri][ci]);
+            };
+            auto commit_from = [&](T* buf, const T (&st)[RI][CI]) {
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                    for (int ci = 0; ci < CI; ++ci)
+                        buf[(wave + ri * NW) * kLdsCols + lane + ci * kWave] = st[ri][ci];
+            };
+            fetch_to(sp, stage);
+            if (c0 + 1 < c1) fetch_to(sp + splane, stage2);
+            commit_from(tile[0], stage);
             __syncthreads();
             int p = 0;
-            for (int c = c0; c < c1; ++c, op += (MODE == 2 ? 0 : oplane), p ^= 1) {
+            // `hold` carries channel c+1 (in flight or landed), `spare` is free for channel c+2
+            auto iteration = [&](int c, T (&hold)[RI][CI], T (&spare)[RI][CI]) {
                 const bool more = c + 1 < c1;
                 if constexpr (MODE == 2) {
                     if (more) {
@@ -367,7 +387,7 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
                             gnxt[r] = gb[static_cast<size_t>(c + 1 - c0) * fplane + static_cast<size_t>(yfs[r]) * Wf + pixr0] / kK2;
                     }
                 }
-                if (more) fetch(sp + static_cast<size_t>(c + 1 - c0) * splane);   // in flight during the math
+                if (c + 2 < c1) fetch_to(sp + static_cast<size_t>(c + 2 - c0) * splane, spare);
                 const rsrc_t ro = make_rsrc(op, obytes);
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
@@ -400,23 +420,43 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) gcur[r] = gnxt[r];
                 }
-                if (more) commit(tile[p ^ 1]);
+                if (more) commit_from(tile[p ^ 1], hold);
                 __syncthreads();
+                op += (MODE == 2 ? 0 : oplane);
+                p ^= 1;
+            };
+            for (int c = c0; c < c1; c += 2) {
+                iteration(c, stage2, stage);
+                if (c + 1 < c1) iteration(c + 1, stage, stage2);
             }
             if constexpr (MODE == 2) {
 #pragma unroll
                 for (int r = 0; r < RPT; ++r)
                     if (inx && iny[r]) {
+                        // the tap weights again, from the flow (L2): keeping 4 k RPT of them live across the
+                        // channel loop would cost a third of the register file
+                        const size_t pix = static_cast<size_t>(yfs[r]) * Wf + pixr0;
+                        T fx0 = fb[pix], fy0 = fb[fplane + pix];
+                        asm volatile("" : "+v"(fx0), "+v"(fy0));
+                        T xr[K], yb2[K];
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
+                            const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yfs[r]);
+                            xr[j] = dx - floor_t(dx);
+                            yb2[j] = dy - floor_t(dy);
+                        }
 #pragma unroll
                         for (int i = 0; i < K; ++i)
 #pragma unroll
                             for (int j = 0; j < K; ++j) {
                                 const T* t0 = &coef[r][i * (K + 1) + j];
-                                T v = (wxl[r][j] * wyt[r][i]) * t0[0];
-                                v = fma_t<T>(wxr[r][j] * wyt[r][i], t0[1], v);
-                                v = fma_t<T>(wxl[r][j] * wyb[r][i], t0[K + 1], v);
-                                v = fma_t<T>(wxr[r][j] * wyb[r][i], t0[K + 2], v);
-                                atomic_add(op + (i * K + j) * fplane + static_cast<size_t>(yfs[r]) * Wf + pixr0, v);
+                                const T xl = 1 - xr[j], yt2 = 1 - yb2[i];
+                                T v = (xl * yt2) * t0[0];
+                                v = fma_t<T>(xr[j] * yt2, t0[1], v);
+                                v = fma_t<T>(xl * yb2[i], t0[K + 1], v);
+                                v = fma_t<T>(xr[j] * yb2[i], t0[K + 2], v);
+                                atomic_add(op + (i * K + j) * fplane + pix, v);
                             }
                     }
             }

@@ -346,3 +346,27 @@ def correlation_colmax(source, target):
         _lib.check(_lib.load().ffwm_correlation_colmax(_ptr(source), _ptr(target), _ptr(out), B, N, C, _lib.F32, stream),
                    "ffwm_correlation_colmax")
     return out
+
+
+# ---------------------------------------------------------------- conv weight gradient (MFMA)
+def conv3x3_wgrad_supported(input, grad_output):
+    """Shapes the MFMA weight-gradient kernel takes: float32 NCHW, W a multiple of 64, below 4 GiB."""
+    return (input.dtype == torch.float32 and grad_output.dtype == torch.float32 and input.is_cuda
+            and input.shape[3] % 64 == 0 and input.numel() * 4 < (1 << 32) - 64 and grad_output.numel() * 4 < (1 << 32) - 64)
+
+
+def conv3x3_wgrad(input, grad_output, grad_weight=None):
+    """grad_weight[K,C,3,3] (+= when given, zero-filled otherwise) of a 3x3 / stride 1 / pad 1 convolution."""
+    _check("conv3x3_wgrad", input, grad_output, grad_weight)
+    B, C, H, W = input.shape
+    Bg, K, Hg, Wg = grad_output.shape
+    if (Bg, Hg, Wg) != (B, H, W):
+        raise ValueError("conv3x3_wgrad: grad_output %s does not match input %s" % (tuple(grad_output.shape), tuple(input.shape)))
+    if grad_weight is None:
+        grad_weight = input.new_zeros((K, C, 3, 3))
+    elif tuple(grad_weight.shape) != (K, C, 3, 3):
+        raise ValueError("conv3x3_wgrad: grad_weight has the wrong shape")
+    with _on_device(input) as stream:
+        _lib.check(_lib.load().ffwm_conv3x3_wgrad(_ptr(input), _ptr(grad_output), _ptr(grad_weight), B, C, K, H, W,
+                                                  _dtype_code(input), stream), "ffwm_conv3x3_wgrad")
+    return grad_weight

@@ -70,7 +70,8 @@ def part_grids(lm_F):
 
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
-                 warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True):
+                 warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True,
+                 mfma_wgrad=None):
         self.device = torch.device(device)
         self.titers = titers
         torch.manual_seed(seed)
@@ -91,6 +92,12 @@ class FFWMTrainer(object):
 
         # spectral norm of netG's 52 and netD's 9 convs: one batched launch per forward call instead
         # of ~12 tiny kernels per layer (GPU only -- the CPU baseline keeps PyTorch's per-layer hooks)
+        if mfma_wgrad is None:
+            mfma_wgrad = self.device.type == "cuda"
+        if mfma_wgrad:
+            # weight gradients of the large-image 3x3 layers on the hand-written MFMA kernel (conv.py)
+            from .conv import route_conv_wgrad
+            self.mfma_wgrad_layers = route_conv_wgrad(self.netG)
         if fused_spectral_norm is None:
             fused_spectral_norm = self.device.type == "cuda"
         if fused_spectral_norm:

@@ -3,7 +3,13 @@ weight gradient (torch.ops.aten.convolution_backward with output masks).
 
     python tools/exp_conv_micro.py
 """
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ffwm_amd import ops  # noqa: E402
 
 SHAPES = [  # (B, Cin, Cout, H, k)
     (8, 195, 195, 128, 3), (8, 195, 195, 64, 3), (8, 128, 128, 128, 3), (8, 384, 384, 32, 3),
@@ -43,8 +49,13 @@ def main():
         g = timeit(lambda: bw([False, True, False]))
         bb = timeit(lambda: bw([False, False, True]))
         flop = 2.0 * B * H * H * ci * co * k * k
-        print("%-28s %9.1f %9.1f %9.1f %9.1f   %6.1f %6.1f %6.1f" % (
-            "%dx%d->%d @%d k%d" % (B, ci, co, H, k), f, d, g, bb, flop / f / 1e6, flop / d / 1e6, flop / g / 1e6))
+        mine = ""
+        if k == 3 and H % 64 == 0:
+            dw = torch.zeros(co, ci, 3, 3, device=dev)
+            m = timeit(lambda: ops.conv3x3_wgrad(x, go, dw))
+            mine = "  | mfma wgrad %8.1f us %6.1f TF (incl. launch glue)" % (m, flop / m / 1e6)
+        print("%-28s %9.1f %9.1f %9.1f %9.1f   %6.1f %6.1f %6.1f%s" % (
+            "%dx%d->%d @%d k%d" % (B, ci, co, H, k), f, d, g, bb, flop / f / 1e6, flop / d / 1e6, flop / g / 1e6, mine))
 
 
 if __name__ == "__main__":
