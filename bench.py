@@ -129,9 +129,14 @@ def kernel_rows(rows, tag):
         if r["avg_ms"] <= 0:
             continue
         bps = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3)
-        out.append({"kernel": name, "where": tag, "launches": r["launches"], "avg_us": round(r["avg_ms"] * 1e3, 2),
-                    "total_ms": round(r["total_ms"], 3), "alg_MB": round(r["bytes_per_launch"] / 1e6, 3),
-                    "GBps": round(bps / 1e9, 1), "frac_hbm_peak": round(bps / HBM_PEAK, 4)})
+        row = {"kernel": name, "where": tag, "launches": r["launches"], "avg_us": round(r["avg_ms"] * 1e3, 2),
+               "total_ms": round(r["total_ms"], 3), "alg_MB": round(r["bytes_per_launch"] / 1e6, 3),
+               "GBps": round(bps / 1e9, 1), "frac_hbm_peak": round(bps / HBM_PEAK, 4)}
+        if r.get("flops_per_launch", 0) > 0:      # the MFMA kernels (conv3x3_wgrad, correlation_colmax)
+            fps = r["flops_per_launch"] / (r["avg_ms"] * 1e-3)
+            row.update({"alg_GFLOP": round(r["flops_per_launch"] / 1e9, 3), "TFLOPs": round(fps / 1e12, 2),
+                        "frac_mfma_fp32_peak": round(fps / FP32_PEAK, 4)})
+        out.append(row)
     return out
 
 
@@ -366,19 +371,37 @@ def main():
             # the roofline kernel of an HBM-bound path = the hand-written kernel that moves the most
             # algorithmic bytes in a step (launch-latency-bound helpers on a few hundred KB -- guided filter
             # on 24 planes, spectral norm on 61 small matrices -- are listed in `kernels` with the rest)
-            top = max(inrun, key=lambda r: r["alg_MB"] * r["launches"])
-            pmc = pmc_traffic().get(top["kernel"]) if args.workload == "train" else None     # measured on the train workload
-            result["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"], "peak": HBM_PEAK / 1e9,
-                                  "unit": "GB/s", "frac": top["frac_hbm_peak"],
-                                  "traffic": pmc["traffic_bytes"] if pmc else None,
-                                  "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                                    "of this command; bytes per launch, FETCH_SIZE x2 per the gfx950 calibration)"
-                                  if pmc else None,
-                                  "avg_us": top["avg_us"], "alg_MB_per_launch": top["alg_MB"],
-                                  "launches": top["launches"],
-                                  "note": "hand-written HIP kernel moving the most algorithmic bytes per step; HIP events "
-                                          "on its launch stream" + (" (eager steps run right after the graph-replayed "
-                                          "timed region)" if args.workload == "train" and args.graph == "on" else "")}
+            def hbm_roofline(top):
+                pmc = pmc_traffic().get(top["kernel"]) if args.workload == "train" else None     # measured on the train workload
+                return {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"], "peak": HBM_PEAK / 1e9,
+                        "unit": "GB/s", "frac": top["frac_hbm_peak"],
+                        "traffic": pmc["traffic_bytes"] if pmc else None,
+                        "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                          "of this command; bytes per launch, FETCH_SIZE x2 per the gfx950 calibration)"
+                        if pmc else None,
+                        "avg_us": top["avg_us"], "alg_MB_per_launch": top["alg_MB"], "launches": top["launches"],
+                        "note": "hand-written HIP kernel moving the most algorithmic bytes per step; HIP events "
+                                "on its launch stream" + (" (eager steps run right after the graph-replayed "
+                                "timed region)" if args.workload == "train" and args.graph == "on" else "")}
+            hbm_rows = [r for r in inrun if "TFLOPs" not in r]
+            mfma_rows = [r for r in inrun if "TFLOPs" in r]
+            dominant = max(inrun, key=lambda r: r["total_ms"])
+            if "TFLOPs" in dominant:
+                # the dominant hand-written kernel of the step is a contraction on the matrix cores: its roofline
+                # is the fp32 MFMA peak (157.3 TFLOP/s dense); algorithmic flops = 2 * 9 * B H W C K per launch
+                pmc = pmc_traffic().get(dominant["kernel"]) if args.workload == "train" else None
+                result["roofline"] = {"bound": "mfma", "kernel": dominant["kernel"], "achieved": dominant["TFLOPs"],
+                                      "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": dominant["frac_mfma_fp32_peak"],
+                                      "traffic": pmc["traffic_bytes"] if pmc else None,
+                                      "avg_us": dominant["avg_us"], "alg_GFLOP_per_launch": dominant["alg_GFLOP"],
+                                      "launches": dominant["launches"],
+                                      "note": "hand-written kernel with the largest share of the step (fp32-in / fp32-accumulate "
+                                              "v_mfma_f32_32x32x2_f32); flops and duration averaged over the layer shapes of "
+                                              "the step; HIP events on its launch stream"}
+                if hbm_rows:
+                    result["roofline_hbm"] = hbm_roofline(max(hbm_rows, key=lambda r: r["alg_MB"] * r["launches"]))
+            else:
+                result["roofline"] = hbm_roofline(max(hbm_rows or mfma_rows, key=lambda r: r["alg_MB"] * r["launches"]))
         else:
             result["roofline"] = None
         result["kernels"] = inrun

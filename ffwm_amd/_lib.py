@@ -23,6 +23,7 @@ _SIGNATURES = {
     "ffwm_block_extractor_forward": [_p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_block_extractor_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_conv3x3_wgrad": [_p, _p, _p] + [_i64] * 5 + [_i, _p],
+    "ffwm_conv3x3_wgrad_block": [_p, _p, _p] + [_i64] * 9 + [_i, _p],
     "ffwm_block_attention_forward": [_p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_block_attention_backward": [_p, _p, _p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_local_attn_reshape_forward": [_p, _p] + [_i64] * 3 + [_i, _i, _p],
@@ -42,6 +43,7 @@ _SIGNATURES = {
     "ffwm_prof_collect": [],
     "ffwm_prof_get": [_i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),
                       ctypes.POINTER(ctypes.c_double)],
+    "ffwm_prof_get_flops": [_i, ctypes.POINTER(ctypes.c_double)],
     "ffwm_prof_reset": [],
     "ffwm_set_option": [ctypes.c_char_p, _i],
     "ffwm_abi_version": [],
@@ -93,7 +95,7 @@ def prof_reset():
 
 
 def prof_collect():
-    """-> {kernel_name: {"launches": n, "total_ms": ms, "avg_ms": ms, "bytes_per_launch": b}}"""
+    """-> {kernel_name: {"launches": n, "total_ms": ms, "avg_ms": ms, "bytes_per_launch": b, "flops_per_launch": f}}"""
     lib = load()
     n = lib.ffwm_prof_collect()
     rows = {}
@@ -104,9 +106,12 @@ def prof_collect():
         nbytes = ctypes.c_double()
         check(lib.ffwm_prof_get(i, name, 128, ctypes.byref(launches), ctypes.byref(ms),
                                 ctypes.byref(nbytes)), "ffwm_prof_get")
+        flops = ctypes.c_double()
+        check(lib.ffwm_prof_get_flops(i, ctypes.byref(flops)), "ffwm_prof_get_flops")
         k = max(launches.value, 1)
         rows[name.value.decode()] = {"launches": launches.value, "total_ms": ms.value,
-                                     "avg_ms": ms.value / k, "bytes_per_launch": nbytes.value / k}
+                                     "avg_ms": ms.value / k, "bytes_per_launch": nbytes.value / k,
+                                     "flops_per_launch": flops.value / k}
     return rows
 
 

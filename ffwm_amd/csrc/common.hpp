@@ -37,7 +37,7 @@ Options& options();
 // profiling is enabled (ffwm_prof_enable).  `bytes` = algorithmic bytes of that launch.
 class LaunchScope {
   public:
-    LaunchScope(const char* name, hipStream_t stream, double bytes);
+    LaunchScope(const char* name, hipStream_t stream, double bytes, double flops = 0.0);   // flops: MFMA kernels
     ~LaunchScope();
 
   private:

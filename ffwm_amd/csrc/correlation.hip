@@ -130,7 +130,7 @@ extern "C" int ffwm_correlation_colmax(const void* source, const void* target, v
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned grid = static_cast<unsigned>(B * col_tiles);
     // "bytes" of this compute-bound kernel: operands read once + result (the roofline that matters is MFMA)
-    LaunchScope ls("correlation_colmax", st, 4.0 * B * (2.0 * N * C + N));
+    LaunchScope ls("correlation_colmax", st, 4.0 * B * (2.0 * N * C + N), 2.0 * B * N * N * C);
     const size_t lds = 2 * static_cast<size_t>(kCorRows) * (C + 4) * sizeof(float);
     allow_large_lds(reinterpret_cast<const void*>(corr_colmax_kernel<4>));
     if (C == 64)

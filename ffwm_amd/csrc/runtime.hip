@@ -64,11 +64,11 @@ namespace {
 struct Pending {
     const char* name;
     hipEvent_t start, stop;
-    double bytes;
+    double bytes, flops;
 };
 struct Row {
     int64_t launches = 0;
-    double ms = 0, bytes = 0;
+    double ms = 0, bytes = 0, flops = 0;
 };
 std::mutex g_mu;
 bool g_prof = false;
@@ -89,11 +89,11 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
-LaunchScope::LaunchScope(const char* name, hipStream_t stream, double bytes)
+LaunchScope::LaunchScope(const char* name, hipStream_t stream, double bytes, double flops)
     : slot_(-1), stream_(stream) {
     if (!g_prof) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    Pending p{name, take_event(), take_event(), bytes};
+    Pending p{name, take_event(), take_event(), bytes, flops};
     if (!p.start || !p.stop) return;
     (void)hipEventRecord(p.start, stream);
     g_pending.push_back(p);
@@ -133,6 +133,7 @@ int ffwm_prof_collect(void) {
             r.launches += 1;
             r.ms += ms;
             r.bytes += p.bytes;
+            r.flops += p.flops;
         }
         g_pool.push_back(p.start);
         g_pool.push_back(p.stop);
@@ -157,6 +158,16 @@ int ffwm_prof_get(int row, char* name, int name_len, int64_t* launches, double* 
     if (launches) *launches = kv.second.launches;
     if (total_ms) *total_ms = kv.second.ms;
     if (algorithmic_bytes) *algorithmic_bytes = kv.second.bytes;
+    return FFWM_OK;
+}
+
+int ffwm_prof_get_flops(int row, double* algorithmic_flops) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (row < 0 || row >= static_cast<int>(g_snapshot.size())) {
+        set_error("ffwm_prof_get_flops: row %d out of range", row);
+        return FFWM_ERR_ARG;
+    }
+    if (algorithmic_flops) *algorithmic_flops = g_snapshot[row].second.flops;
     return FFWM_OK;
 }
 

@@ -225,6 +225,13 @@ int ffwm_block_attention_backward(const void* source, const void* flow_field, co
 int ffwm_conv3x3_wgrad(const void* input, const void* grad_output, void* grad_weight, int64_t B, int64_t C,
                        int64_t K, int64_t H, int64_t W, int dtype, void* stream);
 
+/* The same, restricted to the block grad_weight[k_begin:k_end, c_begin:c_end] (tensor extents and strides are
+ * still K and C): lets a caller keep the 64-channel MFMA tiles full and hand a thin remainder -- e.g. channels
+ * 192..194 of the reference's 195-channel layers -- to another routine. */
+int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* grad_weight, int64_t B, int64_t C,
+                             int64_t K, int64_t H, int64_t W, int64_t k_begin, int64_t k_end, int64_t c_begin,
+                             int64_t c_end, int dtype, void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded
@@ -234,6 +241,8 @@ int ffwm_prof_enable(int on);
 int ffwm_prof_collect(void);
 int ffwm_prof_get(int row, char* name, int name_len, int64_t* launches, double* total_ms,
                   double* algorithmic_bytes);
+/* total algorithmic flops of row `row` (non-zero for the MFMA kernels: conv3x3_wgrad, correlation_colmax) */
+int ffwm_prof_get_flops(int row, double* algorithmic_flops);
 int ffwm_prof_reset(void);
 
 /* Tuning/ablation switches (bench and tests only): returns the previous value, or

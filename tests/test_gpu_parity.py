@@ -925,6 +925,9 @@ def test_correlation_colmax_matches_bmm_max(shape):
     (1, 64, 64, 9, 128),       # two strips, odd height
     (3, 7, 70, 5, 64),         # fewer channels than a tile, several k tiles
     (2, 128, 33, 40, 64),      # row chunks
+    (1, 67, 130, 6, 64),       # thin remainders on both sides (3 input channels, 2 output channels): packed variant
+    (2, 66, 64, 5, 128),       # thin input-channel remainder only
+    (1, 64, 193, 7, 64),       # thin output-channel remainder only (swapped operands, flipped taps)
 ])
 def test_conv3x3_wgrad_matches_aten(shape):
     """fp32 MFMA weight gradient vs ATen's float64 convolution_backward (fp32 fma chains in a different
