@@ -29,12 +29,17 @@ class _Conv3x3MfmaWgrad(Function):
         go = grad_output.contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         gx = gb = gw = None
-        if need_x or need_b:
-            gx, _, gb = torch.ops.aten.convolution_backward(
-                go, x, weight, [weight.shape[0]] if need_b else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                [bool(need_x), False, bool(need_b)])
         if need_w:
-            gw = ops.conv3x3_wgrad(x if x.is_contiguous() else x.contiguous(), go)
+            # the bias gradient is a row sum of the operand the MFMA kernel streams anyway
+            if need_b:
+                gb = torch.zeros(weight.shape[0], device=go.device, dtype=go.dtype)
+            gw = ops.conv3x3_wgrad(x if x.is_contiguous() else x.contiguous(), go, None, gb)
+        if need_x or (need_b and gb is None):
+            gx, _, gb2 = torch.ops.aten.convolution_backward(
+                go, x, weight, [weight.shape[0]] if (need_b and gb is None) else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                [bool(need_x), False, bool(need_b and gb is None)])
+            if gb is None:
+                gb = gb2
         return gx, gw, gb
 
 

@@ -61,7 +61,7 @@ struct WgradGeo {
 template <bool PACKED>
 __global__ void __launch_bounds__(kBlock, 1)
 conv3x3_wgrad_kernel(const float* __restrict__ Sp, const float* __restrict__ Ap, float* __restrict__ dW, WgradGeo g,
-                     unsigned s_bytes, unsigned a_bytes) {
+                     unsigned s_bytes, unsigned a_bytes, float* __restrict__ dbias) {
     constexpr int MT = PACKED ? 128 : 64;                   // A rows per workgroup
     constexpr int GQ = MT / 16;                             // float4 of the A row per thread
     constexpr int kAFloats = MT * kWgPG;
@@ -173,6 +173,10 @@ conv3x3_wgrad_kernel(const float* __restrict__ Sp, const float* __restrict__ Ap,
 
     const int a_base = (wk * 32 + l31) * kWgPG + half * 32;
     const int b_base = (wc * 32 + l31) * kWgPX + half * 32 + 3;      // index of x - 1 for step 0
+    // bias gradient (sum of grad_output over the pixels): the waves of the first S tile that read a given A row
+    // once (wc == 0) add up what they load for the MFMAs anyway
+    const bool want_bias = !PACKED && dbias != nullptr && ct == 0 && wc == 0;
+    float bias_sum = 0.f;
     // PACKED: column l31 = (channel l31 / 9, tap l31 % 9); columns 27..31 shadow column 0 and are never stored
     const int pcol = l31 < 27 ? l31 : 0;
     const int pch = pcol / 9, ptap = pcol - pch * 9, pr = ptap / 3, psx = ptap - pr * 3;
@@ -219,6 +223,7 @@ conv3x3_wgrad_kernel(const float* __restrict__ Sp, const float* __restrict__ Ap,
 #pragma unroll 2
                 for (int i = 0; i < 32; i += 4) {
                     const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + i);
+                    if (want_bias) bias_sum += (a4.x + a4.y) + (a4.z + a4.w);      // the conv's bias gradient: row sums of A
                     float bw[3][6];
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
@@ -246,6 +251,11 @@ conv3x3_wgrad_kernel(const float* __restrict__ Sp, const float* __restrict__ Ap,
         }
     }
 
+    if (want_bias) {
+        bias_sum += __shfl_xor(bias_sum, 32, kWave);
+        const int kk = k0 + wk * 32 + l31;
+        if (half == 0 && kk < g.a_end) atomic_add(dbias + kk, bias_sum);
+    }
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     if constexpr (PACKED) {
         // 27 consecutive floats per (row, normal orientation); small either way: straight from the registers
@@ -282,11 +292,29 @@ conv3x3_wgrad_kernel(const float* __restrict__ Sp, const float* __restrict__ Ap,
     }
 }
 
+// Bias gradient of the few output channels the full tiles do not cover: one block per (channel, image) plane.
+__global__ void __launch_bounds__(kBlock)
+bias_rows_kernel(const float* __restrict__ gO, float* __restrict__ dbias, int K, int k_begin, int nk, int plane) {
+    __shared__ float red[kBlock / kWave];
+    const int k = k_begin + blockIdx.x % nk, b = blockIdx.x / nk;
+    const float* p = gO + (static_cast<size_t>(b) * K + k) * plane;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < plane; i += kBlock) s += p[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kBlock / kWave; ++w) t += red[w];
+        atomic_add(dbias + k, t);
+    }
+}
+
 // One launch: A rows [a_begin, a_end) x S channels [s_begin, s_end).
 template <bool PACKED>
 int launch_wgrad(const char* name, const float* S, const float* A, float* dW, int64_t B, int64_t St, int64_t At, int64_t H,
                  int64_t W, int64_t a_begin, int64_t a_end, int64_t s_begin, int64_t s_end, int64_t out_stride_a,
-                 int64_t out_stride_s, int flip, hipStream_t st) {
+                 int64_t out_stride_s, int flip, hipStream_t st, float* dbias = nullptr) {
     if (a_begin >= a_end || s_begin >= s_end) return FFWM_OK;
     constexpr int MT = PACKED ? 128 : 64;
     WgradGeo g;
@@ -315,7 +343,7 @@ int launch_wgrad(const char* name, const float* S, const float* A, float* dW, in
                                     9.0 * (s_end - s_begin) * (a_end - a_begin)),
                    2.0 * 9.0 * static_cast<double>(B) * H * W * (s_end - s_begin) * (a_end - a_begin));
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<PACKED>, dim3(static_cast<unsigned>(tiles * nsplit)), dim3(kBlock), lds, st, S, A, dW,
-                       g, static_cast<unsigned>(B * St * H * W * 4), static_cast<unsigned>(B * At * H * W * 4));
+                       g, static_cast<unsigned>(B * St * H * W * 4), static_cast<unsigned>(B * At * H * W * 4), dbias);
     return check_launch("ffwm_conv3x3_wgrad");
 }
 
@@ -324,9 +352,9 @@ int launch_wgrad(const char* name, const float* S, const float* A, float* dW, in
 
 using namespace ffwm;
 
-extern "C" int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* grad_weight, int64_t B, int64_t C,
-                                        int64_t K, int64_t H, int64_t W, int64_t k_begin, int64_t k_end, int64_t c_begin,
-                                        int64_t c_end, int dtype, void* stream) {
+extern "C" int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* grad_weight, void* grad_bias,
+                                        int64_t B, int64_t C, int64_t K, int64_t H, int64_t W, int64_t k_begin, int64_t k_end,
+                                        int64_t c_begin, int64_t c_end, int dtype, void* stream) {
     const char* fn = "ffwm_conv3x3_wgrad";
     FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only (fp32 MFMA)", fn);
     FFWM_REQUIRE(input && grad_output && grad_weight, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
@@ -346,14 +374,27 @@ extern "C" int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_outp
     auto thin = [](int64_t lo, int64_t hi) { const int64_t n = hi - lo, r = n % kWgTile; return (n > kWgTile && r > 0 && r <= 3) ? r : 0; };
     const int64_t km = k_end - thin(k_begin, k_end), cm = c_end - thin(c_begin, c_end);
     // full tiles: A = grad_output rows [k_begin, km), S = input channels [c_begin, cm)
-    if (int rc = launch_wgrad<false>("conv3x3_wgrad", X, G, dW, B, C, K, H, W, k_begin, km, c_begin, cm, C * 9, 9, 0, st)) return rc;
+    float* db = (float*)grad_bias;
+    const bool main_has_bias = db && km > k_begin && cm > c_begin;      // the full-tile launch sums its A rows on the way
+    if (int rc = launch_wgrad<false>("conv3x3_wgrad", X, G, dW, B, C, K, H, W, k_begin, km, c_begin, cm, C * 9, 9, 0, st,
+                                     main_has_bias ? db : nullptr))
+        return rc;
+    if (db) {
+        const int64_t r0 = main_has_bias ? km : k_begin;                 // rows nobody summed yet
+        if (r0 < k_end) {
+            LaunchScope ls("conv_bias_rows", st, 4.0 * B * (k_end - r0) * H * W);
+            hipLaunchKernelGGL(bias_rows_kernel, dim3(static_cast<unsigned>(B * (k_end - r0))), dim3(kBlock), 0, st, G, db, (int)K,
+                               (int)r0, (int)(k_end - r0), (int)(H * W));
+            if (int rc = check_launch(fn)) return rc;
+        }
+    }
     // remainder columns: every output channel x input channels [cm, c_end), taps packed into the MFMA columns
     if (int rc = launch_wgrad<true>("conv3x3_wgrad_packed", X, G, dW, B, C, K, H, W, k_begin, k_end, cm, c_end, C * 9, 9, 0, st)) return rc;
     // remainder rows: operands swapped (A = input channels [c_begin, cm), S = grad_output channels [km, k_end)), taps flipped
     return launch_wgrad<true>("conv3x3_wgrad_packed", G, X, dW, B, K, C, H, W, c_begin, cm, km, k_end, 9, C * 9, 1, st);
 }
 
-extern "C" int ffwm_conv3x3_wgrad(const void* input, const void* grad_output, void* grad_weight, int64_t B, int64_t C,
-                                  int64_t K, int64_t H, int64_t W, int dtype, void* stream) {
-    return ffwm_conv3x3_wgrad_block(input, grad_output, grad_weight, B, C, K, H, W, 0, K, 0, C, dtype, stream);
+extern "C" int ffwm_conv3x3_wgrad(const void* input, const void* grad_output, void* grad_weight, void* grad_bias, int64_t B,
+                                  int64_t C, int64_t K, int64_t H, int64_t W, int dtype, void* stream) {
+    return ffwm_conv3x3_wgrad_block(input, grad_output, grad_weight, grad_bias, B, C, K, H, W, 0, K, 0, C, dtype, stream);
 }

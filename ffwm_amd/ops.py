@@ -355,9 +355,13 @@ def conv3x3_wgrad_supported(input, grad_output):
             and input.shape[3] % 64 == 0 and input.numel() * 4 < (1 << 32) - 64 and grad_output.numel() * 4 < (1 << 32) - 64)
 
 
-def conv3x3_wgrad(input, grad_output, grad_weight=None):
-    """grad_weight[K,C,3,3] (+= when given, zero-filled otherwise) of a 3x3 / stride 1 / pad 1 convolution."""
+def conv3x3_wgrad(input, grad_output, grad_weight=None, grad_bias=None):
+    """grad_weight[K,C,3,3] of a 3x3 / stride 1 / pad 1 convolution (+= when given, zero-filled otherwise); a given
+    (zero-filled) grad_bias[K] receives the bias gradient from the same pass."""
     _check("conv3x3_wgrad", input, grad_output, grad_weight)
+    if grad_bias is not None and not (grad_bias.is_cuda and grad_bias.device == input.device and grad_bias.dtype == input.dtype
+                                      and grad_bias.is_contiguous()):
+        raise ValueError("conv3x3_wgrad: grad_bias must be a contiguous tensor on the input's device, same dtype")
     B, C, H, W = input.shape
     Bg, K, Hg, Wg = grad_output.shape
     if (Bg, Hg, Wg) != (B, H, W):
@@ -366,7 +370,9 @@ def conv3x3_wgrad(input, grad_output, grad_weight=None):
         grad_weight = input.new_zeros((K, C, 3, 3))
     elif tuple(grad_weight.shape) != (K, C, 3, 3):
         raise ValueError("conv3x3_wgrad: grad_weight has the wrong shape")
+    if grad_bias is not None and tuple(grad_bias.shape) != (K,):
+        raise ValueError("conv3x3_wgrad: grad_bias has the wrong shape")
     with _on_device(input) as stream:
-        _lib.check(_lib.load().ffwm_conv3x3_wgrad(_ptr(input), _ptr(grad_output), _ptr(grad_weight), B, C, K, H, W,
-                                                  _dtype_code(input), stream), "ffwm_conv3x3_wgrad")
+        _lib.check(_lib.load().ffwm_conv3x3_wgrad(_ptr(input), _ptr(grad_output), _ptr(grad_weight), _ptr(grad_bias), B, C, K,
+                                                  H, W, _dtype_code(input), stream), "ffwm_conv3x3_wgrad")
     return grad_weight

@@ -216,20 +216,20 @@ int ffwm_block_attention_backward(const void* source, const void* flow_field, co
                                   void* grad_weights, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
                                   int64_t Wf, int kernel_size, int dtype, void* stream);
 
-/* Weight gradient of a 3x3 / stride 1 / pad 1 / dilation 1 / groups 1 convolution (the layer type of the
- * FFWM and FlowNet conv stacks, models/base_networks.py:59-165,274-347; ATen's convolution_backward
- * grad_weight output) on fp32-in / fp32-accumulate MFMA, NCHW, no transposes:
+/* Weight (and bias) gradient of a 3x3 / stride 1 / pad 1 / dilation 1 / groups 1 convolution (the layer type of
+ * the FFWM and FlowNet conv stacks, models/base_networks.py:59-165,274-347; the grad_weight / grad_bias outputs of
+ * ATen's convolution_backward) on fp32-in / fp32-accumulate MFMA, NCHW, no transposes:
  *     grad_weight[K,C,3,3][k,c,r,s] += sum_{b,y,x} grad_output[b,k,y,x] * input[b,c,y+r-1,x+s-1]
+ *     grad_bias[K][k]               += sum_{b,y,x} grad_output[b,k,y,x]        (NULL: skipped)
  * input[B,C,H,W], grad_output[B,K,H,W] contiguous float32, W a multiple of 64; the caller zero-fills
- * grad_weight (pixel slices are combined with atomics). */
-int ffwm_conv3x3_wgrad(const void* input, const void* grad_output, void* grad_weight, int64_t B, int64_t C,
-                       int64_t K, int64_t H, int64_t W, int dtype, void* stream);
+ * grad_weight and grad_bias (pixel slices are combined with atomics). */
+int ffwm_conv3x3_wgrad(const void* input, const void* grad_output, void* grad_weight, void* grad_bias, int64_t B,
+                       int64_t C, int64_t K, int64_t H, int64_t W, int dtype, void* stream);
 
-/* The same, restricted to the block grad_weight[k_begin:k_end, c_begin:c_end] (tensor extents and strides are
- * still K and C): lets a caller keep the 64-channel MFMA tiles full and hand a thin remainder -- e.g. channels
- * 192..194 of the reference's 195-channel layers -- to another routine. */
-int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* grad_weight, int64_t B, int64_t C,
-                             int64_t K, int64_t H, int64_t W, int64_t k_begin, int64_t k_end, int64_t c_begin,
+/* The same, restricted to the block grad_weight[k_begin:k_end, c_begin:c_end] and grad_bias[k_begin:k_end] (tensor
+ * extents and strides are still K and C). */
+int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* grad_weight, void* grad_bias, int64_t B,
+                             int64_t C, int64_t K, int64_t H, int64_t W, int64_t k_begin, int64_t k_end, int64_t c_begin,
                              int64_t c_end, int dtype, void* stream);
 
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------

@@ -939,8 +939,10 @@ def test_conv3x3_wgrad_matches_aten(shape):
     go = torch.randn(B, K, H, W, generator=g)
     ref = torch.ops.aten.convolution_backward(go.double(), x.double(), torch.zeros(K, C, 3, 3, dtype=torch.float64), None,
                                               [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-    dw = ops.conv3x3_wgrad(x.to(DEV), go.to(DEV))
+    db = torch.zeros(K, device=DEV)
+    dw = ops.conv3x3_wgrad(x.to(DEV), go.to(DEV), None, db)
     _close(dw, ref.float(), 1e-5, relative=True)
+    _close(db, go.double().sum((0, 2, 3)).float(), 1e-5, relative=True)
     # accumulate semantics
     dw2 = ops.conv3x3_wgrad(x.to(DEV), go.to(DEV), dw.clone())
     _close(dw2, 2 * ref.float(), 1e-5, relative=True)
