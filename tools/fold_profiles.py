@@ -11,9 +11,9 @@ import shutil
 import sys
 
 SCOPES = {   # launch scope -> kernel-name prefix (template arguments included where they select the variant)
-    "block_extractor_bwd_far": "be_bwd_far2_kernel<float, 3>",
-    "block_extractor_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4>",
-    "block_extractor_fwd_lds": "be_fwd_lds_kernel<float, 3, 4>",
+    "block_extractor_bwd_far": "be_bwd_far2_kernel<float, 3, false>",
+    "block_extractor_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, false>",
+    "block_extractor_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 0>",
     "conv3x3_wgrad": "conv3x3_wgrad_kernel<false>",
     "conv3x3_wgrad_packed": "conv3x3_wgrad_kernel<true>",
     "guided_filter_bwd": "gf_backward_kernel<float>",
