@@ -22,6 +22,7 @@ _SIGNATURES = {
     # name: argtypes
     "ffwm_block_extractor_forward": [_p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_block_extractor_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_adam_step": [_p, _p, _p, _p, _i64] + [ctypes.c_double] * 4 + [_i64, _i, _p],
     "ffwm_conv3x3_wgrad": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _p],
     "ffwm_conv3x3_wgrad_block": [_p, _p, _p, _p] + [_i64] * 9 + [_i, _p],
     "ffwm_block_attention_forward": [_p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],

@@ -17,6 +17,10 @@ import torch
 import torch.distributed as dist
 
 
+def _pad4(n):
+    return (n + 3) & ~3
+
+
 class BucketedGradReducer(object):
     def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True):
         self.group = process_group
@@ -29,42 +33,62 @@ class BucketedGradReducer(object):
         self.buckets = []          # dicts: flat, params, pending, launched, handle
         self._bucket_of = {}
         self._view = {}            # param -> its slice of the bucket
-        cur, cur_bytes = [], 0
+        groups, cur, cur_bytes = [], [], 0
         for p in ordered:
             nbytes = p.numel() * p.element_size()
             if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
-                self._seal(cur)
+                groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
         if cur:
-            self._seal(cur)
+            groups.append(cur)
+        # ONE flat gradient array for all buckets (a bucket is a slice of it) when dtype and device are uniform:
+        # zero_grad is one memset, and a flat optimizer (ffwm_amd/optim.py:FlatAdam) can sweep a contiguous
+        # range of parameters.  Every parameter starts on a 16-byte boundary (padding elements stay zero).
+        self.flat = None
+        self.offset = {}           # param -> (begin, end) in elements of self.flat
+        uniform = bool(ordered) and all(p.dtype == ordered[0].dtype and p.device == ordered[0].device for p in ordered)
+        if uniform:
+            total = sum(_pad4(p.numel()) for p in ordered)
+            self.flat = torch.zeros(total, dtype=ordered[0].dtype, device=ordered[0].device)
+        base = 0
+        for plist in groups:
+            base = self._seal(plist, base)
         self.overlap = True
         self._hooks = []
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _seal(self, plist):
-        total = sum(p.numel() for p in plist)
-        flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
+    def _seal(self, plist, base):
+        total = sum(_pad4(p.numel()) for p in plist)
+        if self.flat is not None:
+            flat = self.flat[base:base + total]
+        else:
+            flat = torch.zeros(total, dtype=plist[0].dtype, device=plist[0].device)
         off = 0
         for p in plist:
             n = p.numel()
             view = flat[off:off + n].view_as(p)
             p.grad = view                             # autograd accumulates in place into the bucket
             self._view[p] = view
-            off += n
+            self.offset[p] = (base + off, base + off + n)
+            off += _pad4(n)
         b = {"flat": flat, "params": plist, "pending": len(plist), "launched": False, "handle": None}
         for p in plist:
             self._bucket_of[p] = b
         self.buckets.append(b)
+        return base + total
 
     # ------------------------------------------------------------------ per step
     def zero_grad(self):
         """Replaces optimizer.zero_grad(): keeps the bucket views alive."""
+        if self.flat is not None:
+            self.flat.zero_()
         for b in self.buckets:
-            b["flat"].zero_()
+            if self.flat is None:
+                b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["launched"] = False
             b["handle"] = None

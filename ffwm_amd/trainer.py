@@ -71,7 +71,7 @@ def part_grids(lm_F):
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
                  warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True,
-                 mfma_wgrad=None):
+                 mfma_wgrad=None, flat_adam=None):
         self.device = torch.device(device)
         self.titers = titers
         torch.manual_seed(seed)
@@ -117,9 +117,6 @@ class FFWMTrainer(object):
         # capturable form keeps the step counter on the device without the per-parameter kernels of the
         # foreach implementation (1275 extra launches per step, measured)
         kw = {"fused": True, "capturable": cap} if self.device.type == "cuda" else {}
-        self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999), **kw)
-        self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), **kw)
-        self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999), **kw)
         self.world_size = world_size
         self.batched_losses = batched_losses
         self._graphs = None
@@ -127,6 +124,19 @@ class FFWMTrainer(object):
         self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
                                          bucket_bytes=bucket_bytes)
         self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes)
+        if flat_adam is None:
+            flat_adam = self.device.type == "cuda" and not cap
+        self.flat_adam = bool(flat_adam)
+        if self.flat_adam:
+            # parameters, gradients and moments as flat arrays: one streaming kernel per optimizer step (csrc/adam.hip)
+            from .optim import FlatAdam
+            self.opt_F = FlatAdam(flow_params, self.red_G, lr=0.00005, betas=(0.5, 0.999))
+            self.opt_G = FlatAdam(list(self.netG.parameters()), self.red_G, lr=0.0004, betas=(0.5, 0.999))
+            self.opt_D = FlatAdam(list(self.netD.parameters()), self.red_D, lr=0.0004, betas=(0.5, 0.999))
+        else:
+            self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999), **kw)
+            self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), **kw)
+            self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=0.0004, betas=(0.5, 0.999), **kw)
         self.losses = {}
 
     # ------------------------------------------------------------------ stand-in for the pretrained flow nets
@@ -326,7 +336,8 @@ class FFWMTrainer(object):
         The batch is copied into static device buffers before every replay; the `titers` branch
         (< 20000 / >= 20000) is frozen at capture time -- re-capture when it flips."""
         assert self.device.type == "cuda" and self._graphs is None
-        if not all(g.get("capturable", False) for o in (self.opt_F, self.opt_G, self.opt_D) for g in o.param_groups):
+        if not all(g.get("capturable", False) for o in (self.opt_F, self.opt_G, self.opt_D)
+                   for g in getattr(o, "param_groups", [{}])):
             raise RuntimeError("capture() needs FFWMTrainer(..., capturable=True)")
         self._static = {k: v.clone() for k, v in b.items()}
         sb = self._static
@@ -459,9 +470,12 @@ class FlowNetTrainer(object):
         self.Correctness = PerceptualCorrectness(self.vgg, self.warp)
         self.criterionLD = MultiScaleLDLoss()
         params = [p for n, p in self.flowNet.named_parameters() if not n.startswith("inter_conv_occ")]
-        kw = {"fused": True} if self.device.type == "cuda" else {}
-        self.optimizer = torch.optim.Adam(params, lr=0.0004, betas=(0.5, 0.999), **kw)
         self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes)
+        if self.device.type == "cuda":
+            from .optim import FlatAdam
+            self.optimizer = FlatAdam(params, self.reducer, lr=0.0004, betas=(0.5, 0.999))
+        else:
+            self.optimizer = torch.optim.Adam(params, lr=0.0004, betas=(0.5, 0.999))
         self.losses = {}
 
     def step(self, b):

@@ -232,6 +232,12 @@ int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* g
                              int64_t C, int64_t K, int64_t H, int64_t W, int64_t k_begin, int64_t k_end, int64_t c_begin,
                              int64_t c_end, int dtype, void* stream);
 
+/* One Adam step (no weight decay, no amsgrad: torch.optim.Adam as models/ffwm_model.py:46-49 and
+ * models/flownet_model.py:33 construct it) over FLAT float32 arrays of n elements, 16-byte aligned: parameters,
+ * gradients, first and second moments.  `step` is the 1-based step count (bias corrections 1 - beta^step). */
+int ffwm_adam_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr,
+                   double beta1, double beta2, double eps, int64_t step, int dtype, void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded

@@ -123,4 +123,4 @@ def test_reducer_is_a_noop_without_process_group():
     net(torch.ones(2, 4)).sum().backward()
     red.finish()
     assert torch.allclose(net.weight.grad, torch.full((3, 4), 2.0))
-    assert red.grad_bytes() == (12 + 3) * 4
+    assert red.grad_bytes() == (12 + 4) * 4          # every parameter starts on a 16-byte boundary: the 3-element bias takes 4

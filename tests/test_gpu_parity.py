@@ -970,3 +970,40 @@ def test_conv_wgrad_routing_matches_aten_autograd():
     ref(x).square().mean().backward()
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         _close(p.grad, q.grad.cpu(), 1e-5, relative=True)
+
+
+# ------------------------------------------------------------------------- flat Adam
+def test_flat_adam_matches_torch_adam():
+    """FlatAdam (one kernel over flat parameter / gradient / moment arrays) against torch.optim.Adam on the same
+    gradients for several steps; parameters stay the modules' own Parameter objects (views of the flat array)."""
+    import copy
+    import torch.nn as nn
+    from ffwm_amd.dp import BucketedGradReducer
+    from ffwm_amd.optim import FlatAdam
+    torch.manual_seed(5)
+    net = nn.Sequential(nn.Conv2d(3, 7, 3, 1, 1), nn.BatchNorm2d(7), nn.LeakyReLU(0.2), nn.Conv2d(7, 5, 3, 1, 1),
+                        nn.Flatten(), nn.Linear(5 * 8 * 8, 3)).to(DEV)
+    ref = copy.deepcopy(net)
+    red = BucketedGradReducer(net.parameters(), bucket_bytes=1 << 10)       # several buckets, one flat array
+    opt = FlatAdam(list(net.parameters()), red, lr=4e-4, betas=(0.5, 0.999))
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=4e-4, betas=(0.5, 0.999))
+    names = [n for n, _ in net.named_parameters()]
+    for step in range(4):
+        x = torch.randn(4, 3, 8, 8, device=DEV, generator=torch.Generator(device=DEV).manual_seed(step))
+        red.zero_grad()
+        net(x).square().mean().backward()
+        red.finish()
+        # the same gradients for both (a conv bias in front of BatchNorm only receives rounding noise, which Adam
+        # normalises to full-size steps: two backward passes would not agree on it)
+        for p, q in zip(net.parameters(), ref.parameters()):
+            q.grad = p.grad.detach().clone()
+        opt.step()
+        opt_ref.step()
+        with torch.no_grad():
+            for p, q in zip(net.parameters(), ref.parameters()):
+                _close(p.detach(), q.detach().cpu(), 2e-6, relative=True)
+                q.copy_(p)          # same inputs for the next step: one step of arithmetic is compared at a time
+    assert [n for n, _ in net.named_parameters()] == names
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.data_ptr() >= opt.params.data_ptr() and p.data_ptr() < opt.params.data_ptr() + opt.params.numel() * 4
+        _close(p.detach(), q.detach().cpu(), 2e-6, relative=True)
