@@ -1,0 +1,311 @@
+// bn_lrelu.hip -- training-mode BatchNorm2d fused with the LeakyReLU that follows it.
+//
+// Reference: every conv block of FlowNet (models/base_networks.py:12-31: conv -> BatchNorm2d -> LeakyReLU(0.2)),
+// of FFWM's encoder / decoder / residual blocks (:207-264) and of the discriminators (:381-413) is
+// nn.BatchNorm2d in training mode followed by nn.LeakyReLU: ~110 pairs per train step, each two kernels forward
+// (statistics + normalise, then the activation's read-modify-write) and two backward.  Here a pair is ONE kernel
+// per direction:
+//   forward : per channel, mean and biased variance over (B, H, W) -- double accumulators, one pass --, running
+//             statistics updated in place exactly like F.batch_norm (momentum, unbiased variance), then
+//             y = lrelu(gamma (x - mean) invstd + beta); the second read of x comes from L2.
+//   backward: the activation's mask is recomputed from x (pre = gamma xhat + beta), so the forward output is not
+//             needed: g = dy * (pre > 0 ? 1 : slope); sum(g), sum(g xhat) per channel; then
+//             dx = gamma invstd (g - mean(g) - xhat mean(g xhat)), dgamma = sum(g xhat), dbeta = sum(g).
+// Decomposition: a workgroup per channel streams that channel's B planes (float4, coalesced); channels with few
+// elements (the 8x8 ... 2x2 layers with up to 1024 channels) take one WAVE per channel instead, four to a
+// workgroup.  A channel's statistics never leave the workgroup: no atomics, no second launch.
+#include "common.hpp"
+
+namespace ffwm {
+namespace {
+
+constexpr int kBnThreads = 1024;
+
+struct BnGeo {
+    int B, C, HW;
+    float eps, momentum, slope;
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// sum of two doubles over the group (a whole 1024-thread block through LDS, or one wave)
+template <int THREADS>
+__device__ __forceinline__ void group_sum2(double& a, double& b, double* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if constexpr (THREADS > kWave) {
+        constexpr int NW = THREADS / kWave;
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        __syncthreads();                       // red may still be read from the previous use
+        if (lane == 0) {
+            red[wave] = a;
+            red[NW + wave] = b;
+        }
+        __syncthreads();
+        double sa = 0, sb = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            sa += red[w];
+            sb += red[NW + w];
+        }
+        a = sa;
+        b = sb;
+    }
+}
+
+// THREADS = threads that share one channel (1024: block per channel; 64: wave per channel)
+template <int THREADS>
+__global__ void __launch_bounds__(kBnThreads)
+bn_lrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ y,
+                    float* __restrict__ save_mean, float* __restrict__ save_invstd, BnGeo g) {
+    __shared__ double red[2 * (kBnThreads / kWave)];
+    constexpr int CPB = kBnThreads / THREADS;              // channels per block
+    const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
+    const int c = blockIdx.x * CPB + sub;
+    const bool live = c < g.C;
+    const int cc = live ? c : g.C - 1;                     // dead sub-groups shadow a valid channel, store nothing
+    const size_t cstride = static_cast<size_t>(g.C) * g.HW;
+    const float* xc = x + static_cast<size_t>(cc) * g.HW;
+    const int hw4 = (g.HW % 4 == 0) ? g.HW / 4 : 0;
+    double s = 0, ss = 0;
+    // flat index j over (plane b, float4 i): four independent loads in flight per thread
+    const int total4 = g.B * hw4;
+    auto addr4 = [&](const float* base, int j) {
+        const int b = j / hw4, i = j - b * hw4;
+        return reinterpret_cast<const float4*>(base + b * cstride) + i;
+    };
+    if (hw4) {
+        for (int j0 = t; j0 < total4; j0 += 4 * THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * THREADS;
+                v[u] = j < total4 ? *addr4(xc, j) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += (static_cast<double>(v[u].x) + static_cast<double>(v[u].y)) + (static_cast<double>(v[u].z) + static_cast<double>(v[u].w));
+                ss += (static_cast<double>(v[u].x) * v[u].x + static_cast<double>(v[u].y) * v[u].y) +
+                      (static_cast<double>(v[u].z) * v[u].z + static_cast<double>(v[u].w) * v[u].w);
+            }
+        }
+    } else {
+        for (int b = 0; b < g.B; ++b) {
+            const float* p = xc + b * cstride;
+            for (int i = t; i < g.HW; i += THREADS) {
+                const double v = p[i];
+                s += v;
+                ss += v * v;
+            }
+        }
+    }
+    group_sum2<THREADS>(s, ss, red);
+    const double n = static_cast<double>(g.B) * g.HW;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    var = var > 0 ? var : 0;
+    const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(g.eps)));
+    const float meanf = static_cast<float>(mean);
+    if (live && t == 0) {
+        save_mean[c] = meanf;
+        save_invstd[c] = invstd;
+        if (run_mean) {        // F.batch_norm: running = (1 - momentum) running + momentum batch; variance unbiased
+            const double unbiased = n > 1 ? var * n / (n - 1) : var;
+            run_mean[c] = (1.f - g.momentum) * run_mean[c] + g.momentum * meanf;
+            run_var[c] = (1.f - g.momentum) * run_var[c] + g.momentum * static_cast<float>(unbiased);
+        }
+    }
+    const float ga = gamma ? gamma[cc] : 1.f, be = beta ? beta[cc] : 0.f;
+    const float sc = ga * invstd, sh = be - meanf * ga * invstd;
+    if (!live) return;
+    float* yc = y + static_cast<size_t>(c) * g.HW;
+    if (hw4) {
+        for (int j0 = t; j0 < total4; j0 += 4 * THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * THREADS;
+                v[u] = j < total4 ? *addr4(xc, j) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * THREADS;
+                if (j < total4) {
+                    float4 o;
+                    o.x = lrelu(v[u].x * sc + sh, g.slope);
+                    o.y = lrelu(v[u].y * sc + sh, g.slope);
+                    o.z = lrelu(v[u].z * sc + sh, g.slope);
+                    o.w = lrelu(v[u].w * sc + sh, g.slope);
+                    *const_cast<float4*>(addr4(yc, j)) = o;
+                }
+            }
+        }
+    } else {
+        for (int b = 0; b < g.B; ++b) {
+            const float* p = xc + b * cstride;
+            float* q = yc + b * cstride;
+            for (int i = t; i < g.HW; i += THREADS) q[i] = lrelu(p[i] * sc + sh, g.slope);
+        }
+    }
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(kBnThreads)
+bn_lrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, const float* __restrict__ save_mean,
+                    const float* __restrict__ save_invstd, float* __restrict__ dx, float* __restrict__ dgamma,
+                    float* __restrict__ dbeta, BnGeo g) {
+    __shared__ double red[2 * (kBnThreads / kWave)];
+    constexpr int CPB = kBnThreads / THREADS;
+    const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
+    const int c = blockIdx.x * CPB + sub;
+    const bool live = c < g.C;
+    const int cc = live ? c : g.C - 1;
+    const size_t cstride = static_cast<size_t>(g.C) * g.HW;
+    const float* xc = x + static_cast<size_t>(cc) * g.HW;
+    const float* dyc = dy + static_cast<size_t>(cc) * g.HW;
+    const float mean = save_mean[cc], invstd = save_invstd[cc];
+    const float ga = gamma ? gamma[cc] : 1.f, be = beta ? beta[cc] : 0.f;
+    const int hw4 = (g.HW % 4 == 0) ? g.HW / 4 : 0;
+    // g = dy * lrelu'(gamma xhat + beta)
+    auto gval = [&](float xv, float dv, float& xhat) {
+        xhat = (xv - mean) * invstd;
+        return (ga * xhat + be) > 0.f ? dv : dv * g.slope;
+    };
+    double s = 0, sx = 0;
+    const int total4 = g.B * hw4;
+    auto addr4 = [&](const float* base, int j) {
+        const int b = j / hw4, i = j - b * hw4;
+        return reinterpret_cast<const float4*>(base + b * cstride) + i;
+    };
+    if (hw4) {
+        for (int j0 = t; j0 < total4; j0 += 2 * THREADS) {
+            float4 v[2], e[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + u * THREADS;
+                v[u] = j < total4 ? *addr4(xc, j) : float4{0.f, 0.f, 0.f, 0.f};
+                e[u] = j < total4 ? *addr4(dyc, j) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float xh;
+                float gv = gval(v[u].x, e[u].x, xh); s += gv; sx += static_cast<double>(gv) * xh;
+                gv = gval(v[u].y, e[u].y, xh); s += gv; sx += static_cast<double>(gv) * xh;
+                gv = gval(v[u].z, e[u].z, xh); s += gv; sx += static_cast<double>(gv) * xh;
+                gv = gval(v[u].w, e[u].w, xh); s += gv; sx += static_cast<double>(gv) * xh;
+            }
+        }
+    } else {
+        for (int b = 0; b < g.B; ++b) {
+            const float* p = xc + b * cstride;
+            const float* d = dyc + b * cstride;
+            for (int i = t; i < g.HW; i += THREADS) {
+                float xh;
+                const float gv = gval(p[i], d[i], xh);
+                s += gv;
+                sx += static_cast<double>(gv) * xh;
+            }
+        }
+    }
+    group_sum2<THREADS>(s, sx, red);
+    if (live && t == 0) {
+        if (dgamma) dgamma[c] = static_cast<float>(sx);
+        if (dbeta) dbeta[c] = static_cast<float>(s);
+    }
+    if (!live || !dx) return;
+    const double n = static_cast<double>(g.B) * g.HW;
+    const float mg = static_cast<float>(s / n), mgx = static_cast<float>(sx / n);
+    const float k = ga * invstd;
+    float* dxc = dx + static_cast<size_t>(c) * g.HW;
+    if (hw4) {
+        for (int j0 = t; j0 < total4; j0 += 2 * THREADS) {
+            float4 v[2], e[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + u * THREADS;
+                v[u] = j < total4 ? *addr4(xc, j) : float4{0.f, 0.f, 0.f, 0.f};
+                e[u] = j < total4 ? *addr4(dyc, j) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = j0 + u * THREADS;
+                if (j < total4) {
+                    float4 o;
+                    float xh;
+                    float gv = gval(v[u].x, e[u].x, xh); o.x = k * (gv - mg - xh * mgx);
+                    gv = gval(v[u].y, e[u].y, xh); o.y = k * (gv - mg - xh * mgx);
+                    gv = gval(v[u].z, e[u].z, xh); o.z = k * (gv - mg - xh * mgx);
+                    gv = gval(v[u].w, e[u].w, xh); o.w = k * (gv - mg - xh * mgx);
+                    *const_cast<float4*>(addr4(dxc, j)) = o;
+                }
+            }
+        }
+    } else {
+        for (int b = 0; b < g.B; ++b) {
+            const float* p = xc + b * cstride;
+            const float* d = dyc + b * cstride;
+            float* q = dxc + b * cstride;
+            for (int i = t; i < g.HW; i += THREADS) {
+                float xh;
+                const float gv = gval(p[i], d[i], xh);
+                q[i] = k * (gv - mg - xh * mgx);
+            }
+        }
+    }
+}
+
+int check_bn(const char* fn, int64_t B, int64_t C, int64_t HW, int dtype) {
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(B > 0 && C > 0 && HW > 0 && B * HW > 1, FFWM_ERR_ARG, "%s: need B, C, H*W > 0 and more than one value per channel", fn);
+    FFWM_REQUIRE(B < (1LL << 20) && C < (1LL << 24) && HW < (1LL << 30), FFWM_ERR_SIZE, "%s: tensor too large", fn);
+    return FFWM_OK;
+}
+
+}  // namespace
+}  // namespace ffwm
+
+using namespace ffwm;
+
+extern "C" int ffwm_bn_lrelu_forward(const void* x, const void* weight, const void* bias, void* running_mean,
+                                     void* running_var, void* y, void* save_mean, void* save_invstd, int64_t B, int64_t C,
+                                     int64_t HW, double eps, double momentum, double negative_slope, int dtype, void* stream) {
+    const char* fn = "ffwm_bn_lrelu_forward";
+    if (int rc = check_bn(fn, B, C, HW, dtype)) return rc;
+    FFWM_REQUIRE(x && y && save_mean && save_invstd, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FFWM_ERR_ARG, "%s: running_mean and running_var go together", fn);
+    const BnGeo g{(int)B, (int)C, (int)HW, (float)eps, (float)momentum, (float)negative_slope};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LaunchScope ls("bn_lrelu_fwd", st, 4.0 * 2.0 * B * C * HW);
+    if (B * HW >= 2048)
+        hipLaunchKernelGGL((bn_lrelu_fwd_kernel<kBnThreads>), dim3((unsigned)C), dim3(kBnThreads), 0, st, (const float*)x,
+                           (const float*)weight, (const float*)bias, (float*)running_mean, (float*)running_var, (float*)y,
+                           (float*)save_mean, (float*)save_invstd, g);
+    else
+        hipLaunchKernelGGL((bn_lrelu_fwd_kernel<kWave>), dim3((unsigned)((C + 15) / 16)), dim3(kBnThreads), 0, st, (const float*)x,
+                           (const float*)weight, (const float*)bias, (float*)running_mean, (float*)running_var, (float*)y,
+                           (float*)save_mean, (float*)save_invstd, g);
+    return check_launch(fn);
+}
+
+extern "C" int ffwm_bn_lrelu_backward(const void* x, const void* grad_out, const void* weight, const void* bias,
+                                      const void* save_mean, const void* save_invstd, void* grad_x, void* grad_weight,
+                                      void* grad_bias, int64_t B, int64_t C, int64_t HW, double negative_slope, int dtype,
+                                      void* stream) {
+    const char* fn = "ffwm_bn_lrelu_backward";
+    if (int rc = check_bn(fn, B, C, HW, dtype)) return rc;
+    FFWM_REQUIRE(x && grad_out && save_mean && save_invstd, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    const BnGeo g{(int)B, (int)C, (int)HW, 0.f, 0.f, (float)negative_slope};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LaunchScope ls("bn_lrelu_bwd", st, 4.0 * 3.0 * B * C * HW);
+    if (B * HW >= 2048)
+        hipLaunchKernelGGL((bn_lrelu_bwd_kernel<kBnThreads>), dim3((unsigned)C), dim3(kBnThreads), 0, st, (const float*)x,
+                           (const float*)grad_out, (const float*)weight, (const float*)bias, (const float*)save_mean,
+                           (const float*)save_invstd, (float*)grad_x, (float*)grad_weight, (float*)grad_bias, g);
+    else
+        hipLaunchKernelGGL((bn_lrelu_bwd_kernel<kWave>), dim3((unsigned)((C + 15) / 16)), dim3(kBnThreads), 0, st, (const float*)x,
+                           (const float*)grad_out, (const float*)weight, (const float*)bias, (const float*)save_mean,
+                           (const float*)save_invstd, (float*)grad_x, (float*)grad_weight, (float*)grad_bias, g);
+    return check_launch(fn);
+}

@@ -1,0 +1,113 @@
+"""Training-mode BatchNorm2d fused with the LeakyReLU that follows it (csrc/bn_lrelu.hip).
+
+The conv blocks of the reference (models/base_networks.py:12-31 FlowNet, :207-264 FFWM, :381-413 discriminators) are
+``conv -> nn.BatchNorm2d -> nn.LeakyReLU(0.2)``.  ``fuse_bn_lrelu(net)`` re-classes each such BatchNorm2d in place
+(parameters, buffers and state-dict keys untouched) and replaces the LeakyReLU that follows it in the same
+``nn.Sequential`` by ``nn.Identity`` (no parameters: the container's indices, hence every key, stay the same).
+In eval mode, on the CPU, or for inputs the kernel does not take, the module is exactly BatchNorm2d + leaky_relu.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _launch(fn_name, x, *args):
+    dev = x.device.index
+    cur = torch.cuda.current_device()
+    if cur != dev:
+        torch.cuda.set_device(dev)
+    try:
+        fn = getattr(_lib.load(), fn_name)
+        _lib.check(fn(*args, _lib.F32, torch.cuda.current_stream(dev).cuda_stream), fn_name)
+    finally:
+        if cur != dev:
+            torch.cuda.set_device(cur)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class _BnLreluFunction(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, slope):
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        save_invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        _launch("ffwm_bn_lrelu_forward", x, _p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var), _p(y),
+                _p(save_mean), _p(save_invstd), B, C, H * W, float(eps), float(momentum), float(slope))
+        ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        B, C, H, W = x.shape
+        go = grad_y.contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty(C, device=x.device, dtype=torch.float32) if (need_w and weight is not None) else None
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if (need_b and bias is not None) else None
+        _launch("ffwm_bn_lrelu_backward", x, _p(x), _p(go), _p(weight), _p(bias), _p(save_mean), _p(save_invstd), _p(dx),
+                _p(dw), _p(db), B, C, H * W, ctx.slope)
+        return dx, dw, db, None, None, None, None, None
+
+
+# Below this many elements a BatchNorm + LeakyReLU pair is launch-bound either way and the two native ops cost
+# less host time than one Python autograd Function; above it the saved read-modify-write passes win.
+MIN_FUSED_NUMEL = 1 << 20
+
+
+def _kernel_ok(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() >= MIN_FUSED_NUMEL and x.is_contiguous()
+            and x.data_ptr() % 16 == 0)
+
+
+class BatchNormLeakyReLU2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d followed by leaky_relu(negative_slope); one kernel per direction in training mode on the GPU."""
+
+    negative_slope = 0.2
+    _pending_batches = 0
+
+    def forward(self, x):
+        if (self.training and self.momentum is not None and _kernel_ok(x)
+                and (self.weight is None or self.weight.dtype == torch.float32)):
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                # the counter only matters for momentum=None and for checkpoints: count on the host, add when a
+                # state dict is taken (one tiny kernel per BatchNorm and step otherwise)
+                self._pending_batches += 1
+            rm = self.running_mean if self.track_running_stats else None
+            rv = self.running_var if self.track_running_stats else None
+            return _BnLreluFunction.apply(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, self.negative_slope)
+        return F.leaky_relu(super().forward(x), self.negative_slope)
+
+    def flush_batch_counter(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked += self._pending_batches
+        self._pending_batches = 0
+
+
+def _flush_hook(module, *args, **kwargs):
+    module.flush_batch_counter()
+
+
+def fuse_bn_lrelu(net):
+    """Re-class every BatchNorm2d that is directly followed by a LeakyReLU in an nn.Sequential; returns the count."""
+    n = 0
+    for seq in [m for m in net.modules() if isinstance(m, nn.Sequential)]:
+        keys = list(seq._modules.keys())
+        for ka, kb in zip(keys, keys[1:]):
+            a, b = seq._modules[ka], seq._modules[kb]
+            if type(a) is nn.BatchNorm2d and type(b) is nn.LeakyReLU:
+                a.__class__ = BatchNormLeakyReLU2d
+                a.negative_slope = b.negative_slope
+                a._pending_batches = 0
+                a.register_state_dict_pre_hook(_flush_hook)
+                seq._modules[kb] = nn.Identity()
+                n += 1
+    return n

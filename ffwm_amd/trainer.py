@@ -71,7 +71,7 @@ def part_grids(lm_F):
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
                  warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True,
-                 mfma_wgrad=None, flat_adam=None):
+                 mfma_wgrad=None, flat_adam=None, fused_bn=None):
         self.device = torch.device(device)
         self.titers = titers
         torch.manual_seed(seed)
@@ -98,6 +98,12 @@ class FFWMTrainer(object):
             # weight gradients of the large-image 3x3 layers on the hand-written MFMA kernel (conv.py)
             from .conv import route_conv_wgrad
             self.mfma_wgrad_layers = route_conv_wgrad(self.netG)
+        if fused_bn is None:
+            fused_bn = self.device.type == "cuda"
+        if fused_bn:
+            # BatchNorm2d + LeakyReLU pairs of the conv blocks as one kernel per direction (norm.py, csrc/bn_lrelu.hip)
+            from .norm import fuse_bn_lrelu
+            self.fused_bn_layers = sum(fuse_bn_lrelu(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD))
         if fused_spectral_norm is None:
             fused_spectral_norm = self.device.type == "cuda"
         if fused_spectral_norm:

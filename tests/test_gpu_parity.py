@@ -1007,3 +1007,47 @@ def test_flat_adam_matches_torch_adam():
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert p.data_ptr() >= opt.params.data_ptr() and p.data_ptr() < opt.params.data_ptr() + opt.params.numel() * 4
         _close(p.detach(), q.detach().cpu(), 2e-6, relative=True)
+
+
+# ------------------------------------------------------------------------- fused BatchNorm2d + LeakyReLU
+@pytest.mark.parametrize("shape", [(8, 64, 32, 32), (4, 195, 64, 64), (8, 1024, 2, 2), (3, 37, 5, 7), (2, 16, 9, 9), (8, 5, 128, 128)])
+def test_bn_lrelu_matches_batchnorm_plus_leaky_relu(shape):
+    import copy
+    import torch.nn as nn
+    from ffwm_amd import norm
+    from ffwm_amd.norm import BatchNormLeakyReLU2d, fuse_bn_lrelu
+    B, C, H, W = shape
+    norm.MIN_FUSED_NUMEL = 1          # the size gate is a host-overhead heuristic: test every shape on the kernel
+    torch.manual_seed(C)
+    ref = nn.Sequential(nn.Conv2d(C, C, 1), nn.BatchNorm2d(C), nn.LeakyReLU(0.2, inplace=True)).to(DEV)
+    with torch.no_grad():
+        ref[1].weight.uniform_(0.5, 1.5)
+        ref[1].bias.uniform_(-0.5, 0.5)
+        ref[0].weight.copy_(torch.eye(C).view(C, C, 1, 1))        # the conv is the identity: BN sees the input itself
+        ref[0].bias.zero_()
+    fus = copy.deepcopy(ref)
+    assert fuse_bn_lrelu(fus) == 1 and isinstance(fus[1], BatchNormLeakyReLU2d) and isinstance(fus[2], nn.Identity)
+    assert list(fus.state_dict().keys()) == list(ref.state_dict().keys())
+    g = _gen(60 + C)
+    for step in range(2):
+        x = (torch.randn(B, C, H, W, generator=g) * 2 + 0.7).to(DEV)
+        go = torch.randn(B, C, H, W, generator=g).to(DEV)
+        outs = []
+        for net in (ref, fus):
+            xi = x.clone().requires_grad_(True)
+            net.zero_grad()
+            y = net(xi)
+            y.backward(go)
+            outs.append((y.detach(), xi.grad, net[1].weight.grad, net[1].bias.grad))
+        for a, b in zip(outs[0], outs[1]):
+            _close(b, a.cpu(), 2e-5, relative=True)
+    sd_r, sd_f = ref.state_dict(), fus.state_dict()
+    for k in sd_r:
+        if sd_r[k].dtype.is_floating_point:
+            _close(sd_f[k], sd_r[k].cpu(), 1e-5, relative=True)
+        else:
+            assert int(sd_f[k]) == int(sd_r[k]) == 2, k           # num_batches_tracked, flushed by the state-dict hook
+    # eval mode: running statistics + activation through the unfused path
+    ref.eval(), fus.eval()
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    _close(fus(x), ref(x).cpu(), 1e-5, relative=True)

@@ -11,6 +11,9 @@ import shutil
 import sys
 
 SCOPES = {   # launch scope -> kernel-name prefix (template arguments included where they select the variant)
+    "adam_flat": "adam_flat_kernel",
+    "bn_lrelu_bwd": "bn_lrelu_bwd_kernel<1024>",
+    "bn_lrelu_fwd": "bn_lrelu_fwd_kernel<1024>",
     "block_extractor_bwd_far": "be_bwd_far2_kernel<float, 3, false>",
     "block_extractor_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, false>",
     "block_extractor_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 0>",
