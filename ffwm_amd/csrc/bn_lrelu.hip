@@ -24,6 +24,9 @@ constexpr int kBnThreads = 1024;
 struct BnGeo {
     int B, C, HW;
     float eps, momentum, slope;
+    // a channel split over S workgroups (blockIdx.y): phase 1 adds the slice's two sums to scratch[2 c], [2 c + 1]
+    // (doubles, zero-filled by the caller), phase 2 reads them and applies; phase 0 = one workgroup does both
+    int S, phase;
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -58,7 +61,7 @@ template <int THREADS>
 __global__ void __launch_bounds__(kBnThreads)
 bn_lrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ y,
-                    float* __restrict__ save_mean, float* __restrict__ save_invstd, BnGeo g) {
+                    float* __restrict__ save_mean, float* __restrict__ save_invstd, BnGeo g, double* __restrict__ scratch) {
     __shared__ double red[2 * (kBnThreads / kWave)];
     constexpr int CPB = kBnThreads / THREADS;              // channels per block
     const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
@@ -70,13 +73,18 @@ bn_lrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
     const int hw4 = (g.HW % 4 == 0) ? g.HW / 4 : 0;
     double s = 0, ss = 0;
     // flat index j over (plane b, float4 i): four independent loads in flight per thread
-    const int total4 = g.B * hw4;
+    const int all4 = g.B * hw4;
+    const int chunk = (all4 + g.S - 1) / g.S;
+    const int first4 = blockIdx.y * chunk;                 // this workgroup's slice of the flat (plane, float4) index
+    const int total4 = min(all4, first4 + chunk);
     auto addr4 = [&](const float* base, int j) {
         const int b = j / hw4, i = j - b * hw4;
         return reinterpret_cast<const float4*>(base + b * cstride) + i;
     };
-    if (hw4) {
-        for (int j0 = t; j0 < total4; j0 += 4 * THREADS) {
+    if (g.phase == 2) {
+        // statistics already reduced over the slices
+    } else if (hw4) {
+        for (int j0 = first4 + t; j0 < total4; j0 += 4 * THREADS) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -100,14 +108,25 @@ bn_lrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
             }
         }
     }
-    group_sum2<THREADS>(s, ss, red);
+    if (g.phase != 2) group_sum2<THREADS>(s, ss, red);
+    if (g.phase == 1) {
+        if (live && t == 0) {
+            atomic_add(scratch + 2 * c, s);
+            atomic_add(scratch + 2 * c + 1, ss);
+        }
+        return;
+    }
+    if (g.phase == 2) {
+        s = scratch[2 * cc];
+        ss = scratch[2 * cc + 1];
+    }
     const double n = static_cast<double>(g.B) * g.HW;
     const double mean = s / n;
     double var = ss / n - mean * mean;
     var = var > 0 ? var : 0;
     const float invstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(g.eps)));
     const float meanf = static_cast<float>(mean);
-    if (live && t == 0) {
+    if (live && t == 0 && blockIdx.y == 0) {
         save_mean[c] = meanf;
         save_invstd[c] = invstd;
         if (run_mean) {        // F.batch_norm: running = (1 - momentum) running + momentum batch; variance unbiased
@@ -121,7 +140,7 @@ bn_lrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
     if (!live) return;
     float* yc = y + static_cast<size_t>(c) * g.HW;
     if (hw4) {
-        for (int j0 = t; j0 < total4; j0 += 4 * THREADS) {
+        for (int j0 = first4 + t; j0 < total4; j0 += 4 * THREADS) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -155,7 +174,7 @@ __global__ void __launch_bounds__(kBnThreads)
 bn_lrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
                     const float* __restrict__ beta, const float* __restrict__ save_mean,
                     const float* __restrict__ save_invstd, float* __restrict__ dx, float* __restrict__ dgamma,
-                    float* __restrict__ dbeta, BnGeo g) {
+                    float* __restrict__ dbeta, BnGeo g, double* __restrict__ scratch) {
     __shared__ double red[2 * (kBnThreads / kWave)];
     constexpr int CPB = kBnThreads / THREADS;
     const int sub = threadIdx.x / THREADS, t = threadIdx.x % THREADS;
@@ -174,13 +193,18 @@ bn_lrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, c
         return (ga * xhat + be) > 0.f ? dv : dv * g.slope;
     };
     double s = 0, sx = 0;
-    const int total4 = g.B * hw4;
+    const int all4 = g.B * hw4;
+    const int chunk = (all4 + g.S - 1) / g.S;
+    const int first4 = blockIdx.y * chunk;                 // this workgroup's slice of the flat (plane, float4) index
+    const int total4 = min(all4, first4 + chunk);
     auto addr4 = [&](const float* base, int j) {
         const int b = j / hw4, i = j - b * hw4;
         return reinterpret_cast<const float4*>(base + b * cstride) + i;
     };
-    if (hw4) {
-        for (int j0 = t; j0 < total4; j0 += 2 * THREADS) {
+    if (g.phase == 2) {
+        // sums already reduced over the slices
+    } else if (hw4) {
+        for (int j0 = first4 + t; j0 < total4; j0 += 2 * THREADS) {
             float4 v[2], e[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -209,8 +233,19 @@ bn_lrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, c
             }
         }
     }
-    group_sum2<THREADS>(s, sx, red);
-    if (live && t == 0) {
+    if (g.phase != 2) group_sum2<THREADS>(s, sx, red);
+    if (g.phase == 1) {
+        if (live && t == 0) {
+            atomic_add(scratch + 2 * c, s);
+            atomic_add(scratch + 2 * c + 1, sx);
+        }
+        return;
+    }
+    if (g.phase == 2) {
+        s = scratch[2 * cc];
+        sx = scratch[2 * cc + 1];
+    }
+    if (live && t == 0 && blockIdx.y == 0) {
         if (dgamma) dgamma[c] = static_cast<float>(sx);
         if (dbeta) dbeta[c] = static_cast<float>(s);
     }
@@ -220,7 +255,7 @@ bn_lrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, c
     const float k = ga * invstd;
     float* dxc = dx + static_cast<size_t>(c) * g.HW;
     if (hw4) {
-        for (int j0 = t; j0 < total4; j0 += 2 * THREADS) {
+        for (int j0 = first4 + t; j0 < total4; j0 += 2 * THREADS) {
             float4 v[2], e[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -268,44 +303,73 @@ int check_bn(const char* fn, int64_t B, int64_t C, int64_t HW, int dtype) {
 
 using namespace ffwm;
 
+// slices per channel when the caller provides scratch: enough workgroups for the chip, slices of >= 16 K elements
+static int bn_slices(int64_t B, int64_t C, int64_t HW, const void* scratch) {
+    if (!scratch || HW % 4 != 0 || B * HW < 2048) return 1;
+    int64_t S = (1024 + C - 1) / C;
+    const int64_t cap = B * HW / 16384;
+    if (S > cap) S = cap;
+    if (S > 32) S = 32;
+    return S < 2 ? 1 : static_cast<int>(S);
+}
+
 extern "C" int ffwm_bn_lrelu_forward(const void* x, const void* weight, const void* bias, void* running_mean,
-                                     void* running_var, void* y, void* save_mean, void* save_invstd, int64_t B, int64_t C,
-                                     int64_t HW, double eps, double momentum, double negative_slope, int dtype, void* stream) {
+                                     void* running_var, void* y, void* save_mean, void* save_invstd, void* scratch, int64_t B,
+                                     int64_t C, int64_t HW, double eps, double momentum, double negative_slope, int dtype,
+                                     void* stream) {
     const char* fn = "ffwm_bn_lrelu_forward";
     if (int rc = check_bn(fn, B, C, HW, dtype)) return rc;
     FFWM_REQUIRE(x && y && save_mean && save_invstd, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
     FFWM_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FFWM_ERR_ARG, "%s: running_mean and running_var go together", fn);
-    const BnGeo g{(int)B, (int)C, (int)HW, (float)eps, (float)momentum, (float)negative_slope};
+    BnGeo g{(int)B, (int)C, (int)HW, (float)eps, (float)momentum, (float)negative_slope, 1, 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     LaunchScope ls("bn_lrelu_fwd", st, 4.0 * 2.0 * B * C * HW);
-    if (B * HW >= 2048)
-        hipLaunchKernelGGL((bn_lrelu_fwd_kernel<kBnThreads>), dim3((unsigned)C), dim3(kBnThreads), 0, st, (const float*)x,
-                           (const float*)weight, (const float*)bias, (float*)running_mean, (float*)running_var, (float*)y,
-                           (float*)save_mean, (float*)save_invstd, g);
-    else
-        hipLaunchKernelGGL((bn_lrelu_fwd_kernel<kWave>), dim3((unsigned)((C + 15) / 16)), dim3(kBnThreads), 0, st, (const float*)x,
-                           (const float*)weight, (const float*)bias, (float*)running_mean, (float*)running_var, (float*)y,
-                           (float*)save_mean, (float*)save_invstd, g);
+#define FFWM_BN_FWD(THR, GRID)                                                                                              \
+    hipLaunchKernelGGL((bn_lrelu_fwd_kernel<THR>), GRID, dim3(kBnThreads), 0, st, (const float*)x, (const float*)weight,    \
+                       (const float*)bias, (float*)running_mean, (float*)running_var, (float*)y, (float*)save_mean,         \
+                       (float*)save_invstd, g, (double*)scratch)
+    const int S = bn_slices(B, C, HW, scratch);
+    if (S > 1) {
+        g.S = S;
+        g.phase = 1;
+        FFWM_BN_FWD(kBnThreads, dim3((unsigned)C, (unsigned)S));
+        g.phase = 2;
+        FFWM_BN_FWD(kBnThreads, dim3((unsigned)C, (unsigned)S));
+    } else if (B * HW >= 2048) {
+        FFWM_BN_FWD(kBnThreads, dim3((unsigned)C));
+    } else {
+        FFWM_BN_FWD(kWave, dim3((unsigned)((C + 15) / 16)));
+    }
+#undef FFWM_BN_FWD
     return check_launch(fn);
 }
 
 extern "C" int ffwm_bn_lrelu_backward(const void* x, const void* grad_out, const void* weight, const void* bias,
                                       const void* save_mean, const void* save_invstd, void* grad_x, void* grad_weight,
-                                      void* grad_bias, int64_t B, int64_t C, int64_t HW, double negative_slope, int dtype,
-                                      void* stream) {
+                                      void* grad_bias, void* scratch, int64_t B, int64_t C, int64_t HW, double negative_slope,
+                                      int dtype, void* stream) {
     const char* fn = "ffwm_bn_lrelu_backward";
     if (int rc = check_bn(fn, B, C, HW, dtype)) return rc;
     FFWM_REQUIRE(x && grad_out && save_mean && save_invstd, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
-    const BnGeo g{(int)B, (int)C, (int)HW, 0.f, 0.f, (float)negative_slope};
+    BnGeo g{(int)B, (int)C, (int)HW, 0.f, 0.f, (float)negative_slope, 1, 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     LaunchScope ls("bn_lrelu_bwd", st, 4.0 * 3.0 * B * C * HW);
-    if (B * HW >= 2048)
-        hipLaunchKernelGGL((bn_lrelu_bwd_kernel<kBnThreads>), dim3((unsigned)C), dim3(kBnThreads), 0, st, (const float*)x,
-                           (const float*)grad_out, (const float*)weight, (const float*)bias, (const float*)save_mean,
-                           (const float*)save_invstd, (float*)grad_x, (float*)grad_weight, (float*)grad_bias, g);
-    else
-        hipLaunchKernelGGL((bn_lrelu_bwd_kernel<kWave>), dim3((unsigned)((C + 15) / 16)), dim3(kBnThreads), 0, st, (const float*)x,
-                           (const float*)grad_out, (const float*)weight, (const float*)bias, (const float*)save_mean,
-                           (const float*)save_invstd, (float*)grad_x, (float*)grad_weight, (float*)grad_bias, g);
+#define FFWM_BN_BWD(THR, GRID)                                                                                              \
+    hipLaunchKernelGGL((bn_lrelu_bwd_kernel<THR>), GRID, dim3(kBnThreads), 0, st, (const float*)x, (const float*)grad_out,  \
+                       (const float*)weight, (const float*)bias, (const float*)save_mean, (const float*)save_invstd,        \
+                       (float*)grad_x, (float*)grad_weight, (float*)grad_bias, g, (double*)scratch)
+    const int S = bn_slices(B, C, HW, scratch);
+    if (S > 1) {
+        g.S = S;
+        g.phase = 1;
+        FFWM_BN_BWD(kBnThreads, dim3((unsigned)C, (unsigned)S));
+        g.phase = 2;
+        FFWM_BN_BWD(kBnThreads, dim3((unsigned)C, (unsigned)S));
+    } else if (B * HW >= 2048) {
+        FFWM_BN_BWD(kBnThreads, dim3((unsigned)C));
+    } else {
+        FFWM_BN_BWD(kWave, dim3((unsigned)((C + 15) / 16)));
+    }
+#undef FFWM_BN_BWD
     return check_launch(fn);
 }

@@ -31,6 +31,14 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _scratch(x):
+    """2 C zero-filled doubles when a channel is worth splitting over several workgroups (few channels, large planes)."""
+    C = x.shape[1]
+    if C < 512 and x.numel() // C >= 32768:
+        return torch.zeros(2 * C, device=x.device, dtype=torch.float64)
+    return None
+
+
 class _BnLreluFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, slope):
@@ -39,7 +47,7 @@ class _BnLreluFunction(Function):
         save_mean = torch.empty(C, device=x.device, dtype=torch.float32)
         save_invstd = torch.empty(C, device=x.device, dtype=torch.float32)
         _launch("ffwm_bn_lrelu_forward", x, _p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var), _p(y),
-                _p(save_mean), _p(save_invstd), B, C, H * W, float(eps), float(momentum), float(slope))
+                _p(save_mean), _p(save_invstd), _p(_scratch(x)), B, C, H * W, float(eps), float(momentum), float(slope))
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.slope = float(slope)
         return y
@@ -54,7 +62,7 @@ class _BnLreluFunction(Function):
         dw = torch.empty(C, device=x.device, dtype=torch.float32) if (need_w and weight is not None) else None
         db = torch.empty(C, device=x.device, dtype=torch.float32) if (need_b and bias is not None) else None
         _launch("ffwm_bn_lrelu_backward", x, _p(x), _p(go), _p(weight), _p(bias), _p(save_mean), _p(save_invstd), _p(dx),
-                _p(dw), _p(db), B, C, H * W, ctx.slope)
+                _p(dw), _p(db), _p(_scratch(x)), B, C, H * W, ctx.slope)
         return dx, dw, db, None, None, None, None, None
 
 

@@ -236,17 +236,18 @@ int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* g
  * models/base_networks.py:12-31,207-264,381-413): y = leaky_relu(F.batch_norm(x, running_mean, running_var, weight,
  * bias, training=True, momentum, eps), negative_slope).  x, y [B,C,H,W] contiguous float32 (16-byte aligned),
  * HW = H*W; weight / bias [C] or NULL; running_mean / running_var [C] updated in place (both NULL: not tracked);
- * save_mean / save_invstd [C] are written for the backward pass. */
+ * save_mean / save_invstd [C] are written for the backward pass.  scratch: NULL, or 2*C ZERO-FILLED doubles -- with it a
+ * channel with few workgroups' worth of parallelism (C < 1024) is split over several workgroups (two launches). */
 int ffwm_bn_lrelu_forward(const void* x, const void* weight, const void* bias, void* running_mean, void* running_var,
-                          void* y, void* save_mean, void* save_invstd, int64_t B, int64_t C, int64_t HW, double eps,
-                          double momentum, double negative_slope, int dtype, void* stream);
+                          void* y, void* save_mean, void* save_invstd, void* scratch, int64_t B, int64_t C, int64_t HW,
+                          double eps, double momentum, double negative_slope, int dtype, void* stream);
 
 /* grad_x [B,C,H,W], grad_weight [C], grad_bias [C] are OVERWRITTEN (each channel is produced by one workgroup); any
  * of them may be NULL.  The activation mask is recomputed from x, the forward output is not needed. */
 int ffwm_bn_lrelu_backward(const void* x, const void* grad_out, const void* weight, const void* bias,
                            const void* save_mean, const void* save_invstd, void* grad_x, void* grad_weight,
-                           void* grad_bias, int64_t B, int64_t C, int64_t HW, double negative_slope, int dtype,
-                           void* stream);
+                           void* grad_bias, void* scratch, int64_t B, int64_t C, int64_t HW, double negative_slope,
+                           int dtype, void* stream);
 
 /* One Adam step (no weight decay, no amsgrad: torch.optim.Adam as models/ffwm_model.py:46-49 and
  * models/flownet_model.py:33 construct it) over FLAT float32 arrays of n elements, 16-byte aligned: parameters,

@@ -1010,7 +1010,8 @@ def test_flat_adam_matches_torch_adam():
 
 
 # ------------------------------------------------------------------------- fused BatchNorm2d + LeakyReLU
-@pytest.mark.parametrize("shape", [(8, 64, 32, 32), (4, 195, 64, 64), (8, 1024, 2, 2), (3, 37, 5, 7), (2, 16, 9, 9), (8, 5, 128, 128)])
+@pytest.mark.parametrize("shape", [(8, 64, 32, 32), (4, 195, 64, 64), (8, 1024, 2, 2), (3, 37, 5, 7), (2, 16, 9, 9), (8, 5, 128, 128),
+                                   (8, 64, 128, 128), (3, 130, 64, 128)])      # the last three split a channel over workgroups
 def test_bn_lrelu_matches_batchnorm_plus_leaky_relu(shape):
     import copy
     import torch.nn as nn
