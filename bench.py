@@ -243,7 +243,10 @@ def main():
     # fresh box.  Exhaustive find mode multiplies that start-up cost by the number of candidate
     # solvers (~10 min), so it is opt-in; the default is MIOpen's heuristic ("immediate") choice.
     torch.backends.cudnn.benchmark = os.environ.get("FFWM_MIOPEN_FIND", "0") == "1"
-    from ffwm_amd import _lib
+    from ffwm_amd import _lib, miopen_tuning
+    # solver selection from the in-tree find-db (ffwm_amd/miopen_db, 245 KB of MIOpen's own text records for the
+    # convolutions of this workload on gfx950 / 256 CUs): immediate mode, no find pass at start-up
+    miopen_db = miopen_tuning.install()
     _lib.load()                                # fail loudly if the HIP library is missing
 
     result = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
@@ -273,6 +276,7 @@ def main():
                                               "all losses, 3x Adam), synthetic MultiPIE-shaped 128x128",
                                   "batch_per_gpu": bs, "global_batch": bs * world,
                                   "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed else "eager",
+                                  "miopen": "immediate mode%s" % (" + in-tree find-db (ffwm_amd/miopen_db)" if miopen_db else ", heuristic solver choice"),
                                   "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))
                                   if args.mfma_wgrad == "on" else "vendor library",
                                   "titers_branch": "<20000" if args.titers < 20000 else ">=20000",

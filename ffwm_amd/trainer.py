@@ -77,6 +77,9 @@ class FFWMTrainer(object):
         torch.manual_seed(seed)
         self.warp = warp if warp is not None else WarpNet()
         self.flowNetF = nets.FlowNet(ngf).to(self.device)
+        if self.device.type == "cuda":
+            from . import miopen_tuning
+            miopen_tuning.install()      # solver selection for the conv stacks; before the first convolution
         self.flowNetB = nets.FlowNet(ngf).to(self.device)
         self.netG = nets.FFWM(sn=True, warp_flipcat=warp_flipcat).to(self.device)
         self.netD = nets.MSDiscriminator(128, sigmoid=False).to(self.device)
@@ -467,6 +470,9 @@ class FlowNetTrainer(object):
         self.device = torch.device(device)
         torch.manual_seed(seed)
         self.warp = warp if warp is not None else WarpNet()
+        if self.device.type == "cuda":
+            from . import miopen_tuning
+            miopen_tuning.install()
         self.flowNet = nets.FlowNet(ngf).to(self.device)
         self.vgg = nets.VGG19("relu3_1").to(self.device).eval()
         broadcast_module_state([self.flowNet, self.vgg])
