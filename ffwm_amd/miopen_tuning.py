@@ -30,7 +30,8 @@ def install():
             if not name.endswith(".txt"):
                 continue
             src, out = os.path.join(DB_DIR, name), os.path.join(dst, name)
-            if not os.path.exists(out):                 # several ranks may race: write aside, then rename atomically
+            if not os.path.exists(out) or os.path.getsize(out) < os.path.getsize(src):
+                # (MIOpen only appends: a shorter copy is stale.)  Several ranks may race: write aside, rename atomically
                 tmp = "%s.%d.tmp" % (out, os.getpid())
                 shutil.copyfile(src, tmp)
                 os.replace(tmp, out)
