@@ -34,6 +34,9 @@ def timeit(fn, n=10):
 
 def main():
     dev = torch.device("cuda", 0)
+    # FFWM_MIOPEN_FIND=1: let MIOpen benchmark its solvers per shape (what the in-tree find-db encodes for the
+    # layers the bench actually runs); default: MIOpen's heuristic (immediate-mode) choice
+    torch.backends.cudnn.benchmark = os.environ.get("FFWM_MIOPEN_FIND", "0") == "1"
     print("%-28s %9s %9s %9s %9s   TF: fwd dgrad wgrad" % ("layer", "fwd us", "dgrad us", "wgrad us", "bias us"))
     for B, ci, co, H, k in SHAPES:
         x = torch.randn(B, ci, H, H, device=dev)

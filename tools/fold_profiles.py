@@ -45,6 +45,8 @@ def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/refresh"
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     raw = json.load(open(os.path.join(src, "bench_pmc_raw.json")))
+    if not raw:
+        print("no PMC data in %s (counter passes failed?): profiles/r01_pmc_traffic.json left as it is" % src)
     out = {
         "_about": "HBM-side traffic per dispatch from rocprofv3 PMC passes of `python bench.py --steps 2 --warmup 2 "
                   "--no-cpu-baseline` (one pass with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; they do not fit one pass; "
@@ -65,7 +67,8 @@ def main():
         write = sum(v["write_KiB"] * v["dispatches"] for _, v in rows) / n
         out[scope] = {"kernel": prefix, "dispatches": n, "fetch_KiB": round(fetch, 1), "write_KiB": round(write, 1),
                       "traffic_bytes": int((FETCH_CORRECTION * fetch + write) * 1024)}
-    json.dump(out, open(os.path.join(root, "profiles", "r01_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    if raw:
+        json.dump(out, open(os.path.join(root, "profiles", "r01_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for a, b in (("train_step_kernel_stats.csv", "r01_train_step_kernel_stats.csv"),
                  ("ffwm_kernels_whole_run.csv", "r01_ffwm_kernels_rocprofv3.csv"),
                  ("bench_default.json", "r01_bench_default.json")):
