@@ -332,6 +332,57 @@ def test_block_extractor_constant_flow_is_unfold_on_gpu():
         assert torch.equal(out, unf)
 
 
+def test_cfg5_full_size_properties(oracle):
+    """BASELINE configs[4] per GPU -- source [4,128,256,256], flow [4,2,256,256] ~ U[-2,2), k = 3, attention
+    [4,9,256,256] -- is too large for the oracle as a whole (1.2 GB of output), so the full-size run is pinned by
+    properties that do not depend on the size: channel / sample slices against the oracle (the ops are independent
+    per sample and, forward, per channel), the exact adjoint identity <J s, G> = <s, J^T G> between forward and
+    d(source), linearity in the source, the sum over channels that d(flow) is, and the pixel-shuffle identity."""
+    from ffwm_amd import ops
+    g = _gen(77)
+    B, C, H, W, k = 4, 128, 256, 256, 3
+    src = torch.rand(B, C, H, W, generator=g)
+    flow = torch.rand(B, 2, H, W, generator=g) * 4 - 2
+    s_d, f_d = src.to(DEV), flow.to(DEV)
+    out = ops.block_extractor_forward(s_d, f_d, k)
+    assert tuple(out.shape) == (B, C, 3 * H, 3 * W)
+    # (1) slices against the oracle, bit-exact forward
+    for b, c in ((0, 0), (3, 127), (1, 64)):
+        ref = oracle.block_extractor_forward(src[b:b + 1, c:c + 1].contiguous(), flow[b:b + 1].contiguous(), k)
+        assert torch.equal(out[b:b + 1, c:c + 1].cpu(), ref)
+    # (2) adjoint: <BE(s), G> == <s, BE^T(G)>, accumulated in float64
+    G = torch.rand(B, C, 3 * H, 3 * W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    gs = torch.zeros_like(s_d)
+    gf = torch.zeros_like(f_d)
+    ops.block_extractor_backward(s_d, f_d, G, k, gs, gf)
+    lhs = (out.double() * G.double()).sum().item()
+    rhs = (s_d.double() * gs.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs), (lhs, rhs)
+    # (3) d(source) slice against the oracle (channels are independent); d(flow) of one sample = sum over its channels
+    b, c = 2, 17
+    gs_ref, _ = oracle.block_extractor_backward(src[b:b + 1, c:c + 1].contiguous(), flow[b:b + 1].contiguous(),
+                                                G[b:b + 1, c:c + 1].cpu().contiguous(), k)
+    _close(gs[b:b + 1, c:c + 1], gs_ref, BWD_TOL[torch.float32], relative=True)
+    _, gf_ref = oracle.block_extractor_backward(src[b:b + 1].contiguous(), flow[b:b + 1].contiguous(), G[b:b + 1].cpu().contiguous(), k)
+    _close(gf[b:b + 1], gf_ref, 1e-4, relative=True)
+    # (4) linearity in the source
+    s2 = torch.rand(B, C, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    mix = ops.block_extractor_forward(0.5 * s_d + s2, f_d, k)
+    _close(mix, (0.5 * out + ops.block_extractor_forward(s2, f_d, k)).cpu(), 2e-6)
+    del mix, G, gs
+    # (5) local_attn_reshape at full size is pixel_shuffle, bit for bit, and its backward the inverse
+    attn = torch.rand(B, 9, H, W, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    r = ops.local_attn_reshape_forward(attn, k)
+    assert torch.equal(r, F.pixel_shuffle(attn, k))
+    gi = torch.zeros_like(attn)
+    ops.local_attn_reshape_backward(r, k, gi)
+    assert torch.equal(gi, attn)
+    # (6) the fused consumer at full size equals the composition of the full-size ops
+    fused = ops.block_attention_forward(s_d, f_d, attn, k)
+    comp = F.avg_pool2d(out * r, k, k)
+    _close(fused, comp.cpu(), 2e-6)
+
+
 # ------------------------------------------------------------------------- local_attn_reshape
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("k,B,H,W", [(3, 2, 10, 10), (2, 1, 7, 9), (5, 2, 60, 60), (7, 1, 122, 122),
