@@ -10,7 +10,12 @@ The reference has no working multi-GPU path; this is new.  Design fo
   * a bucket's all-reduce is launched from an autograd post-accumulate hook the moment its last
     gradient is written, i.e. it overlaps with the rest of backward; ``finish()`` waits for all of
     them (and launches any bucket whose parameters got no gradient this step);
-  * parameters that never receive gradients (FlowNet's ``inter_conv_occ*``) are left out.
+  * parameters that never receive gradients (FlowNet's ``inter_conv_occ*``) are left out;
+  * ``gather=True`` (the eager default on the GPU): ``param.grad`` is None during backward, so autograd hands every
+    parameter its freshly produced gradient without a kernel, and a bucket's gradients are packed into the flat
+    array by ONE multi-tensor copy when its last gradient arrives (world > 1) or in ``finish()`` (world 1) --
+    instead of one ``grad += new`` launch per parameter (~600 tiny kernels per train step).  ``gather=False`` keeps
+    the views installed as ``param.grad`` all the time (static addresses: what a captured hipGraph needs).
 Works with any ``torch.distributed`` backend: ``nccl`` (= RCCL) on GPUs, ``gloo`` in the CPU tests.
 """
 import torch
@@ -22,7 +27,7 @@ def _pad4(n):
 
 
 class BucketedGradReducer(object):
-    def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True):
+    def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True, gather=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.average = average
@@ -56,6 +61,8 @@ class BucketedGradReducer(object):
         for plist in groups:
             base = self._seal(plist, base)
         self.overlap = True
+        self.gather = False
+        self.set_gather(gather)
         self._hooks = []
         if self.world > 1:
             for p in params:
@@ -91,7 +98,35 @@ class BucketedGradReducer(object):
                 b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["launched"] = False
+            b["packed"] = False
             b["handle"] = None
+            if self.gather:
+                for p in b["params"]:
+                    p.grad = None             # autograd will install its own tensor: no accumulation kernel
+
+    def set_gather(self, on):
+        """Switch between packing the gradients after backward (True) and accumulating in place into the views."""
+        self.gather = bool(on)
+        for b in self.buckets:
+            b["packed"] = False
+            for p in b["params"]:
+                p.grad = None if self.gather else self._view[p]
+
+    def _pack(self, b):
+        """gather mode: one multi-tensor copy of the bucket's fresh gradients into the flat array; the views become
+        ``param.grad`` (what the optimizers read)."""
+        if b.get("packed"):
+            return
+        b["packed"] = True
+        src, dst = [], []
+        for p in b["params"]:
+            g, view = p.grad, self._view[p]
+            if g is not None and g.data_ptr() != view.data_ptr():
+                src.append(g if g.shape == view.shape else g.reshape(view.shape))
+                dst.append(view)
+            p.grad = view
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def _launch(self, b):
         b["launched"] = True
@@ -107,6 +142,12 @@ class BucketedGradReducer(object):
         if not self.overlap:
             return
         b = self._bucket_of[p]
+        if self.gather:
+            b["pending"] -= 1
+            if b["pending"] == 0 and not b["launched"]:
+                self._pack(b)
+                self._launch(b)
+            return
         view = self._view[p]
         if p.grad is not view and (p.grad is None or p.grad.data_ptr() != view.data_ptr()):
             # someone replaced .grad (e.g. optimizer.zero_grad(set_to_none=True)): fold it back
@@ -119,6 +160,10 @@ class BucketedGradReducer(object):
 
     def finish(self):
         """Block (stream-wise) until every bucket is reduced; call before optimizer.step()."""
+        if self.gather:
+            for b in self.buckets:
+                if not b["launched"]:
+                    self._pack(b)
         if self.world == 1:
             return
         for b in self.buckets:

@@ -130,9 +130,11 @@ class FFWMTrainer(object):
         self.batched_losses = batched_losses
         self._graphs = None
         self._static = None
+        # eager steps pack the gradients into the flat arrays after backward (no per-parameter accumulation kernel);
+        # a captured graph needs static gradient addresses: in-place accumulation into the views
         self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
-                                         bucket_bytes=bucket_bytes)
-        self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes)
+                                         bucket_bytes=bucket_bytes, gather=not cap)
+        self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes, gather=not cap)
         if flat_adam is None:
             flat_adam = self.device.type == "cuda" and not cap
         self.flat_adam = bool(flat_adam)
@@ -482,7 +484,7 @@ class FlowNetTrainer(object):
         self.Correctness = PerceptualCorrectness(self.vgg, self.warp)
         self.criterionLD = MultiScaleLDLoss()
         params = [p for n, p in self.flowNet.named_parameters() if not n.startswith("inter_conv_occ")]
-        self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes)
+        self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes, gather=True)
         if self.device.type == "cuda":
             from .optim import FlatAdam
             self.optimizer = FlatAdam(params, self.reducer, lr=0.0004, betas=(0.5, 0.999))

@@ -45,7 +45,7 @@ def _gan_step(g, d, red_g, red_d, x, y):
     red_g.finish()
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, gather=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -58,8 +58,8 @@ def _worker(rank, world, port, ret):
                         list(ref_g.parameters()) + list(ref_d.parameters())):
             assert torch.equal(a, b), "broadcast did not synchronise the weights"
         gparams = list(g.parameters()) + list(unused.parameters())
-        red_g = BucketedGradReducer(gparams, bucket_bytes=512)       # tiny buckets: several per set
-        red_d = BucketedGradReducer(d.parameters(), bucket_bytes=1 << 20)
+        red_g = BucketedGradReducer(gparams, bucket_bytes=512, gather=gather)       # tiny buckets: several per set
+        red_d = BucketedGradReducer(d.parameters(), bucket_bytes=1 << 20, gather=gather)
         assert len(red_g.buckets) > 1 and len(red_d.buckets) == 1
         gen = torch.Generator().manual_seed(7)
         xs = torch.rand(world, 2, 3, 8, 8, generator=gen)
@@ -106,11 +106,14 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_bucketed_reducer_world2_gloo():
+@pytest.mark.parametrize("gather", [False, True])
+def test_bucketed_reducer_world2_gloo(gather):
+    """gather=False: gradients accumulate in place into the bucket views; gather=True: autograd installs fresh
+    gradients and a bucket is packed by one multi-tensor copy when its last gradient arrives."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, gather), nprocs=world, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
 
 
