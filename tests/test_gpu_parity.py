@@ -1103,3 +1103,30 @@ def test_bn_lrelu_matches_batchnorm_plus_leaky_relu(shape):
     ref.eval(), fus.eval()
     x = torch.randn(B, C, H, W, generator=g).to(DEV)
     _close(fus(x), ref(x).cpu(), 1e-5, relative=True)
+
+
+def test_checkpoints_round_trip_with_flat_parameters(tmp_path):
+    """FlatAdam re-points param.data into flat arrays: state dicts must still save compactly, load in place (the
+    parameters stay views of the flat arrays, so the optimizer keeps seeing them) and match the reference key names."""
+    from ffwm_amd import trainer
+    dev = torch.device(DEV)
+    a = trainer.FFWMTrainer(dev, seed=3)
+    assert a.flat_adam and a.red_G.gather
+    batch = trainer.synthetic_batch(2, dev, seed=4)
+    a.step(batch, batch_increment=0)
+    a.save_networks(str(tmp_path), "latest")
+    size = (tmp_path / "latest_net_netG.pth").stat().st_size
+    n_g = sum(v.numel() * v.element_size() for v in a.netG.state_dict().values())
+    assert size < 1.05 * n_g + (1 << 20)                       # not the whole flat array per tensor
+    b = trainer.FFWMTrainer(dev, seed=9)
+    b.load_networks(str(tmp_path), "latest")
+    for name in ("netG", "flowNetF", "flowNetB", "netD"):
+        sa, sb = getattr(a, name).state_dict(), getattr(b, name).state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (name, k)
+    lo, hi = b.opt_G.params.data_ptr(), b.opt_G.params.data_ptr() + 4 * b.opt_G.params.numel()
+    assert all(lo <= p.data_ptr() < hi for p in b.netG.parameters())
+    before = b.opt_G.params.clone()
+    b.step(batch, batch_increment=0)
+    assert not torch.equal(before, b.opt_G.params)            # the loaded weights are the ones being optimised
