@@ -752,6 +752,34 @@ def test_train_step_graph_replay_matches_eager(split):
     assert (pe - pg).abs().max().item() <= 5e-3
 
 
+def test_train_step_fast_paths_match_the_plain_pytorch_paths():
+    """The same seeded trainer twice: every hand-written helper around the warp path switched off (vendor weight
+    gradients, torch.optim.Adam, nn.BatchNorm2d + nn.LeakyReLU, per-layer spectral-norm hooks, per-parameter gradient
+    accumulation) against the defaults.  One step from identical weights: same losses; the first update of the
+    weights agrees to the noise the float atomics of the backward kernels allow."""
+    from ffwm_amd import trainer
+    batch = trainer.synthetic_batch(2, DEV, seed=5)
+    plain = trainer.FFWMTrainer(DEV, seed=1, mfma_wgrad=False, flat_adam=False, fused_bn=False, fused_spectral_norm=False,
+                                batched_losses=False, capturable=False)
+    plain.red_G.set_gather(False)
+    plain.red_D.set_gather(False)
+    fast = trainer.FFWMTrainer(DEV, seed=1)
+    assert fast.flat_adam and fast.mfma_wgrad_layers == 32 and fast.fused_bn_layers > 40 and fast.red_G.gather
+    for (n, p), (_, q) in zip(plain.netG.named_parameters(), fast.netG.named_parameters()):
+        assert torch.equal(p, q), n
+    lp, lf = plain.step(batch), fast.step(batch)
+    torch.cuda.synchronize()
+    for k in lp:
+        a, b = float(lp[k].detach()), float(lf[k].detach())
+        assert abs(a - b) <= 2e-3 * (1 + abs(a)), (k, a, b)
+    # Adam's first step moves every weight by ~lr * sign(grad): compare where the gradient is not rounding noise
+    for net in ("netG", "netD"):
+        pp = torch.cat([p.detach().flatten() for p in getattr(plain, net).parameters()])
+        pf = torch.cat([p.detach().flatten() for p in getattr(fast, net).parameters()])
+        agree = ((pp - pf).abs() <= 1e-4).float().mean().item()
+        assert agree >= 0.97, (net, agree)
+
+
 # ------------------------------------------------------------------------- batched spectral norm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_fused_spectral_norm_matches_torch_hooks(dtype):
