@@ -15,6 +15,14 @@
  *   ffwm_resample2d_backward        <- resample2d_cuda.backward         cuda/resample2d_package/resample2d_cuda.cc:16-26
  *   ffwm_warp_forward / _backward   <- WarpNet.forward (F.grid_sample)  models/base_networks.py:168-173, fused with the
  *                                      flip + concat of FFWM.forward    models/base_networks.py:326-329
+ *   ffwm_guided_filter_*            <- GuidedFilter.forward             models/external_function.py:239-277
+ *   ffwm_affine_regularization      <- AffineRegularizationLoss.__call__ models/losses.py:200-219
+ *   ffwm_correlation_colmax         <- max(bmm(source, target), dim=1)  models/losses.py:347-353
+ *   ffwm_block_attention_*          <- avg_pool2d(BlockExtractor * LocalAttnReshape)  (composition of the ops above)
+ *   ffwm_spectral_norm_*            <- torch.nn.utils.spectral_norm hooks models/base_networks.py:5,218-264,381-413
+ *   ffwm_conv3x3_wgrad[_block]      <- convolution_backward grad_weight / grad_bias of the nn.Conv2d(., ., 3, 1, 1) layers
+ *   ffwm_bn_lrelu_*                 <- nn.BatchNorm2d (training) + nn.LeakyReLU of the conv blocks  models/base_networks.py:12-31
+ *   ffwm_adam_step                  <- torch.optim.Adam.step            models/ffwm_model.py:46-49,151-160
  *
  * Conventions
  *   - dtype: FFWM_F32 or FFWM_F64 (the reference dispatches AT_DISPATCH_FLOATING_TYPES).
