@@ -11,6 +11,8 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ffwm_amd import ops  # noqa: E402
 
+SHAPES_195 = [(8, 195, 195, 128, 3), (8, 192, 192, 128, 3), (8, 195, 192, 128, 3), (8, 192, 195, 128, 3), (8, 3, 195, 128, 3),
+              (8, 195, 3, 128, 3), (8, 256, 256, 128, 3), (8, 224, 224, 128, 3)]
 SHAPES = [  # (B, Cin, Cout, H, k)
     (8, 195, 195, 128, 3), (8, 195, 195, 64, 3), (8, 128, 128, 128, 3), (8, 384, 384, 32, 3),
     (8, 195, 195, 128, 1), (8, 256, 256, 32, 3), (8, 128, 128, 64, 3), (8, 195, 256, 64, 3),
@@ -38,7 +40,7 @@ def main():
     # layers the bench actually runs); default: MIOpen's heuristic (immediate-mode) choice
     torch.backends.cudnn.benchmark = os.environ.get("FFWM_MIOPEN_FIND", "0") == "1"
     print("%-28s %9s %9s %9s %9s   TF: fwd dgrad wgrad" % ("layer", "fwd us", "dgrad us", "wgrad us", "bias us"))
-    for B, ci, co, H, k in SHAPES:
+    for B, ci, co, H, k in (SHAPES_195 if os.environ.get("FFWM_SHAPES") == "195" else SHAPES):
         x = torch.randn(B, ci, H, H, device=dev)
         w = torch.randn(co, ci, k, k, device=dev) * 0.05
         b = torch.zeros(co, device=dev)
