@@ -111,6 +111,23 @@ class BlockAttention(nn.Module):
                                             self.kernel_size)
 
 
+class MaxFeatureMapFunction(Function):
+    """apply(x[B, 2C, ...]) -> max(x[:, :C], x[:, C:]): LightCNN's mfm activation (lightcnn/light_cnn.py `mfm.forward`:
+    torch.split + torch.max), forward and backward one kernel each; ties share the gradient like ATen's maximum."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        assert x.is_contiguous() and x.size(1) % 2 == 0
+        ctx.save_for_backward(x)
+        return ops.mfm_forward(x)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, = ctx.saved_tensors
+        return ops.mfm_backward(x, grad_y.contiguous())
+
+
 class LocalAttnReshapeFunction(Function):
     """apply(inputs[B,k*k,H,W], kernel_size) -> [B,1,k*H,k*W]"""
 

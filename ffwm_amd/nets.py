@@ -253,7 +253,11 @@ class mfm(nn.Module):
         self.filter = nn.Conv2d(cin, 2 * cout, k, s, p) if type == 1 else nn.Linear(cin, 2 * cout)
 
     def forward(self, x):
-        a, b = torch.split(self.filter(x), self.out_channels, 1)
+        h = self.filter(x)
+        if h.is_cuda and h.dtype == torch.float32 and h.is_contiguous():
+            from .external_function import MaxFeatureMapFunction       # one kernel per direction (csrc/mfm.hip)
+            return MaxFeatureMapFunction.apply(h)
+        a, b = torch.split(h, self.out_channels, 1)
         return torch.max(a, b)
 
 

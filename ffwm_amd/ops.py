@@ -376,3 +376,37 @@ def conv3x3_wgrad(input, grad_output, grad_weight=None, grad_bias=None):
         _lib.check(_lib.load().ffwm_conv3x3_wgrad(_ptr(input), _ptr(grad_output), _ptr(grad_weight), _ptr(grad_bias), B, C, K,
                                                   H, W, _dtype_code(input), stream), "ffwm_conv3x3_wgrad")
     return grad_weight
+
+
+# ---------------------------------------------------------------- LightCNN max-feature-map
+def _mfm_dims(x):
+    if x.dim() < 2 or x.shape[1] % 2:
+        raise ValueError("mfm: need [B, 2C, ...], got %s" % (tuple(x.shape),))
+    hw = 1
+    for d in x.shape[2:]:
+        hw *= d
+    return x.shape[0], x.shape[1] // 2, hw
+
+
+def mfm_forward(x):
+    """max(x[:, :C], x[:, C:]) of a contiguous float32 [B, 2C, ...] tensor."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise NotImplementedError("mfm_forward: contiguous float32 GPU tensors only")
+    B, C, HW = _mfm_dims(x)
+    y = x.new_empty((B, C) + tuple(x.shape[2:]))
+    if y.numel():
+        with _on_device(x) as stream:
+            _lib.check(_lib.load().ffwm_mfm_forward(_ptr(x), _ptr(y), B, C, HW, _lib.F32, stream), "ffwm_mfm_forward")
+    return y
+
+
+def mfm_backward(x, grad_y):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and grad_y.is_contiguous() and grad_y.dtype == x.dtype):
+        raise NotImplementedError("mfm_backward: contiguous float32 GPU tensors only")
+    B, C, HW = _mfm_dims(x)
+    dx = torch.empty_like(x)
+    if dx.numel():
+        with _on_device(x) as stream:
+            _lib.check(_lib.load().ffwm_mfm_backward(_ptr(x), _ptr(grad_y), _ptr(dx), B, C, HW, _lib.F32, stream),
+                       "ffwm_mfm_backward")
+    return dx

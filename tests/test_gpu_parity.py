@@ -1158,3 +1158,24 @@ def test_checkpoints_round_trip_with_flat_parameters(tmp_path):
     before = b.opt_G.params.clone()
     b.step(batch, batch_increment=0)
     assert not torch.equal(before, b.opt_G.params)            # the loaded weights are the ones being optimised
+
+
+# ------------------------------------------------------------------------- LightCNN max-feature-map
+@pytest.mark.parametrize("shape", [(3, 10, 7, 9), (8, 192, 32, 32), (5, 512), (2, 6, 1, 3)])
+def test_mfm_matches_split_max(shape):
+    from ffwm_amd.external_function import MaxFeatureMapFunction
+    g = _gen(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    x.view(-1)[::7] = 0.25                                  # ties between the halves: both get half the gradient
+    x.view(shape[0], 2, -1)[:, 1] = torch.where(torch.rand(shape[0], x[0].numel() // 2, generator=g) < 0.1,
+                                                 x.view(shape[0], 2, -1)[:, 0], x.view(shape[0], 2, -1)[:, 1])
+    go = torch.randn(shape[0], shape[1] // 2, *shape[2:], generator=g)
+    xr = x.clone().requires_grad_(True)
+    a, b = torch.split(xr, shape[1] // 2, 1)
+    ref = torch.max(a, b)
+    ref.backward(go)
+    xd = x.to(DEV).requires_grad_(True)
+    out = MaxFeatureMapFunction.apply(xd)
+    out.backward(go.to(DEV))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    assert torch.equal(xd.grad.cpu(), xr.grad)

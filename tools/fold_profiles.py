@@ -21,6 +21,8 @@ SCOPES = {   # launch scope -> kernel-name prefix (template arguments included w
     "conv3x3_wgrad_packed": "conv3x3_wgrad_kernel<true>",
     "guided_filter_bwd": "gf_backward_kernel<float>",
     "guided_filter_fwd": "gf_forward_kernel<float>",
+    "mfm_bwd": "mfm_bwd",
+    "mfm_fwd": "mfm_fwd",
     "local_attn_reshape_bwd": "lar_bwd_kernel<float, 3, false>",
     "local_attn_reshape_fwd": "lar_fwd_kernel<float, 3>",
     "resample2d_bwd_input1_plane": "rs_bwd1_plane_kernel<float, 2>",
