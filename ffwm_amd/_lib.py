@@ -24,8 +24,9 @@ _SIGNATURES = {
     "ffwm_block_extractor_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_bn_lrelu_forward": [_p] * 9 + [_i64] * 3 + [ctypes.c_double] * 3 + [_i, _p],
     "ffwm_bn_lrelu_backward": [_p] * 10 + [_i64] * 3 + [ctypes.c_double] + [_i, _p],
-    "ffwm_mfm_forward": [_p, _p] + [_i64] * 3 + [_i, _p],
-    "ffwm_mfm_backward": [_p, _p, _p] + [_i64] * 3 + [_i, _p],
+    "ffwm_mfm_forward": [_p, _p, _p] + [_i64] * 3 + [_i, _p],
+    "ffwm_mfm_backward": [_p, _p, _p, _p] + [_i64] * 3 + [_i, _p],
+    "ffwm_bias_relu_forward": [_p, _p, _p] + [_i64] * 3 + [_i, _p],
     "ffwm_adam_step": [_p, _p, _p, _p, _i64] + [ctypes.c_double] * 4 + [_i64, _i, _p],
     "ffwm_conv3x3_wgrad": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _p],
     "ffwm_conv3x3_wgrad_block": [_p, _p, _p, _p] + [_i64] * 9 + [_i, _p],

@@ -112,20 +112,43 @@ class BlockAttention(nn.Module):
 
 
 class MaxFeatureMapFunction(Function):
-    """apply(x[B, 2C, ...]) -> max(x[:, :C], x[:, C:]): LightCNN's mfm activation (lightcnn/light_cnn.py `mfm.forward`:
-    torch.split + torch.max), forward and backward one kernel each; ties share the gradient like ATen's maximum."""
+    """apply(x[B, 2C, ...], bias=None) -> max(x[:, :C] + bias[:C], x[:, C:] + bias[C:]): LightCNN's mfm activation
+    (lightcnn/light_cnn.py `mfm.forward`: torch.split + torch.max) with the bias of the layer in front folded in,
+    forward and backward one kernel each; ties share the gradient like ATen's maximum."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, bias=None):
         _require_cuda(x)
         assert x.is_contiguous() and x.size(1) % 2 == 0
-        ctx.save_for_backward(x)
-        return ops.mfm_forward(x)
+        ctx.save_for_backward(x, bias)
+        return ops.mfm_forward(x, bias)
 
     @staticmethod
     def backward(ctx, grad_y):
-        x, = ctx.saved_tensors
-        return ops.mfm_backward(x, grad_y.contiguous())
+        x, bias = ctx.saved_tensors
+        dx = ops.mfm_backward(x, grad_y.contiguous(), bias)
+        db = None
+        if bias is not None and ctx.needs_input_grad[1]:
+            db = dx.sum(dim=[0] + list(range(2, dx.dim())))
+        return dx, db
+
+
+class BiasReLUFunction(Function):
+    """apply(h[B, C, ...], bias[C]) -> relu(h + bias): the bias add and nn.ReLU behind a convolution as one pass."""
+
+    @staticmethod
+    def forward(ctx, h, bias):
+        _require_cuda(h)
+        y = ops.bias_relu_forward(h, bias)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        y, = ctx.saved_tensors
+        gh = torch.ops.aten.threshold_backward(grad_y, y, 0)
+        gb = gh.sum(dim=[0] + list(range(2, gh.dim()))) if ctx.needs_input_grad[1] else None
+        return gh, gb
 
 
 class LocalAttnReshapeFunction(Function):

@@ -10,6 +10,8 @@ flow-guided warp inside netG's warp-attention module goes through the hand-writt
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -243,6 +245,10 @@ class MSDiscriminator(nn.Module):
         return total
 
 
+# bias + activation of the frozen feature networks as one kernel (csrc/mfm.hip); FFWM_FUSED_ACT=0 keeps the module path
+FUSED_ACTIVATIONS = os.environ.get("FFWM_FUSED_ACT", "1") != "0"
+
+
 # =============================================================================== LightCNN-29
 class mfm(nn.Module):
     """max-feature-map: conv/linear to 2*out channels, elementwise max of the halves."""
@@ -253,11 +259,16 @@ class mfm(nn.Module):
         self.filter = nn.Conv2d(cin, 2 * cout, k, s, p) if type == 1 else nn.Linear(cin, 2 * cout)
 
     def forward(self, x):
-        h = self.filter(x)
-        if h.is_cuda and h.dtype == torch.float32 and h.is_contiguous():
-            from .external_function import MaxFeatureMapFunction       # one kernel per direction (csrc/mfm.hip)
-            return MaxFeatureMapFunction.apply(h)
-        a, b = torch.split(h, self.out_channels, 1)
+        f = self.filter
+        if FUSED_ACTIVATIONS and x.is_cuda and x.dtype == torch.float32:
+            # the layer without its bias, then bias + max-feature-map as one kernel per direction (csrc/mfm.hip)
+            from .external_function import MaxFeatureMapFunction
+            if isinstance(f, nn.Conv2d):
+                h = F.conv2d(x, f.weight, None, f.stride, f.padding, f.dilation, f.groups)
+            else:
+                h = F.linear(x, f.weight, None)
+            return MaxFeatureMapFunction.apply(h.contiguous(), f.bias)
+        a, b = torch.split(f(x), self.out_channels, 1)
         return torch.max(a, b)
 
 
@@ -344,8 +355,24 @@ class VGG19(nn.Module):
 
     def forward(self, x):
         out = {}
+        fused = FUSED_ACTIVATIONS and x.is_cuda and x.dtype == torch.float32
         for name in self.slices:
-            x = getattr(self, name)(x)
+            if fused:
+                # conv without its bias, then bias + ReLU as one pass (csrc/mfm.hip: bias_relu) instead of the vendor
+                # library's separate bias add followed by the activation's own read-modify-write
+                from .external_function import BiasReLUFunction
+                mods = list(getattr(self, name).children())
+                i = 0
+                while i < len(mods):
+                    m = mods[i]
+                    if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and m.bias is not None:
+                        x = BiasReLUFunction.apply(F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups), m.bias)
+                        i += 2
+                    else:
+                        x = m(x)
+                        i += 1
+            else:
+                x = getattr(self, name)(x)
             out[name] = x
         return out
 

@@ -388,25 +388,49 @@ def _mfm_dims(x):
     return x.shape[0], x.shape[1] // 2, hw
 
 
-def mfm_forward(x):
-    """max(x[:, :C], x[:, C:]) of a contiguous float32 [B, 2C, ...] tensor."""
+def _bias_ok(x, bias, n):
+    if bias is None:
+        return
+    if not (bias.is_cuda and bias.dtype == x.dtype and bias.is_contiguous() and bias.numel() == n):
+        raise ValueError("bias must be a contiguous float32 GPU vector of %d elements" % n)
+
+
+def mfm_forward(x, bias=None):
+    """max(x[:, :C] + bias[:C], x[:, C:] + bias[C:]) of a contiguous float32 [B, 2C, ...] tensor."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
         raise NotImplementedError("mfm_forward: contiguous float32 GPU tensors only")
     B, C, HW = _mfm_dims(x)
+    _bias_ok(x, bias, 2 * C)
     y = x.new_empty((B, C) + tuple(x.shape[2:]))
     if y.numel():
         with _on_device(x) as stream:
-            _lib.check(_lib.load().ffwm_mfm_forward(_ptr(x), _ptr(y), B, C, HW, _lib.F32, stream), "ffwm_mfm_forward")
+            _lib.check(_lib.load().ffwm_mfm_forward(_ptr(x), _ptr(bias), _ptr(y), B, C, HW, _lib.F32, stream), "ffwm_mfm_forward")
     return y
 
 
-def mfm_backward(x, grad_y):
+def mfm_backward(x, grad_y, bias=None):
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and grad_y.is_contiguous() and grad_y.dtype == x.dtype):
         raise NotImplementedError("mfm_backward: contiguous float32 GPU tensors only")
     B, C, HW = _mfm_dims(x)
+    _bias_ok(x, bias, 2 * C)
     dx = torch.empty_like(x)
     if dx.numel():
         with _on_device(x) as stream:
-            _lib.check(_lib.load().ffwm_mfm_backward(_ptr(x), _ptr(grad_y), _ptr(dx), B, C, HW, _lib.F32, stream),
+            _lib.check(_lib.load().ffwm_mfm_backward(_ptr(x), _ptr(bias), _ptr(grad_y), _ptr(dx), B, C, HW, _lib.F32, stream),
                        "ffwm_mfm_backward")
     return dx
+
+
+def bias_relu_forward(h, bias, out=None):
+    """relu(h + bias[None, :, None, None]) of a contiguous float32 [B, C, ...] tensor; out may be h itself."""
+    if not (h.is_cuda and h.dtype == torch.float32 and h.is_contiguous()):
+        raise NotImplementedError("bias_relu_forward: contiguous float32 GPU tensors only")
+    B, C = h.shape[0], h.shape[1]
+    HW = h.numel() // max(B * C, 1)
+    _bias_ok(h, bias, C)
+    y = torch.empty_like(h) if out is None else out
+    if y.numel():
+        with _on_device(h) as stream:
+            _lib.check(_lib.load().ffwm_bias_relu_forward(_ptr(h), _ptr(bias), _ptr(y), B, C, HW, _lib.F32, stream),
+                       "ffwm_bias_relu_forward")
+    return y

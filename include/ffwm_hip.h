@@ -23,6 +23,7 @@
  *   ffwm_conv3x3_wgrad[_block]      <- convolution_backward grad_weight / grad_bias of the nn.Conv2d(., ., 3, 1, 1) layers
  *   ffwm_bn_lrelu_*                 <- nn.BatchNorm2d (training) + nn.LeakyReLU of the conv blocks  models/base_networks.py:12-31
  *   ffwm_mfm_*                      <- mfm.forward (split + max)        lightcnn/light_cnn.py
+ *   ffwm_bias_relu_forward          <- conv bias add + nn.ReLU of VGG19  models/losses.py:398-519
  *   ffwm_adam_step                  <- torch.optim.Adam.step            models/ffwm_model.py:46-49,151-160
  *
  * Conventions
@@ -259,11 +260,16 @@ int ffwm_bn_lrelu_backward(const void* x, const void* grad_out, const void* weig
                            int dtype, void* stream);
 
 /* LightCNN's max-feature-map activation (lightcnn/light_cnn.py `mfm.forward`: torch.split + torch.max):
- * y[B,C,HW] = max(x[B,0:C,HW], x[B,C:2C,HW]); backward grad_x[B,2C,HW] (overwritten) with ATen's tie rule for
+ * y[B,C,HW] = max(x[B,0:C,HW] + bias[0:C], x[B,C:2C,HW] + bias[C:2C]); bias [2C] or NULL (the bias of the layer in front,
+ * folded in: bit-identical to adding it first); backward grad_x[B,2C,HW] (overwritten) with ATen's tie rule for
  * `maximum` (equal halves share the gradient).  Contiguous float32. */
-int ffwm_mfm_forward(const void* x, void* y, int64_t B, int64_t C, int64_t HW, int dtype, void* stream);
-int ffwm_mfm_backward(const void* x, const void* grad_y, void* grad_x, int64_t B, int64_t C, int64_t HW, int dtype,
-                      void* stream);
+int ffwm_mfm_forward(const void* x, const void* bias, void* y, int64_t B, int64_t C, int64_t HW, int dtype, void* stream);
+int ffwm_mfm_backward(const void* x, const void* bias, const void* grad_y, void* grad_x, int64_t B, int64_t C, int64_t HW,
+                      int dtype, void* stream);
+
+/* y[B,C,HW] = relu(h[B,C,HW] + bias[C]) -- the bias add and ReLU behind the frozen VGG19 convs (models/losses.py:398-519)
+ * as one pass; y may alias h. */
+int ffwm_bias_relu_forward(const void* h, const void* bias, void* y, int64_t B, int64_t C, int64_t HW, int dtype, void* stream);
 
 /* One Adam step (no weight decay, no amsgrad: torch.optim.Adam as models/ffwm_model.py:46-49 and
  * models/flownet_model.py:33 construct it) over FLAT float32 arrays of n elements, 16-byte aligned: parameters,

@@ -1179,3 +1179,60 @@ def test_mfm_matches_split_max(shape):
     out.backward(go.to(DEV))
     assert torch.equal(out.detach().cpu(), ref.detach())
     assert torch.equal(xd.grad.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("shape", [(3, 10, 7, 9), (4, 96, 16, 16), (5, 512), (2, 6, 1, 3)])
+def test_mfm_with_folded_bias_matches_bias_add_then_split_max(shape):
+    from ffwm_amd.external_function import MaxFeatureMapFunction
+    g = _gen(sum(shape) + 1)
+    x = torch.randn(*shape, generator=g)
+    bias = torch.randn(shape[1], generator=g)
+    go = torch.randn(shape[0], shape[1] // 2, *shape[2:], generator=g)
+    xr, br = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    a, b = torch.split(xr + br.view(1, -1, *([1] * (x.dim() - 2))), shape[1] // 2, 1)
+    ref = torch.max(a, b)
+    ref.backward(go)
+    xd, bd = x.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    out = MaxFeatureMapFunction.apply(xd, bd)
+    out.backward(go.to(DEV))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    assert torch.equal(xd.grad.cpu(), xr.grad)
+    _close(bd.grad, br.grad, 1e-5, relative=True)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (4, 64, 32, 32), (3, 8, 1, 2)])
+def test_bias_relu_matches_add_then_relu(shape):
+    from ffwm_amd.external_function import BiasReLUFunction
+    g = _gen(sum(shape) + 2)
+    h, bias, go = torch.randn(*shape, generator=g), torch.randn(shape[1], generator=g), torch.randn(*shape, generator=g)
+    hr, br = h.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = torch.relu(hr + br.view(1, -1, 1, 1))
+    ref.backward(go)
+    hd, bd = h.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    out = BiasReLUFunction.apply(hd, bd)
+    out.backward(go.to(DEV))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    assert torch.equal(hd.grad.cpu(), hr.grad)
+    _close(bd.grad, br.grad, 1e-5, relative=True)
+
+
+def test_vgg_and_lightcnn_fused_activations_match_the_module_paths():
+    """VGG19 (bias + ReLU folded) and LightCNN29 (bias + max-feature-map folded) on the GPU against the same modules
+    run layer by layer through nn.Sequential / the unfused mfm branch."""
+    from ffwm_amd import nets
+    torch.manual_seed(4)
+    vgg = nets.VGG19("relu3_1").to(DEV).eval()
+    x = torch.rand(2, 3, 64, 64, device=DEV)
+    fused = vgg(x)
+    y = x
+    for name in vgg.slices:
+        y = getattr(vgg, name)(y)
+        _close(fused[name], y.cpu(), 1e-5, relative=True)
+    light = nets.LightCNN29().to(DEV).eval()
+    g1 = torch.rand(2, 1, 128, 128, device=DEV)
+    outs = light(g1)
+    ref = nets.LightCNN29()
+    ref.load_state_dict(light.state_dict())
+    outs_ref = ref.eval()(g1.cpu())                       # CPU tensors take the unfused branch
+    for a, b in zip(outs if isinstance(outs, (tuple, list)) else [outs], outs_ref if isinstance(outs_ref, (tuple, list)) else [outs_ref]):
+        _close(a, b, 2e-4, relative=True)
