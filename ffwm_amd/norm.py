@@ -46,8 +46,9 @@ class _BnLreluFunction(Function):
         y = torch.empty_like(x)
         save_mean = torch.empty(C, device=x.device, dtype=torch.float32)
         save_invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        scratch = _scratch(x)          # (freed after the launch: the caching allocator reuses it in stream order only)
         _launch("ffwm_bn_lrelu_forward", x, _p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var), _p(y),
-                _p(save_mean), _p(save_invstd), _p(_scratch(x)), B, C, H * W, float(eps), float(momentum), float(slope))
+                _p(save_mean), _p(save_invstd), _p(scratch), B, C, H * W, float(eps), float(momentum), float(slope))
         ctx.save_for_backward(x, weight, bias, save_mean, save_invstd)
         ctx.slope = float(slope)
         return y
@@ -61,8 +62,9 @@ class _BnLreluFunction(Function):
         dx = torch.empty_like(x) if need_x else None
         dw = torch.empty(C, device=x.device, dtype=torch.float32) if (need_w and weight is not None) else None
         db = torch.empty(C, device=x.device, dtype=torch.float32) if (need_b and bias is not None) else None
+        scratch = _scratch(x)
         _launch("ffwm_bn_lrelu_backward", x, _p(x), _p(go), _p(weight), _p(bias), _p(save_mean), _p(save_invstd), _p(dx),
-                _p(dw), _p(db), _p(_scratch(x)), B, C, H * W, ctx.slope)
+                _p(dw), _p(db), _p(scratch), B, C, H * W, ctx.slope)
         return dx, dw, db, None, None, None, None, None
 
 
