@@ -46,12 +46,14 @@ class _Conv3x3MfmaWgrad(Function):
 def wgrad_route_ok(x, weight):
     """Layers whose weight gradient the MFMA kernel computes faster than the vendor library on MI355X
     (tools/exp_conv_micro.py): fp32, >= 64 channels on both sides, image rows a multiple of 64 pixels, and
-    either a 128-pixel-wide image or a channel count the vendor kernels tile badly (not a multiple of 64)."""
+    either a 128-pixel-wide image or a channel count the vendor kernels tile badly (not a multiple of 64); plus the
+    layers between an RGB image and >= 64 feature channels at 128 x 128 (3 channels x 9 taps fit one MFMA tile)."""
     K, C = weight.shape[0], weight.shape[1]
     W = x.shape[3]
+    wide = min(C, K) >= 64 and (W >= 128 or C % 64 != 0 or K % 64 != 0)
+    rgb = min(C, K) <= 3 and max(C, K) >= 64 and W >= 128          # image <-> features: the packed-tap variant alone
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
-            and W % 64 == 0 and min(C, K) >= 64 and (W >= 128 or C % 64 != 0 or K % 64 != 0)
-            and ops.conv3x3_wgrad_supported(x, x))
+            and W % 64 == 0 and (wide or rgb) and ops.conv3x3_wgrad_supported(x, x))
 
 
 class MfmaWgradConv2d(nn.Conv2d):
@@ -65,7 +67,9 @@ class MfmaWgradConv2d(nn.Conv2d):
 
 def eligible(m):
     return (type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
-            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros" and min(m.in_channels, m.out_channels) >= 64)
+            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"
+            and (min(m.in_channels, m.out_channels) >= 64
+                 or (min(m.in_channels, m.out_channels) <= 3 and max(m.in_channels, m.out_channels) >= 64)))
 
 
 def route_conv_wgrad(net):

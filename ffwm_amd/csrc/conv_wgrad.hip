@@ -375,7 +375,11 @@ extern "C" int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_outp
     const float* G = (const float*)grad_output;
     float* dW = (float*)grad_weight;
     // thin remainders (<= 3 channels beyond the last full 64-tile) take the packed variant
-    auto thin = [](int64_t lo, int64_t hi) { const int64_t n = hi - lo, r = n % kWgTile; return (n > kWgTile && r > 0 && r <= 3) ? r : 0; };
+    // (a range of at most 3 channels is all remainder: the first / last layers that read or write an RGB image)
+    auto thin = [](int64_t lo, int64_t hi) {
+        const int64_t n = hi - lo, r = n % kWgTile;
+        return n <= 3 ? n : ((n > kWgTile && r > 0 && r <= 3) ? r : 0);
+    };
     const int64_t km = k_end - thin(k_begin, k_end), cm = c_end - thin(c_begin, c_end);
     // full tiles: A = grad_output rows [k_begin, km), S = input channels [c_begin, cm)
     float* db = (float*)grad_bias;
