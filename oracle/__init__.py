@@ -1,15 +1,17 @@
 """TEST INFRASTRUCTURE ONLY -- ctypes front end of the CPU oracle (oracle/ffwm_oracle.c).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-this package; nothing under ``ffwm_amd/`` does (tests/test_product_isolation.py enforces it).
+this package; nothing under ``ffwm_amd/`` does (tests/test_abi_cpu.py::test_product_path_never_touches_the_oracle
+enforces it).
 
 Each function takes contiguous CPU torch tensors (float32 or float64) and returns new
 tensors, mirroring what the reference's CUDA ops compute:
 
 * block_extractor  -- /root/reference/cuda/block_extractor/block_extractor_kernel.cu:21-170
 * local_attn_reshape -- cuda/local_attn_reshape/local_attn_reshape_kernel.cu:21-108
-* resample2d       -- cuda/resample2d_package/resample2d_kernel.cu:21-330  (parity unpinned by
-  the reference: it ships no test for this op)
+* resample2d       -- cuda/resample2d_package/resample2d_kernel.cu:21-330
+  all three pinned to golden vectors produced by the reference's own kernels on gfx950
+  (oracle/build_ref.py -> oracle/_ref/, tests/golden/reference_ops_gfx950.pt, tests/test_oracle_ref_golden.py)
 * warp             -- models/base_networks.py:168-173 (F.grid_sample bilinear/zeros/align_corners=False)
 """
 import ctypes

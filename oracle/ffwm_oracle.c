@@ -10,16 +10,15 @@
  * library; the HIP product path (ffwm_amd/) never does.
  *
  * Parity pin status (see DESIGN.md "Oracle"):
- *   block_extractor, local_attn_reshape : pinned by the reference's own gradcheck recipes and
- *       range(9) known answer (cuda/[op]/test_[op].py) + exact PyTorch identities
- *       (pixel_shuffle, shifted grid_sample(border, align_corners=True), unfold).
- *   warp (grid_sample)                   : pinned at run time against torch's CPU grid_sample.
- *   resample2d                           : PARITY UNPINNED by the reference (it ships no test and
- *       the call path is dead code); pinned only by autograd-of-forward
- *       self-consistency and hand-derived small cases.
- *
- * The reference CUDA sources cannot be compiled here (CUDA-only ATen headers, no nvcc):
- * there is no oracle/_ref build.
+ *   block_extractor, local_attn_reshape, resample2d : PINNED TO THE REFERENCE'S OWN KERNELS.  oracle/build_ref.py
+ *       compiles cuda/<op>/<op>_kernel.cu + <op>_cuda.cc from where they lie under /root/reference for gfx950
+ *       (PyTorch-ROCm's hipify step + hipcc, no stand-in headers; see that file for the one host-side token it
+ *       patches) into oracle/_ref/; tests/golden/make_ref_ops_golden.py ran them on an MI355X and
+ *       tests/golden/reference_ops_gfx950.pt holds what they returned; tests/test_oracle_ref_golden.py checks every
+ *       function here against those vectors (forward <= 1e-6 fp32 / 1e-13 fp64).  Before that round they were pinned
+ *       by the reference's gradcheck recipes and range(9) known answer (cuda/[op]/test_[op].py) and by exact PyTorch
+ *       identities (pixel_shuffle, shifted grid_sample(border, align_corners=True), unfold) -- those tests remain.
+ *   warp (grid_sample)                   : pinned against torch's CPU grid_sample and the reference WarpNet fixture.
  *
  * Build: make -C oracle   ->  oracle/libffwm_oracle.so
  */
