@@ -46,14 +46,28 @@ def _digest():
     return h.hexdigest()
 
 
+def _src_digest(src):
+    h = hashlib.sha256()
+    for p in [src] + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "ffwm_hip.h")]:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+    stamp, digest = obj + ".digest", _src_digest(src)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return obj                      # unchanged translation unit: keep the object
     cmd = [hipcc()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(digest)
     return obj
 
 

@@ -120,6 +120,267 @@ rs_fwd_kernel(const T* __restrict__ in1, const T* __restrict__ in2, T* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------ K1, LDS-staged (fp32)
+// The direct kernel above is bound by its per-lane gathers: 4*HALF^2 buffer loads per pixel and channel, every
+// lane on its own cache line when the flow is not smooth (TA-bound: 0.63 TB/s at [8,64,512,512]).  Here
+//   * a block owns a 64 x (4*RPT) pixel tile and ALL channels of its slab: the Gaussian weights (double exp, as the
+//     reference's SAFE_DIV promotion implies) and tap positions are formed once per pixel and kept in registers;
+//   * the block reduces the bounding box of its taps in UNCLAMPED source coordinates (wave shuffles + one LDS hop).
+//     If every pixel is regular (finite, |coordinate| < 2^20) and the box fits BOXH x BOXW, the clamp-extended box
+//     of FOUR channels at a time is staged in LDS with row-contiguous coalesced loads, channel-interleaved: a cell
+//     is one float4 = the same source pixel of 4 channels.  A pixel's (2*HALF)^2 neighbourhood is then a dense
+//     square at one LDS base + immediates, and ONE ds_read_b128 (256 B/clk/CU, the wide-read rate) feeds four
+//     channel accumulators -- 4x fewer LDS instructions and half the LDS cycles per byte of per-channel ds_read_b32;
+//   * the box of channel group g+1 is requested before group g is processed and committed after it (two buffers,
+//     one barrier per group);
+//   * otherwise the block falls back to direct gathers (block-uniform, data-dependent).
+// Per tap the reference's arithmetic is kept: w = yP * xP (one rounding), val = fma(w, in, val) -- nvcc's default
+// -fmad contraction of `val += yP * xP * in` (resample2d_kernel.cu:82-85) -- taps in the reference's order.
+constexpr int kRsBoxW = 80;
+
+template <int HALF, int RPT, bool DB>
+__global__ void __launch_bounds__(kBlock)
+rs_fwd_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out, int C,
+                  int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate) {
+    constexpr int NW = kBlock / kWave;
+    constexpr int NT = 2 * HALF;                 // taps per axis
+    constexpr int TH = NW * RPT;                 // tile rows
+    constexpr int BOXH = TH + 12;
+    constexpr int NCELL = BOXH * kRsBoxW;
+    constexpr int NI = (NCELL + kBlock - 1) / kBlock;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* tile = reinterpret_cast<f32x4*>(smem_raw);          // [DB ? 2 : 1][NCELL]
+    __shared__ int red[4][NW];
+    __shared__ int flag;
+
+    unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = tid % tiles_x;
+    tid /= tiles_x;
+    const int ty = tid % tiles_y;
+    tid /= tiles_y;
+    const int slab = tid % cslabs;
+    const int b = tid / cslabs;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int x_raw = tx * kTileX + lane;
+    const bool inx = x_raw < W;
+    const int x = inx ? x_raw : W - 1;               // out-of-tile lanes shadow a valid pixel, never store
+    if (threadIdx.x == 0) flag = 0;
+
+    // ---- per-pixel taps and weights (resample2d_kernel.cu:47-80), once for all channels
+    float w[RPT][NT * NT];                           // product weights, [row position][col position]
+    float sum[RPT];
+    int u0[RPT], v0[RPT], ys[RPT];
+    bool iny[RPT];
+    bool regular = true;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fb = in2 + static_cast<size_t>(b) * 3 * plane;
+    int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yraw = ty * TH + wave + r * NW;
+        iny[r] = yraw < H;
+        const int y = iny[r] ? yraw : H - 1;
+        ys[r] = y;
+        const size_t poff = static_cast<size_t>(y) * W + x;
+        RsTaps<float, HALF> t;
+        const float dx = fb[poff], dy = fb[plane + poff], sg = fb[2 * plane + poff];
+        make_rs_taps<float, HALF>(t, dx, dy, sg, x, y, Hi, Wi, 1, false);
+        sum[r] = t.sum;
+        const float flx = floor_t(static_cast<float>(x) + dx), fly = floor_t(static_cast<float>(y) + dy);
+        const float lim = static_cast<float>(1 << 20);
+        const bool ok = (flx > -lim) && (flx < lim) && (fly > -lim) && (fly < lim);      // also rejects NaN
+        regular = regular && ok;
+        u0[r] = ok ? static_cast<int>(flx) - (HALF - 1) : 0;
+        v0[r] = ok ? static_cast<int>(fly) - (HALF - 1) : 0;
+        umin = min(umin, u0[r]); umax = max(umax, u0[r] + NT - 1);
+        vmin = min(vmin, v0[r]); vmax = max(vmax, v0[r] + NT - 1);
+        // position p <-> tap: p = HALF-1-f is the "left/top" tap f, p = HALF+f the "right/bottom" tap f
+        float wxp[NT], wyp[NT];
+#pragma unroll
+        for (int f = 0; f < HALF; ++f) {
+            wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
+            wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
+        }
+#pragma unroll
+        for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+            for (int pc = 0; pc < NT; ++pc) w[r][pr * NT + pc] = wyp[pr] * wxp[pc];
+    }
+
+    // ---- block-wide bounding box of the taps, unclamped coordinates
+    umin = wave_min(umin); umax = wave_max(umax); vmin = wave_min(vmin); vmax = wave_max(vmax);
+    if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
+    __syncthreads();
+    if (!regular) flag = 1;            // benign race: every writer stores 1
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        umin = min(umin, red[0][k]); umax = max(umax, red[1][k]);
+        vmin = min(vmin, red[2][k]); vmax = max(vmax, red[3][k]);
+    }
+    __syncthreads();
+    const int bw = umax - umin + 1, bh = vmax - vmin + 1;
+    const bool use_lds = (flag == 0) && bw <= kRsBoxW && bh <= BOXH;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * sizeof(float));
+    const unsigned obytes = static_cast<unsigned>(plane * sizeof(float));
+    const float* ip = in1 + (static_cast<size_t>(b) * C + c0) * iplane;
+    float* op = out + (static_cast<size_t>(b) * C + c0) * plane;
+    unsigned obase[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        obase[r] = (inx && iny[r] && !(ablate & 2)) ? (static_cast<unsigned>(ys[r]) * W + static_cast<unsigned>(x)) * 4u : 0xFFFFFFF0u;  // OOB store is dropped
+
+    // the reference's tap order: for fy, fx: TL, TR, BL, BR
+    auto for_each_tap = [&](auto&& body) {
+#pragma unroll
+        for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < HALF; ++fx) {
+                body(HALF - 1 - fy, HALF - 1 - fx);
+                body(HALF - 1 - fy, HALF + fx);
+                body(HALF + fy, HALF - 1 - fx);
+                body(HALF + fy, HALF + fx);
+            }
+    };
+
+    if (use_lds) {
+        // staging map: thread t copies box cells t, t + 256, ...; cell i = (i / BOXW, i % BOXW) holds
+        // in1[clamp(vmin + r)][clamp(umin + c)] of 4 channels.
+        unsigned goff[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = threadIdx.x + k * kBlock;
+            const int r = i / kRsBoxW, cc = i - r * kRsBoxW;
+            const int gy = min(max(vmin + r, 0), Hi - 1), gx = min(max(umin + cc, 0), Wi - 1);
+            goff[k] = (r < bh && cc < bw && !(ablate & 1)) ? (static_cast<unsigned>(gy) * Wi + gx) * 4u : 0xFFFFFFF0u;   // OOB reads 0
+        }
+        f32x4 stage[NI];
+        auto fetch = [&](int c) {                   // channels c .. c+3 (missing ones read 0)
+            const float* p0 = ip + static_cast<size_t>(c - c0) * iplane;
+            const rsrc_t r0 = make_rsrc(p0, ibytes);
+            const rsrc_t r1 = make_rsrc(p0 + iplane, c + 1 < c1 ? ibytes : 0u);
+            const rsrc_t r2 = make_rsrc(p0 + 2 * iplane, c + 2 < c1 ? ibytes : 0u);
+            const rsrc_t r3 = make_rsrc(p0 + 3 * iplane, c + 3 < c1 ? ibytes : 0u);
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                stage[k].x = buf_ld<float>(r0, goff[k]);
+                stage[k].y = buf_ld<float>(r1, goff[k]);
+                stage[k].z = buf_ld<float>(r2, goff[k]);
+                stage[k].w = buf_ld<float>(r3, goff[k]);
+            }
+        };
+        auto commit = [&](f32x4* buf) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int i = threadIdx.x + k * kBlock;
+                if (i < NCELL) buf[i] = stage[k];
+            }
+        };
+        int lbase[RPT];
+        float inv[RPT];
+        bool tame = true;               // every sum of this wave's pixels is a normal, comfortably scaled float
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            lbase[r] = (v0[r] - vmin) * kRsBoxW + (u0[r] - umin);
+            inv[r] = 1.0f / sum[r];
+            tame = tame && (sum[r] >= 1e-30f) && (sum[r] <= 1e30f);
+        }
+        const bool fast_div = __builtin_amdgcn_ballot_w64(!tame) == 0;      // wave-uniform
+        fetch(c0);
+        commit(tile);
+        __syncthreads();
+        int p = 0;
+        for (int c = c0; c < c1; c += 4) {
+            const bool more = c + 4 < c1;
+            if (more) fetch(c + 4);
+            const f32x4* tb = tile + p * NCELL;
+            const float* o0 = op + static_cast<size_t>(c - c0) * plane;
+            const rsrc_t ro0 = make_rsrc(o0, obytes);
+            const rsrc_t ro1 = make_rsrc(o0 + plane, c + 1 < c1 ? obytes : 0u);
+            const rsrc_t ro2 = make_rsrc(o0 + 2 * plane, c + 2 < c1 ? obytes : 0u);
+            const rsrc_t ro3 = make_rsrc(o0 + 3 * plane, c + 3 < c1 ? obytes : 0u);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const f32x4* nb = tb + lbase[r];
+                f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};       // v_pk_fma_f32: two channels per instruction
+                for_each_tap([&](int pr, int pc) {
+                    const f32x4 v = nb[pr * kRsBoxW + pc];
+                    const float wt = w[r][pr * NT + pc];
+                    const f32x2 ww = {wt, wt};
+                    a01 = __builtin_elementwise_fma(ww, v.xy, a01);
+                    a23 = __builtin_elementwise_fma(ww, v.zw, a23);
+                });
+                const float s = sum[r];
+                float q0, q1, q2, q3;
+                if (fast_div) {
+                    // a / s with ONE IEEE reciprocal per pixel: q = RN(a * y), r = a - q * s (exact, fma), q' = RN(q + r * y)
+                    // is the correctly rounded quotient when y = RN(1 / s) (Markstein); 3 instructions instead of the
+                    // 12-instruction division sequence per output
+                    const float y = inv[r];
+                    q0 = a01.x * y; q1 = a01.y * y; q2 = a23.x * y; q3 = a23.y * y;
+                    q0 = __builtin_fmaf(__builtin_fmaf(-q0, s, a01.x), y, q0);
+                    q1 = __builtin_fmaf(__builtin_fmaf(-q1, s, a01.y), y, q1);
+                    q2 = __builtin_fmaf(__builtin_fmaf(-q2, s, a23.x), y, q2);
+                    q3 = __builtin_fmaf(__builtin_fmaf(-q3, s, a23.y), y, q3);
+                } else {
+                    q0 = static_cast<float>(safe_div<float>(a01.x, s)); q1 = static_cast<float>(safe_div<float>(a01.y, s));
+                    q2 = static_cast<float>(safe_div<float>(a23.x, s)); q3 = static_cast<float>(safe_div<float>(a23.y, s));
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q0), ro0, obase[r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q1), ro1, obase[r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q2), ro2, obase[r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q3), ro3, obase[r], 0, 0);
+            }
+            if (more) {
+                if constexpr (DB) {
+                    commit(tile + (p ^ 1) * NCELL);
+                    __syncthreads();
+                    p ^= 1;
+                } else {                 // one buffer: other blocks of the CU cover the two barriers
+                    __syncthreads();
+                    commit(tile);
+                    __syncthreads();
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- fallback: direct gathers (flow wider than the box / irregular pixel); the clamped tap offsets are
+    // re-derived here instead of being carried through the LDS path's registers
+    unsigned col[RPT][NT], row[RPT][NT];             // clamped byte offsets, position order
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const size_t poff = static_cast<size_t>(ys[r]) * W + x;
+        const float fxv = static_cast<float>(x) + fb[poff], fyv = static_cast<float>(ys[r]) + fb[plane + poff];
+        const float flx = floor_t(fxv), fly = floor_t(fyv);
+#pragma unroll
+        for (int f = 0; f < HALF; ++f) {
+            col[r][HALF - 1 - f] = static_cast<unsigned>(clamp_index(flx - static_cast<float>(f), Wi)) * 4u;
+            col[r][HALF + f] = static_cast<unsigned>(clamp_index(flx + static_cast<float>(f + 1), Wi)) * 4u;
+            row[r][HALF - 1 - f] = static_cast<unsigned>(clamp_index(fly - static_cast<float>(f), Hi)) * static_cast<unsigned>(Wi) * 4u;
+            row[r][HALF + f] = static_cast<unsigned>(clamp_index(fly + static_cast<float>(f + 1), Hi)) * static_cast<unsigned>(Wi) * 4u;
+        }
+    }
+    for (int c = c0; c < c1; ++c, ip += iplane, op += plane) {
+        const rsrc_t rs = make_rsrc(ip, ibytes);
+        const rsrc_t ro = make_rsrc(op, obytes);
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            float val = 0;
+            for_each_tap([&](int pr, int pc) {
+                val = __builtin_fmaf(w[r][pr * NT + pc], buf_ld<float>(rs, row[r][pr] + col[r][pc]), val);
+            });
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, static_cast<float>(safe_div<float>(val, sum[r]))), ro, obase[r], 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ K2
 template <typename T, int HALF>
 __global__ void __launch_bounds__(kBlock)
@@ -519,8 +780,43 @@ template <typename T>
 int launch_fwd(const T* in1, const T* in2, T* out, int64_t B, int64_t C, int64_t Hi, int64_t Wi,
                int64_t H, int64_t W, int ks, int dil, hipStream_t st) {
     const double bytes = sizeof(T) * static_cast<double>(B) * H * W * (2.0 * C + 3.0);
-    const Geometry g = plan(B, C, H, W, 16);
     const int remap = options().xcd_remap;
+    if constexpr (sizeof(T) == 4) {
+        const int half = ks / 2;
+        if (dil == 1 && half >= 1 && half <= 3 && options().rs_fwd_variant != 1) {
+            // tile rows 4 * rpt; channels cut into slabs of a multiple of 4 until there are >= 2 blocks per CU
+            const int tiles_x = static_cast<int>((W + kTileX - 1) / kTileX);
+            const int v = options().rs_fwd_variant;
+            int rpt = (v == 2 || v == 6) ? 4 : (v == 3 || v == 7) ? 1 : (v == 4 || v == 5) ? 2
+                      : (B * tiles_x * ((H + 7) / 8) >= 2048 ? 2 : 1);      // measured: 64 x 8 tiles >= 64 x 16 > 64 x 4 at HBM-resident sizes
+            const bool db = !(v >= 5 && v <= 7);
+            const int tiles_y = static_cast<int>((H + 4 * rpt - 1) / (4 * rpt));
+            const int64_t spatial = B * tiles_x * tiles_y;
+            int cs = static_cast<int>((C + 3) / 4 * 4);
+            while (cs > 4 && spatial * ((C + cs - 1) / cs) < 512) cs = (cs / 2 + 3) / 4 * 4;
+            const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            const unsigned grid = static_cast<unsigned>(spatial * cslabs);
+            const size_t lds = static_cast<size_t>(db ? 2 : 1) * (4 * rpt + 12) * kRsBoxW * 16;
+            LaunchScope ls("resample2d_fwd_lds", st, bytes);
+#define FFWM_RS_FWD_LDS(HH, RR, DD)                                                                        \
+    do {                                                                                                   \
+        allow_large_lds(reinterpret_cast<const void*>(rs_fwd_lds_kernel<HH, RR, DD>));                     \
+        hipLaunchKernelGGL((rs_fwd_lds_kernel<HH, RR, DD>), dim3(grid), dim3(kBlock), lds, st, in1, in2, out, \
+                           (int)C, (int)Hi, (int)Wi, (int)H, (int)W, tiles_x, tiles_y, cslabs, cs, remap, options().ablate); \
+    } while (0)
+#define FFWM_RS_FWD_LDS_H(RR, DD)                                                                          \
+    do {                                                                                                   \
+        if (half == 1) FFWM_RS_FWD_LDS(1, RR, DD); else if (half == 2) FFWM_RS_FWD_LDS(2, RR, DD); else FFWM_RS_FWD_LDS(3, RR, DD); \
+    } while (0)
+            if (rpt == 4) { if (db) FFWM_RS_FWD_LDS_H(4, true); else FFWM_RS_FWD_LDS_H(4, false); }
+            else if (rpt == 2) { if (db) FFWM_RS_FWD_LDS_H(2, true); else FFWM_RS_FWD_LDS_H(2, false); }
+            else { if (db) FFWM_RS_FWD_LDS_H(1, true); else FFWM_RS_FWD_LDS_H(1, false); }
+#undef FFWM_RS_FWD_LDS_H
+#undef FFWM_RS_FWD_LDS
+            return check_launch("ffwm_resample2d_forward(lds)");
+        }
+    }
+    const Geometry g = plan(B, C, H, W, 16);
     LaunchScope ls("resample2d_fwd", st, bytes);
 #define FFWM_RS_FWD(HH)                                                                             \
     case 2 * HH:                                                                                    \

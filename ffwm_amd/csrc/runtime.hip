@@ -34,8 +34,14 @@ void allow_large_lds(const void* kernel) {
     static std::mutex mu;
     static std::set<const void*> done;
     std::lock_guard<std::mutex> lk(mu);
-    if (done.insert(kernel).second)
-        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    if (done.insert(kernel).second) {
+        // kernels with static __shared__ variables: static + dynamic must stay <= 160 KiB or the call fails
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess) {
+            (void)hipGetLastError();   // do not leave a sticky error for the next check_launch()
+            if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes - 2048) != hipSuccess)
+                (void)hipGetLastError();
+        }
+    }
 }
 
 Options& options() {
@@ -198,6 +204,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "be_bwd_halo")) slot = &o.be_bwd_halo;
     else if (!strcmp(key, "warp_fwd_variant")) slot = &o.warp_fwd_variant;
     else if (!strcmp(key, "be_bwd_rows")) slot = &o.be_bwd_rows;
+    else if (!strcmp(key, "rs_fwd_variant")) slot = &o.rs_fwd_variant;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;
