@@ -1,24 +1,29 @@
 #!/usr/bin/env python
 """bench.py -- FFWM flow-warp hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|flownet|flowtrain|warp|ops]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|flownet|flowtrain|warp|warpatt|ops]
 
-Default workload = BASELINE.json configs[2]: the full FFWM train step (netG + netD + flowNetF +
-flowNetB, all losses, three Adam optimizers) on synthetic MultiPIE-shaped 128x128 tensors, batch 8
-PER GPU (weak scaling; N > 1 is configs[3]: DP with RCCL all-reduce of gradient buckets overlapped
-with backward).  One "step" = one optimisation step on one batch resident in HBM.  fp32 throughout
-(the reference's dtype).  Rank 0 prints ONE JSON line:
+Default workload = BASELINE.json configs[2]: the full FFWM train step (netG + netD + flowNetF + flowNetB, all losses,
+three Adam optimizers) on synthetic MultiPIE-shaped 128x128 tensors, batch 8 PER GPU (weak scaling; N > 1 is
+configs[3]: DP with RCCL all-reduce of gradient buckets overlapped with backward).  One "step" = one optimisation step
+on one batch resident in HBM.  fp32 throughout (the reference's dtype).  Rank 0 prints ONE JSON line:
 
-  metric/value/unit : train img/s, whole job
-  roofline          : the hand-written HIP kernel that moves the most algorithmic bytes inside the
-                      timed region, timed live with HIP events on its launch stream (ffwm_prof_*),
-                      algorithmic bytes per launch / average duration vs the 8 TB/s HBM peak;
-                      traffic = PMC-measured HBM-side bytes per launch (profiles/r01_pmc_traffic.json)
-  kernels           : the same figures for every hand-written kernel seen in the timed region, and
-                      for the stand-alone operator shapes of configs[0]/[4] (cfg-1 resample2d, cfg-5
-                      block_extractor / local_attn_reshape), measured right after the timed region
-  cpu_baseline      : (N=1, rank 0) the same train step on the host CPU cores -- this repo's PyTorch
-                      modules with the oracle's C/OpenMP warp -- on a bounded sample (batch 8, 2 steps after a warm-up step)
+  metric/value/unit : train img/s, whole job (W untimed steps, then exactly K steps between barrier + synchronize)
+  roofline          : the SURVEY 8 a1-a6 kernel (warp / resample2d / block_extractor / local_attn_reshape family) that
+                      moves the most algorithmic bytes inside the timed region: algorithmic bytes per launch / average
+                      launch duration (HIP events on its launch stream, ffwm_prof_*) vs the 8 TB/s HBM peak;
+                      traffic = PMC-measured HBM bytes per launch (profiles/r02_pmc_traffic.json, rocprofv3 FETCH_SIZE /
+                      WRITE_SIZE passes of this same command) or null when no valid measurement is committed
+  roofline_mfma     : the hand-written MFMA kernel with the largest share of the step (conv weight gradients)
+  kernels           : the same figures for every hand-written kernel seen in the timed region and for the stand-alone
+                      operator shapes of configs[0] / [4] (cfg-1 resample2d, cfg-5 block_extractor / local_attn_reshape)
+  subpaths          : (N = 1) the other scopes SURVEY 8(d) asks for, each timed the same way on a few steps:
+                      warp_attention_path (netG's warp + flip + cat + attention convs + multiply, base_networks.py:323-333,
+                      forward and forward + backward), flownet_fwd_cfg2 (BASELINE configs[1]), train_titers_ge_20000
+                      (the guided-filter branch of ffwm_model.py:97-105), train_flow_init_random
+  cpu_baseline      : (N = 1, rank 0) the same train step on the host CPU cores -- this repo's PyTorch modules with the
+                      oracle's C/OpenMP warp -- on a bounded sample, all usable cores; cpu_baseline_n4 = 4 threads, the
+                      reference's own setting (train_ffwm.py:59)
 
 Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
                    --master-port P bench.py --gpus N --steps K --warmup W
@@ -37,8 +42,10 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP32_PEAK = 157.3e12       # FLOP/s, fp32 vector/MFMA
-TRAIN_FLOP_PER_IMG = 444e9  # ~222 GMAC per image for the full train step
-FLOWNET_FLOP_PER_IMG = 4.35e9
+REF_TRAIN_FLOP_PER_IMG = 444e9   # the REFERENCE's step, ~222 GMAC per image (quoted for comparison only)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+# launch scopes of the SURVEY 8 a1-a6 operators (ffwm_prof_* names)
+HOT_PATH_PREFIXES = ("warp", "resample2d", "block_extractor", "local_attn_reshape", "block_attention")
 
 
 def parse():
@@ -46,11 +53,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=["train", "flownet", "flowtrain", "warp", "ops"])
+    ap.add_argument("--workload", default="train", choices=["train", "flownet", "flowtrain", "warp", "warpatt", "ops"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 8 train, 6 flownet)")
     ap.add_argument("--titers", type=int, default=0, help="0 = warm-up branch (<20000), 20000 = guided-filter branch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone cfg-1 / cfg-5 operator shapes")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `subpaths` legs (N = 1 only)")
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--flow-init", default="fit-identity", choices=["fit-identity", "random"],
                     help="train workload: stand-in for the reference's PRETRAINED flow nets -- fit flowNetF/B to the identity "
@@ -59,6 +67,8 @@ def parse():
                     help="weight gradients of netG's large 3x3 convs on the hand-written MFMA kernel (off: vendor library)")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="train workload: replay the step from captured hipGraphs, or run it eagerly (default: measured faster on ROCm 7.2)")
+    ap.add_argument("--flownet-path", default="lean", choices=["lean", "module"],
+                    help="flownet workload: the launch-lean eval path (BatchNorm folded, fused heads, hipGraph) or the nn.Module")
     return ap.parse_args()
 
 
@@ -86,6 +96,8 @@ def init_dist(args):
 
 
 def timed(step_fn, steps, warmup, world):
+    """W untimed steps, then exactly K steps between (barrier + synchronize) on both sides; max over ranks.
+    Returns (seconds, launch-scope rows of the hand-written kernels inside the timed region)."""
     for _ in range(warmup):
         step_fn()
     from ffwm_amd import _lib
@@ -112,15 +124,16 @@ def timed(step_fn, steps, warmup, world):
 
 
 def pmc_traffic():
-    """HBM-side bytes per dispatch measured with rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
-    runs of this same command, FETCH_SIZE doubled per the gfx950 calibration) -- profiles/r01_pmc_traffic.json.
-    PMC counters cannot be read from inside the process, so the committed measurement is attached."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM-side bytes per dispatch measured with rocprofv3 PMC passes of this same command (tools/refresh_profiles.sh:
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, --kernel-include-regex ffwm; FETCH_SIZE doubled per the gfx950
+    calibration).  PMC counters cannot be read from inside the process, so the committed measurement is attached.  A scope
+    whose fetch or write count is missing / zero is NOT reported (tools/fold_profiles.py refuses to write such rows)."""
     try:
-        with open(path) as f:
-            return {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        with open(PMC_FILE) as f:
+            data = json.load(f)
     except (OSError, ValueError):
         return {}
+    return {k: v for k, v in data.items() if not k.startswith("_") and v.get("fetch_KiB", 0) > 0 and v.get("write_KiB", 0) > 0}
 
 
 def kernel_rows(rows, tag):
@@ -140,20 +153,25 @@ def kernel_rows(rows, tag):
     return out
 
 
+def is_hot_path(row):
+    return row["kernel"].startswith(HOT_PATH_PREFIXES)
+
+
 def standalone_kernels(reps=10):
-    """cfg-1 / cfg-5 operator shapes, HIP-event timed through the library profiler."""
+    """cfg-1 / cfg-5 operator shapes, HIP-event timed through the library profiler; plus
+    resample2d at an HBM-resident shape (cfg-1's 8.6 MB live in L2)."""
     from ffwm_amd import _lib, ops
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
     rows = []
 
-    def run(tag, fn):
+    def run(tag, fn, n=reps):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
         _lib.prof_reset()
         _lib.prof_enable(True)
-        for _ in range(reps):
+        for _ in range(n):
             fn()
         torch.cuda.synchronize()
         _lib.prof_enable(False)
@@ -165,7 +183,9 @@ def standalone_kernels(reps=10):
     run("cfg5/GPU block_extractor k=3 src[4,128,256,256] flow~U[-2,2)", lambda: ops.block_extractor_forward(src, flow, 3, out=out))
     gs, gf = torch.zeros_like(src), torch.zeros_like(flow)
     run("cfg5/GPU block_extractor k=3 backward", lambda: ops.block_extractor_backward(src, flow, out, 3, gs, gf))
-    del src, out, gs, gf
+    wide = (torch.rand(4, 2, 256, 256, generator=g) * 128 - 64).to(dev)
+    run("cfg5/GPU block_extractor k=3 flow~U[-64,64) (gather fallback)", lambda: ops.block_extractor_forward(src, wide, 3, out=out), 3)
+    del src, out, gs, gf, wide
     attn = torch.rand(4, 9, 256, 256, generator=g).to(dev)
     o = torch.empty(4, 1, 768, 768, device=dev)
     gi = torch.empty_like(attn)
@@ -176,14 +196,18 @@ def standalone_kernels(reps=10):
     o = torch.empty_like(in1)
     go = torch.rand(1, 64, 128, 128, generator=g).to(dev)
     g1, g2 = torch.zeros_like(in1), torch.empty_like(in2)
-    run("cfg1 resample2d ks=4 [1,64,128,128]", lambda: ops.resample2d_forward(in1, in2, 4, 1, out=o))
+    run("cfg1 resample2d ks=4 [1,64,128,128] flow~U[-3,3)", lambda: ops.resample2d_forward(in1, in2, 4, 1, out=o))
     run("cfg1 resample2d ks=4 backward", lambda: ops.resample2d_backward(in1, in2, go, 4, 1, g1, g2))
+    in1 = torch.rand(8, 64, 512, 512, generator=g).to(dev)
+    in2 = torch.cat((torch.rand(8, 2, 512, 512, generator=g) * 6 - 3, torch.full((8, 1, 512, 512), 2.0)), 1).to(dev)
+    o = torch.empty_like(in1)
+    run("HBM-resident resample2d ks=4 [8,64,512,512] flow~U[-3,3)", lambda: ops.resample2d_forward(in1, in2, 4, 1, out=o), 5)
     return rows
 
 
 def host_threads():
     """Threads for the CPU leg: the cores this process may run on, capped at 16 -- PyTorch's CPU
-    convolutions at batch 2 stop scaling (and then collapse) well before that on a many-core host."""
+    convolutions at batch 8 stop scaling (and then collapse) well before that on a many-core host."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -193,12 +217,11 @@ def host_threads():
 
 def cpu_train_baseline(titers):
     """The same train step on the host cores: this repo's modules on CPU, warps through the oracle's
-    C/OpenMP restatement (test infrastructure, used here only as the CPU comparison leg)."""
+    C/OpenMP restatement (test infrastructure, used here only as the CPU comparison leg).  Two settings:
+    all usable cores (<= 16), and 4 threads -- the reference's own (train_ffwm.py:59)."""
     import oracle
     from ffwm_amd import trainer
     oracle.build()
-    cores = host_threads()
-    torch.set_num_threads(cores)
 
     def warp(images, flow, mode="bilinear"):
         return oracle.WarpOracleFn.apply(images, flow, False)
@@ -206,17 +229,29 @@ def cpu_train_baseline(titers):
     def warp_flipcat(feat, flow):
         return oracle.WarpOracleFn.apply(feat, flow, True)
 
-    bs, steps = 8, 2
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    bs = 8
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     t = trainer.FFWMTrainer("cpu", seed=0, titers=titers, warp=warp, warp_flipcat=warp_flipcat)
     batch = trainer.synthetic_batch(bs, "cpu", seed=1)
     t.step(batch)                                  # untimed: allocator / oneDNN primitive warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        t.step(batch)
-    dt = time.perf_counter() - t0
-    return {"value": round(bs * steps / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "%d full FFWM train steps, batch %d, after 1 warm-up step, %d torch/OpenMP threads, %.1f s"
-                      % (steps, bs, cores, dt)}
+    out = {}
+    for key, n, steps in (("cpu_baseline", cores, 2), ("cpu_baseline_n4", min(4, cores), 1)):
+        torch.set_num_threads(n)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t.step(batch)
+        dt = time.perf_counter() - t0
+        out[key] = {"value": round(bs * steps / dt, 4), "unit": "img/s", "cores": n, "kind": "port",
+                    "host_cores_usable": usable,
+                    "sample": "%d full FFWM train step(s), batch %d, after 1 warm-up step, %d torch/OpenMP threads, %.1f s"
+                              % (steps, bs, n, dt)}
+    return out
 
 
 def cpu_ops_baseline():
@@ -231,8 +266,95 @@ def cpu_ops_baseline():
     oracle.block_extractor_forward(src, flow, 3)
     dt = time.perf_counter() - t0
     nbytes = 4.0 * (32 * 65536 + 2 * 65536 + 32 * 9 * 65536)
-    return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": "oracle block_extractor forward, src [1,32,256,256] (1/16 of cfg-5 per GPU), %.2f s" % dt}
+    return {"cpu_baseline": {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+                             "sample": "oracle block_extractor forward, src [1,32,256,256] (1/16 of cfg-5 per GPU), %.2f s" % dt}}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def smooth_flow(bs, s):
+    """identity grid + ~3 px of low-frequency displacement: what a trained FlowNet produces"""
+    lin = (torch.arange(s, dtype=torch.float32) + 0.5) / s * 2 - 1
+    yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+    amp = 6.0 / s
+    fx = xx + amp * torch.sin(3.1 * yy + 0.3) * torch.cos(2.3 * xx)
+    fy = yy + amp * torch.cos(2.7 * xx - 0.2) * torch.sin(1.9 * yy)
+    return torch.stack((fx, fy), 0).unsqueeze(0).repeat(bs, 1, 1, 1).contiguous()
+
+
+def hot_rows_summary(rows):
+    """bytes-weighted HBM fraction of the a1-a6 kernels among `rows` + the per-kernel list"""
+    hot = [r for r in rows if is_hot_path(r)]
+    tot_b = sum(r["alg_MB"] * r["launches"] for r in hot)
+    tot_t = sum(r["total_ms"] for r in hot)
+    return {"warp_kernels_GBps": round(tot_b / tot_t, 1) if tot_t > 0 else None,
+            "warp_kernels_frac_hbm_peak": round(tot_b * 1e6 / (tot_t * 1e-3) / HBM_PEAK, 4) if tot_t > 0 else None,
+            "kernels": [{k: r[k] for k in ("kernel", "launches", "avg_us", "alg_MB", "GBps", "frac_hbm_peak")} for r in hot]}
+
+
+def run_warp_attention(dev, bs, steps, warmup, world, seed=1):
+    """netG's warp-attention module alone (base_networks.py:323-333): warp + flip + cat (HIP) -> att convs -> multiply,
+    three levels, batch `bs`.  Returns forward-only and forward + backward figures."""
+    from ffwm_amd import flops, nets
+    from ffwm_amd.spectral_norm import fuse_spectral_norm
+    torch.manual_seed(0)
+    mod = nets.WarpAttention(sn=True).to(dev).train()
+    fuse_spectral_norm(mod)
+    g = torch.Generator().manual_seed(seed)
+    feats = [torch.rand(bs, c, s, s, generator=g).to(dev).requires_grad_(True) for c, s in mod.LEVELS]
+    flows = [smooth_flow(bs, s).to(dev).requires_grad_(True) for _, s in mod.LEVELS]
+    gos = [torch.rand(bs, 2 * c, s, s, generator=g).to(dev) for c, s in mod.LEVELS]
+
+    def fwd():
+        with torch.no_grad():
+            mod(feats, flows)
+
+    def fwd_bwd():
+        for t in feats + flows:
+            t.grad = None
+        for p in mod.parameters():
+            p.grad = None
+        torch.autograd.backward(mod(feats, flows), gos)
+    fl = flops.count_step([mod], fwd_bwd)
+    dt_f, rows_f = timed(fwd, steps, warmup, world)
+    dt_b, rows_b = timed(fwd_bwd, steps, warmup, world)
+    imgs = bs * world * steps
+    ceil_fb = FP32_PEAK / (fl["total"] / bs)
+    return {"scope": "warp + flip + cat (HIP) + attention convs (conv block + sigmoid residual block, spectral norm) + multiply; "
+                     "3 levels ([128,32,32], [64,64,64], [64,128,128] per image), batch %d, smooth flows" % bs,
+            "fwd_img_per_s": round(imgs / dt_f, 1), "fwd_ms": round(dt_f / steps * 1e3, 3),
+            "fwd_bwd_img_per_s": round(imgs / dt_b, 1), "fwd_bwd_ms": round(dt_b / steps * 1e3, 3),
+            "conv_GFLOP_per_img": {"fwd": round(fl["fwd"] / bs / 1e9, 2), "fwd_bwd": round(fl["total"] / bs / 1e9, 2)},
+            "fp32_ceiling_img_per_s": {"fwd": round(FP32_PEAK / (fl["fwd"] / bs), 0), "fwd_bwd": round(ceil_fb, 0)},
+            "fp32_flop_frac": {"fwd": round(imgs / dt_f * fl["fwd"] / bs / FP32_PEAK, 4),
+                               "fwd_bwd": round(imgs / dt_b * fl["total"] / bs / FP32_PEAK, 4)},
+            "note": "the att convs are %.1f GFLOP per image forward + backward: the north_star's 3000 img/s is above the fp32 "
+                    "ceiling of %.0f img/s for this scope with backward, and below the forward-only ceiling" % (fl["total"] / bs / 1e9, ceil_fb),
+            "warp_fwd": hot_rows_summary(kernel_rows(rows_f, "warp_attention fwd")),
+            "warp_fwd_bwd": hot_rows_summary(kernel_rows(rows_b, "warp_attention fwd+bwd"))}, dt_b, rows_b
+
+
+def run_flownet(dev, bs, steps, warmup, world, path, seed=1):
+    from ffwm_amd import flops, nets
+    torch.manual_seed(0)
+    net = nets.FlowNet(64).to(dev).eval()
+    x = torch.rand(bs, 3, 128, 128, generator=torch.Generator().manual_seed(seed)).to(dev)
+    with torch.no_grad():
+        fl = flops.count_step([net], lambda: net(x))
+    if path == "lean":
+        from ffwm_amd import flownet_eval
+        lean = flownet_eval.FoldedFlowNet(net, graph=True)
+
+        def step():
+            lean(x)
+    else:
+        def step():
+            with torch.no_grad():
+                net(x)
+    dt, rows = timed(step, steps, warmup, world)
+    imgs = bs * world * steps
+    return {"img_per_s": round(imgs / dt, 1), "ms_per_fwd": round(dt / steps * 1e3, 4), "batch": bs, "path": path,
+            "conv_GFLOP_per_img": round(fl["fwd"] / bs / 1e9, 3),
+            "fp32_flop_frac": round(imgs / dt / world * fl["fwd"] / bs / FP32_PEAK, 5)}, dt, rows
 
 
 def main():
@@ -251,9 +373,11 @@ def main():
 
     result = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    extras = {}
+    t = None
 
     if args.workload == "train":
-        from ffwm_amd import trainer
+        from ffwm_amd import flops, trainer
         bs = args.batch or 8
         t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers,
                                 bucket_bytes=args.bucket_mb << 20, capturable=args.graph == "on",
@@ -261,6 +385,8 @@ def main():
         batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
         flow_fit = t.pretrain_flow_identity(batch) if args.flow_init == "fit-identity" else None
         graphed = args.graph == "on"
+        nets_all = [t.flowNetF, t.flowNetB, t.netG, t.netD, t.lightCNN, t.vgg]
+        step_flops = flops.count_step(nets_all, lambda: t.step(batch, batch_increment=0))       # one untimed eager step
         if graphed:
             t.capture(batch, warmup=max(2, args.warmup))
         dt, rows = timed(lambda: t.step(batch, batch_increment=0), args.steps, args.warmup, world)
@@ -270,6 +396,7 @@ def main():
             t.release_graphs()
             _, rows = timed(lambda: t.step(batch, batch_increment=0), 2, 1, world)
         imgs = bs * world * args.steps
+        own = step_flops["total"] / bs
         result.update({"metric": "train img/s (128x128, full FFWM GAN step)", "value": round(imgs / dt, 2),
                        "unit": "img/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
                        "config": {"workload": "BASELINE configs[2]: full FFWM train step (netG+netD+flowNetF+flowNetB, "
@@ -285,56 +412,56 @@ def main():
                                                 "pretrained flowNetF/B checkpoints), final L1 %s" % [round(v, 3) for v in flow_fit])
                                   if flow_fit else "randomly initialised"},
                        "img_per_s_per_gpu": round(imgs / dt / world, 2),
-                       "fp32_flop_frac": round(imgs / dt / world * TRAIN_FLOP_PER_IMG / FP32_PEAK, 4),
+                       "conv_GFLOP_per_img": {"this_step": round(own / 1e9, 1), "fwd": round(step_flops["fwd"] / bs / 1e9, 1),
+                                              "bwd": round(step_flops["bwd"] / bs / 1e9, 1),
+                                              "reference_step_estimate": REF_TRAIN_FLOP_PER_IMG / 1e9,
+                                              "note": "counted over every conv / linear call of one step (ffwm_amd/flops.py); "
+                                                      "lower than the reference's estimate because frozen LightCNN / VGG19 get no "
+                                                      "weight gradients, target-side extractors run under no_grad and the LightCNN "
+                                                      "passes are deduplicated (result-preserving)"},
+                       "fp32_flop_frac": round(imgs / dt / world * own / FP32_PEAK, 4),
+                       "fp32_ceiling_img_per_s_per_gpu": round(FP32_PEAK / own, 1),
                        "losses": {k: round(v, 5) for k, v in t.loss_values().items()}})
-        if world > 1:
-            result["config"]["grad_bytes_per_step"] = t.red_G.grad_bytes() + t.red_D.grad_bytes()
+        result["config"]["grad_bytes_per_step"] = t.red_G.grad_bytes() + t.red_D.grad_bytes()
+        result["config"]["grad_buckets"] = len(t.red_G.buckets) + len(t.red_D.buckets)
+        result["config"]["bucket_MiB"] = args.bucket_mb
     elif args.workload == "flownet":
-        from ffwm_amd import nets
         bs = args.batch or 6
-        torch.manual_seed(0)
-        net = nets.FlowNet(64).to(dev).eval()
-        x = torch.rand(bs, 3, 128, 128, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
-
-        def step():
-            with torch.no_grad():
-                net(x)
-        dt, rows = timed(step, args.steps, args.warmup, world)
-        imgs = bs * world * args.steps
-        result.update({"metric": "FlowNetF forward img/s (128x128)", "value": round(imgs / dt, 2), "unit": "img/s",
-                       "ms_per_step": round(dt / args.steps * 1e3, 3),
-                       "config": {"workload": "BASELINE configs[1]: FlowNetF forward-only, bs=%d" % bs,
+        r, dt, rows = run_flownet(dev, bs, args.steps, args.warmup, world, args.flownet_path, seed=1 + rank)
+        result.update({"metric": "FlowNetF forward img/s (128x128)", "value": r["img_per_s"], "unit": "img/s",
+                       "ms_per_step": round(dt / args.steps * 1e3, 4),
+                       "config": {"workload": "BASELINE configs[1]: FlowNetF forward-only, bs=%d" % bs, "path": args.flownet_path,
                                   "batch_per_gpu": bs, "parallelism": "dp%d" % world},
-                       "fp32_flop_frac": round(imgs / dt / world * FLOWNET_FLOP_PER_IMG / FP32_PEAK, 5)})
+                       "conv_GFLOP_per_img": r["conv_GFLOP_per_img"], "fp32_flop_frac": r["fp32_flop_frac"]})
     elif args.workload == "flowtrain":
         # FlowNet pre-training step (train_flow.py / models/flownet_model.py:57-78): the only trainer of the
         # reference that runs the custom ops; README.md:105,116 trains it with batch 6
         from ffwm_amd import trainer
         bs = args.batch or 6
-        t = trainer.FlowNetTrainer(dev, world_size=world, seed=0, bucket_bytes=args.bucket_mb << 20)
+        ft = trainer.FlowNetTrainer(dev, world_size=world, seed=0, bucket_bytes=args.bucket_mb << 20)
         batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
-        dt, rows = timed(lambda: t.step(batch), args.steps, args.warmup, world)
+        dt, rows = timed(lambda: ft.step(batch), args.steps, args.warmup, world)
         imgs = bs * world * args.steps
         result.update({"metric": "FlowNet pre-training img/s (128x128)", "value": round(imgs / dt, 2), "unit": "img/s",
                        "ms_per_step": round(dt / args.steps * 1e3, 3),
                        "config": {"workload": "FlowNetModel train step (correctness + affine regularisation + landmark "
                                               "losses, Adam), synthetic 128x128", "batch_per_gpu": bs,
                                   "parallelism": "dp%d" % world, "weights": "seeded random init"},
-                       "losses": {k: round(v, 5) for k, v in t.loss_values().items()}})
+                       "losses": {k: round(v, 5) for k, v in ft.loss_values().items()}})
+    elif args.workload == "warpatt":
+        bs = args.batch or 8
+        r, dt, rows = run_warp_attention(dev, bs, args.steps, args.warmup, world, seed=1 + rank)
+        result.update({"metric": "warp+attention path img/s (3 netG levels, fwd+bwd)", "value": r["fwd_bwd_img_per_s"], "unit": "img/s",
+                       "ms_per_step": r["fwd_bwd_ms"],
+                       "config": {"workload": "netG warp-attention module (base_networks.py:323-333), 3 levels, fwd+bwd", "batch_per_gpu": bs,
+                                  "parallelism": "dp%d" % world}, "warp_attention_path": r})
     elif args.workload == "warp":
-        # the warp + flip + cat sub-path of netG's warp-attention, forward + backward, bs images
+        # the warp + flip + cat kernels of netG's warp-attention alone, forward + backward, bs images
         from ffwm_amd.external_function import WarpFlipCat
         bs = args.batch or 8
         g = torch.Generator().manual_seed(1 + rank)
         feats = [torch.rand(bs, c, s, s, generator=g).to(dev).requires_grad_(True) for c, s in ((128, 32), (64, 64), (64, 128))]
-        def smooth(s):      # identity grid + ~3 px of low-frequency displacement: what a trained FlowNet produces
-            lin = (torch.arange(s, dtype=torch.float32) + 0.5) / s * 2 - 1
-            yy, xx = torch.meshgrid(lin, lin, indexing="ij")
-            amp = 6.0 / s
-            fx = xx + amp * torch.sin(3.1 * yy + 0.3) * torch.cos(2.3 * xx)
-            fy = yy + amp * torch.cos(2.7 * xx - 0.2) * torch.sin(1.9 * yy)
-            return torch.stack((fx, fy), 0).unsqueeze(0).repeat(bs, 1, 1, 1).contiguous()
-        flows = [smooth(s).to(dev).requires_grad_(True) for s in (32, 64, 128)]
+        flows = [smooth_flow(bs, s).to(dev).requires_grad_(True) for s in (32, 64, 128)]
         gos = [torch.rand(bs, 2 * c, s, s, generator=g).to(dev) for c, s in ((128, 32), (64, 64), (64, 128))]
         mod = WarpFlipCat()
 
@@ -344,9 +471,9 @@ def main():
                 mod(f, fl).backward(go)
         dt, rows = timed(step, args.steps, args.warmup, world)
         imgs = bs * world * args.steps
-        result.update({"metric": "warp+flip+cat path img/s (3 netG levels, fwd+bwd)", "value": round(imgs / dt, 2),
+        result.update({"metric": "warp+flip+cat kernels img/s (3 netG levels, fwd+bwd)", "value": round(imgs / dt, 2),
                        "unit": "img/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
-                       "config": {"workload": "netG warp-attention warp sub-path (warp + flip + cat), 3 levels, fwd+bwd, smooth flows", "batch_per_gpu": bs,
+                       "config": {"workload": "netG warp-attention warp kernels (warp + flip + cat), 3 levels, fwd+bwd, smooth flows", "batch_per_gpu": bs,
                                   "parallelism": "dp%d" % world}})
     else:   # ops: cfg-5 per GPU block_extractor forward + backward
         from ffwm_amd import ops
@@ -369,56 +496,94 @@ def main():
                        "config": {"workload": "BASELINE configs[4] per GPU: block_extractor fwd+bwd", "batch_per_gpu": bs,
                                   "parallelism": "dp%d" % world}})
 
+    # ---- the other scopes of SURVEY 8(d), N = 1 only (they do not take part in the scaling curve)
+    if args.workload == "train" and world == 1 and not args.no_extras:
+        from ffwm_amd import trainer
+        bs = args.batch or 8
+        try:
+            r, _, _ = run_warp_attention(dev, bs, 20, 5, world)
+            extras["warp_attention_path"] = r
+        except Exception as e:
+            extras["warp_attention_path"] = {"error": repr(e)}
+        for path in ("lean", "module"):
+            try:
+                r, _, _ = run_flownet(dev, 6, 30, 10, world, path)
+                extras["flownet_fwd_cfg2" if path == "lean" else "flownet_fwd_cfg2_module_path"] = r
+            except Exception as e:
+                extras["flownet_fwd_cfg2" if path == "lean" else "flownet_fwd_cfg2_module_path"] = {"error": repr(e)}
+        try:
+            # the other titers branch on the SAME trainer (ffwm_model.py:97-105: >= 20000 adds the guided filters on the
+            # 64 / 32 px outputs and the two-sided identity loss)
+            keep = t.titers
+            t.titers = 20000 if keep < 20000 else 0
+            dt2, _ = timed(lambda: t.step(batch, batch_increment=0), 5, 3, world)
+            extras["train_titers_ge_20000" if keep < 20000 else "train_titers_lt_20000"] = {
+                "img_per_s": round(bs * 5 / dt2, 2), "ms_per_step": round(dt2 / 5 * 1e3, 3), "steps": 5, "warmup": 3}
+            t.titers = keep
+        except Exception as e:
+            extras["train_titers_other_branch"] = {"error": repr(e)}
+        try:
+            other = "random" if args.flow_init == "fit-identity" else "fit-identity"
+            t2 = trainer.FFWMTrainer(dev, world_size=1, seed=0, titers=args.titers, bucket_bytes=args.bucket_mb << 20,
+                                     mfma_wgrad=args.mfma_wgrad == "on")
+            if other == "fit-identity":
+                t2.pretrain_flow_identity(batch)
+            dt3, _ = timed(lambda: t2.step(batch, batch_increment=0), 5, 3, world)
+            extras["train_flow_init_" + other.replace("-", "_")] = {
+                "img_per_s": round(bs * 5 / dt3, 2), "ms_per_step": round(dt3 / 5 * 1e3, 3), "steps": 5, "warmup": 3,
+                "note": "an untrained FlowNet outputs tanh(~0): every pixel samples the image centre (all lanes on one cache "
+                        "line, all scatter-adds on four cells) -- an access pattern real training never produces"
+                        if other == "random" else ""}
+            del t2
+        except Exception as e:
+            extras["train_flow_init_other"] = {"error": repr(e)}
+        result["subpaths"] = extras
+
     if rank == 0:
         inrun = kernel_rows(rows, "timed region")
-        if inrun:
-            # the roofline kernel of an HBM-bound path = the hand-written kernel that moves the most
-            # algorithmic bytes in a step (launch-latency-bound helpers on a few hundred KB -- guided filter
-            # on 24 planes, spectral norm on 61 small matrices -- are listed in `kernels` with the rest)
-            def hbm_roofline(top):
-                pmc = pmc_traffic().get(top["kernel"]) if args.workload == "train" else None     # measured on the train workload
-                return {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBps"], "peak": HBM_PEAK / 1e9,
-                        "unit": "GB/s", "frac": top["frac_hbm_peak"],
-                        "traffic": pmc["traffic_bytes"] if pmc else None,
-                        "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                          "of this command; bytes per launch, FETCH_SIZE x2 per the gfx950 calibration)"
-                        if pmc else None,
-                        "avg_us": top["avg_us"], "alg_MB_per_launch": top["alg_MB"], "launches": top["launches"],
-                        "note": "hand-written HIP kernel moving the most algorithmic bytes per step; HIP events "
-                                "on its launch stream" + (" (eager steps run right after the graph-replayed "
-                                "timed region)" if args.workload == "train" and args.graph == "on" else "")}
-            hbm_rows = [r for r in inrun if "TFLOPs" not in r]
-            mfma_rows = [r for r in inrun if "TFLOPs" in r]
-            dominant = max(inrun, key=lambda r: r["total_ms"])
-            if "TFLOPs" in dominant:
-                # the dominant hand-written kernel of the step is a contraction on the matrix cores: its roofline
-                # is the fp32 MFMA peak (157.3 TFLOP/s dense); algorithmic flops = 2 * 9 * B H W C K per launch
-                pmc = pmc_traffic().get(dominant["kernel"]) if args.workload == "train" else None
-                result["roofline"] = {"bound": "mfma", "kernel": dominant["kernel"], "achieved": dominant["TFLOPs"],
-                                      "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": dominant["frac_mfma_fp32_peak"],
-                                      "traffic": pmc["traffic_bytes"] if pmc else None,
-                                      "avg_us": dominant["avg_us"], "alg_GFLOP_per_launch": dominant["alg_GFLOP"],
-                                      "launches": dominant["launches"],
-                                      "note": "hand-written kernel with the largest share of the step (fp32-in / fp32-accumulate "
-                                              "v_mfma_f32_32x32x2_f32); flops and duration averaged over the layer shapes of "
-                                              "the step; HIP events on its launch stream"}
-                if hbm_rows:
-                    result["roofline_hbm"] = hbm_roofline(max(hbm_rows, key=lambda r: r["alg_MB"] * r["launches"]))
+        traffic = pmc_traffic() if args.workload == "train" else {}      # measured on the default train workload
+
+        def roofline_row(top, bound):
+            pmc = traffic.get(top["kernel"])
+            base = {"bound": bound, "kernel": top["kernel"], "avg_us": top["avg_us"], "launches": top["launches"],
+                    "traffic": pmc["traffic_bytes"] if pmc else None,
+                    "traffic_source": ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                       "command (--kernel-include-regex ffwm), bytes per launch, FETCH_SIZE x2 per the gfx950 calibration")
+                    if pmc else None}
+            if bound == "hbm":
+                base.update({"achieved": top["GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": top["frac_hbm_peak"],
+                             "alg_MB_per_launch": top["alg_MB"],
+                             "note": "SURVEY 8 a1-a6 kernel moving the most algorithmic bytes per step; HIP events on its launch stream"})
             else:
-                result["roofline"] = hbm_roofline(max(hbm_rows or mfma_rows, key=lambda r: r["alg_MB"] * r["launches"]))
+                base.update({"achieved": top["TFLOPs"], "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": top["frac_mfma_fp32_peak"],
+                             "alg_GFLOP_per_launch": top["alg_GFLOP"],
+                             "note": "hand-written fp32-in / fp32-accumulate MFMA kernel (v_mfma_f32_32x32x2_f32); flops and duration "
+                                     "averaged over the layer shapes of the step"})
+            return base
+        hot = [r for r in inrun if is_hot_path(r) and "TFLOPs" not in r]
+        mfma = [r for r in inrun if "TFLOPs" in r]
+        other_hbm = [r for r in inrun if not is_hot_path(r) and "TFLOPs" not in r]
+        if hot:
+            result["roofline"] = roofline_row(max(hot, key=lambda r: r["alg_MB"] * r["launches"]), "hbm")
+            result["roofline"].update(hot_rows_summary(inrun))
+            result["roofline"].pop("kernels", None)
+        elif other_hbm:
+            result["roofline"] = roofline_row(max(other_hbm, key=lambda r: r["alg_MB"] * r["launches"]), "hbm")
         else:
             result["roofline"] = None
+        if mfma:
+            result["roofline_mfma"] = roofline_row(max(mfma, key=lambda r: r["total_ms"]), "mfma")
+        if other_hbm and hot:
+            result["roofline_hbm_other"] = roofline_row(max(other_hbm, key=lambda r: r["alg_MB"] * r["launches"]), "hbm")
         result["kernels"] = inrun
         if not args.no_kernels:
             result["kernels"] = inrun + standalone_kernels()
-        traffic = pmc_traffic() if args.workload == "train" else {}
         for row in result["kernels"]:
-            if row["kernel"] in traffic and (row["where"] == "timed region" or not row["kernel"].startswith("warp")):
+            if row["kernel"] in traffic and row["where"] == "timed region":
                 row["pmc_traffic_MB"] = round(traffic[row["kernel"]]["traffic_bytes"] / 1e6, 3)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_train_baseline(args.titers) if args.workload in ("train",) \
-                    else cpu_ops_baseline()
+                result.update(cpu_train_baseline(args.titers) if args.workload in ("train",) else cpu_ops_baseline())
             except Exception as e:      # the baseline leg must never take the measurement down
                 result["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(result))

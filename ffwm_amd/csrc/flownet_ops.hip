@@ -1,0 +1,205 @@
+// flownet_ops.hip -- the small layers of FlowNet's eval forward (BASELINE configs[1]) for gfx950.
+//
+// /root/reference/models/base_networks.py:59-165 at batch 6 is ~215 kernel launches per forward through the stock
+// library path, 80 % of them shorter than 10 us: per conv block a convolution, a bias add, an eval BatchNorm and a
+// LeakyReLU; per flow head an NHWC implicit-GEMM for TWO output channels wrapped in three layout transposes and a
+// zero-fill, a bias add and a tanh; per flow upsampler a 2 -> 2 channel transposed convolution with the same wrapping;
+// per decoder level a concatenation copy.  With BatchNorm folded into the conv weights (ffwm_amd/flownet_eval.py) what
+// remains around the dense convolutions is done here, one launch each:
+//   ffwm_bias_act_forward   y = act(h + bias[c]), act in {none, LeakyReLU, tanh}; written in place and / or into a channel
+//                           slice of the next concatenation buffer (no torch.cat kernel)
+//   ffwm_flow_head_forward  3x3 / pad 1 convolution C -> 2 + bias + tanh (predict_flow*, :45-49): HBM-bound on its input,
+//                           channels split over the lanes for the tiny planes (1024 channels at 2 x 2)
+//   ffwm_flow_up_forward    ConvTranspose2d(2, 2, 4, 2, 1) + bias (upsampled_flow*_to_*, :104-109) into the cat slice
+#include "common.hpp"
+
+namespace ffwm {
+namespace {
+
+template <int ACT>
+__device__ __forceinline__ float act_f(float v, float slope) {
+    if constexpr (ACT == 1) return v > 0.f ? v : v * slope;        // ATen leaky_relu: x > 0 ? x : x * slope
+    if constexpr (ACT == 2) return tanhf(v);
+    return v;
+}
+
+// one thread per 4 consecutive pixels of one (b, c) plane when HW % 4 == 0, else per pixel
+template <int ACT, int VEC>
+__global__ void __launch_bounds__(kBlock)
+bias_act_kernel(const float* __restrict__ h, const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ y2,
+                int64_t total, int C, int HW, int64_t ybs, int64_t y2bs, float slope) {
+    const int hwv = HW / VEC;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int64_t plane = i / hwv;
+        const int p = static_cast<int>(i - plane * hwv) * VEC;
+        const int c = static_cast<int>(plane % C);
+        const int64_t b = plane / C;
+        const float bc = bias ? bias[c] : 0.f;
+        const float* src = h + plane * HW + p;
+        if constexpr (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            const float4 o = {act_f<ACT>(v.x + bc, slope), act_f<ACT>(v.y + bc, slope), act_f<ACT>(v.z + bc, slope), act_f<ACT>(v.w + bc, slope)};
+            if (y) *reinterpret_cast<float4*>(y + b * ybs + static_cast<int64_t>(c) * HW + p) = o;
+            if (y2) *reinterpret_cast<float4*>(y2 + b * y2bs + static_cast<int64_t>(c) * HW + p) = o;
+        } else {
+            const float o = act_f<ACT>(*src + bc, slope);
+            if (y) y[b * ybs + static_cast<int64_t>(c) * HW + p] = o;
+            if (y2) y2[b * y2bs + static_cast<int64_t>(c) * HW + p] = o;
+        }
+    }
+}
+
+// 3x3 / stride 1 / pad 1 convolution C -> 2 + bias + tanh.  A block = P pixels x S channel splits (P * S = 256):
+// P = 64 for planes >= 64 pixels (a wave covers 64 consecutive pixels: coalesced rows), smaller powers of two for the
+// 2 x 2 ... 4 x 4 planes so that the 1024 input channels are spread over all 256 threads.  Partial sums meet in LDS.
+template <int P>
+__global__ void __launch_bounds__(kBlock)
+flow_head_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                 float* __restrict__ y, int C, int H, int W, int tiles) {
+    constexpr int S = kBlock / P;
+    __shared__ float red[2][S][P];
+    const int px_l = threadIdx.x % P, split = threadIdx.x / P;
+    const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
+    const int HW = H * W;
+    const int p = tile * P + px_l;
+    const bool live = p < HW;
+    const int py = live ? p / W : 0, pxx = live ? p - py * W : 0;
+    unsigned off[9];
+    float msk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = py + k / 3 - 1, xx = pxx + k % 3 - 1;
+        const bool in = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        off[k] = in ? static_cast<unsigned>(yy * W + xx) : 0u;
+        msk[k] = in ? 1.f : 0.f;
+    }
+    float a0 = 0.f, a1 = 0.f;
+    const float* xb = x + static_cast<int64_t>(b) * C * HW;
+    for (int c = split; c < C; c += S) {
+        const float* xc = xb + static_cast<int64_t>(c) * HW;
+        const float* w0 = w + static_cast<int64_t>(c) * 9;                       // w[0][c][:][:]
+        const float* w1 = w + (static_cast<int64_t>(C) + c) * 9;                 // w[1][c][:][:]
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float v = msk[k] != 0.f ? xc[off[k]] : 0.f;
+            a0 = __builtin_fmaf(v, w0[k], a0);
+            a1 = __builtin_fmaf(v, w1[k], a1);
+        }
+    }
+    red[0][split][px_l] = a0;
+    red[1][split][px_l] = a1;
+    __syncthreads();
+    if (split < 2 && live) {                      // thread (px, co = split) folds the S partial sums of its output
+        float s = bias ? bias[split] : 0.f;
+#pragma unroll
+        for (int k = 0; k < S; ++k) s += red[split][k][px_l];
+        y[(static_cast<int64_t>(b) * 2 + split) * HW + p] = tanhf(s);
+    }
+}
+
+// ConvTranspose2d(2, 2, kernel 4, stride 2, pad 1) + bias: out[b, co, y, x] = bias[co] + sum_ci sum_ky,kx
+// in[b, ci, (y + 1 - ky) / 2, (x + 1 - kx) / 2] * w[ci, co, ky, kx] over the taps whose division is exact and in range.
+__global__ void __launch_bounds__(kBlock)
+flow_up_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+               float* __restrict__ out, int64_t total, int H, int W, int64_t obs) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int xo = static_cast<int>(i % Wo);
+        const int yo = static_cast<int>((i / Wo) % Ho);
+        const int64_t b = i / (static_cast<int64_t>(Wo) * Ho);
+        float a0 = bias ? bias[0] : 0.f, a1 = bias ? bias[1] : 0.f;
+        const float* ib = in + b * 2 * H * W;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int ty = yo + 1 - ky;
+            if (ty < 0 || (ty & 1) || (ty >> 1) >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int tx = xo + 1 - kx;
+                if (tx < 0 || (tx & 1) || (tx >> 1) >= W) continue;
+                const int ip = (ty >> 1) * W + (tx >> 1);
+                const float v0 = ib[ip], v1 = ib[H * W + ip];
+                const int k = ky * 4 + kx;
+                a0 = __builtin_fmaf(v0, w[k], a0);            // w[ci = 0][co = 0]
+                a0 = __builtin_fmaf(v1, w[32 + k], a0);       // w[1][0]
+                a1 = __builtin_fmaf(v0, w[16 + k], a1);       // w[0][1]
+                a1 = __builtin_fmaf(v1, w[48 + k], a1);       // w[1][1]
+            }
+        }
+        float* ob = out + b * obs + static_cast<int64_t>(yo) * Wo + xo;
+        ob[0] = a0;
+        ob[static_cast<int64_t>(Ho) * Wo] = a1;
+    }
+}
+
+unsigned ew_grid(int64_t n) {
+    int64_t blocks = (n + kBlock - 1) / kBlock;
+    return static_cast<unsigned>(blocks > 256 * 32 ? 256 * 32 : (blocks < 1 ? 1 : blocks));
+}
+
+}  // namespace
+}  // namespace ffwm
+
+using namespace ffwm;
+
+extern "C" int ffwm_bias_act_forward(const void* h, const void* bias, void* y, void* y2, int64_t B, int64_t C, int64_t HW,
+                                     int64_t y_batch_stride, int64_t y2_batch_stride, int act, double negative_slope,
+                                     int dtype, void* stream) {
+    const char* fn = "ffwm_bias_act_forward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(h && (y || y2), FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(B > 0 && C > 0 && HW > 0 && HW < (1LL << 31) && act >= 0 && act <= 2, FFWM_ERR_ARG, "%s: bad sizes / activation", fn);
+    FFWM_REQUIRE((!y || y_batch_stride >= C * HW) && (!y2 || y2_batch_stride >= C * HW), FFWM_ERR_ARG,
+                 "%s: a destination batch stride is smaller than C * HW", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(h) % 16 == 0) &&
+                     (!y || (reinterpret_cast<uintptr_t>(y) % 16 == 0 && y_batch_stride % 4 == 0)) &&
+                     (!y2 || (reinterpret_cast<uintptr_t>(y2) % 16 == 0 && y2_batch_stride % 4 == 0));
+    const int64_t total = B * C * HW / (vec ? 4 : 1);
+    LaunchScope ls("flownet_bias_act", st, 4.0 * B * C * HW * (1.0 + (y ? 1 : 0) + (y2 ? 1 : 0)));
+#define FFWM_BA(ACT, VEC)                                                                                              \
+    hipLaunchKernelGGL((bias_act_kernel<ACT, VEC>), dim3(ew_grid(total)), dim3(kBlock), 0, st, (const float*)h,        \
+                       (const float*)bias, (float*)y, (float*)y2, total, (int)C, (int)HW, y_batch_stride, y2_batch_stride, \
+                       (float)negative_slope)
+    if (vec) {
+        if (act == 0) FFWM_BA(0, 4); else if (act == 1) FFWM_BA(1, 4); else FFWM_BA(2, 4);
+    } else {
+        if (act == 0) FFWM_BA(0, 1); else if (act == 1) FFWM_BA(1, 1); else FFWM_BA(2, 1);
+    }
+#undef FFWM_BA
+    return check_launch(fn);
+}
+
+extern "C" int ffwm_flow_head_forward(const void* x, const void* weight, const void* bias, void* y, int64_t B, int64_t C,
+                                      int64_t H, int64_t W, int dtype, void* stream) {
+    const char* fn = "ffwm_flow_head_forward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(x && weight && y, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H * W < (1LL << 28), FFWM_ERR_ARG, "%s: bad sizes", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t HW = H * W;
+    LaunchScope ls("flownet_flow_head", st, 4.0 * (B * C * HW + 18.0 * C + 2.0 * B * HW));
+#define FFWM_FH(P)                                                                                                     \
+    do {                                                                                                               \
+        const int tiles = static_cast<int>((HW + P - 1) / P);                                                          \
+        hipLaunchKernelGGL((flow_head_kernel<P>), dim3(static_cast<unsigned>(B * tiles)), dim3(kBlock), 0, st,         \
+                           (const float*)x, (const float*)weight, (const float*)bias, (float*)y, (int)C, (int)H, (int)W, tiles); \
+    } while (0)
+    if (HW >= 64) FFWM_FH(64); else if (HW >= 16) FFWM_FH(16); else FFWM_FH(4);
+#undef FFWM_FH
+    return check_launch(fn);
+}
+
+extern "C" int ffwm_flow_up_forward(const void* flow, const void* weight, const void* bias, void* out, int64_t B, int64_t H,
+                                    int64_t W, int64_t out_batch_stride, int dtype, void* stream) {
+    const char* fn = "ffwm_flow_up_forward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(flow && weight && out, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(B > 0 && H > 0 && W > 0 && H * W < (1LL << 26) && out_batch_stride >= 8 * H * W, FFWM_ERR_ARG, "%s: bad sizes", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = B * 4 * H * W;
+    LaunchScope ls("flownet_flow_up", st, 4.0 * (B * 2 * H * W + 2.0 * total));
+    hipLaunchKernelGGL(flow_up_kernel, dim3(ew_grid(total)), dim3(kBlock), 0, st, (const float*)flow, (const float*)weight,
+                       (const float*)bias, (float*)out, total, (int)H, (int)W, out_batch_stride);
+    return check_launch(fn);
+}

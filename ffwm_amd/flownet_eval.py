@@ -1,0 +1,166 @@
+"""FlowNet eval forward as a launch-lean path (BASELINE configs[1]: FlowNetF forward, batch 6).
+
+`nets.FlowNet.forward` (= /root/reference/models/base_networks.py:116-165) through the stock library path is ~215 kernel
+launches at batch 6, 80 % of them under 10 us: the step is bound by launches and by tiny helper kernels, not by the
+2.18 GMAC per image.  `FoldedFlowNet` computes the SAME function with
+
+* eval-mode BatchNorm folded into the weights and bias of the convolution in front of it (exact up to rounding:
+  w' = w * gamma / sqrt(var + eps), b' = (b - mean) * gamma / sqrt(var + eps) + beta) -- :12-31 is conv -> BN -> LeakyReLU;
+* one epilogue kernel per conv block (`ffwm_bias_act_forward`: bias + LeakyReLU) that also writes the result into its
+  channel slice of the decoder's concatenation buffer, so `torch.cat` (:133-151) launches nothing;
+* the seven `predict_flow*` heads (:45-49, 3x3 conv to TWO channels + tanh) and the six 2 -> 2 channel flow upsamplers
+  (:104-109) as direct HIP kernels instead of implicit-GEMM launches wrapped in layout transposes;
+* the whole forward replayed from ONE captured hipGraph (`graph=True`), removing the host launch cost of the remaining
+  ~110 kernels.
+
+The dense 3x3 / 4x4 convolutions stay on MIOpen (fp32 Winograd / implicit GEMM on the matrix cores).  Weights are
+snapshotted at construction: build it from a network in `.eval()` and rebuild after the weights change.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+LRELU, TANH, NONE = 1, 2, 0
+
+
+def _fold(conv, bn):
+    """(weight, bias) of conv followed by eval-mode bn.  Conv2d weight [Co,Ci,k,k]; ConvTranspose2d weight [Ci,Co,k,k]."""
+    w = conv.weight.detach()
+    b = conv.bias.detach() if conv.bias is not None else torch.zeros(bn.num_features, device=w.device, dtype=w.dtype)
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    if isinstance(conv, nn.ConvTranspose2d):
+        w = w * scale.view(1, -1, 1, 1)
+    else:
+        w = w * scale.view(-1, 1, 1, 1)
+    b = (b - bn.running_mean.detach()) * scale + bn.bias.detach()
+    return w.contiguous(), b.contiguous()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def bias_act(h, bias, act, y=None, y2=None, slope=0.2):
+    """y / y2: None, or a 4-D view [B, C, H, W] whose samples are contiguous (a channel slice of a contiguous buffer)."""
+    B, C, H, W = h.shape
+    hw = H * W
+    if y is None and y2 is None:
+        y = h
+    for d in (y, y2):
+        if d is not None:
+            assert d.shape == h.shape and d.stride(1) == hw and d.stride(3) == 1 and d.stride(2) == W
+    _lib.check(_lib.load().ffwm_bias_act_forward(
+        h.data_ptr(), None if bias is None else bias.data_ptr(), None if y is None else y.data_ptr(),
+        None if y2 is None else y2.data_ptr(), B, C, hw, 0 if y is None else y.stride(0), 0 if y2 is None else y2.stride(0),
+        act, float(slope), _lib.F32, _stream(h)), "ffwm_bias_act_forward")
+    return y if y is not None else y2
+
+
+def flow_head(x, weight, bias):
+    B, C, H, W = x.shape
+    y = torch.empty(B, 2, H, W, device=x.device, dtype=x.dtype)
+    _lib.check(_lib.load().ffwm_flow_head_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), B, C, H, W,
+                                                  _lib.F32, _stream(x)), "ffwm_flow_head_forward")
+    return y
+
+
+def flow_up(flow, weight, bias, out):
+    """out: [B, 2, 2H, 2W] view whose samples are contiguous (the last two channels of a concatenation buffer)."""
+    B, _, H, W = flow.shape
+    assert out.shape == (B, 2, 2 * H, 2 * W) and out.stride(1) == 4 * H * W
+    _lib.check(_lib.load().ffwm_flow_up_forward(flow.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+                                                out.stride(0), _lib.F32, _stream(flow)), "ffwm_flow_up_forward")
+    return out
+
+
+class FoldedFlowNet(object):
+    def __init__(self, net, graph=False):
+        if net.training:
+            raise ValueError("FoldedFlowNet folds eval-mode BatchNorm statistics: call net.eval() first")
+        p = next(net.parameters())
+        if not p.is_cuda or p.dtype != torch.float32:
+            raise NotImplementedError("FoldedFlowNet: float32 GPU networks only")
+        self.device = p.device
+        self.blocks = {}
+        for name, mod in net.named_children():
+            if isinstance(mod, nn.Sequential) and len(mod) >= 2 and isinstance(mod[1], nn.BatchNorm2d):
+                conv = mod[0]
+                w, b = _fold(conv, mod[1])
+                slope = mod[2].negative_slope if len(mod) > 2 and isinstance(mod[2], nn.LeakyReLU) else 0.2
+                self.blocks[name] = (isinstance(conv, nn.ConvTranspose2d), w, b, conv.stride, conv.padding, slope)
+        self.heads = {L: (getattr(net, "predict_flow%d" % L)[0].weight.detach().contiguous(),
+                          getattr(net, "predict_flow%d" % L)[0].bias.detach().contiguous()) for L in range(7)}
+        self.ups = {L: (getattr(net, "upsampled_flow%d_to_%d" % (L + 1, L)).weight.detach().contiguous(),
+                        getattr(net, "upsampled_flow%d_to_%d" % (L + 1, L)).bias.detach().contiguous()) for L in range(6)}
+        self.use_graph = bool(graph)
+        self._graph = None
+        self._static_in = None
+        self._static_out = None
+
+    # conv (no bias: it is added by the epilogue) -> bias + LeakyReLU, in place and / or into a cat slice
+    def _block(self, name, x, dst=None, dst2=None):
+        transposed, w, b, stride, padding, slope = self.blocks[name]
+        h = F.conv_transpose2d(x, w, None, stride, padding) if transposed else F.conv2d(x, w, None, stride, padding)
+        if dst is None and dst2 is None:
+            return bias_act(h, b, LRELU, slope=slope)
+        bias_act(h, b, LRELU, y=dst if dst is not None else h, y2=dst2, slope=slope)
+        return dst if dst is not None else h
+
+    def _forward(self, x):
+        B = x.size(0)
+        f = self._block("conv0", x)
+        skips = {}
+        cats = {}
+        for L in range(1, 7):
+            f = self._block("conv%d" % L, f)
+            if 3 <= L <= 5:
+                # the level's concatenation buffer (skip, deconv output, upsampled flow): the encoder epilogue writes the
+                # skip in place AND into its slice
+                cs, hs = self.blocks["conv%d_1" % L][1].size(0), f.size(2)
+                cd = self.blocks["deconv%d" % L][1].size(1)
+                cats[L] = torch.empty(B, cs + cd + 2, hs, hs, device=x.device, dtype=x.dtype)
+                f = self._block("conv%d_1" % L, f, dst=None, dst2=cats[L][:, :cs])
+            else:
+                f = self._block("conv%d_1" % L, f)
+            skips[L] = f
+        flow = flow_head(f, *self.heads[6])
+        flows = {}
+        cat = None
+        for L in range(5, -1, -1):
+            src = f if L == 5 else cat
+            cd = self.blocks["deconv%d" % L][1].size(1)
+            hs = src.size(2) * 2
+            if L >= 3:
+                buf = cats[L]
+                cs = buf.size(1) - cd - 2
+            else:
+                cs = 0
+                buf = torch.empty(B, cd + 2, hs, hs, device=x.device, dtype=x.dtype)
+            self._block("deconv%d" % L, src, dst=buf[:, cs:cs + cd])
+            flow_up(flow, *self.ups[L], out=buf[:, cs + cd:])
+            cat = buf
+            flow = flow_head(self._block("inter_conv%d" % L, cat), *self.heads[L])
+            flows[L] = flow
+        return flows[0], flows[1], flows[2]
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if not self.use_graph:
+            return self._forward(x)
+        if self._graph is None or self._static_in.shape != x.shape:
+            self._static_in = x.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):                     # warm-up outside the capture (MIOpen solver selection, allocations)
+                    self._forward(self._static_in)
+            torch.cuda.current_stream().wait_stream(s)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static_out = self._forward(self._static_in)
+        if x.data_ptr() != self._static_in.data_ptr():
+            self._static_in.copy_(x, non_blocking=True)
+        self._graph.replay()
+        return self._static_out

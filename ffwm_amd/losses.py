@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from . import ops
-from .external_function import BlockExtractor, LocalAttnReshape
+from .external_function import BlockExtractor, LocalAttnReshape, Resample2d
 
 
 class _FusedAffineReg(Function):
@@ -151,23 +151,26 @@ class PerceptualCorrectness(nn.Module):
     the flow, and neither the images nor VGG are trained, so they are evaluated under no_grad -- the
     reference back-propagates through a [B, N^2, N^2] matrix (1 GiB per sample at relu1_1) for nothing."""
 
-    def __init__(self, vgg, warp, layer=("relu1_1", "relu2_1", "relu3_1", "relu4_1")):
+    def __init__(self, vgg, warp, layer=("relu1_1", "relu2_1", "relu3_1", "relu4_1"), resample=None):
         super().__init__()
         self.vgg = vgg
         self.warp = warp
         self.layer = list(layer)
         self.eps = 1e-8
+        # losses.py:329: the Gaussian-weighted resampler of the `use_bilinear_sampling=False` branch (the one call site
+        # of resample2d in the reference; its flow argument is handed over unscaled, exactly as the reference does)
+        self.resample = resample if resample is not None else Resample2d(4, 1, sigma=2)
 
-    def forward(self, target, source, flow_list, used_layers, norm_mask=None):
+    def forward(self, target, source, flow_list, used_layers, norm_mask=None, use_bilinear_sampling=True):
         used_layers = sorted(used_layers, reverse=True)
         with torch.no_grad():
             self.target_vgg, self.source_vgg = self.vgg(target), self.vgg(source)
         loss = 0
         for i in range(len(flow_list)):
-            loss = loss + self.calculate_loss(flow_list[i], self.layer[used_layers[i]], norm_mask)
+            loss = loss + self.calculate_loss(flow_list[i], self.layer[used_layers[i]], norm_mask, use_bilinear_sampling)
         return loss
 
-    def calculate_loss(self, flow, layer, norm_mask=None):
+    def calculate_loss(self, flow, layer, norm_mask=None, use_bilinear_sampling=False):       # the reference's default (:342)
         target_vgg = self.target_vgg[layer]
         source_vgg = self.source_vgg[layer]
         b, c, h, w = target_vgg.shape
@@ -182,7 +185,10 @@ class PerceptualCorrectness(nn.Module):
                 correction_max = ops.correlation_colmax(source_norm, target_norm)   # MFMA, no [b, N2, N2] matrix
             else:
                 correction_max = torch.bmm(source_norm, target_norm).max(dim=1)[0]  # [b, N2]
-        input_sample = self.warp(source_vgg, flow).reshape(b, c, -1)
+        if use_bilinear_sampling:                                                  # losses.py:356-357
+            input_sample = self.warp(source_vgg, flow).reshape(b, c, -1)
+        else:                                                                      # losses.py:358-359 -> resample2d
+            input_sample = self.resample(source_vgg.contiguous(), flow.contiguous()).reshape(b, c, -1)
         correction_sample = F.cosine_similarity(input_sample, target_all)          # [b, N2]
         loss_map = torch.exp(-correction_sample / (correction_max + self.eps))
         e1 = torch.exp(torch.tensor(-1.0, dtype=loss_map.dtype, device=loss_map.device))

@@ -213,6 +213,30 @@ class FFWM(nn.Module):
         return out + (att,) if return_att else out
 
 
+class WarpAttention(nn.Module):
+    """The warp-attention module of netG by itself (base_networks.py:323-333), all three levels: warp the encoder
+    feature with the flow, flip, concatenate (one HIP kernel), run the attention convs `att_i` on it (conv block +
+    sigmoid residual block, spectrally normalised: :283-291), multiply.  This is the "warp+attention path" of
+    BASELINE.json's 3000 img/s target; bench.py times it forward + backward (`subpaths.warp_attention_path`).
+    Same submodule names (`att0`..`att2`) and widths as FFWM, so its weights are a slice of a netG state dict."""
+
+    LEVELS = ((128, 32), (64, 64), (64, 128))          # (encoder channels, plane size) of e2 / e1 / e0
+
+    def __init__(self, sn=True, warp_flipcat=None):
+        super().__init__()
+        for i, (c, _) in enumerate(self.LEVELS):
+            setattr(self, "att%d" % i, nn.Sequential(_conv_block(2 * c, 2 * c, 3, 1, 1, sn=sn),
+                                                     ResidualBlock(2 * c, 2 * c, activ="sigmoid", sn=sn)))
+        self._fused = warp_flipcat if warp_flipcat is not None else WarpFlipCat()
+
+    def forward(self, feats, flows):
+        outs = []
+        for i, (feat, flow) in enumerate(zip(feats, flows)):
+            skip = self._fused(feat, flow)
+            outs.append(skip * getattr(self, "att%d" % i)(skip))
+        return outs
+
+
 # =============================================================================== discriminator
 class MSDiscriminator(nn.Module):
     """Multi-scale spectral-norm patch discriminator (base_networks.py:354-437): one 3-conv net per

@@ -106,6 +106,10 @@ def _flush_hook(module, *args, **kwargs):
     module.flush_batch_counter()
 
 
+def _reset_hook(module, *args, **kwargs):
+    module._pending_batches = 0            # a loaded num_batches_tracked replaces whatever was counted before the load
+
+
 def fuse_bn_lrelu(net):
     """Re-class every BatchNorm2d that is directly followed by a LeakyReLU in an nn.Sequential; returns the count."""
     n = 0
@@ -118,6 +122,7 @@ def fuse_bn_lrelu(net):
                 a.negative_slope = b.negative_slope
                 a._pending_batches = 0
                 a.register_state_dict_pre_hook(_flush_hook)
+                a.register_load_state_dict_pre_hook(_reset_hook)
                 seq._modules[kb] = nn.Identity()
                 n += 1
     return n

@@ -59,12 +59,18 @@ def build_part_grid(lm, d):
     return (base.unsqueeze(0) + centre) / 64.0
 
 
-def part_grids(lm_F):
-    """Eye / nose / mouth centres from the landmark table (ffwm_model.py:217-234)."""
+def part_grids(lm_F, torch15_integer_division=False):
+    """Eye / nose / mouth centres from the landmark table (ffwm_model.py:217-234).
+
+    The mouth centre is `(min + max) / 2` on integer landmarks.  On the PyTorch of this image (>= 1.6) that is TRUE
+    division -- what the reference's code computes when imported here, and what tests/golden/reference_modules.pt pins
+    (default).  Under the reference's pinned PyTorch 1.5 (README.md:14) the same line floor-divides: the grid moves by
+    half a pixel whenever min + max is odd; `torch15_integer_division=True` reproduces that."""
     el, er = lm_F[:, 63:64], lm_F[:, 515:516]
     nc = lm_F[:, 429:430]
     mouth = torch.cat((lm_F[:, 64:128], lm_F[:, 516:580]), 1)
-    mc = (mouth.min(1, keepdim=True)[0] + mouth.max(1, keepdim=True)[0]) / 2
+    mc = mouth.min(1, keepdim=True)[0] + mouth.max(1, keepdim=True)[0]
+    mc = torch.div(mc, 2, rounding_mode="floor") if (torch15_integer_division and not mc.is_floating_point()) else mc / 2
     return [build_part_grid(c, 32) for c in (el, er, nc, mc)]
 
 
@@ -165,6 +171,10 @@ class FFWMTrainer(object):
             return torch.stack((xx, yy), 0).unsqueeze(0)
         targets = [grid(128), grid(64), grid(32)]
         last = []
+        # the throw-away optimisation must not drive the step's gradient reducer: its post-accumulate hooks would count
+        # these backward passes and launch all-reduces nobody waits for
+        overlap_before = self.red_G.overlap
+        self.red_G.set_overlap(False)
         for net in (self.flowNetF, self.flowNetB):
             params = [p for n, p in net.named_parameters() if not n.startswith("inter_conv_occ")]
             grads_before = [p.grad for p in params]          # views into the reducer's buckets: keep them
@@ -179,6 +189,8 @@ class FFWMTrainer(object):
             for p, g in zip(params, grads_before):
                 p.grad = g
             last.append(float(loss.detach()))
+        self.red_G.set_overlap(overlap_before)
+        self.red_G.zero_grad()                           # pending / launched counters back to a clean step
         broadcast_module_state([self.flowNetF, self.flowNetB])
         return last
 

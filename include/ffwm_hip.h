@@ -271,6 +271,24 @@ int ffwm_mfm_backward(const void* x, const void* bias, const void* grad_y, void*
  * as one pass; y may alias h. */
 int ffwm_bias_relu_forward(const void* h, const void* bias, void* y, int64_t B, int64_t C, int64_t HW, int dtype, void* stream);
 
+/* ---- FlowNet eval forward (models/base_networks.py:59-165, BASELINE configs[1]): the layers around the dense convolutions
+ * once BatchNorm is folded into the conv weights (ffwm_amd/flownet_eval.py).  Contiguous float32.
+ *
+ * ffwm_bias_act_forward: y = act(h[B,C,HW] + bias[C]) (bias may be NULL); act 0 = none, 1 = LeakyReLU(negative_slope),
+ * 2 = tanh.  Two optional destinations (either may be NULL, y may alias h): channel c of sample b is written at
+ * y + b * y_batch_stride + c * HW, so a destination can be a channel slice of a wider concatenation buffer
+ * (torch.cat of base_networks.py:133-151 without its copy kernel). */
+int ffwm_bias_act_forward(const void* h, const void* bias, void* y, void* y2, int64_t B, int64_t C, int64_t HW,
+                          int64_t y_batch_stride, int64_t y2_batch_stride, int act, double negative_slope, int dtype,
+                          void* stream);
+/* predict_flow* (base_networks.py:45-49): y[B,2,H,W] = tanh(conv2d(x[B,C,H,W], weight[2,C,3,3], bias[2], stride 1, pad 1)) */
+int ffwm_flow_head_forward(const void* x, const void* weight, const void* bias, void* y, int64_t B, int64_t C, int64_t H,
+                           int64_t W, int dtype, void* stream);
+/* upsampled_flow*_to_* (base_networks.py:104-109): out = conv_transpose2d(flow[B,2,H,W], weight[2,2,4,4], bias[2], stride 2,
+ * pad 1) -> [B,2,2H,2W], sample b written at out + b * out_batch_stride (a channel slice of the concatenation buffer). */
+int ffwm_flow_up_forward(const void* flow, const void* weight, const void* bias, void* out, int64_t B, int64_t H, int64_t W,
+                         int64_t out_batch_stride, int dtype, void* stream);
+
 /* One Adam step (no weight decay, no amsgrad: torch.optim.Adam as models/ffwm_model.py:46-49 and
  * models/flownet_model.py:33 construct it) over FLAT float32 arrays of n elements, 16-byte aligned: parameters,
  * gradients, first and second moments.  `step` is the 1-based step count (bias corrections 1 - beta^step). */

@@ -48,13 +48,15 @@ def _worker(rank, world, port, ret):
         batch = trainer.synthetic_batch(2, dev, seed=100 + rank)          # different data per rank
         t.pretrain_flow_identity(batch, steps=3)
         assert same_on_all_ranks(flat([t.flowNetF, t.flowNetB])), "flow nets differ after the pre-fit broadcast"
-        for _ in range(2):
-            t.step(batch)
+        # ten steps on per-rank data: BatchNorm statistics and the spectral-norm power-iteration vectors evolve PER RANK
+        # (dp.py: DDP's default behaviour), the weights must stay in lock-step through the averaged gradients
+        for i in range(10):
+            t.step(batch if i % 2 == 0 else trainer.synthetic_batch(2, dev, seed=200 + 10 * i + rank))
         torch.cuda.synchronize()
         vals = t.loss_values()
         assert all(torch.isfinite(torch.tensor(v)) for v in vals.values()), vals
         # identical averaged gradients -> identical Adam updates on every rank
-        assert same_on_all_ranks(flat(nets_), tol=1e-6), "weights diverged across ranks after two DP steps"
+        assert same_on_all_ranks(flat(nets_), tol=1e-6), "weights diverged across ranks after ten DP steps"
         assert same_on_all_ranks(t.red_G.buckets[0]["flat"], tol=0.0), "gradient buckets differ across ranks"
         ret[rank] = "ok"
     except Exception as e:
@@ -70,3 +72,26 @@ def test_dp_train_step_two_ranks_on_one_gpu():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def test_bench_launch_path_two_ranks_gloo():
+    """`bench.py --gpus 2` exactly as the driver launches it (python -m torch.distributed.run, one rank per process,
+    RANK / LOCAL_RANK / WORLD_SIZE from the environment), with FFWM_DIST_BACKEND=gloo so the two ranks may share
+    this box's single GPU: init_dist, per-rank batches, the reducers, the barrier + max-over-ranks timing and the ONE
+    JSON line from rank 0.  (RCCL itself needs one device per rank: that run is the driver's.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFWM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--flow-init", "random", "--no-kernels", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["grad_bytes_per_step"] > 400e6 and out["config"]["grad_buckets"] >= 2

@@ -1,0 +1,156 @@
+"""Rows a7 / a8 on the MI355X against the REFERENCE's modules (tests/golden/reference_modules.pt, produced by importing
+/root/reference/models/base_networks.py -- tests/golden/make_golden.py) -- run with ``-m gpu``.
+
+* `nets.FlowNet(4)` (base_networks.py:59-165) eval and train mode on the GPU with the fused BatchNorm + LeakyReLU kernel
+  FORCED for every pair (the production size gate of 1 M elements is lifted), against `flownet4_eval` / `flownet4_train`.
+* `nets.FFWM(sn=True)` (base_networks.py:274-347) eval on the GPU with the HIP `WarpFlipCat` kernel on the warp-attention
+  path (:323-333) and the batched spectral-norm kernels, against `ffwm_eval`.
+* full-size property runs: FlowNet(64) forward at batch 6 (BASELINE configs[1]) and one FFWM train step at batch 8
+  (configs[2]): finite, and equal to the unfused PyTorch paths.
+
+Tolerance: 1e-4 max abs diff (the north_star's fp32 bound) on tanh / sigmoid outputs in [-1, 1]; the CPU fixture test
+(tests/test_nets_golden.py) holds 2e-5 with ATen's CPU convolutions, the GPU runs MIOpen's.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import fill  # noqa: E402
+
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(os.path.join(HERE, "golden", "reference_modules.pt"))
+
+
+def _sub(t, s):
+    return t[..., ::s, ::s]
+
+
+def _close(a, b, tol=TOL):
+    d = (a.detach().cpu() - b).abs().max().item()
+    assert d <= tol, "max abs diff %.3e > %.1e" % (d, tol)
+    return d
+
+
+@pytest.fixture
+def every_bn_pair_fused(monkeypatch):
+    from ffwm_amd import norm
+    monkeypatch.setattr(norm, "MIN_FUSED_NUMEL", 0)
+    return norm
+
+
+def test_flownet4_on_gpu_matches_reference_fixture(gold, every_bn_pair_fused):
+    import copy
+    from ffwm_amd import nets
+    norm = every_bn_pair_fused
+    plain = fill.fill_module(nets.FlowNet(4)).to(DEV)          # nn.BatchNorm2d + nn.LeakyReLU, the stock GPU path
+    net = copy.deepcopy(plain)
+    fused = norm.fuse_bn_lrelu(net)
+    assert fused >= 30, fused                      # every conv block of FlowNet is conv + BN + LeakyReLU(0.2)
+    x = fill.image(2, 3, 128, 128, "flownet_in").to(DEV)
+    with torch.no_grad():
+        net.eval()                                  # eval mode: running statistics, the fused kernel stands aside
+        f128, f64, f32 = net(x)
+        g = gold["flownet4_eval"]
+        _close(_sub(f128, 2), g["flow128_s2"])
+        _close(f64, g["flow64"])
+        _close(f32, g["flow32"])
+        assert abs(f128.double().sum().item() - g["sum128"].item()) < 5e-2
+        # train mode: batch statistics through bn_lrelu_fwd_kernel.  Batch 2 at ngf = 4 normalises the 2 x 2 level over
+        # EIGHT values per channel, which amplifies the rounding of whatever convolution algorithm ran in front: the
+        # stock GPU path (MIOpen convolutions + ATen batch norm) itself sits 2-4e-4 from the CPU-made fixture.  So:
+        # the fused kernel must agree with the stock GPU path to 1e-4, and with the fixture to 1e-4 beyond what the stock
+        # GPU path deviates by.
+        net.train()
+        plain.train()
+        fused_out, plain_out = net(x), plain(x)
+        g = gold["flownet4_train"]
+        for a, b, ref in zip(fused_out, plain_out, (None, g["flow64"], g["flow32"])):
+            _close(a, b.cpu())
+            if ref is not None:
+                stock = (b.cpu() - ref).abs().max().item()
+                _close(a, ref, TOL + 2 * stock)
+        stock = (_sub(plain_out[0], 2).cpu() - g["flow128_s2"]).abs().max().item()
+        _close(_sub(fused_out[0], 2), g["flow128_s2"], TOL + 2 * stock)
+        assert stock <= 2e-3, stock
+        _close(net.conv0[1].running_mean, g["bn_mean_conv0"], 1e-5)
+
+
+def test_ffwm_generator_on_gpu_with_hip_warp_matches_reference_fixture(gold):
+    """netG with the product's own warp: WarpFlipCat (csrc/warp.hip) replaces grid_sample + flip + cat of
+    base_networks.py:326-329, fuse_spectral_norm replaces the 52 per-layer hooks."""
+    from ffwm_amd import nets
+    from ffwm_amd.external_function import WarpFlipCat
+    from ffwm_amd.spectral_norm import fuse_spectral_norm
+    netG = fill.fill_module(nets.FFWM(sn=True)).to(DEV).eval()
+    assert isinstance(netG._fused, WarpFlipCat)
+    fuse_spectral_norm(netG)
+    img = fill.image(1, 3, 128, 128, "netG_in").to(DEV)
+    flows = [fill.flow_field(1, s, s, "netG_flow%d" % s).to(DEV) for s in (32, 64, 128)]
+    with torch.no_grad():
+        r32, r64, r128, att = netG(img, flow=flows, return_att=True)
+    g = gold["ffwm_eval"]
+    _close(r32, g["rec32"])
+    _close(r64, g["rec64"])
+    _close(_sub(r128, 2), g["rec128_s2"])
+    _close(_sub(att, 8), g["att_s8"])
+    assert abs(r128.double().sum().item() - g["sum128"].item()) < 0.2
+    assert abs(att.double().sum().item() - g["att_sum"].item()) < 2.0
+
+
+def test_flownet64_batch6_forward_full_size_properties(every_bn_pair_fused):
+    """BASELINE configs[1]: FlowNetF forward-only, batch 6, 128 x 128 -- finite, in tanh's range, shaped as
+    base_networks.py:157-165 returns them, and the fused train-mode path equals nn.BatchNorm2d + nn.LeakyReLU."""
+    import copy
+    from ffwm_amd import nets
+    norm = every_bn_pair_fused
+    torch.manual_seed(0)
+    plain = nets.FlowNet(64).to(DEV)
+    fused = copy.deepcopy(plain)
+    assert norm.fuse_bn_lrelu(fused) >= 30
+    x = torch.rand(6, 3, 128, 128, generator=torch.Generator().manual_seed(1)).to(DEV)
+    with torch.no_grad():
+        for mode in ("eval", "train"):
+            getattr(plain, mode)()
+            getattr(fused, mode)()
+            a, b = plain(x), fused(x)
+            for fa, fb, s in zip(a, b, (128, 64, 32)):
+                assert tuple(fa.shape) == (6, 2, s, s)
+                assert torch.isfinite(fb).all() and fb.abs().max().item() <= 1.0
+                assert (fa - fb).abs().max().item() <= TOL, mode
+    # the launch-lean eval path (BatchNorm folded into the convolutions) against the module path
+    from ffwm_amd import flownet_eval
+    lean = flownet_eval.FoldedFlowNet(plain.eval())
+    with torch.no_grad():
+        for fa, fb in zip(plain(x), lean(x)):
+            assert (fa - fb).abs().max().item() <= TOL
+
+
+def test_ffwm_train_step_batch8_full_size_properties():
+    """BASELINE configs[2] at its real batch: one full FFWM train step (netG + netD + flowNetF/B, all losses, three
+    optimisers) at batch 8 -- finite losses, and the hand-written fast paths agree with the plain PyTorch paths."""
+    from ffwm_amd import trainer
+    batch = trainer.synthetic_batch(8, DEV, seed=11)
+    plain = trainer.FFWMTrainer(DEV, seed=2, mfma_wgrad=False, flat_adam=False, fused_bn=False, fused_spectral_norm=False,
+                                batched_losses=False, capturable=False)
+    plain.red_G.set_gather(False)
+    plain.red_D.set_gather(False)
+    fast = trainer.FFWMTrainer(DEV, seed=2)
+    lp, lf = plain.step(batch), fast.step(batch)
+    torch.cuda.synchronize()
+    for k in lp:
+        a, b = float(lp[k].detach()), float(lf[k].detach())
+        assert a == a and b == b and abs(b) < 1e6, (k, a, b)
+        assert abs(a - b) <= 2e-3 * (1 + abs(a)), (k, a, b)
+    for p in fast.netG.parameters():
+        assert torch.isfinite(p).all()

@@ -134,3 +134,35 @@ def test_live_block_extractor_and_reshape_cfg5_slice_against_the_reference_exten
     r_ref = torch.zeros(4, 1, 768, 768, device=DEV)
     lar.forward(attn, r_ref, 3)
     assert torch.equal(ops.local_attn_reshape_forward(attn, 3), r_ref)
+
+
+def test_perceptual_correctness_resample2d_branch_against_the_oracle_composition(oracle):
+    """The one call site of resample2d in the reference: PerceptualCorrectness.calculate_loss with
+    use_bilinear_sampling=False -> Resample2d(4, 1, sigma=2) (models/losses.py:329,356-359).  The HIP Function
+    inside the loss (value and gradient w.r.t. the flow) against the same loss composed on the CPU from the oracle's
+    resample2d (which tests/test_oracle_ref_golden.py pins to the reference's kernels)."""
+    import torch.nn as nn
+    from ffwm_amd.losses import PerceptualCorrectness
+
+    class OracleResample(nn.Module):
+        def forward(self, input1, flow):
+            sigma = torch.full((flow.size(0), 1, flow.size(2), flow.size(3)), 2.0, dtype=flow.dtype)
+            return oracle.Resample2dOracleFn.apply(input1.contiguous(), torch.cat((flow, sigma), 1).contiguous(), 4, 1, True)
+
+    g = torch.Generator().manual_seed(5)
+    tgt = torch.rand(2, 8, 16, 16, generator=g) + 0.1
+    src = torch.rand(2, 8, 16, 16, generator=g) + 0.1
+    flow = (torch.rand(2, 2, 32, 32, generator=g) * 2 - 1)
+    mask = (torch.rand(2, 1, 32, 32, generator=g) > 0.4).float()
+    results = []
+    for dev, resample in ((DEV, None), ("cpu", OracleResample())):
+        pc = PerceptualCorrectness(vgg=None, warp=None, resample=resample)
+        pc.target_vgg = {"relu1_1": tgt.to(dev)}
+        pc.source_vgg = {"relu1_1": src.to(dev)}
+        fl = flow.to(dev).requires_grad_(True)
+        loss = pc.calculate_loss(fl, "relu1_1", mask.to(dev))            # default: the resample2d branch
+        loss.backward()
+        results.append((float(loss), fl.grad.cpu()))
+    (lg, gg), (lc, gc) = results
+    assert abs(lg - lc) <= 1e-5 * (1 + abs(lc)), (lg, lc)
+    assert (gg - gc).abs().max().item() <= 1e-5 * (1 + gc.abs().max().item())

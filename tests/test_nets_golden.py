@@ -147,5 +147,5 @@ def test_flownet_pretraining_losses_match_reference(gold):
     pc.source_vgg = {"relu1_1": fill.image(2, 8, 16, 16, "pc_source") + 0.1}
     pflow = fill.flow_field(2, 32, 32, "pc_flow")
     pmask = (fill.image(2, 1, 32, 32, "pc_mask") > 0.4).float()
-    assert abs(float(pc.calculate_loss(pflow, "relu1_1", pmask)) - float(gold["correctness"]["masked"])) <= 1e-5
-    assert abs(float(pc.calculate_loss(pflow, "relu1_1", None)) - float(gold["correctness"]["unmasked"])) <= 1e-5
+    assert abs(float(pc.calculate_loss(pflow, "relu1_1", pmask, True)) - float(gold["correctness"]["masked"])) <= 1e-5
+    assert abs(float(pc.calculate_loss(pflow, "relu1_1", None, True)) - float(gold["correctness"]["unmasked"])) <= 1e-5
