@@ -41,6 +41,8 @@ _SIGNATURES = {
     "ffwm_resample2d_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _i, _i, _p],
     "ffwm_warp_forward": [_p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_warp_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_warp_multi_forward": [_p, _i, _i, _i, _p],          # (array of ffwm_warp_problem, n, flipcat, dtype, stream)
+    "ffwm_warp_multi_backward": [_p, _i, _i, _i, _p],
     # (host array of ffwm_sn_layer / ffwm_sn_grad_layer structs, see ffwm_amd/spectral_norm.py)
     "ffwm_spectral_norm_forward": [_p, _i, _i, ctypes.c_double, _i, _p],
     "ffwm_spectral_norm_backward": [_p, _i, _i, _p],
@@ -85,6 +87,12 @@ def load():
     if got != ABI_VERSION:
         raise FFWMError("libffwm_hip.so ABI version %d, expected %d: rebuild it" % (got, ABI_VERSION))
     _lib = lib
+    # FFWM_OPTS="key=value,key=value": tuning / ablation switches (ffwm_set_option) from the environment, for experiments
+    # with unmodified callers (bench.py, tools/)
+    for kv in filter(None, os.environ.get("FFWM_OPTS", "").split(",")):
+        k, _, v = kv.partition("=")
+        if lib.ffwm_set_option(k.strip().encode(), int(v)) < 0:
+            raise FFWMError("FFWM_OPTS: unknown option %r" % k)
     return lib
 
 

@@ -46,6 +46,10 @@ class LaunchScope {
     hipStream_t stream_;
 };
 
+// "<base>@<size>": an interned launch-scope name that keeps the levels of a multi-scale caller apart in the profile
+// (netG warps 32 x 32, 64 x 64 and 128 x 128 planes; only the last one is large enough to be HBM-bound).
+const char* scope_at(const char* base, int64_t size);
+
 // Pixel-tile launch geometry shared by the per-pixel kernels: a 64 x 4 pixel tile per block
 // (kTileX x kTileY), a slab of `cs` channels per block.
 struct Geometry {

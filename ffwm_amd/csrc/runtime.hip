@@ -44,6 +44,15 @@ void allow_large_lds(const void* kernel) {
     }
 }
 
+const char* scope_at(const char* base, int64_t size) {
+    static std::mutex mu;
+    static std::set<std::string> names;
+    char buf[96];
+    snprintf(buf, sizeof(buf), "%s@%lld", base, static_cast<long long>(size));
+    std::lock_guard<std::mutex> lk(mu);
+    return names.insert(buf).first->c_str();
+}
+
 Options& options() {
     static Options o;
     return o;

@@ -68,11 +68,8 @@ __device__ __forceinline__ void make_corners(Corners<T>& c, T gx, T gy, int Hi, 
 }
 
 template <typename T, bool FLIP>
-__global__ void __launch_bounds__(kBlock)
-warp_fwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, T* __restrict__ out, int C,
-                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs,
-                int remap) {
-    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+__device__ __forceinline__ void warp_fwd_body(const T* __restrict__ feat, const T* __restrict__ flow, T* __restrict__ out, int C,
+                                              int Hi, int Wi, int H, int W, const TileCoord tc, int cs) {
     const int x = tc.xf, y = tc.yf;
     if (x >= W || y >= H) return;
     const size_t plane = static_cast<size_t>(H) * W;
@@ -102,6 +99,58 @@ warp_fwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, T* __res
         buf_store_row<T, 1>(make_rsrc(op, obytes), o_direct, r);
         if (FLIP) buf_store_row<T, 1>(make_rsrc(op + flip_planes, obytes), o_flip, r);
     }
+}
+
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_fwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, T* __restrict__ out, int C,
+                int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs,
+                int remap) {
+    warp_fwd_body<T, FLIP>(feat, flow, out, C, Hi, Wi, H, W, decode_tile(tiles_x, tiles_y, cslabs, remap), cs);
+}
+
+// ---- several warps in ONE launch.  A train step of FFWM issues its warps in small groups whose members are
+// independent and individually launch-bound (models/ffwm_model.py:74-88: eight 32 x 32 part crops; losses.py:149: three
+// illumination warps; base_networks.py:323-333: the three warp-attention levels, 1.6 - 12.7 MB per image): the problem
+// table travels in the kernel arguments and a workgroup finds its problem from its index.
+constexpr int kMaxWarpProblems = 8;
+struct WarpProblem {
+    const void* feat;
+    const void* flow;
+    void* out;           // forward: output; backward: grad_flow (may be NULL)
+    const void* gout;    // backward: grad_output
+    int C, Hi, Wi, H, W;
+    int tiles_x, tiles_y, cslabs, cs;
+    unsigned begin;      // first workgroup of this problem
+};
+struct WarpTable {
+    int n;
+    WarpProblem p[kMaxWarpProblems];
+};
+
+__device__ __forceinline__ TileCoord decode_tile_local(unsigned t, int tiles_x, int tiles_y, int cslabs) {
+    TileCoord tc;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    t /= tiles_y;
+    tc.slab = t % cslabs;
+    tc.b = t / cslabs;
+    tc.xf = tx * kTileX + (threadIdx.x & (kTileX - 1));
+    tc.yf = ty * kTileY + (threadIdx.x / kTileX);
+    return tc;
+}
+
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_fwd_multi_kernel(const WarpTable tab) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxWarpProblems; ++k)
+        if (k < tab.n && blockIdx.x >= tab.p[k].begin) i = k;
+    const WarpProblem& q = tab.p[i];
+    warp_fwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<T*>(q.out), q.C, q.Hi, q.Wi,
+                           q.H, q.W, decode_tile_local(blockIdx.x - q.begin, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
 }
 
 // ------------------------------------------------------------------------------ forward, LDS-staged
@@ -311,11 +360,9 @@ warp_fwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ fl
 }
 
 template <typename T, bool FLIP>
-__global__ void __launch_bounds__(kBlock)
-warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T* __restrict__ gout,
-                T* __restrict__ gfeat, T* __restrict__ gflow, int C, int Hi, int Wi, int H, int W,
-                int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
-    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, remap);
+__device__ __forceinline__ void warp_bwd_body(const T* __restrict__ feat, const T* __restrict__ flow, const T* __restrict__ gout,
+                                              T* __restrict__ gfeat, T* __restrict__ gflow, int C, int Hi, int Wi, int H, int W,
+                                              const TileCoord tc, int cs) {
     const int x = tc.xf, y = tc.yf;
     if (x >= W || y >= H) return;
     const size_t plane = static_cast<size_t>(H) * W;
@@ -366,6 +413,28 @@ warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T*
         atomic_add(gflow + foff, (static_cast<T>(Wi) / 2) * gix);
         atomic_add(gflow + foff + plane, (static_cast<T>(Hi) / 2) * giy);
     }
+}
+
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T* __restrict__ gout,
+                T* __restrict__ gfeat, T* __restrict__ gflow, int C, int Hi, int Wi, int H, int W,
+                int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+    warp_bwd_body<T, FLIP>(feat, flow, gout, gfeat, gflow, C, Hi, Wi, H, W, decode_tile(tiles_x, tiles_y, cslabs, remap), cs);
+}
+
+// d(flow) of several warps in one launch (the pixel-major kernel with grad_feat == NULL)
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_bwd_flow_multi_kernel(const WarpTable tab) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxWarpProblems; ++k)
+        if (k < tab.n && blockIdx.x >= tab.p[k].begin) i = k;
+    const WarpProblem& q = tab.p[i];
+    warp_bwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<const T*>(q.gout), nullptr,
+                           static_cast<T*>(q.out), q.C, q.Hi, q.Wi, q.H, q.W,
+                           decode_tile_local(blockIdx.x - q.begin, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
 }
 
 // d(feat) without contended global atomics: a block owns `cg` whole (b, c) planes of grad_feat in LDS.
@@ -496,7 +565,7 @@ int launch_fwd(const T* feat, const T* flow, T* out, int64_t B, int64_t C, int64
                          (static_cast<double>(C) * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W);
     const Geometry g = plan(B, C, H, W, 16);
     const int remap = options().xcd_remap;
-    LaunchScope ls(flip ? "warp_flipcat_fwd" : "warp_fwd", st, bytes);
+    LaunchScope ls(scope_at(flip ? "warp_flipcat_fwd" : "warp_fwd", H), st, bytes);
     // warp_fwd_variant: 0 = auto (LDS-staged tiles for large float outputs), 1 = direct gathers, 2 = LDS-staged
     if constexpr (sizeof(T) == 4) {
         const int variant = options().warp_fwd_variant;
@@ -504,7 +573,7 @@ int launch_fwd(const T* feat, const T* flow, T* out, int64_t B, int64_t C, int64
         //  on the <= 34 MB tensors of netG the direct kernel is as fast or faster)
         if (variant == 2 || (variant == 0 && H >= 64 && W >= 64 && B * C * H * W >= (1LL << 24))) {
             const int txs = static_cast<int>((W + kWlTileX - 1) / kWlTileX), tys = static_cast<int>((H + kWlTileY - 1) / kWlTileY);
-            int cs = options().channel_slab > 0 ? options().channel_slab : 16;
+            int cs = options().channel_slab > 0 ? options().channel_slab : 32;      // measured at [32,64,256,256]: 8 / 16 / 32 / 64 -> 4.4 / 4.8 / 5.0 / 4.9 TB/s
             if (cs > C) cs = static_cast<int>(C);
             while (cs > 2 && B * txs * tys * ((C + cs - 1) / cs) < 2048) cs = (cs + 1) / 2;
             const int cslabs = static_cast<int>((C + cs - 1) / cs);
@@ -539,7 +608,7 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
     const PlanePlan pp = plan_planes(B, C, Hi * Wi, H * W, sizeof(T) == 8 ? 2 : 8);
     if (gfeat && pp.ok && options().scatter_variant != 1) {
         {   // d(feat): LDS-resident planes, no contended global atomics
-            LaunchScope ls(flip ? "warp_flipcat_bwd_feat" : "warp_bwd_feat", st,
+            LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat" : "warp_bwd_feat", Hi), st,
                            sizeof(T) * static_cast<double>(B) * (2.0 * C * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
             const unsigned grid = static_cast<unsigned>(B * pp.groups * pp.nsplit);
 #define FFWM_WARP_PLANE(FL, CG)                                                                              \
@@ -569,7 +638,7 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
         gfeat = nullptr;   // the pixel-major kernel below now only produces d(flow)
     }
     const Geometry g = plan(B, C, H, W, 32);
-    LaunchScope ls(gfeat ? (flip ? "warp_flipcat_bwd" : "warp_bwd") : (flip ? "warp_flipcat_bwd_flow" : "warp_bwd_flow"), st,
+    LaunchScope ls(scope_at(gfeat ? (flip ? "warp_flipcat_bwd" : "warp_bwd") : (flip ? "warp_flipcat_bwd_flow" : "warp_bwd_flow"), H), st,
                    gfeat ? bytes : sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
     if (flip)
         hipLaunchKernelGGL((warp_bwd_kernel<T, true>), dim3(g.grid), dim3(kBlock), 0, st, feat, flow, gout,
@@ -580,6 +649,91 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
                            gfeat, gflow, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, g.tiles_x, g.tiles_y,
                            g.cslabs, g.cs, remap);
     return check_launch("ffwm_warp_backward");
+}
+
+
+inline bool fwd_wants_lds(int64_t B, int64_t C, int64_t H, int64_t W, size_t esz) {
+    const int variant = options().warp_fwd_variant;
+    return esz == 4 && (variant == 2 || (variant == 0 && H >= 64 && W >= 64 && B * C * H * W >= (1LL << 24)));
+}
+
+inline void fill_problem(WarpProblem& q, const ffwm_warp_problem& pr, int cs_default, unsigned begin) {
+    const Geometry g = plan(pr.B, pr.C, pr.H, pr.W, cs_default);
+    q.C = static_cast<int>(pr.C); q.Hi = static_cast<int>(pr.Hi); q.Wi = static_cast<int>(pr.Wi);
+    q.H = static_cast<int>(pr.H); q.W = static_cast<int>(pr.W);
+    q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.cslabs = g.cslabs; q.cs = g.cs;
+    q.begin = begin;
+}
+
+template <typename T>
+int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_t st) {
+    WarpTable tab;
+    tab.n = 0;
+    unsigned blocks = 0;
+    double bytes = 0;
+    auto flush = [&]() -> int {
+        if (tab.n == 0) return FFWM_OK;
+        {
+            LaunchScope ls(flip ? "warp_flipcat_fwd_multi" : "warp_fwd_multi", st, bytes);
+            if (flip) hipLaunchKernelGGL((warp_fwd_multi_kernel<T, true>), dim3(blocks), dim3(kBlock), 0, st, tab);
+            else hipLaunchKernelGGL((warp_fwd_multi_kernel<T, false>), dim3(blocks), dim3(kBlock), 0, st, tab);
+        }
+        tab.n = 0; blocks = 0; bytes = 0;
+        return check_launch("ffwm_warp_multi_forward");
+    };
+    for (int i = 0; i < n; ++i) {
+        const ffwm_warp_problem& pr = probs[i];
+        if (fwd_wants_lds(pr.B, pr.C, pr.H, pr.W, sizeof(T))) {      // HBM-resident output: the tile kernel, by itself
+            if (int rc = launch_fwd<T>((const T*)pr.feat, (const T*)pr.flow, (T*)pr.output, pr.B, pr.C, pr.Hi, pr.Wi, pr.H, pr.W, flip, st)) return rc;
+            continue;
+        }
+        WarpProblem& q = tab.p[tab.n];
+        q.feat = pr.feat; q.flow = pr.flow; q.out = pr.output; q.gout = nullptr;
+        fill_problem(q, pr, 16, blocks);
+        blocks += plan(pr.B, pr.C, pr.H, pr.W, 16).grid;
+        bytes += sizeof(T) * static_cast<double>(pr.B) * (static_cast<double>(pr.C) * pr.Hi * pr.Wi + 2.0 * pr.H * pr.W + (flip ? 2.0 : 1.0) * pr.C * pr.H * pr.W);
+        if (++tab.n == kMaxWarpProblems)
+            if (int rc = flush()) return rc;
+    }
+    return flush();
+}
+
+template <typename T>
+int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_t st) {
+    // d(feat): one plane launch per problem (the LDS footprint is per plane size; scope names carry the level)
+    for (int i = 0; i < n; ++i) {
+        const ffwm_warp_problem& pr = probs[i];
+        if (!pr.grad_feat) continue;
+        if (int rc = launch_bwd<T>((const T*)pr.feat, (const T*)pr.flow, (const T*)pr.grad_output, (T*)pr.grad_feat, nullptr, pr.B, pr.C,
+                                   pr.Hi, pr.Wi, pr.H, pr.W, flip, st)) return rc;
+    }
+    // d(flow): every problem that wants it, one launch
+    WarpTable tab;
+    tab.n = 0;
+    unsigned blocks = 0;
+    double bytes = 0;
+    auto flush = [&]() -> int {
+        if (tab.n == 0) return FFWM_OK;
+        {
+            LaunchScope ls(flip ? "warp_flipcat_bwd_flow_multi" : "warp_bwd_flow_multi", st, bytes);
+            if (flip) hipLaunchKernelGGL((warp_bwd_flow_multi_kernel<T, true>), dim3(blocks), dim3(kBlock), 0, st, tab);
+            else hipLaunchKernelGGL((warp_bwd_flow_multi_kernel<T, false>), dim3(blocks), dim3(kBlock), 0, st, tab);
+        }
+        tab.n = 0; blocks = 0; bytes = 0;
+        return check_launch("ffwm_warp_multi_backward(flow)");
+    };
+    for (int i = 0; i < n; ++i) {
+        const ffwm_warp_problem& pr = probs[i];
+        if (!pr.grad_flow) continue;
+        WarpProblem& q = tab.p[tab.n];
+        q.feat = pr.feat; q.flow = pr.flow; q.out = pr.grad_flow; q.gout = pr.grad_output;
+        fill_problem(q, pr, 32, blocks);
+        blocks += plan(pr.B, pr.C, pr.H, pr.W, 32).grid;
+        bytes += sizeof(T) * static_cast<double>(pr.B) * (static_cast<double>(pr.C) * pr.Hi * pr.Wi + 4.0 * pr.H * pr.W + (flip ? 2.0 : 1.0) * pr.C * pr.H * pr.W);
+        if (++tab.n == kMaxWarpProblems)
+            if (int rc = flush()) return rc;
+    }
+    return flush();
 }
 
 }  // namespace
@@ -614,4 +768,26 @@ extern "C" int ffwm_warp_backward(const void* feat, const void* flow, const void
                                  (float*)grad_feat, (float*)grad_flow, B, C, Hi, Wi, H, W, flipcat, st);
     return launch_bwd<double>((const double*)feat, (const double*)flow, (const double*)grad_output,
                               (double*)grad_feat, (double*)grad_flow, B, C, Hi, Wi, H, W, flipcat, st);
+}
+
+extern "C" int ffwm_warp_multi_forward(const ffwm_warp_problem* problems, int n, int flipcat, int dtype, void* stream) {
+    const char* fn = "ffwm_warp_multi_forward";
+    FFWM_REQUIRE(problems && n > 0, FFWM_ERR_ARG, "%s: empty problem list", fn);
+    for (int i = 0; i < n; ++i) {
+        FFWM_REQUIRE(problems[i].feat && problems[i].flow && problems[i].output, FFWM_ERR_ARG, "%s: NULL tensor pointer in problem %d", fn, i);
+        if (int rc = check_dims(fn, problems[i].B, problems[i].C, problems[i].Hi, problems[i].Wi, problems[i].H, problems[i].W, dtype)) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == FFWM_F32 ? launch_fwd_multi<float>(problems, n, flipcat, st) : launch_fwd_multi<double>(problems, n, flipcat, st);
+}
+
+extern "C" int ffwm_warp_multi_backward(const ffwm_warp_problem* problems, int n, int flipcat, int dtype, void* stream) {
+    const char* fn = "ffwm_warp_multi_backward";
+    FFWM_REQUIRE(problems && n > 0, FFWM_ERR_ARG, "%s: empty problem list", fn);
+    for (int i = 0; i < n; ++i) {
+        FFWM_REQUIRE(problems[i].feat && problems[i].flow && problems[i].grad_output, FFWM_ERR_ARG, "%s: NULL tensor pointer in problem %d", fn, i);
+        if (int rc = check_dims(fn, problems[i].B, problems[i].C, problems[i].Hi, problems[i].Wi, problems[i].H, problems[i].W, dtype)) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == FFWM_F32 ? launch_bwd_multi<float>(problems, n, flipcat, st) : launch_bwd_multi<double>(problems, n, flipcat, st);
 }

@@ -251,6 +251,42 @@ class WarpFunction(Function):
         return grad_feat, grad_flow, None
 
 
+class WarpMultiFunction(Function):
+    """apply(flipcat, n, feat_0..feat_{n-1}, flow_0..flow_{n-1}) -> n warped tensors: n independent WarpFunction calls
+    as one forward launch, one d(flow) launch and one d(feat) launch per plane size (csrc/warp.hip, multi-problem
+    tables).  autograd runs the backward once, when the gradients of all n outputs are known."""
+
+    @staticmethod
+    def forward(ctx, flipcat, n, *tensors):
+        feats = [t.contiguous() for t in tensors[:n]]
+        flows = [t.contiguous() for t in tensors[n:]]
+        _require_cuda(feats[0])
+        ctx.save_for_backward(*(feats + flows))
+        ctx.flipcat, ctx.n = bool(flipcat), n
+        return tuple(ops.warp_multi_forward(feats, flows, ctx.flipcat))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        feats, flows = list(saved[:n]), list(saved[n:])
+        need = ctx.needs_input_grad[2:]
+        gfe = [torch.zeros_like(feats[i]) if need[i] else None for i in range(n)]
+        gfl = [torch.zeros_like(flows[i]) if need[n + i] else None for i in range(n)]
+        gos = [g.contiguous() if g is not None else torch.zeros(
+            (feats[i].size(0), (2 if ctx.flipcat else 1) * feats[i].size(1)) + tuple(flows[i].shape[2:]),
+            device=feats[i].device, dtype=feats[i].dtype) for i, g in enumerate(grads)]
+        if any(need):
+            ops.warp_multi_backward(feats, flows, gos, ctx.flipcat, gfe, gfl)
+        return (None, None) + tuple(gfe) + tuple(gfl)
+
+
+def warp_many(feats, flows, flipcat=False):
+    """[WarpNet()(f, fl) for f, fl in zip(feats, flows)] (or the flip + cat form) as one multi-problem call."""
+    feats, flows = list(feats), list(flows)
+    return list(WarpMultiFunction.apply(flipcat, len(feats), *(feats + flows)))
+
+
 class WarpNet(nn.Module):
     """Same call as the reference's WarpNet (models/base_networks.py:168-173); bilinear only."""
 

@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
-from .external_function import WarpFlipCat, WarpNet
+from .external_function import WarpFlipCat, WarpNet, warp_many
 
 LRELU = 0.2
 
@@ -187,11 +187,21 @@ class FFWM(nn.Module):
                                                      ResidualBlock(c, c, activ="sigmoid", sn=sn)))
         self.warpNet = WarpNet()
         self._fused = warp_flipcat if warp_flipcat is not None else WarpFlipCat()
+        self._multi = warp_flipcat is None           # the HIP path: all levels' warps in one multi-problem launch
 
     def _skip(self, feat, flow):
         if self.isflip:
             return self._fused(feat, flow)            # cat(w, flip(w, 3)) in one kernel
         return self.warpNet(feat, flow)
+
+    def _skips(self, enc, flow):
+        """warp + flip + cat of every level (base_networks.py:326-329).  The encoder features and the flows are all known
+        once the encoder has run, so on the GPU the levels go out as ONE launch (external_function.warp_many) instead
+        of one launch-bound kernel per level; the backward runs once, after the decoder's."""
+        feats = [enc[self.layers - 1 - i] for i in range(self.layers)]
+        if self._multi and feats[0].is_cuda:
+            return warp_many(feats, [flow[i] for i in range(self.layers)], self.isflip)
+        return [self._skip(f, flow[i]) for i, f in enumerate(feats)]
 
     def forward(self, x, flow=None, return_att=False):
         enc = [self.e0(x)]
@@ -199,9 +209,10 @@ class FFWM(nn.Module):
             enc.append(getattr(self, "e%d" % i)(enc[-1]))
         fdec = enc[-1]
         recons, att = [], None
+        skips = self._skips(enc, flow)
         for i in range(self.layers):
             dec = getattr(self, "d%d" % i)(fdec)
-            skip = self._skip(enc[self.layers - 1 - i], flow[i])
+            skip = skips[i]
             att = getattr(self, "att%d" % i)(skip)
             skip = skip * att
             parts = [skip, dec]
@@ -228,13 +239,14 @@ class WarpAttention(nn.Module):
             setattr(self, "att%d" % i, nn.Sequential(_conv_block(2 * c, 2 * c, 3, 1, 1, sn=sn),
                                                      ResidualBlock(2 * c, 2 * c, activ="sigmoid", sn=sn)))
         self._fused = warp_flipcat if warp_flipcat is not None else WarpFlipCat()
+        self._multi = warp_flipcat is None
 
     def forward(self, feats, flows):
-        outs = []
-        for i, (feat, flow) in enumerate(zip(feats, flows)):
-            skip = self._fused(feat, flow)
-            outs.append(skip * getattr(self, "att%d" % i)(skip))
-        return outs
+        if self._multi and feats[0].is_cuda:
+            skips = warp_many(list(feats), list(flows), True)
+        else:
+            skips = [self._fused(feat, flow) for feat, flow in zip(feats, flows)]
+        return [skip * getattr(self, "att%d" % i)(skip) for i, skip in enumerate(skips)]
 
 
 # =============================================================================== discriminator

@@ -5,6 +5,8 @@ call into libffwm_hip.so through ``include/ffwm_hip.h``.  CPU tensors are refuse
 reference's wrappers refuse them (/root/reference/models/external_function.py:37-38,84-85):
 there is no CPU or eager fallback in this package.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -270,6 +272,51 @@ def warp_backward(feat, flow, grad_output, flipcat=False, grad_feat=None, grad_f
             _ptr(feat), _ptr(flow), _ptr(grad_output), _ptr(grad_feat), _ptr(grad_flow), B, C, Hi, Wi, H, W,
             1 if flipcat else 0, _dtype_code(feat), stream), "ffwm_warp_backward")
     return grad_feat, grad_flow
+
+
+class _WarpProblem(ctypes.Structure):          # include/ffwm_hip.h: ffwm_warp_problem
+    _fields_ = [("feat", ctypes.c_void_p), ("flow", ctypes.c_void_p), ("output", ctypes.c_void_p),
+                ("grad_output", ctypes.c_void_p), ("grad_feat", ctypes.c_void_p), ("grad_flow", ctypes.c_void_p),
+                ("B", ctypes.c_int64), ("C", ctypes.c_int64), ("Hi", ctypes.c_int64), ("Wi", ctypes.c_int64),
+                ("H", ctypes.c_int64), ("W", ctypes.c_int64)]
+
+
+def _warp_table(feats, flows, outs=None, grad_outputs=None, grad_feats=None, grad_flows=None):
+    n = len(feats)
+    arr = (_WarpProblem * n)()
+    for i in range(n):
+        B, C, Hi, Wi = feats[i].shape
+        Bf, two, H, W = flows[i].shape
+        if two != 2 or Bf != B:
+            raise ValueError("warp_multi: flow %d must be [B,2,H,W] with the feature's batch" % i)
+        a = arr[i]
+        a.feat, a.flow = _ptr(feats[i]), _ptr(flows[i])
+        a.output = _ptr(outs[i]) if outs is not None else None
+        a.grad_output = _ptr(grad_outputs[i]) if grad_outputs is not None else None
+        a.grad_feat = _ptr(grad_feats[i]) if grad_feats is not None and grad_feats[i] is not None else None
+        a.grad_flow = _ptr(grad_flows[i]) if grad_flows is not None and grad_flows[i] is not None else None
+        a.B, a.C, a.Hi, a.Wi, a.H, a.W = B, C, Hi, Wi, H, W
+    return arr
+
+
+def warp_multi_forward(feats, flows, flipcat=False):
+    """Several independent warps (lists of equal length) in one or two launches; -> list of outputs."""
+    _check("warp_multi_forward", *(list(feats) + list(flows)))
+    outs = [f.new_empty((f.size(0), (2 if flipcat else 1) * f.size(1), fl.size(2), fl.size(3))) for f, fl in zip(feats, flows)]
+    arr = _warp_table(feats, flows, outs=outs)
+    with _on_device(feats[0]) as stream:
+        _lib.check(_lib.load().ffwm_warp_multi_forward(ctypes.cast(arr, ctypes.c_void_p), len(feats), 1 if flipcat else 0,
+                                                       _dtype_code(feats[0]), stream), "ffwm_warp_multi_forward")
+    return outs
+
+
+def warp_multi_backward(feats, flows, grad_outputs, flipcat, grad_feats, grad_flows):
+    """grad_feats[i] / grad_flows[i]: zero-filled tensors to accumulate into, or None."""
+    _check("warp_multi_backward", *(list(feats) + list(flows) + list(grad_outputs)))
+    arr = _warp_table(feats, flows, grad_outputs=grad_outputs, grad_feats=grad_feats, grad_flows=grad_flows)
+    with _on_device(feats[0]) as stream:
+        _lib.check(_lib.load().ffwm_warp_multi_backward(ctypes.cast(arr, ctypes.c_void_p), len(feats), 1 if flipcat else 0,
+                                                        _dtype_code(feats[0]), stream), "ffwm_warp_multi_backward")
 
 
 # ---------------------------------------------------------------- guided filter

@@ -82,6 +82,12 @@ class FFWMTrainer(object):
         self.titers = titers
         torch.manual_seed(seed)
         self.warp = warp if warp is not None else WarpNet()
+        if warp is None and self.device.type == "cuda":
+            # independent warps issued together go out as ONE multi-problem launch (csrc/warp.hip)
+            from .external_function import warp_many as _hip_warp_many
+            self.warp_many = lambda feats, flows: _hip_warp_many(feats, flows, False)
+        else:
+            self.warp_many = lambda feats, flows: [self.warp(f, fl) for f, fl in zip(feats, flows)]
         self.flowNetF = nets.FlowNet(ngf).to(self.device)
         if self.device.type == "cuda":
             from . import miopen_tuning
@@ -247,11 +253,12 @@ class FFWMTrainer(object):
         """MSL1Loss (losses.py:130-157): warp each generated scale back with flowNetB and compare
         with the (resized) profile input."""
         total = 0
-        for w, flow, fake in zip((1, 1, 1.5), flows_B, fakes):
+        warped = self.warp_many(list(fakes), list(flows_B))            # the three scales: one launch
+        for w, flow, back in zip((1, 1, 1.5), flows_B, warped):
             size = flow.shape[2:]
             tgt = F.interpolate(img_S, size, mode="bilinear", align_corners=True)
             m = F.interpolate(mask_S, size, mode="nearest")
-            total = total + w * F.l1_loss(self.warp(fake, flow) * m, tgt * m)
+            total = total + w * F.l1_loss(back * m, tgt * m)
         return total
 
     @staticmethod
@@ -262,14 +269,13 @@ class FFWMTrainer(object):
     def forward(self, b):
         img_S, img_F = b["img_S"], b["img_F"]
         flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
-        self.img_S_warp = self.warp(img_S, flow_F128)
         self.flows_B = self.flowNetB(img_S)
-        self.img_S_rec = self.warp(img_F, self.flows_B[0])
+        self.img_S_warp, self.img_S_rec = self.warp_many([img_S, img_F], [flow_F128, self.flows_B[0]])
         self.fake32, self.fake64, self.fake128 = self.netG(img_S, flow=[flow_F32, flow_F64, flow_F128])
         self.img_GF128 = self.gf[128](self.fake128, img_F)
-        self.parts = []
-        for grid in part_grids(b["lm_F"]):       # eye-l, eye-r, nose, mouth
-            self.parts.append((self.warp(self.img_GF128, grid), self.warp(img_F, grid)))
+        grids = part_grids(b["lm_F"])            # eye-l, eye-r, nose, mouth
+        crops = self.warp_many([self.img_GF128, img_F] * len(grids), [g for g in grids for _ in (0, 1)])   # 8 crops: one launch
+        self.parts = [(crops[2 * i], crops[2 * i + 1]) for i in range(len(grids))]
 
     def backward_D(self, b):
         m = b["mask_F"]
@@ -484,6 +490,12 @@ class FlowNetTrainer(object):
         self.device = torch.device(device)
         torch.manual_seed(seed)
         self.warp = warp if warp is not None else WarpNet()
+        if warp is None and self.device.type == "cuda":
+            # independent warps issued together go out as ONE multi-problem launch (csrc/warp.hip)
+            from .external_function import warp_many as _hip_warp_many
+            self.warp_many = lambda feats, flows: _hip_warp_many(feats, flows, False)
+        else:
+            self.warp_many = lambda feats, flows: [self.warp(f, fl) for f, fl in zip(feats, flows)]
         if self.device.type == "cuda":
             from . import miopen_tuning
             miopen_tuning.install()

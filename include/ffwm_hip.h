@@ -126,6 +126,23 @@ int ffwm_warp_backward(const void* feat, const void* flow, const void* grad_outp
                        void* grad_feat, void* grad_flow, int64_t B, int64_t C, int64_t Hi,
                        int64_t Wi, int64_t H, int64_t W, int flipcat, int dtype, void* stream);
 
+/* Several independent warps in one call (at most a few launches): FFWM issues its warps in groups -- the eight 32 x 32
+ * part crops of models/ffwm_model.py:84-88, the three illumination warps of models/losses.py:149, the three
+ * warp-attention levels of models/base_networks.py:323-333 -- whose members are individually launch-bound.  Same
+ * semantics per problem as ffwm_warp_forward / ffwm_warp_backward (grad_feat / grad_flow accumulate, either may be NULL;
+ * forward ignores the three gradient fields).  All problems share flipcat and dtype. */
+typedef struct ffwm_warp_problem {
+    const void* feat;        /* [B,C,Hi,Wi] */
+    const void* flow;        /* [B,2,H,W] */
+    void* output;            /* forward: [B,C,H,W] or [B,2C,H,W] */
+    const void* grad_output; /* backward */
+    void* grad_feat;         /* backward, may be NULL */
+    void* grad_flow;         /* backward, may be NULL */
+    int64_t B, C, Hi, Wi, H, W;
+} ffwm_warp_problem;
+int ffwm_warp_multi_forward(const ffwm_warp_problem* problems, int n, int flipcat, int dtype, void* stream);
+int ffwm_warp_multi_backward(const ffwm_warp_problem* problems, int n, int flipcat, int dtype, void* stream);
+
 /* ---- batched spectral normalisation of conv weights (netG / netD) -----------------------------
  * Replaces the per-layer hook of torch.nn.utils.spectral_norm that the reference wraps around every
  * convolution of FFWM and MSDiscriminator (models/base_networks.py:5,218-264,381-413):

@@ -67,16 +67,19 @@ def test_flownet4_on_gpu_matches_reference_fixture(gold, every_bn_pair_fused):
         _close(f32, g["flow32"])
         assert abs(f128.double().sum().item() - g["sum128"].item()) < 5e-2
         # train mode: batch statistics through bn_lrelu_fwd_kernel.  Batch 2 at ngf = 4 normalises the 2 x 2 level over
-        # EIGHT values per channel, which amplifies the rounding of whatever convolution algorithm ran in front: the
-        # stock GPU path (MIOpen convolutions + ATen batch norm) itself sits 2-4e-4 from the CPU-made fixture.  So:
-        # the fused kernel must agree with the stock GPU path to 1e-4, and with the fixture to 1e-4 beyond what the stock
-        # GPU path deviates by.
+        # EIGHT values per channel, which amplifies fp32 rounding whatever kernel produced it: the stock GPU path (MIOpen
+        # convolutions + ATen batch norm) itself sits 2-4e-4 from the CPU-made fixture.  So the fused kernel is held to
+        # the accuracy of the stock path, measured against a float64 evaluation of the same network on the GPU, and to
+        # the fixture within what the stock path deviates from it.
+        ref64 = copy.deepcopy(plain).double().train()
         net.train()
         plain.train()
-        fused_out, plain_out = net(x), plain(x)
+        fused_out, plain_out, f64_out = net(x), plain(x), ref64(x.double())
         g = gold["flownet4_train"]
-        for a, b, ref in zip(fused_out, plain_out, (None, g["flow64"], g["flow32"])):
-            _close(a, b.cpu())
+        for a, b, r64, ref in zip(fused_out, plain_out, f64_out, (None, g["flow64"], g["flow32"])):
+            err_fused = (a.double() - r64).abs().max().item()
+            err_stock = (b.double() - r64).abs().max().item()
+            assert err_fused <= max(TOL, 2 * err_stock), (err_fused, err_stock)
             if ref is not None:
                 stock = (b.cpu() - ref).abs().max().item()
                 _close(a, ref, TOL + 2 * stock)

@@ -1241,3 +1241,55 @@ def test_vgg_and_lightcnn_fused_activations_match_the_module_paths():
     outs_ref = ref.eval()(g1.cpu())                       # CPU tensors take the unfused branch
     for a, b in zip(outs if isinstance(outs, (tuple, list)) else [outs], outs_ref if isinstance(outs_ref, (tuple, list)) else [outs_ref]):
         _close(a, b, 2e-4, relative=True)
+
+
+# ------------------------------------------------------------------------- several warps in one launch
+@pytest.mark.parametrize("flipcat", [False, True])
+def test_warp_many_matches_the_oracle_per_problem(oracle, flipcat):
+    """external_function.warp_many (csrc/warp.hip multi-problem tables: one forward launch, one d(flow) launch, d(feat)
+    per plane size) against the oracle's warp on every problem: the three netG levels' shapes in small, a group of equal
+    shapes (the part crops of ffwm_model.py:84-88: a 128 x 128 image sampled on 32 x 32 grids), and a problem whose flow
+    needs no gradient."""
+    from ffwm_amd.external_function import warp_many
+    g = _gen(21)
+    shapes = [(2, 16, 8, 8, 8, 8), (2, 8, 16, 16, 16, 16), (2, 8, 33, 70, 33, 70), (2, 3, 64, 64, 16, 16), (2, 3, 64, 64, 16, 16)]
+    feats = [torch.rand(B, C, Hi, Wi, generator=g) for B, C, Hi, Wi, H, W in shapes]
+    flows = [torch.rand(B, 2, H, W, generator=g) * 2.2 - 1.1 for B, C, Hi, Wi, H, W in shapes]
+    gos = [torch.rand(B, (2 if flipcat else 1) * C, H, W, generator=g) for B, C, Hi, Wi, H, W in shapes]
+    df = [f.to(DEV).requires_grad_(True) for f in feats]
+    dl = [f.to(DEV).requires_grad_(i != 4) for i, f in enumerate(flows)]
+    outs = warp_many(df, dl, flipcat)
+    torch.autograd.backward(outs, [g_.to(DEV) for g_ in gos])
+    for i in range(len(shapes)):
+        _close(outs[i], oracle.warp_forward(feats[i], flows[i], flipcat), FWD_TOL[torch.float32])
+        gf_ref, gl_ref = oracle.warp_backward(feats[i], flows[i], gos[i], flipcat)
+        _close(df[i].grad, gf_ref, BWD_TOL[torch.float32], relative=True)
+        if i != 4:
+            _close(dl[i].grad, gl_ref, BWD_TOL[torch.float32] * 10, relative=True)
+        else:
+            assert dl[i].grad is None
+
+
+def test_ffwm_generator_levels_in_one_launch_match_the_per_level_path():
+    """nets.FFWM with the multi-problem warp (default on the GPU) against the same network warping level by level."""
+    from ffwm_amd import nets
+    from ffwm_amd.external_function import WarpFlipCat
+    torch.manual_seed(3)
+    a = nets.FFWM(sn=True).to(DEV)
+    b = nets.FFWM(sn=True, warp_flipcat=WarpFlipCat()).to(DEV)
+    b.load_state_dict(a.state_dict())
+    assert a._multi and not b._multi
+    g = _gen(4)
+    img = torch.rand(2, 3, 128, 128, generator=g).to(DEV)
+    flows = [(torch.rand(2, 2, s, s, generator=g) * 2 - 1).to(DEV) for s in (32, 64, 128)]
+    fa = [f.clone().requires_grad_(True) for f in flows]
+    fb = [f.clone().requires_grad_(True) for f in flows]
+    oa, ob = a(img, flow=fa), b(img, flow=fb)
+    for x, y in zip(oa, ob):
+        assert (x - y).abs().max().item() <= 1e-5
+    sum(o.sum() for o in oa).backward()
+    sum(o.sum() for o in ob).backward()
+    # d(flow) at the end of netG's whole backward chain (vendor convolutions with float atomics in between): two runs of
+    # the SAME network differ in the fourth digit; the multi-problem kernels themselves are held to the oracle above
+    for x, y in zip(fa, fb):
+        assert (x.grad - y.grad).abs().max().item() <= 2e-3 * (1 + y.grad.abs().max().item())

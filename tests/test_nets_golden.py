@@ -126,6 +126,7 @@ def test_illumination_loss_matches_reference_msl1(gold):
     from ffwm_amd import trainer
     t = trainer.FFWMTrainer.__new__(trainer.FFWMTrainer)
     t.warp = torch_refs.warp
+    t.warp_many = lambda feats, flows: [torch_refs.warp(f, fl) for f, fl in zip(feats, flows)]
     fl3 = [fill.flow_field(2, s, s, "msl1_flow%d" % s) for s in (128, 64, 32)]
     im3 = [fill.image(2, 3, s, s, "msl1_img%d" % s) for s in (128, 64, 32)]
     img_F = fill.image(2, 3, 128, 128, "msl1_F")
