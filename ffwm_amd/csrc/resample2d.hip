@@ -593,6 +593,418 @@ rs_bwd2_kernel(const T* __restrict__ in1, const T* __restrict__ in2, const T* __
     gp[2 * plane] = static_cast<T>(safe_div<T>(g1s, sum) - safe_div<T>(sgs * S, sum * sum));
 }
 
+// ------------------------------------------------------------------------------------ K2 + K3, LDS tiles (fp32)
+// The backward kernels on the forward's tile structure (rs_fwd_lds_kernel): a block owns a 64 x (4*RPT) pixel tile and a
+// slab of channels, forms taps and Gaussian weights once per pixel, and works through the channels four at a time.
+//
+// rs_bwd2_lds_kernel (d_input2): the clamp-extended source box of 4 channels is staged in LDS exactly as in the forward;
+// per tap ONE ds_read_b128 feeds acc[tap] += gO_c * in1_c[tap] for the 4 channels (the reference's K3 re-reads 8 gathers
+// per (channel, tap) in two passes).  The quotient rule (:252-328) is linear in the 4*HALF^2 accumulators, so channel
+// slabs (used when the tiles alone do not fill the chip) combine by atomically adding their partial results.
+//
+// rs_bwd1_tile_kernel (d_input1): the box is an ACCUMULATOR in LDS (double cells, 4 channels interleaved: ds_add_f64
+// retires a wave in ~9 clk, ds_add_f32 in ~190 -- tools/ubench/atomics.hip).  Every pixel adds its 4*HALF^2 normalised
+// weights x 4 channel gradients into the box in UNCLAMPED coordinates; after the group's pixels the box is folded onto
+// the clamped image and every non-zero cell goes to grad_input1 with ONE global atomic (~1.8 per pixel and channel
+// instead of 4*HALF^2).  No plane-size limit (the plane kernel above needs a whole plane in LDS).
+template <int HALF, int RPT>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd2_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2, const float* __restrict__ gout,
+                   float* __restrict__ gin2, int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs,
+                   int remap) {
+    constexpr int NW = kBlock / kWave;
+    constexpr int NT = 2 * HALF;
+    constexpr int NA = NT * NT;
+    constexpr int TH = NW * RPT;
+    constexpr int BOXH = TH + 12;
+    constexpr int NCELL = BOXH * kRsBoxW;
+    constexpr int NI = (NCELL + kBlock - 1) / kBlock;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f32x4* tile = reinterpret_cast<f32x4*>(smem_raw);          // [2][NCELL]
+    __shared__ int red[4][NW];
+    __shared__ int flag;
+
+    unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = tid % tiles_x;
+    tid /= tiles_x;
+    const int ty = tid % tiles_y;
+    tid /= tiles_y;
+    const int slab = tid % cslabs;
+    const int b = tid / cslabs;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int x_raw = tx * kTileX + lane;
+    const bool inx = x_raw < W;
+    const int x = inx ? x_raw : W - 1;
+    if (threadIdx.x == 0) flag = 0;
+
+    RsTaps<float, HALF> t[RPT];
+    float sg[RPT];
+    int u0[RPT], v0[RPT], ys[RPT];
+    bool iny[RPT];
+    bool regular = true;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fb = in2 + static_cast<size_t>(b) * 3 * plane;
+    int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yraw = ty * TH + wave + r * NW;
+        iny[r] = yraw < H;
+        const int y = iny[r] ? yraw : H - 1;
+        ys[r] = y;
+        const size_t poff = static_cast<size_t>(y) * W + x;
+        const float dx = fb[poff], dy = fb[plane + poff];
+        sg[r] = fb[2 * plane + poff];
+        make_rs_taps<float, HALF>(t[r], dx, dy, sg[r], x, y, Hi, Wi, 1, false);
+        const float flx = floor_t(static_cast<float>(x) + dx), fly = floor_t(static_cast<float>(y) + dy);
+        const float lim = static_cast<float>(1 << 20);
+        const bool ok = (flx > -lim) && (flx < lim) && (fly > -lim) && (fly < lim);
+        regular = regular && ok;
+        u0[r] = ok ? static_cast<int>(flx) - (HALF - 1) : 0;
+        v0[r] = ok ? static_cast<int>(fly) - (HALF - 1) : 0;
+        umin = min(umin, u0[r]); umax = max(umax, u0[r] + NT - 1);
+        vmin = min(vmin, v0[r]); vmax = max(vmax, v0[r] + NT - 1);
+    }
+    umin = wave_min(umin); umax = wave_max(umax); vmin = wave_min(vmin); vmax = wave_max(vmax);
+    if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
+    __syncthreads();
+    if (!regular) flag = 1;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        umin = min(umin, red[0][k]); umax = max(umax, red[1][k]);
+        vmin = min(vmin, red[2][k]); vmax = max(vmax, red[3][k]);
+    }
+    __syncthreads();
+    const int bw = umax - umin + 1, bh = vmax - vmin + 1;
+    const bool use_lds = (flag == 0) && bw <= kRsBoxW && bh <= BOXH;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * sizeof(float));
+    const unsigned obytes = static_cast<unsigned>(plane * sizeof(float));
+    const float* ip = in1 + (static_cast<size_t>(b) * C + c0) * iplane;
+    const float* gp = gout + (static_cast<size_t>(b) * C + c0) * plane;
+    unsigned poffb[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) poffb[r] = (static_cast<unsigned>(ys[r]) * W + static_cast<unsigned>(x)) * 4u;
+
+    float acc[RPT][NA];                      // reference order: k = 4 * (fy * HALF + fx) + {TL, TR, BL, BR}
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+#pragma unroll
+        for (int k = 0; k < NA; ++k) acc[r][k] = 0.f;
+
+    // visit the taps in the reference's order, handing the body (k, row position, column position)
+    auto for_each_tap = [&](auto&& body) {
+#pragma unroll
+        for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < HALF; ++fx) {
+                const int k = 4 * (fy * HALF + fx);
+                body(k + 0, HALF - 1 - fy, HALF - 1 - fx);
+                body(k + 1, HALF - 1 - fy, HALF + fx);
+                body(k + 2, HALF + fy, HALF - 1 - fx);
+                body(k + 3, HALF + fy, HALF + fx);
+            }
+    };
+
+    if (use_lds) {
+        unsigned goff[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = threadIdx.x + k * kBlock;
+            const int r = i / kRsBoxW, cc = i - r * kRsBoxW;
+            const int gy = min(max(vmin + r, 0), Hi - 1), gx = min(max(umin + cc, 0), Wi - 1);
+            goff[k] = (r < bh && cc < bw) ? (static_cast<unsigned>(gy) * Wi + gx) * 4u : 0xFFFFFFF0u;
+        }
+        f32x4 stage[NI];
+        auto fetch = [&](int c) {
+            const float* p0 = ip + static_cast<size_t>(c - c0) * iplane;
+            const rsrc_t r0 = make_rsrc(p0, ibytes);
+            const rsrc_t r1 = make_rsrc(p0 + iplane, c + 1 < c1 ? ibytes : 0u);
+            const rsrc_t r2 = make_rsrc(p0 + 2 * iplane, c + 2 < c1 ? ibytes : 0u);
+            const rsrc_t r3 = make_rsrc(p0 + 3 * iplane, c + 3 < c1 ? ibytes : 0u);
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                stage[k].x = buf_ld<float>(r0, goff[k]);
+                stage[k].y = buf_ld<float>(r1, goff[k]);
+                stage[k].z = buf_ld<float>(r2, goff[k]);
+                stage[k].w = buf_ld<float>(r3, goff[k]);
+            }
+        };
+        auto commit = [&](f32x4* buf) {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int i = threadIdx.x + k * kBlock;
+                if (i < NCELL) buf[i] = stage[k];
+            }
+        };
+        int lbase[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) lbase[r] = (v0[r] - vmin) * kRsBoxW + (u0[r] - umin);
+        fetch(c0);
+        commit(tile);
+        __syncthreads();
+        int p = 0;
+        for (int c = c0; c < c1; c += 4) {
+            const bool more = c + 4 < c1;
+            if (more) fetch(c + 4);
+            const f32x4* tb = tile + p * NCELL;
+            const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
+            const rsrc_t rg0 = make_rsrc(g0, obytes);
+            const rsrc_t rg1 = make_rsrc(g0 + plane, c + 1 < c1 ? obytes : 0u);        // missing channels: g = 0
+            const rsrc_t rg2 = make_rsrc(g0 + 2 * plane, c + 2 < c1 ? obytes : 0u);
+            const rsrc_t rg3 = make_rsrc(g0 + 3 * plane, c + 3 < c1 ? obytes : 0u);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const float gx = buf_ld<float>(rg0, poffb[r]), gy = buf_ld<float>(rg1, poffb[r]);
+                const float gz = buf_ld<float>(rg2, poffb[r]), gw = buf_ld<float>(rg3, poffb[r]);
+                const f32x4* nb = tb + lbase[r];
+                for_each_tap([&](int k, int pr, int pc) {
+                    const f32x4 v = nb[pr * kRsBoxW + pc];
+                    float a = acc[r][k];
+                    a = __builtin_fmaf(gx, v.x, a);
+                    a = __builtin_fmaf(gy, v.y, a);
+                    a = __builtin_fmaf(gz, v.z, a);
+                    a = __builtin_fmaf(gw, v.w, a);
+                    acc[r][k] = a;
+                });
+            }
+            if (more) {
+                commit(tile + (p ^ 1) * NCELL);
+                __syncthreads();
+                p ^= 1;
+            }
+        }
+    } else {
+        // fallback: direct gathers through the clamped tap offsets
+        for (int c = c0; c < c1; ++c, ip += iplane, gp += plane) {
+            const rsrc_t rs = make_rsrc(ip, ibytes);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const float g = gp[poffb[r] / 4u];
+                for_each_tap([&](int k, int pr, int pc) {
+                    const int fyq = pr < HALF ? 2 * (HALF - 1 - pr) : 2 * (pr - HALF) + 1;      // position -> RsTaps entry
+                    const int fxq = pc < HALF ? 2 * (HALF - 1 - pc) : 2 * (pc - HALF) + 1;
+                    acc[r][k] = __builtin_fmaf(g, buf_ld<float>(rs, t[r].row[fyq] + t[r].col[fxq]), acc[r][k]);
+                });
+            }
+        }
+    }
+
+    // quotient rule, resample2d_kernel.cu:252-328, with sum_ch(gO * in1[tap]) factored out (as rs_bwd2_kernel)
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (!(inx && iny[r])) continue;
+        const float sigma = sg[r];
+        const float ns2 = -sigma * sigma, s3 = sigma * sigma * sigma;
+        float g1x = 0, g1y = 0, g1s = 0, sgx = 0, sgy = 0, sgs = 0, S = 0;
+#pragma unroll
+        for (int fy = 0; fy < HALF; ++fy)
+#pragma unroll
+            for (int fx = 0; fx < HALF; ++fx) {
+                const float yT = t[r].wy[2 * fy], yB = t[r].wy[2 * fy + 1], xL = t[r].wx[2 * fx], xR = t[r].wx[2 * fx + 1];
+                const float yT_ = t[r].dy_[2 * fy], yB_ = t[r].dy_[2 * fy + 1], xL_ = t[r].dx_[2 * fx], xR_ = t[r].dx_[2 * fx + 1];
+                const float* a = acc[r] + 4 * (fy * HALF + fx);
+                g1x += static_cast<float>(safe_div<float>(xL_ * yT * xL * a[0], ns2));
+                g1x -= static_cast<float>(safe_div<float>(xR_ * yT * xR * a[1], ns2));
+                g1x += static_cast<float>(safe_div<float>(xL_ * yB * xL * a[2], ns2));
+                g1x -= static_cast<float>(safe_div<float>(xR_ * yB * xR * a[3], ns2));
+                sgx += static_cast<float>(safe_div<float>(xL_ * yT * xL - xR_ * yT * xR + xL_ * yB * xL - xR_ * yB * xR, ns2));
+                g1y += static_cast<float>(safe_div<float>(yT_ * yT * xL * a[0], ns2));
+                g1y += static_cast<float>(safe_div<float>(yT_ * yT * xR * a[1], ns2));
+                g1y -= static_cast<float>(safe_div<float>(yB_ * yB * xL * a[2], ns2));
+                g1y -= static_cast<float>(safe_div<float>(yB_ * yB * xR * a[3], ns2));
+                sgy += static_cast<float>(safe_div<float>(yT_ * yT * xL + yT_ * yT * xR - yB_ * yB * xL - yB_ * yB * xR, ns2));
+                const float dTL = yT_ * yT_ + xL_ * xL_, dTR = yT_ * yT_ + xR_ * xR_;
+                const float dBL = yB_ * yB_ + xL_ * xL_, dBR = yB_ * yB_ + xR_ * xR_;
+                g1s += static_cast<float>(safe_div<float>(dTL * yT * xL * a[0], s3));
+                g1s += static_cast<float>(safe_div<float>(dTR * yT * xR * a[1], s3));
+                g1s += static_cast<float>(safe_div<float>(dBL * yB * xL * a[2], s3));
+                g1s += static_cast<float>(safe_div<float>(dBR * yB * xR * a[3], s3));
+                sgs += static_cast<float>(safe_div<float>(dTL * yT * xL + dTR * yT * xR + dBL * yB * xL + dBR * yB * xR, s3));
+                S += yT * xL * a[0];
+                S += yT * xR * a[1];
+                S += yB * xL * a[2];
+                S += yB * xR * a[3];
+            }
+        const float sum = t[r].sum;
+        float* op = gin2 + static_cast<size_t>(b) * 3 * plane + poffb[r] / 4u;
+        const float rx = static_cast<float>(safe_div<float>(g1x, sum) - safe_div<float>(sgx * S, sum * sum));
+        const float ry = static_cast<float>(safe_div<float>(g1y, sum) - safe_div<float>(sgy * S, sum * sum));
+        const float rs_ = static_cast<float>(safe_div<float>(g1s, sum) - safe_div<float>(sgs * S, sum * sum));
+        if (cslabs == 1) {
+            op[0] = rx; op[plane] = ry; op[2 * plane] = rs_;
+        } else {                              // linear in the accumulators: the slabs' partial results add up (buffer zero-filled by the host)
+            atomic_add(op, rx); atomic_add(op + plane, ry); atomic_add(op + 2 * plane, rs_);
+        }
+    }
+}
+
+template <int HALF, int RPT>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi,
+                    int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+    constexpr int NW = kBlock / kWave;
+    constexpr int NT = 2 * HALF;
+    constexpr int TH = NW * RPT;
+    constexpr int BOXH = TH + 12;
+    constexpr int NCELL = BOXH * kRsBoxW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* box = reinterpret_cast<double*>(smem_raw);          // [NCELL][4]
+    __shared__ int red[4][NW];
+    __shared__ int flag;
+
+    unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = tid % tiles_x;
+    tid /= tiles_x;
+    const int ty = tid % tiles_y;
+    tid /= tiles_y;
+    const int slab = tid % cslabs;
+    const int b = tid / cslabs;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int x_raw = tx * kTileX + lane;
+    const bool inx = x_raw < W;
+    const int x = inx ? x_raw : W - 1;
+    if (threadIdx.x == 0) flag = 0;
+
+    float wn[RPT][NT * NT];                 // SAFE_DIV(w, sum) (:196-199), [row position][col position]
+    int u0[RPT], v0[RPT], ys[RPT];
+    bool live[RPT];
+    bool regular = true;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fb = in2 + static_cast<size_t>(b) * 3 * plane;
+    int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yraw = ty * TH + wave + r * NW;
+        live[r] = inx && yraw < H;
+        const int y = yraw < H ? yraw : H - 1;
+        ys[r] = y;
+        const size_t poff = static_cast<size_t>(y) * W + x;
+        const float dx = fb[poff], dy = fb[plane + poff], sgm = fb[2 * plane + poff];
+        RsTaps<float, HALF> t;
+        make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+        const float flx = floor_t(static_cast<float>(x) + dx), fly = floor_t(static_cast<float>(y) + dy);
+        const float lim = static_cast<float>(1 << 20);
+        const bool ok = (flx > -lim) && (flx < lim) && (fly > -lim) && (fly < lim);
+        regular = regular && ok;
+        u0[r] = ok ? static_cast<int>(flx) - (HALF - 1) : 0;
+        v0[r] = ok ? static_cast<int>(fly) - (HALF - 1) : 0;
+        umin = min(umin, u0[r]); umax = max(umax, u0[r] + NT - 1);
+        vmin = min(vmin, v0[r]); vmax = max(vmax, v0[r] + NT - 1);
+        float wxp[NT], wyp[NT];
+#pragma unroll
+        for (int f = 0; f < HALF; ++f) {
+            wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
+            wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
+        }
+#pragma unroll
+        for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+            for (int pc = 0; pc < NT; ++pc)
+                wn[r][pr * NT + pc] = static_cast<float>(safe_div<float>(wyp[pr] * wxp[pc], t.sum));
+    }
+    umin = wave_min(umin); umax = wave_max(umax); vmin = wave_min(vmin); vmax = wave_max(vmax);
+    if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
+    __syncthreads();
+    if (!regular) flag = 1;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        umin = min(umin, red[0][k]); umax = max(umax, red[1][k]);
+        vmin = min(vmin, red[2][k]); vmax = max(vmax, red[3][k]);
+    }
+    __syncthreads();
+    const int bw = umax - umin + 1, bh = vmax - vmin + 1;
+    const bool use_lds = (flag == 0) && bw <= kRsBoxW && bh <= BOXH;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned obytes = static_cast<unsigned>(plane * sizeof(float));
+    const float* gp = gout + (static_cast<size_t>(b) * C + c0) * plane;
+    float* dp = gin1 + (static_cast<size_t>(b) * C + c0) * iplane;
+    unsigned poffb[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        poffb[r] = live[r] ? (static_cast<unsigned>(ys[r]) * W + static_cast<unsigned>(x)) * 4u : 0xFFFFFFF0u;     // dead lanes read g = 0
+
+    if (use_lds) {
+        int lbase[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) lbase[r] = ((v0[r] - vmin) * kRsBoxW + (u0[r] - umin)) * 4;
+        for (int c = c0; c < c1; c += 4) {
+            for (int i = threadIdx.x; i < NCELL * 2; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
+            __syncthreads();
+            const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
+            const rsrc_t rg0 = make_rsrc(g0, obytes);
+            const rsrc_t rg1 = make_rsrc(g0 + plane, c + 1 < c1 ? obytes : 0u);
+            const rsrc_t rg2 = make_rsrc(g0 + 2 * plane, c + 2 < c1 ? obytes : 0u);
+            const rsrc_t rg3 = make_rsrc(g0 + 3 * plane, c + 3 < c1 ? obytes : 0u);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const float gx = buf_ld<float>(rg0, poffb[r]), gy = buf_ld<float>(rg1, poffb[r]);
+                const float gz = buf_ld<float>(rg2, poffb[r]), gw = buf_ld<float>(rg3, poffb[r]);
+                if (!live[r]) continue;
+                double* nb = box + lbase[r];
+#pragma unroll
+                for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < NT; ++pc) {
+                        const float wq = wn[r][pr * NT + pc];
+                        double* cell = nb + (pr * kRsBoxW + pc) * 4;
+                        lds_add(cell + 0, wq * gx);
+                        lds_add(cell + 1, wq * gy);
+                        lds_add(cell + 2, wq * gz);
+                        lds_add(cell + 3, wq * gw);
+                    }
+            }
+            __syncthreads();
+            // fold the box onto the clamped image: one global atomic per non-zero cell and channel
+            const int nch = c1 - c < 4 ? c1 - c : 4;
+            for (int i = threadIdx.x; i < bh * kRsBoxW; i += kBlock) {
+                const int r = i / kRsBoxW, cc = i - r * kRsBoxW;
+                if (cc >= bw) continue;
+                const int gy = min(max(vmin + r, 0), Hi - 1), gx = min(max(umin + cc, 0), Wi - 1);
+                float* dst = dp + static_cast<size_t>(c - c0) * iplane + static_cast<size_t>(gy) * Wi + gx;
+                const double* cell = box + static_cast<size_t>(i) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = static_cast<float>(cell[q]);
+                    if (q < nch && v != 0.f) atomic_add(dst + static_cast<size_t>(q) * iplane, v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // fallback: per-tap global atomics through clamped offsets
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (!live[r]) continue;
+        const float fxv = static_cast<float>(x) + fb[static_cast<size_t>(ys[r]) * W + x];
+        const float fyv = static_cast<float>(ys[r]) + fb[plane + static_cast<size_t>(ys[r]) * W + x];
+        const float flx = floor_t(fxv), fly = floor_t(fyv);
+        unsigned col[NT], row[NT];
+#pragma unroll
+        for (int f = 0; f < HALF; ++f) {
+            col[HALF - 1 - f] = static_cast<unsigned>(clamp_index(flx - static_cast<float>(f), Wi));
+            col[HALF + f] = static_cast<unsigned>(clamp_index(flx + static_cast<float>(f + 1), Wi));
+            row[HALF - 1 - f] = static_cast<unsigned>(clamp_index(fly - static_cast<float>(f), Hi)) * static_cast<unsigned>(Wi);
+            row[HALF + f] = static_cast<unsigned>(clamp_index(fly + static_cast<float>(f + 1), Hi)) * static_cast<unsigned>(Wi);
+        }
+        for (int c = c0; c < c1; ++c) {
+            const float g = gp[static_cast<size_t>(c - c0) * plane + poffb[r] / 4u];
+            float* d = dp + static_cast<size_t>(c - c0) * iplane;
+#pragma unroll
+            for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+                for (int pc = 0; pc < NT; ++pc) atomic_add(d + row[pr] + col[pc], wn[r][pr * NT + pc] * g);
+        }
+    }
+}
+
 // ------------------------------------------------------------------- any even kernel_size
 // Literal per-element kernels (the reference's decomposition, 64-bit safe indices).
 template <typename T>
@@ -843,7 +1255,60 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
     const int remap = options().xcd_remap;
     const size_t plane_lds = static_cast<size_t>(Hi) * Wi * sizeof(double);     // the LDS accumulator is double
     const int half = ks / 2;
-    if (gin1 && plane_lds <= 131072 && half >= 1 && half <= 3 && options().scatter_variant != 1) {
+    if constexpr (sizeof(T) == 4) {
+        // fp32, dilation 1, kernel_size 2 / 4 / 6: the LDS-tile kernels (scatter_variant 1 = global atomics, 2 = plane kernel)
+        if (dil == 1 && half >= 1 && half <= 3 && options().scatter_variant == 0) {
+            const int tiles_x = static_cast<int>((W + kTileX - 1) / kTileX);
+            auto slabs = [&](int64_t spatial, int& cs, int& cslabs) {
+                cs = static_cast<int>((C + 3) / 4 * 4);
+                while (cs > 4 && spatial * ((C + cs - 1) / cs) < 512) cs = (cs / 2 + 3) / 4 * 4;
+                cslabs = static_cast<int>((C + cs - 1) / cs);
+            };
+            // d_input1: planes that fit LDS whole keep the plane kernel below (measured, cfg-1: 36 vs 47 us; [8,64,128,128]: 218 vs
+            // 235 us); larger planes take the tile kernel ([8,64,512,512]: 3.1 ms vs 57 ms with per-tap global atomics)
+            if (gin1 && (plane_lds > 131072 || options().rs_bwd1_variant == 2)) {
+                const int rpt = H >= 32 ? 4 : 1;
+                const int tiles_y = static_cast<int>((H + 4 * rpt - 1) / (4 * rpt));
+                int cs, cslabs;
+                slabs(B * tiles_x * tiles_y, cs, cslabs);
+                const unsigned grid = static_cast<unsigned>(B * tiles_x * tiles_y * cslabs);
+                const size_t lds = static_cast<size_t>(4 * rpt + 12) * kRsBoxW * 4 * sizeof(double);
+                const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
+                LaunchScope ls("resample2d_bwd_input1_tile", st, bytes);
+#define FFWM_RS_B1T(HH, RR)                                                                                   \
+    do {                                                                                                      \
+        allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_tile_kernel<HH, RR>));                          \
+        hipLaunchKernelGGL((rs_bwd1_tile_kernel<HH, RR>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, \
+                           (int)Hi, (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap);     \
+    } while (0)
+                if (rpt == 4) { if (half == 1) FFWM_RS_B1T(1, 4); else if (half == 2) FFWM_RS_B1T(2, 4); else FFWM_RS_B1T(3, 4); }
+                else { if (half == 1) FFWM_RS_B1T(1, 1); else if (half == 2) FFWM_RS_B1T(2, 1); else FFWM_RS_B1T(3, 1); }
+#undef FFWM_RS_B1T
+                if (int rc = check_launch("ffwm_resample2d_backward(input1, tile)")) return rc;
+                gin1 = nullptr;
+            }
+            if (gin2) {
+                const int tiles_y = static_cast<int>((H + 3) / 4);
+                int cs, cslabs;
+                slabs(B * tiles_x * tiles_y, cs, cslabs);
+                const unsigned grid = static_cast<unsigned>(B * tiles_x * tiles_y * cslabs);
+                const size_t lds = static_cast<size_t>(2) * 16 * kRsBoxW * 16;
+                if (cslabs > 1)          // the slabs' partial results are added atomically
+                    if (hipMemsetAsync(gin2, 0, sizeof(T) * static_cast<size_t>(B) * 3 * H * W, st) != hipSuccess) return FFWM_ERR_LAUNCH;
+                const double bytes = sizeof(T) * static_cast<double>(B) * H * W * (2.0 * C + 6.0);
+                LaunchScope ls("resample2d_bwd_input2_lds", st, bytes);
+#define FFWM_RS_B2L(HH)                                                                                       \
+    hipLaunchKernelGGL((rs_bwd2_lds_kernel<HH, 1>), dim3(grid), dim3(kBlock), lds, st, in1, in2, gout, gin2, (int)C, \
+                       (int)Hi, (int)Wi, (int)H, (int)W, tiles_x, tiles_y, cslabs, cs, remap)
+                if (half == 1) FFWM_RS_B2L(1); else if (half == 2) FFWM_RS_B2L(2); else FFWM_RS_B2L(3);
+#undef FFWM_RS_B2L
+                if (int rc = check_launch("ffwm_resample2d_backward(input2, lds)")) return rc;
+                gin2 = nullptr;
+            }
+            if (!gin1 && !gin2) return FFWM_OK;
+        }
+    }
+    if (gin1 && plane_lds <= 131072 && half >= 1 && half <= 3 && options().scatter_variant != 1) {      // fp64, dilation > 1, or scatter_variant 2
         const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
         int cg = static_cast<int>(131072 / plane_lds);
         if (cg > C) cg = static_cast<int>(C);

@@ -121,7 +121,8 @@ struct WarpProblem {
     const void* gout;    // backward: grad_output
     int C, Hi, Wi, H, W;
     int tiles_x, tiles_y, cslabs, cs;
-    unsigned begin;      // first workgroup of this problem
+    unsigned begin;      // first workgroup of this problem (a multiple of 8: workgroup b runs on XCD b % 8)
+    unsigned nblk;       // its real workgroups; the ids up to the next multiple of 8 exit at once
 };
 struct WarpTable {
     int n;
@@ -149,8 +150,11 @@ warp_fwd_multi_kernel(const WarpTable tab) {
     for (int k = 1; k < kMaxWarpProblems; ++k)
         if (k < tab.n && blockIdx.x >= tab.p[k].begin) i = k;
     const WarpProblem& q = tab.p[i];
+    // every XCD gets a contiguous range of the problem's tiles (neighbouring tiles share source rows: one L2 fetches them)
+    const unsigned t = xcd_remap(blockIdx.x - q.begin, (q.nblk + 7u) & ~7u, 1);
+    if (t >= q.nblk) return;
     warp_fwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<T*>(q.out), q.C, q.Hi, q.Wi,
-                           q.H, q.W, decode_tile_local(blockIdx.x - q.begin, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
+                           q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
 }
 
 // ------------------------------------------------------------------------------ forward, LDS-staged
@@ -432,9 +436,10 @@ warp_bwd_flow_multi_kernel(const WarpTable tab) {
     for (int k = 1; k < kMaxWarpProblems; ++k)
         if (k < tab.n && blockIdx.x >= tab.p[k].begin) i = k;
     const WarpProblem& q = tab.p[i];
+    const unsigned t = xcd_remap(blockIdx.x - q.begin, (q.nblk + 7u) & ~7u, 1);
+    if (t >= q.nblk) return;
     warp_bwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<const T*>(q.gout), nullptr,
-                           static_cast<T*>(q.out), q.C, q.Hi, q.Wi, q.H, q.W,
-                           decode_tile_local(blockIdx.x - q.begin, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
+                           static_cast<T*>(q.out), q.C, q.Hi, q.Wi, q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
 }
 
 // d(feat) without contended global atomics: a block owns `cg` whole (b, c) planes of grad_feat in LDS.
@@ -663,6 +668,7 @@ inline void fill_problem(WarpProblem& q, const ffwm_warp_problem& pr, int cs_def
     q.H = static_cast<int>(pr.H); q.W = static_cast<int>(pr.W);
     q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.cslabs = g.cslabs; q.cs = g.cs;
     q.begin = begin;
+    q.nblk = g.grid;
 }
 
 template <typename T>
@@ -690,7 +696,7 @@ int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
         WarpProblem& q = tab.p[tab.n];
         q.feat = pr.feat; q.flow = pr.flow; q.out = pr.output; q.gout = nullptr;
         fill_problem(q, pr, 16, blocks);
-        blocks += plan(pr.B, pr.C, pr.H, pr.W, 16).grid;
+        blocks += (plan(pr.B, pr.C, pr.H, pr.W, 16).grid + 7u) & ~7u;
         bytes += sizeof(T) * static_cast<double>(pr.B) * (static_cast<double>(pr.C) * pr.Hi * pr.Wi + 2.0 * pr.H * pr.W + (flip ? 2.0 : 1.0) * pr.C * pr.H * pr.W);
         if (++tab.n == kMaxWarpProblems)
             if (int rc = flush()) return rc;
@@ -728,7 +734,7 @@ int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
         WarpProblem& q = tab.p[tab.n];
         q.feat = pr.feat; q.flow = pr.flow; q.out = pr.grad_flow; q.gout = pr.grad_output;
         fill_problem(q, pr, 32, blocks);
-        blocks += plan(pr.B, pr.C, pr.H, pr.W, 32).grid;
+        blocks += (plan(pr.B, pr.C, pr.H, pr.W, 32).grid + 7u) & ~7u;
         bytes += sizeof(T) * static_cast<double>(pr.B) * (static_cast<double>(pr.C) * pr.Hi * pr.Wi + 4.0 * pr.H * pr.W + (flip ? 2.0 : 1.0) * pr.C * pr.H * pr.W);
         if (++tab.n == kMaxWarpProblems)
             if (int rc = flush()) return rc;

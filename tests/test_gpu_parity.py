@@ -476,6 +476,39 @@ def test_resample2d_backward(oracle, case, dtype, quirk):
         _close(g2, g2_ref, BWD_TOL[dtype] * 10, relative=True)
 
 
+@pytest.mark.parametrize("variant", [("scatter_variant", 1), ("scatter_variant", 2), ("rs_bwd1_variant", 2)])
+@pytest.mark.parametrize("case", RS_CASES[:5])
+def test_resample2d_backward_other_scatter_paths(oracle, case, variant):
+    """d_input1 / d_input2 through every path: per-tap global atomics (scatter_variant 1), the pixel-major d_input2 kernel
+    with the LDS-resident plane kernel (scatter_variant 2: what fp64 / dilated calls take), and the LDS-tile d_input1
+    kernel (rs_bwd1_variant 2: the default for planes larger than 128 x 128) forced on small planes."""
+    from ffwm_amd import _lib, ops
+    in1, in2, go, ks, dil = _rs_inputs(case, torch.float32, varying_sigma=True)
+    g1_ref, g2_ref = oracle.resample2d_backward(in1, in2, go, ks, dil)
+    g1 = torch.zeros_like(in1, device=DEV)
+    g2 = torch.empty_like(in2, device=DEV)
+    _lib.set_option(variant[0], variant[1])
+    try:
+        ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), ks, dil, g1, g2)
+    finally:
+        _lib.set_option(variant[0], 0)
+    _close(g1, g1_ref, BWD_TOL[torch.float32], relative=True)
+    _close(g2, g2_ref, BWD_TOL[torch.float32] * 10, relative=True)
+
+
+def test_resample2d_backward_accumulates_into_grad_input1_and_overwrites_grad_input2(oracle):
+    """The boundary's contract (external_function.py:137-138, resample2d_kernel.cu:98-330): grad_input1 is accumulated
+    into (atomics), grad_input2 is written -- also when the channel slabs of the tile kernel add partial results."""
+    from ffwm_amd import ops
+    in1, in2, go, ks, dil = _rs_inputs(RS_CASES[1], torch.float32)
+    g1_ref, g2_ref = oracle.resample2d_backward(in1, in2, go, ks, dil)
+    g1 = torch.ones_like(in1, device=DEV)
+    g2 = torch.full_like(in2, 7.0, device=DEV)
+    ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), ks, dil, g1, g2)
+    _close(g1 - 1, g1_ref, BWD_TOL[torch.float32], relative=True)
+    _close(g2, g2_ref, BWD_TOL[torch.float32] * 10, relative=True)
+
+
 def test_resample2d_cfg1_shape_within_1e4(oracle):
     """BASELINE configs[0]: 1x64x128x128 feature + flow ~ U[-3,3) px, sigma in {0.3, 2, 5},
     (ks,dil) in {(2,1),(4,1)}; target <= 1e-4 max abs diff (fp32)."""
@@ -1271,9 +1304,11 @@ def test_warp_many_matches_the_oracle_per_problem(oracle, flipcat):
 
 
 def test_ffwm_generator_levels_in_one_launch_match_the_per_level_path():
-    """nets.FFWM with the multi-problem warp (default on the GPU) against the same network warping level by level."""
+    """nets.FFWM with the multi-problem warp (default on the GPU) against the same network warping level by level:
+    same outputs; and the autograd wiring of the multi-output Function (one backward for all levels) against three
+    single-level Functions under the same downstream graph."""
     from ffwm_amd import nets
-    from ffwm_amd.external_function import WarpFlipCat
+    from ffwm_amd.external_function import WarpFlipCat, warp_many
     torch.manual_seed(3)
     a = nets.FFWM(sn=True).to(DEV)
     b = nets.FFWM(sn=True, warp_flipcat=WarpFlipCat()).to(DEV)
@@ -1282,14 +1317,19 @@ def test_ffwm_generator_levels_in_one_launch_match_the_per_level_path():
     g = _gen(4)
     img = torch.rand(2, 3, 128, 128, generator=g).to(DEV)
     flows = [(torch.rand(2, 2, s, s, generator=g) * 2 - 1).to(DEV) for s in (32, 64, 128)]
-    fa = [f.clone().requires_grad_(True) for f in flows]
-    fb = [f.clone().requires_grad_(True) for f in flows]
-    oa, ob = a(img, flow=fa), b(img, flow=fb)
-    for x, y in zip(oa, ob):
-        assert (x - y).abs().max().item() <= 1e-5
-    sum(o.sum() for o in oa).backward()
-    sum(o.sum() for o in ob).backward()
-    # d(flow) at the end of netG's whole backward chain (vendor convolutions with float atomics in between): two runs of
-    # the SAME network differ in the fourth digit; the multi-problem kernels themselves are held to the oracle above
-    for x, y in zip(fa, fb):
-        assert (x.grad - y.grad).abs().max().item() <= 2e-3 * (1 + y.grad.abs().max().item())
+    with torch.no_grad():
+        for x, y in zip(a(img, flow=flows), b(img, flow=flows)):
+            assert (x - y).abs().max().item() <= 1e-5
+    # (netG's own backward is chaotic at random initialisation -- a 5e-6 output difference moves d(flow) by 1 % -- so the
+    # gradient wiring is checked under a well-conditioned downstream graph)
+    feats = [torch.rand(2, c, s, s, generator=g).to(DEV) for c, s in ((128, 32), (64, 64), (64, 128))]
+    wts = [torch.rand(2, 2 * c, s, s, generator=g).to(DEV) for c, s in ((128, 32), (64, 64), (64, 128))]
+    fa = [f.clone().requires_grad_(True) for f in feats]
+    la = [f.clone().requires_grad_(True) for f in flows]
+    fb = [f.clone().requires_grad_(True) for f in feats]
+    lb = [f.clone().requires_grad_(True) for f in flows]
+    sum((o * w).sum() for o, w in zip(warp_many(fa, la, True), wts)).backward()
+    single = WarpFlipCat()
+    sum((single(f, fl) * w).sum() for f, fl, w in zip(fb, lb, wts)).backward()
+    for x, y in zip(fa + la, fb + lb):
+        assert (x.grad - y.grad).abs().max().item() <= 1e-5 * (1 + y.grad.abs().max().item())

@@ -1,16 +1,20 @@
-"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r01_*.
+"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r02_*.
 
     python tools/fold_profiles.py [gpurun_out/refresh]
 
-Maps the raw per-kernel PMC averages onto the launch scopes bench.py reports (ffwm_prof_* names), applies
-the FETCH_SIZE x2 calibration of this box (profiles/r01_kbench_pmc_raw.json: a 1.2 GB copy reports half its
-read bytes), and copies the kernel statistics and the default bench line."""
+Maps the raw per-kernel PMC averages (tools/pmc_fold.py) onto the launch scopes bench.py reports (ffwm_prof_* names),
+applies the FETCH_SIZE x2 calibration of this box (profiles/r01_kbench_pmc_raw.json: a 1.2 GB copy reports half its read
+bytes), and copies the kernel statistics and the default bench line.
+
+Refuses to publish what was not measured: the traffic file is only written when BOTH counter passes produced rows, and a
+scope whose FETCH_SIZE or WRITE_SIZE average is missing or zero is left out (round 1 published write-only byte counts as
+"traffic" after the FETCH pass had aborted)."""
 import json
 import os
 import shutil
 import sys
 
-SCOPES = {   # launch scope -> kernel-name prefix (template arguments included where they select the variant)
+SCOPES = {   # launch scope -> kernel-name fragment (template arguments included where they select the variant)
     "adam_flat": "adam_flat_kernel",
     "bn_lrelu_bwd": "bn_lrelu_bwd_kernel<1024>",
     "bn_lrelu_fwd": "bn_lrelu_fwd_kernel<1024>",
@@ -21,63 +25,93 @@ SCOPES = {   # launch scope -> kernel-name prefix (template arguments included w
     "conv3x3_wgrad_packed": "conv3x3_wgrad_kernel<true>",
     "guided_filter_bwd": "gf_backward_kernel<float>",
     "guided_filter_fwd": "gf_forward_kernel<float>",
-    "mfm_bwd": "mfm_bwd",
-    "mfm_fwd": "mfm_fwd",
+    "mfm_bwd": "mfm_bwd4_kernel",
+    "mfm_fwd": "mfm_fwd4_kernel",
     "local_attn_reshape_bwd": "lar_bwd_kernel<float, 3, false>",
     "local_attn_reshape_fwd": "lar_fwd_kernel<float, 3>",
     "resample2d_bwd_input1_plane": "rs_bwd1_plane_kernel<float, 2>",
     "resample2d_bwd_input2": "rs_bwd2_kernel<float, 2>",
-    "resample2d_fwd": "rs_fwd_kernel<float, 2>",
+    "resample2d_fwd_lds": "rs_fwd_lds_kernel<2,",
     "spectral_norm_bwd_apply": "sn_bwd_apply_kernel<float>",
     "spectral_norm_bwd_dot": "sn_bwd_dot_kernel<float>",
     "spectral_norm_fwd_div": "sn_phase3_kernel<float>",
     "spectral_norm_fwd_wtu": "sn_phase1_kernel<float>",
     "spectral_norm_fwd_wv": "sn_phase2_kernel<float>",
-    "warp_bwd_feat": "warp_bwd_feat_plane_kernel<float, false",
-    "warp_bwd_flow": "warp_bwd_kernel<float, false>",
-    "warp_flipcat_bwd_feat": "warp_bwd_feat_plane_kernel<float, true",
-    "warp_flipcat_bwd_flow": "warp_bwd_kernel<float, true>",
-    "warp_flipcat_fwd": "warp_fwd_kernel<float, true>",
-    "warp_fwd": "warp_fwd_kernel<float, false>",
+    "warp_flipcat_fwd_multi": "warp_fwd_multi_kernel<float, true>",
+    "warp_fwd_multi": "warp_fwd_multi_kernel<float, false>",
+    "warp_flipcat_bwd_flow_multi": "warp_bwd_flow_multi_kernel<float, true>",
+    "warp_bwd_flow_multi": "warp_bwd_flow_multi_kernel<float, false>",
+    "warp_flipcat_bwd_feat@128": "warp_bwd_feat_plane_kernel<float, true, 1>",
+    "warp_flipcat_bwd_feat@64": "warp_bwd_feat_plane_kernel<float, true, 2>",
+    "warp_flipcat_bwd_feat@32": "warp_bwd_feat_plane_kernel<float, true, 8>",
 }
 FETCH_CORRECTION = 2.0
+ROUND = "r02"
 
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/refresh"
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    raw = json.load(open(os.path.join(src, "bench_pmc_raw.json")))
-    if not raw:
-        print("no PMC data in %s (counter passes failed?): profiles/r01_pmc_traffic.json left as it is" % src)
+    prof = os.path.join(root, "profiles")
+    raw_path = os.path.join(src, "bench_pmc_raw.json")
+    raw = json.load(open(raw_path)) if os.path.exists(raw_path) else {}
+    have_fetch = any(v.get("FETCH_SIZE", 0) > 0 for v in raw.values())
+    have_write = any(v.get("WRITE_SIZE", 0) > 0 for v in raw.values())
     out = {
-        "_about": "HBM-side traffic per dispatch from rocprofv3 PMC passes of `python bench.py --steps 2 --warmup 2 "
-                  "--no-cpu-baseline` (one pass with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE; they do not fit one pass; "
-                  "tools/refresh_profiles.sh + tools/fold_profiles.py). Averages over the dispatches of each launch scope (the "
-                  "in-step scopes mix layer shapes exactly as bench.py's averages do; flow nets fitted to the identity grid as in "
-                  "the default bench). Units KiB as reported. Calibration on this box (profiles/r01_kbench_pmc_raw.json): a 1.2 GB "
-                  "copy (1,179,648 KiB read + written) reports FETCH_SIZE 589,824 KiB and WRITE_SIZE 1,179,648 KiB, so "
-                  "traffic_bytes = (2 x fetch_KiB + write_KiB) x 1024.",
+        "_about": "HBM-side traffic per dispatch from rocprofv3 counter passes of `python bench.py --steps 2 --warmup 2 "
+                  "--no-cpu-baseline --no-extras` (--pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs -- they do not fit one "
+                  "pass -- with --kernel-include-regex ffwm; tools/refresh_profiles.sh + tools/fold_profiles.py).  Averages over "
+                  "the dispatches of each launch scope (in-step scopes: flow nets fitted to the identity grid as in the default "
+                  "bench; multi-problem warp launches cover all their levels).  Units KiB as reported.  Calibration on this box "
+                  "(profiles/r01_kbench_pmc_raw.json): a 1.2 GB copy (1,179,648 KiB read + written) reports FETCH_SIZE 589,824 "
+                  "KiB and WRITE_SIZE 1,179,648 KiB, so traffic_bytes = (2 x fetch_KiB + write_KiB) x 1024.  Scopes without a "
+                  "non-zero FETCH_SIZE and WRITE_SIZE measurement are omitted.",
         "_calibration": {"copy_1.2GB_expected_KiB_each_way": 1179648, "copy_fetch_KiB": 589824.0, "copy_write_KiB": 1179648.0,
                          "fetch_correction": FETCH_CORRECTION},
     }
-    for scope, prefix in sorted(SCOPES.items()):
-        rows = [(k, v) for k, v in raw.items() if ("::" + prefix) in k]
+    dropped = []
+    for scope, frag in sorted(SCOPES.items()):
+        rows = [v for k, v in raw.items() if ("::" + frag) in k]
         if not rows:
             continue
-        n = sum(v["dispatches"] for _, v in rows)
-        fetch = sum(v["fetch_KiB"] * v["dispatches"] for _, v in rows) / n
-        write = sum(v["write_KiB"] * v["dispatches"] for _, v in rows) / n
-        out[scope] = {"kernel": prefix, "dispatches": n, "fetch_KiB": round(fetch, 1), "write_KiB": round(write, 1),
-                      "traffic_bytes": int((FETCH_CORRECTION * fetch + write) * 1024)}
+        n = sum(v["dispatches"] for v in rows)
+        fetch = sum(v.get("FETCH_SIZE", 0.0) * v["dispatches"] for v in rows) / n
+        write = sum(v.get("WRITE_SIZE", 0.0) * v["dispatches"] for v in rows) / n
+        if fetch <= 0 or write <= 0:
+            dropped.append(scope)
+            continue
+        row = {"kernel": frag, "dispatches": n, "fetch_KiB": round(fetch, 1), "write_KiB": round(write, 1),
+               "traffic_bytes": int((FETCH_CORRECTION * fetch + write) * 1024)}
+        for c in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+                  "SQ_INSTS_VALU", "SQ_INSTS_LDS"):
+            vals = [v[c] * v["dispatches"] for v in rows if c in v]
+            if vals:
+                row[c] = round(sum(vals) / n, 1)
+        out[scope] = row
+    dst = os.path.join(prof, ROUND + "_pmc_traffic.json")
+    if have_fetch and have_write:
+        json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+        print("wrote", dst, "(%d scopes; omitted, no valid fetch/write: %s)" % (len(out) - 2, dropped or "none"))
+    else:
+        print("REFUSED to write %s: FETCH pass %s, WRITE pass %s -- the committed file is left as it is"
+              % (dst, "ok" if have_fetch else "EMPTY", "ok" if have_write else "EMPTY"))
     if raw:
-        json.dump(out, open(os.path.join(root, "profiles", "r01_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
-    for a, b in (("train_step_kernel_stats.csv", "r01_train_step_kernel_stats.csv"),
-                 ("ffwm_kernels_whole_run.csv", "r01_ffwm_kernels_rocprofv3.csv"),
-                 ("bench_default.json", "r01_bench_default.json")):
-        shutil.copy(os.path.join(src, a), os.path.join(root, "profiles", b))
+        json.dump(raw, open(os.path.join(prof, ROUND + "_pmc_raw_per_kernel.json"), "w"), indent=1, sort_keys=True)
+    copies = [("train_step_kernel_stats.csv", "_train_step_kernel_stats.csv"), ("warpatt_kernel_stats.csv", "_warpatt_kernel_stats.csv"),
+              ("flownet_kernel_stats.csv", "_flownet_lean_kernel_stats.csv"), ("flownet_module_kernel_stats.csv", "_flownet_module_kernel_stats.csv"),
+              ("flowtrain_kernel_stats.csv", "_flowtrain_kernel_stats.csv"), ("ops_kernel_stats.csv", "_ops_kernel_stats.csv"),
+              ("ffwm_kernels_whole_run.csv", "_ffwm_kernels_rocprofv3.csv"), ("bench_default.json", "_bench_default.json"),
+              ("warpatt_bench.json", "_bench_warpatt.json"), ("flownet_bench.json", "_bench_flownet.json"),
+              ("flowtrain_bench.json", "_bench_flowtrain.json"), ("ops_bench.json", "_bench_ops.json")]
+    for a, b in copies:
+        p = os.path.join(src, a)
+        if os.path.exists(p) and os.path.getsize(p) > 0:
+            shutil.copy(p, os.path.join(prof, ROUND + b))
+        else:
+            print("missing:", a)
     for k, v in out.items():
         if not k.startswith("_"):
-            print("%-30s %10.3f MB  x%d" % (k, v["traffic_bytes"] / 1e6, v["dispatches"]))
+            print("%-32s %10.3f MB  x%d" % (k, v["traffic_bytes"] / 1e6, v["dispatches"]))
 
 
 if __name__ == "__main__":

@@ -1,22 +1,35 @@
 #!/bin/bash
-# GPU-side half of the profile refresh (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace of the default train bench -> steady-state per-kernel stats (last 2 steps)
-#      and the whole-run stats of the hand-written kernels (incl. the stand-alone cfg-1 / cfg-5 shapes)
-#   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the same command (separate passes, counters only)
-#   3. the default `python bench.py` line
-# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/.
+# GPU-side half of the profile refresh (run through gpurun from the repo root; ~6 min of box time):
+#   1. rocprofv3 --kernel-trace of the default train bench -> steady-state per-kernel stats (last ~2 steps)
+#   2. the same for the other workloads (warpatt, flownet, flowtrain, ops)
+#   3. counter passes of the default command, hand-written kernels only (--kernel-include-regex ffwm: a counter pass
+#      that also instruments MIOpen's kernels aborts with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT): FETCH_SIZE, WRITE_SIZE
+#      and two SQ sets in SEPARATE runs (counters + --kernel-trace only)
+#   4. the default `python bench.py` line
+# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/r02_*.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh
-rm -rf /tmp/kt /tmp/pf /tmp/pw && mkdir -p /tmp/kt /tmp/pf /tmp/pw $OUT
-CMD="python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline"
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- $CMD --no-kernels > $OUT/trace_bench.log 2>&1
-F=$(find /tmp/kt -name "*kernel_trace.csv" | head -1)
-python $R/tools/steady_stats.py $F $OUT/train_step_kernel_stats.csv --window-ms 200 \
-    --header "rocprofv3 --kernel-trace -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernels; last 200 ms of the trace = ~2 eager train steps under the tracer (tools/refresh_profiles.sh)" > $OUT/steady.log 2>&1
-rm -rf /tmp/kt && mkdir -p /tmp/kt
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -- $CMD > $OUT/trace_bench_kernels.log 2>&1
-F=$(find /tmp/kt -name "*kernel_trace.csv" | head -1)
+rm -rf $OUT && mkdir -p $OUT
+trace() {   # tag window-ms bench-args...
+  local TAG=$1 WIN=$2; shift; shift
+  rm -rf /tmp/kt_$TAG && mkdir -p /tmp/kt_$TAG
+  timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -- python $R/bench.py "$@" --no-cpu-baseline --no-kernels --no-extras > $OUT/${TAG}_bench.log 2>&1
+  local F=$(find /tmp/kt_$TAG -name "*kernel_trace.csv" | head -1)
+  python $R/tools/steady_stats.py $F $OUT/${TAG}_kernel_stats.csv --window-ms $WIN \
+      --header "rocprofv3 --kernel-trace -- python bench.py $* --no-cpu-baseline --no-kernels --no-extras; last $WIN ms of the trace (tools/refresh_profiles.sh)" > $OUT/${TAG}_steady.log 2>&1
+  grep -h '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
+}
+trace train_step 200 --steps 6 --warmup 3
+trace warpatt 30 --workload warpatt --steps 20 --warmup 5
+trace flownet 15 --workload flownet --steps 40 --warmup 10
+trace flownet_module 20 --workload flownet --flownet-path module --steps 40 --warmup 10
+trace flowtrain 60 --workload flowtrain --steps 10 --warmup 3
+trace ops 30 --workload ops --steps 10 --warmup 3
+# whole-run statistics of the hand-written kernels of the default command (train steps + stand-alone cfg-1 / cfg-5 shapes)
+rm -rf /tmp/kt_all && mkdir -p /tmp/kt_all
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_all -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras > $OUT/trace_all.log 2>&1
+F=$(find /tmp/kt_all -name "*kernel_trace.csv" | head -1)
 python - "$F" "$OUT/ffwm_kernels_whole_run.csv" <<'PY'
 import collections, csv, sys
 acc = collections.OrderedDict()
@@ -28,19 +41,19 @@ for r in csv.DictReader(open(sys.argv[1])):
     a[0] += 1
     a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 with open(sys.argv[2], "w") as f:
-    f.write("# hand-written kernels over the whole traced run (train steps + stand-alone cfg-1 / cfg-5 shapes), rocprofv3 --kernel-trace\n")
+    f.write("# hand-written kernels over the whole traced run (train steps + stand-alone cfg-1 / cfg-5 shapes), rocprofv3 --kernel-trace -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras\n")
     f.write("Name,Calls,TotalDurationNs,AverageNs\n")
     for n, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         f.write('"%s",%d,%d,%d\n' % (n, c, t, t // c))
 PY
-if [ "${FFWM_REFRESH_PMC:-1}" = "1" ]; then
-# counter passes: MIOpen's heuristic solvers (FFWM_MIOPEN_DB=0) -- with the tuned solver set a counter pass aborts with
-# HSA_STATUS_ERROR_INVALID_PACKET_FORMAT inside a vendor kernel; the traffic of the hand-written kernels does not
-# depend on which vendor kernels run next to them.  Short timeouts: a pass takes ~40 s when it works.
-PMC="python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline"
-FFWM_MIOPEN_DB=0 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- $PMC > $OUT/pmc_fetch.log 2>&1
-FFWM_MIOPEN_DB=0 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- $PMC > $OUT/pmc_write.log 2>&1
-fi
-python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw $OUT/bench_pmc_raw.json > $OUT/pmc_top.txt 2>&1
-timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-tail -c 300 $OUT/bench_default.json
+# counter passes
+PMC="python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras"
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SALU"; do
+  rm -rf /tmp/pmc_$i && mkdir -p /tmp/pmc_$i
+  timeout 600 rocprofv3 --pmc $C --kernel-include-regex "ffwm" --kernel-trace --output-format csv -d /tmp/pmc_$i -- $PMC > $OUT/pmc_pass$i.log 2>&1 || echo "counter pass $i ($C) failed rc=$?" | tee -a $OUT/pmc_failures.txt
+  i=$((i+1))
+done
+python $R/tools/pmc_fold.py $OUT/bench_pmc_raw.json /tmp/pmc_0 /tmp/pmc_1 /tmp/pmc_2 /tmp/pmc_3 > $OUT/pmc_fold.txt 2>&1
+timeout 1200 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+tail -c 400 $OUT/bench_default.json
