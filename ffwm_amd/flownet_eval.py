@@ -16,6 +16,8 @@ launches at batch 6, 80 % of them under 10 us: the step is bound by launches and
 The dense 3x3 / 4x4 convolutions stay on MIOpen (fp32 Winograd / implicit GEMM on the matrix cores).  Weights are
 snapshotted at construction: build it from a network in `.eval()` and rebuild after the weights change.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -75,8 +77,40 @@ def flow_up(flow, weight, bias, out):
     return out
 
 
+def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None, dst2=None):
+    """The hand-written fp32 MFMA convolution (csrc/conv_fwd.hip) with its bias + activation epilogue: fused in the kernel,
+    or -- when the layer has so few output pixels that the launch is cut along the reduction -- as a bias_act pass over
+    the atomically accumulated result.  dst / dst2 as in bias_act (channel slices of concatenation buffers)."""
+    B, C, H, W = x.shape
+    k = weight.size(2)
+    if transposed:
+        K, Ho, Wo = weight.size(1), 2 * H, 2 * W
+    else:
+        K = weight.size(0)
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    lib = _lib.load()
+    flag = ctypes.c_int(0)
+    small = B * Ho * Wo * ((K + 63) // 64) * (1 if transposed else 4) < 256 * 64 * 4      # fewer than 256 tiles: split the reduction
+    direct = dst is not None and dst2 is None and not small
+    y = dst if direct else (torch.zeros if small else torch.empty)(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
+    _lib.check(lib.ffwm_conv2d_forward(x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                       B, C, H, W, K, k, stride, pad, 1 if transposed else 0, y.stride(0), act, float(slope),
+                                       1 if small else 0, ctypes.byref(flag), _lib.F32, _stream(x)), "ffwm_conv2d_forward")
+    if flag.value:                       # split launch: bias + activation as a pass over the accumulated sums
+        if dst is None and dst2 is None:
+            return bias_act(y, bias, act, slope=slope)
+        bias_act(y, bias, act, y=dst if dst is not None else y, y2=dst2, slope=slope)
+        return dst if dst is not None else y
+    if direct or (dst is None and dst2 is None):
+        return y
+    # fused epilogue already applied: only the extra destination(s) remain to be written
+    bias_act(y, None, NONE, y=dst, y2=dst2)
+    return dst if dst is not None else y
+
+
 class FoldedFlowNet(object):
-    def __init__(self, net, graph=False):
+    def __init__(self, net, graph=False, mfma_conv=True):
+        self.mfma_conv = bool(mfma_conv)
         if net.training:
             raise ValueError("FoldedFlowNet folds eval-mode BatchNorm statistics: call net.eval() first")
         p = next(net.parameters())
@@ -102,6 +136,10 @@ class FoldedFlowNet(object):
     # conv (no bias: it is added by the epilogue) -> bias + LeakyReLU, in place and / or into a cat slice
     def _block(self, name, x, dst=None, dst2=None):
         transposed, w, b, stride, padding, slope = self.blocks[name]
+        if self.mfma_conv and (transposed or stride[0] == 2 or x.size(2) <= 8):
+            # the layers MIOpen wraps in layout transposes (stride-2 convolutions, transposed convolutions) and the
+            # weight-streaming 2 x 2 ... 8 x 8 tail: hand-written MFMA kernel with the epilogue fused
+            return conv_mfma(x, w, b, stride[0], padding[0], transposed, LRELU, slope, dst=dst, dst2=dst2)
         h = F.conv_transpose2d(x, w, None, stride, padding) if transposed else F.conv2d(x, w, None, stride, padding)
         if dst is None and dst2 is None:
             return bias_act(h, b, LRELU, slope=slope)

@@ -306,6 +306,17 @@ int ffwm_flow_head_forward(const void* x, const void* weight, const void* bias, 
 int ffwm_flow_up_forward(const void* flow, const void* weight, const void* bias, void* out, int64_t B, int64_t H, int64_t W,
                          int64_t out_batch_stride, int dtype, void* stream);
 
+/* fp32 MFMA implicit-GEMM convolution forward, NCHW, for the layers the vendor library wraps in layout transposes:
+ * nn.Conv2d(C, K, kernel 3 or 4, stride 1 or 2, pad) or -- transposed != 0 -- nn.ConvTranspose2d(C, K, 4, 2, 1)
+ * (weight [C, K, 4, 4]) of models/base_networks.py:12-31,64-112.  output sample b starts at output + b * out_batch_stride
+ * (a channel slice of a concatenation buffer is a valid destination).  act: 0 none, 1 LeakyReLU(negative_slope), 2 tanh,
+ * applied after the bias.  allow_split != 0 lets a layer with few output pixels be cut along its reduction over several
+ * workgroups; *needs_epilogue is then set to 1: the caller must have ZERO-FILLED the output, and bias / activation were NOT
+ * applied (run ffwm_bias_act_forward afterwards).  Exact fp32 (v_mfma_f32_32x32x2_f32). */
+int ffwm_conv2d_forward(const void* input, const void* weight, const void* bias, void* output, int64_t B, int64_t C, int64_t H,
+                        int64_t W, int64_t K, int kernel, int stride, int pad, int transposed, int64_t out_batch_stride,
+                        int act, double negative_slope, int allow_split, int* needs_epilogue, int dtype, void* stream);
+
 /* One Adam step (no weight decay, no amsgrad: torch.optim.Adam as models/ffwm_model.py:46-49 and
  * models/flownet_model.py:33 construct it) over FLAT float32 arrays of n elements, 16-byte aligned: parameters,
  * gradients, first and second moments.  `step` is the 1-based step count (bias corrections 1 - beta^step). */

@@ -1333,3 +1333,37 @@ def test_ffwm_generator_levels_in_one_launch_match_the_per_level_path():
     sum((single(f, fl) * w).sum() for f, fl, w in zip(fb, lb, wts)).backward()
     for x, y in zip(fa + la, fb + lb):
         assert (x.grad - y.grad).abs().max().item() <= 1e-5 * (1 + y.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------- MFMA convolution forward
+@pytest.mark.parametrize("case", [
+    # (B, C, H, W, K, kernel, stride, pad, transposed)
+    (2, 3, 16, 16, 8, 3, 2, 1, False),          # tiny: partial tiles everywhere
+    (6, 64, 128, 128, 64, 3, 2, 1, False),      # FlowNet conv1 (base_networks.py:65)
+    (6, 512, 4, 4, 1024, 3, 2, 1, False),       # conv6: 24 output pixels, split along the reduction
+    (6, 1024, 2, 2, 1024, 3, 1, 1, False),      # conv6_1
+    (3, 70, 9, 11, 130, 3, 1, 1, False),        # ragged everything
+    (2, 64, 32, 32, 128, 4, 2, 1, False),       # netG encoder e1-e3 (4x4 / stride 2)
+    (6, 1024, 2, 2, 512, 4, 2, 1, True),        # deconv5
+    (6, 66, 32, 32, 32, 4, 2, 1, True),         # deconv1
+    (2, 5, 7, 9, 3, 4, 2, 1, True),             # ragged transposed
+])
+def test_conv2d_forward_mfma_matches_aten(case):
+    """csrc/conv_fwd.hip against ATen's float64 convolution: conv + bias + LeakyReLU, plain and transposed, fused and
+    split-reduction launches, and the write into a channel slice of a wider buffer."""
+    from ffwm_amd import flownet_eval
+    B, C, H, W, K, k, stride, pad, transposed = case
+    g = _gen(sum(case[:5]))
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(*((C, K, k, k) if transposed else (K, C, k, k)), generator=g) / (C * k * k) ** 0.5
+    b = torch.randn(K, generator=g)
+    conv = F.conv_transpose2d if transposed else F.conv2d
+    ref = F.leaky_relu(conv(x.double(), w.double(), b.double(), stride, pad), 0.2)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2)
+    tol = 2e-5 * (1 + ref.abs().max().item())
+    assert (y.cpu().double() - ref).abs().max().item() <= tol
+    buf = torch.full((B, K + 5, ref.size(2), ref.size(3)), 7.0, device=DEV)
+    flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2, dst=buf[:, 2:2 + K])
+    assert (buf[:, 2:2 + K].cpu().double() - ref).abs().max().item() <= tol
+    assert (buf[:, :2] == 7).all() and (buf[:, 2 + K:] == 7).all()
