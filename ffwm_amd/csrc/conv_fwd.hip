@@ -34,24 +34,31 @@ struct ConvGeo {
     int Kd;                  // reduction length: C * R * S (MODE 1: C * 4)
     int N;                   // B * Ho * Wo
     int n_tiles, k_tiles;
-    int splitk, chunks;      // chunks (of 32 kd) per split
+    int splitk, chunks;      // chunks (of CPC input channels) per split
     long long out_bs;        // output batch stride in elements
     int oH, oW;              // output plane (MODE 1: 2H x 2W)
     int act;
     float slope;
+    unsigned x_bytes, w_bytes;   // sizes of the input / weight tensors (buffer resources; both < 2^31)
 };
 
-constexpr int kKC = 32;              // kd per chunk
-constexpr int kAP = kKC + 1;         // As pitch
 constexpr int kBP = 64;              // Bs pitch
 
+// A chunk of the reduction = CPC whole input channels x all R*S taps, so that the (channel-in-chunk, r, s) of every staged
+// element is FIXED for the life of the kernel: all address arithmetic happens once, before the loop, and a chunk costs
+// one add per load.  (The first version decoded kd -> (c, r, s) per element and chunk on the scalar unit: 270 SALU
+// instructions per chunk and wave, more issue time than the 16 MFMAs they fed -- SQ counters: SALU 7.6 M vs MFMA 0.44 M.)
 template <int MODE, int R, int S>
 __global__ void __launch_bounds__(kBlock)
 conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
                 const ConvGeo g) {
-    __shared__ float As[64 * kAP];
-    __shared__ float Bs[kKC * kBP];
-    constexpr int RS = R * S;
+    constexpr int RS = MODE == 0 ? R * S : 4;
+    constexpr int CPC = RS == 9 ? 4 : (RS == 16 ? 2 : 8);       // channels per chunk
+    constexpr int KC = CPC * RS;                                  // 36 / 32 / 32 reduction steps per chunk (even: MFMA k = 2)
+    constexpr int AP = KC + 1;                                    // As pitch (odd: conflict-free operand reads)
+    constexpr int NE = KC * 64 / kBlock;                          // staged elements per thread and operand: 9 / 8 / 8
+    __shared__ float As[64 * AP];
+    __shared__ float Bs[KC * kBP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -60,9 +67,16 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     const int split = zz % g.splitk;
     zz /= g.splitk;
     const int py = MODE == 1 ? (zz >> 1) : 0, px = MODE == 1 ? (zz & 1) : 0;
+    constexpr unsigned kOobOff = 0xFFFFFFF0u;
 
-    // ---- the pixel this thread gathers for (fixed over the chunks): nn = tid % 64
+    // branch-free loads: buffer resources over the whole tensors + 32-bit byte offsets; an invalid element gets an offset
+    // beyond the resource and the hardware returns 0
+    const rsrc_t rx = make_rsrc(x, g.x_bytes);
+    const rsrc_t rw = make_rsrc(w, g.w_bytes);
+
+    // ---- B: the pixel this thread gathers for is fixed (nn = tid % 64), and so is each element's tap: kk = wave + 4 i
     const int plane_o = g.Ho * g.Wo;
+    const int HW = g.H * g.W;
     const int gn = n0 + (threadIdx.x & 63);
     const bool gvalid = gn < g.N;
     const int gb = gvalid ? gn / plane_o : 0;
@@ -70,74 +84,92 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     const int goy = gp / g.Wo, gox = gp - goy * g.Wo;
     const int iy0 = MODE == 0 ? goy * g.stride - g.pad : goy + py;     // MODE 1: iy = y' + py - a
     const int ix0 = MODE == 0 ? gox * g.stride - g.pad : gox + px;
-    const float* xb = x + static_cast<size_t>(gb) * g.C * g.H * g.W;
-    const int kkB = threadIdx.x >> 6;             // + 4 i
-    // ---- the weight element this thread stages: kk = tid % 32, m = tid / 32 + 8 i
-    const int kkA = threadIdx.x & 31, mA = threadIdx.x >> 5;
-
-    const int kd_begin = split * g.chunks * kKC;
-    const int kd_end = min(g.Kd, kd_begin + g.chunks * kKC);
-
-    float ra[8], rb[8];
-    auto fetch = [&](int kd0) {
+    unsigned boff[NE];                   // byte offset of the element for channel chunk 0, or kOobOff
+    int bcc[NE];                         // its channel within the chunk (wave-uniform)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // A: Wm[k0 + m][kd0 + kk]
-            const int m = mA + 8 * i, kd = kd0 + kkA;
-            float v = 0.f;
-            if (k0 + m < g.K && kd < kd_end) {
-                if constexpr (MODE == 0) {
-                    v = w[static_cast<size_t>(k0 + m) * g.Kd + kd];
-                } else {                      // ConvTranspose2d weight [C][K][4][4]; kd = c * 4 + a * 2 + b
-                    const int c = kd >> 2, a = (kd >> 1) & 1, bq = kd & 1;
-                    v = w[(static_cast<size_t>(c) * g.K + (k0 + m)) * 16 + (1 - py + 2 * a) * 4 + (1 - px + 2 * bq)];
-                }
-            }
-            ra[i] = v;
+    for (int i = 0; i < NE; ++i) {
+        const int kk = wave + 4 * i;
+        const int cc = kk / RS, rs = kk - cc * RS;
+        int iy, ix;
+        if constexpr (MODE == 0) {
+            iy = iy0 + rs / S; ix = ix0 + rs % S;
+        } else {
+            iy = iy0 - (rs >> 1); ix = ix0 - (rs & 1);
+        }
+        const bool ok = gvalid && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        bcc[i] = cc;
+        boff[i] = ok ? ((static_cast<unsigned>(gb) * g.C + cc) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + ix)) * 4u : kOobOff;
+    }
+    // ---- A: element e = tid + 256 i of the [64 x KC] weight chunk: m = e / KC, kk = e % KC -- fixed as well
+    unsigned aoff[NE];                   // byte offset for chunk 0, or kOobOff
+    int acc_[NE], alds[NE];              // channel within the chunk; LDS slot
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + kBlock * i;
+        const int m = e / KC, kk = e - m * KC;
+        const int cc = kk / RS, rs = kk - cc * RS;
+        acc_[i] = cc;
+        alds[i] = m * AP + kk;
+        if (k0 + m >= g.K) aoff[i] = kOobOff;
+        else if (MODE == 0) aoff[i] = (static_cast<unsigned>(k0 + m) * static_cast<unsigned>(g.Kd) + kk) * 4u;
+        else                       // ConvTranspose2d weight [C][K][4][4]: tap (a, b) = (rs >> 1, rs & 1) -> ky = 1 - py + 2a, kx = 1 - px + 2b
+            aoff[i] = ((static_cast<unsigned>(cc) * g.K + (k0 + m)) * 16u + (1 - py + 2 * (rs >> 1)) * 4 + (1 - px + 2 * (rs & 1))) * 4u;
+    }
+    const unsigned a_step = (MODE == 0 ? static_cast<unsigned>(KC) : static_cast<unsigned>(CPC) * g.K * 16u) * 4u;   // bytes per chunk
+    const unsigned b_step = static_cast<unsigned>(CPC) * static_cast<unsigned>(HW) * 4u;
+
+    const int chunk_begin = split * g.chunks;
+    const int chunk_end = min((g.C + CPC - 1) / CPC, chunk_begin + g.chunks);
+
+    auto fetch = [&](int ch, float (&ra)[NE], float (&rb)[NE]) {
+        const int c0 = ch * CPC;
+        const unsigned ao = static_cast<unsigned>(ch) * a_step, bo = static_cast<unsigned>(ch) * b_step;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const bool cin = c0 + acc_[i] < g.C;                       // only the last chunk can run past C
+            ra[i] = buf_ld<float>(rw, (cin && aoff[i] != kOobOff) ? aoff[i] + ao : kOobOff);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // B: Xg[kd0 + kk][n]
-            const int kd = kd0 + kkB + 4 * i;
-            float v = 0.f;
-            if (gvalid && kd < kd_end) {
-                int c, iy, ix;
-                if constexpr (MODE == 0) {
-                    c = kd / RS;
-                    const int rs = kd - c * RS;
-                    const int r = rs / S, s = rs - r * S;
-                    iy = iy0 + r; ix = ix0 + s;
-                } else {
-                    c = kd >> 2;
-                    iy = iy0 - ((kd >> 1) & 1); ix = ix0 - (kd & 1);
-                }
-                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) v = xb[(static_cast<size_t>(c) * g.H + iy) * g.W + ix];
-            }
-            rb[i] = v;
+        for (int i = 0; i < NE; ++i) {
+            const bool cin = c0 + bcc[i] < g.C;
+            rb[i] = buf_ld<float>(rx, (cin && boff[i] != kOobOff) ? boff[i] + bo : kOobOff);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const float (&ra)[NE], const float (&rb)[NE]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) As[(mA + 8 * i) * kAP + kkA] = ra[i];
+        for (int i = 0; i < NE; ++i) As[alds[i]] = ra[i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) Bs[(kkB + 4 * i) * kBP + (threadIdx.x & 63)] = rb[i];
+        for (int i = 0; i < NE; ++i) Bs[(wave + 4 * i) * kBP + (threadIdx.x & 63)] = rb[i];
     };
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    fetch(kd_begin);
-    for (int kd0 = kd_begin; kd0 < kd_end; kd0 += kKC) {
-        __syncthreads();                 // the previous chunk's operands are consumed
-        commit();
-        __syncthreads();
-        if (kd0 + kKC < kd_end) fetch(kd0 + kKC);      // in flight under the MFMAs
-        const float* ap = As + (wm * 32 + l31) * kAP + half;
+    // software pipeline, prefetch distance 2: the global loads of chunks i+1 and i+2 are in flight while the KC/2 MFMAs per
+    // wave of chunk i run
+    float ra0[NE], rb0[NE], ra1[NE], rb1[NE];
+    auto compute = [&]() {
+        const float* ap = As + (wm * 32 + l31) * AP + half;
         const float* bp = Bs + half * kBP + wn * 32 + l31;
 #pragma unroll
-        for (int q = 0; q < kKC / 2; ++q)
+        for (int q = 0; q < KC / 2; ++q)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * q], bp[2 * q * kBP], acc, 0, 0, 0);
+    };
+    if (chunk_begin < chunk_end) fetch(chunk_begin, ra0, rb0);
+    if (chunk_begin + 1 < chunk_end) fetch(chunk_begin + 1, ra1, rb1);
+    for (int ch = chunk_begin; ch < chunk_end; ch += 2) {
+        __syncthreads();                 // the previous chunk's operands are consumed
+        commit(ra0, rb0);
+        __syncthreads();
+        if (ch + 2 < chunk_end) fetch(ch + 2, ra0, rb0);
+        compute();
+        if (ch + 1 >= chunk_end) break;
+        __syncthreads();
+        commit(ra1, rb1);
+        __syncthreads();
+        if (ch + 3 < chunk_end) fetch(ch + 3, ra1, rb1);
+        compute();
     }
 
     // ---- epilogue.  C/D layout: col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
@@ -201,12 +233,16 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
         FFWM_REQUIRE(g.Ho > 0 && g.Wo > 0, FFWM_ERR_ARG, "%s: empty output", fn);
         g.oH = g.Ho; g.oW = g.Wo; g.Kd = g.C * kernel * kernel;
     }
-    FFWM_REQUIRE(B * g.Ho * g.Wo < (1LL << 31) && static_cast<int64_t>(g.C) * H * W < (1LL << 31), FFWM_ERR_SIZE, "%s: tensor too large", fn);
+    FFWM_REQUIRE(B * g.Ho * g.Wo < (1LL << 31) && B * C * H * W < (1LL << 29) && K * static_cast<int64_t>(g.Kd) * (transposed ? 4 : 1) < (1LL << 29),
+                 FFWM_ERR_SIZE, "%s: tensor too large (input and weight must stay below 2 GiB: 32-bit buffer offsets)", fn);
+    g.x_bytes = static_cast<unsigned>(B * C * H * W * 4);
+    g.w_bytes = static_cast<unsigned>(K * static_cast<int64_t>(g.Kd) * (transposed ? 4 : 1) * 4);
     FFWM_REQUIRE(out_batch_stride >= K * g.oH * g.oW, FFWM_ERR_ARG, "%s: output batch stride smaller than K * Ho * Wo", fn);
     g.N = static_cast<int>(B * g.Ho * g.Wo);
     g.n_tiles = (g.N + 63) / 64;
     g.k_tiles = (g.K + 63) / 64;
-    const int chunks_total = (g.Kd + kKC - 1) / kKC;
+    const int cpc = transposed ? 8 : (kernel == 3 ? 4 : 2);          // channels per chunk (conv_fwd_kernel's CPC)
+    const int chunks_total = (g.C + cpc - 1) / cpc;
     const int64_t tiles = static_cast<int64_t>(g.n_tiles) * g.k_tiles * classes;
     int splitk = 1;
     if (allow_split && tiles < 256) {

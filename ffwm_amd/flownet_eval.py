@@ -136,9 +136,11 @@ class FoldedFlowNet(object):
     # conv (no bias: it is added by the epilogue) -> bias + LeakyReLU, in place and / or into a cat slice
     def _block(self, name, x, dst=None, dst2=None):
         transposed, w, b, stride, padding, slope = self.blocks[name]
-        if self.mfma_conv and (transposed or stride[0] == 2 or x.size(2) <= 8):
-            # the layers MIOpen wraps in layout transposes (stride-2 convolutions, transposed convolutions) and the
-            # weight-streaming 2 x 2 ... 8 x 8 tail: hand-written MFMA kernel with the epilogue fused
+        if self.mfma_conv and (transposed or stride[0] == 2 or x.size(2) <= 32) and x.size(1) >= 32:
+            # the layers MIOpen wraps in layout transposes (stride-2 convolutions, transposed convolutions), the
+            # weight-streaming 2 x 2 ... 8 x 8 tail and the 16 x 16 / 32 x 32 stride-1 layers (measured per layer,
+            # tools/conv_layers.py: faster than the vendor kernel + epilogue everywhere except the >= 64 x 64 stride-1
+            # layers and the thin 18 / 34-channel ones): hand-written MFMA kernel with the epilogue fused
             return conv_mfma(x, w, b, stride[0], padding[0], transposed, LRELU, slope, dst=dst, dst2=dst2)
         h = F.conv_transpose2d(x, w, None, stride, padding) if transposed else F.conv2d(x, w, None, stride, padding)
         if dst is None and dst2 is None:
