@@ -77,7 +77,7 @@ def part_grids(lm_F, torch15_integer_division=False):
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
                  warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True,
-                 mfma_wgrad=None, flat_adam=None, fused_bn=None):
+                 mfma_wgrad=None, flat_adam=None, fused_bn=None, mfma_fwd=None):
         self.device = torch.device(device)
         self.titers = titers
         torch.manual_seed(seed)
@@ -113,6 +113,14 @@ class FFWMTrainer(object):
             # weight gradients of the large-image 3x3 layers on the hand-written MFMA kernel (conv.py)
             from .conv import route_conv_wgrad
             self.mfma_wgrad_layers = route_conv_wgrad(self.netG)
+        if mfma_fwd is None:
+            mfma_fwd = self.device.type == "cuda"
+        self.mfma_fwd_layers = 0
+        if mfma_fwd:
+            # forward (and the 4x4 / stride-2 data gradients) of the stride-2 / transposed / small-plane convolutions on the
+            # hand-written MFMA kernel instead of the vendor's NHWC implicit GEMM + layout transposes (conv.py)
+            from .conv import route_conv_fwd
+            self.mfma_fwd_layers = sum(route_conv_fwd(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD))
         if fused_bn is None:
             fused_bn = self.device.type == "cuda"
         if fused_bn:

@@ -144,7 +144,7 @@ def test_ffwm_train_step_batch8_full_size_properties():
     optimisers) at batch 8 -- finite losses, and the hand-written fast paths agree with the plain PyTorch paths."""
     from ffwm_amd import trainer
     batch = trainer.synthetic_batch(8, DEV, seed=11)
-    plain = trainer.FFWMTrainer(DEV, seed=2, mfma_wgrad=False, flat_adam=False, fused_bn=False, fused_spectral_norm=False,
+    plain = trainer.FFWMTrainer(DEV, seed=2, mfma_wgrad=False, mfma_fwd=False, flat_adam=False, fused_bn=False, fused_spectral_norm=False,
                                 batched_losses=False, capturable=False)
     plain.red_G.set_gather(False)
     plain.red_D.set_gather(False)

@@ -792,7 +792,7 @@ def test_train_step_fast_paths_match_the_plain_pytorch_paths():
     weights agrees to the noise the float atomics of the backward kernels allow."""
     from ffwm_amd import trainer
     batch = trainer.synthetic_batch(2, DEV, seed=5)
-    plain = trainer.FFWMTrainer(DEV, seed=1, mfma_wgrad=False, flat_adam=False, fused_bn=False, fused_spectral_norm=False,
+    plain = trainer.FFWMTrainer(DEV, seed=1, mfma_wgrad=False, mfma_fwd=False, flat_adam=False, fused_bn=False, fused_spectral_norm=False,
                                 batched_losses=False, capturable=False)
     plain.red_G.set_gather(False)
     plain.red_D.set_gather(False)
@@ -1367,3 +1367,27 @@ def test_conv2d_forward_mfma_matches_aten(case):
     flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2, dst=buf[:, 2:2 + K])
     assert (buf[:, 2:2 + K].cpu().double() - ref).abs().max().item() <= tol
     assert (buf[:, :2] == 7).all() and (buf[:, 2 + K:] == 7).all()
+
+
+def test_conv_forward_routing_matches_aten_autograd():
+    """conv.route_conv_fwd: re-classed Conv2d / ConvTranspose2d (forward on csrc/conv_fwd.hip, the 4x4 / stride-2 data
+    gradients too) against the untouched modules -- outputs, input gradients and parameter gradients."""
+    import copy
+    import torch.nn as nn
+    from ffwm_amd import conv
+    torch.manual_seed(7)
+    ref = nn.Sequential(nn.Conv2d(40, 64, 3, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 96, 4, 2, 1), nn.LeakyReLU(0.2),
+                        nn.Conv2d(96, 96, 3, 1, 1), nn.LeakyReLU(0.2), nn.ConvTranspose2d(96, 48, 4, 2, 1), nn.LeakyReLU(0.2),
+                        nn.ConvTranspose2d(48, 33, 4, 2, 1)).to(DEV)
+    fast = copy.deepcopy(ref)
+    assert conv.route_conv_fwd(fast) == 5
+    x = torch.randn(3, 40, 32, 32, generator=_gen(9)).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = ref(xa), fast(xb)
+    assert (ya - yb).abs().max().item() <= 2e-5 * (1 + ya.abs().max().item())
+    go = torch.randn(ya.shape, generator=_gen(10)).to(DEV)
+    ya.backward(go)
+    yb.backward(go)
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * (1 + xa.grad.abs().max().item())
+    for (n, p), (_, q) in zip(ref.named_parameters(), fast.named_parameters()):
+        assert (p.grad - q.grad).abs().max().item() <= 1e-4 * (1 + p.grad.abs().max().item()), n
