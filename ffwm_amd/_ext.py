@@ -1,0 +1,29 @@
+"""The C++ autograd bindings (ffwm_amd/csrc_ext/ffwm_torch.cpp -> ffwm_amd/lib/ffwm_torch_ext.so).
+
+Same kernels, same C ABI as the ctypes path (`_lib`, `ops`, the Python autograd Functions); only the host-side cost per
+call differs (a few microseconds instead of 14-35).  `get()` returns the module, or None when it was not built (the
+callers then use the ctypes Functions); `FFWM_TORCH_EXT=0` switches it off for A/B measurements."""
+import importlib.util
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+EXT_PATH = os.path.join(_HERE, "lib", "ffwm_torch_ext.so")
+_mod = None
+_tried = False
+
+
+def get():
+    global _mod, _tried
+    if _tried:
+        return _mod
+    _tried = True
+    if os.environ.get("FFWM_TORCH_EXT", "1") == "0" or not os.path.exists(EXT_PATH):
+        return None
+    import torch  # noqa: F401  (libtorch must be loaded first)
+    from . import _lib
+    _lib.load()                               # libffwm_hip.so: fail loudly if the kernels themselves are missing
+    spec = importlib.util.spec_from_file_location("ffwm_torch_ext", EXT_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _mod = mod
+    return _mod

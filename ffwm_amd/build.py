@@ -92,5 +92,42 @@ def build(force=False, verbose=False):
     return LIB
 
 
+EXT_SRC = os.path.join(HERE, "csrc_ext", "ffwm_torch.cpp")
+EXT_LIB = os.path.join(LIBDIR, "ffwm_torch_ext.so")
+
+
+def build_ext(force=False, verbose=False):
+    """The C++ autograd bindings (csrc_ext/ffwm_torch.cpp, a pybind11 torch extension linked against libffwm_hip.so):
+    g++ against the PyTorch-ROCm headers, in-tree, no GPU needed.  Returns the path of the module."""
+    import sysconfig
+    import torch
+    build()
+    stamp = EXT_LIB + ".digest"
+    h = hashlib.sha256()
+    for p in (EXT_SRC, os.path.join(HERE, "..", "include", "ffwm_hip.h")):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    digest = h.hexdigest()
+    if not force and os.path.exists(EXT_LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return EXT_LIB
+    tdir = os.path.dirname(torch.__file__)
+    tinc, tlib = os.path.join(tdir, "include"), os.path.join(tdir, "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-DTORCH_EXTENSION_NAME=ffwm_torch_ext",
+           "-I" + tinc, "-I" + os.path.join(tinc, "torch/csrc/api/include"), "-I" + sysconfig.get_paths()["include"],
+           "-I/opt/rocm/include", EXT_SRC, "-o", EXT_LIB, "-L" + tlib, "-L" + LIBDIR, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib,
+           "-lffwm_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", "-ltorch_python"]
+    if verbose:
+        print("g++: compiling the torch extension (csrc_ext/ffwm_torch.cpp)")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building ffwm_torch_ext failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:]))
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return EXT_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_ext(force="--force" in sys.argv, verbose=True))

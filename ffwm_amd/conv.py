@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from . import ops
+from . import _ext, ops
 
 
 class _Conv3x3MfmaWgrad(Function):
@@ -61,6 +61,9 @@ class MfmaWgradConv2d(nn.Conv2d):
 
     def _conv_forward(self, input, weight, bias):
         if torch.is_grad_enabled() and weight.requires_grad and wgrad_route_ok(input, weight):
+            ext = _ext.get()
+            if ext is not None:
+                return ext.conv3x3_mfma_wgrad(input, weight, bias)
             return _Conv3x3MfmaWgrad.apply(input, weight, bias)
         return super()._conv_forward(input, weight, bias)
 
@@ -151,6 +154,9 @@ class MfmaFwdConv2d(nn.Conv2d):
 
     def _conv_forward(self, input, weight, bias):
         if fwd_route_ok(input, weight) and (self.stride[0] == 2 or input.size(2) <= 32):
+            ext = _ext.get()
+            if ext is not None:
+                return ext.conv2d(input, weight, bias, self.stride[0], self.padding[0])
             return _MfmaConv2d.apply(input, weight, bias, self.stride[0], self.padding[0])
         return super()._conv_forward(input, weight, bias)
 
@@ -160,6 +166,9 @@ class MfmaFwdConvTranspose2d(nn.ConvTranspose2d):
 
     def forward(self, input, output_size=None):
         if output_size is None and fwd_route_ok(input, self.weight):
+            ext = _ext.get()
+            if ext is not None:
+                return ext.conv_transpose2d(input, self.weight, self.bias)
             return _MfmaConvTranspose2d.apply(input, self.weight, self.bias)
         return super().forward(input, output_size)
 

@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
+from . import _ext
 from .external_function import WarpFlipCat, WarpNet, warp_many
 
 LRELU = 0.2
@@ -303,6 +304,9 @@ class mfm(nn.Module):
                 h = F.conv2d(x, f.weight, None, f.stride, f.padding, f.dilation, f.groups)
             else:
                 h = F.linear(x, f.weight, None)
+            ext = _ext.get()
+            if ext is not None:
+                return ext.mfm(h.contiguous(), f.bias)
             return MaxFeatureMapFunction.apply(h.contiguous(), f.bias)
         a, b = torch.split(f(x), self.out_channels, 1)
         return torch.max(a, b)
@@ -402,7 +406,9 @@ class VGG19(nn.Module):
                 while i < len(mods):
                     m = mods[i]
                     if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and m.bias is not None:
-                        x = BiasReLUFunction.apply(F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups), m.bias)
+                        h = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+                        ext = _ext.get()
+                        x = ext.bias_relu(h, m.bias) if ext is not None else BiasReLUFunction.apply(h, m.bias)
                         i += 2
                     else:
                         x = m(x)

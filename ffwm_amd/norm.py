@@ -6,12 +6,14 @@ The conv blocks of the reference (models/base_networks.py:12-31 FlowNet, :207-26
 ``nn.Sequential`` by ``nn.Identity`` (no parameters: the container's indices, hence every key, stay the same).
 In eval mode, on the CPU, or for inputs the kernel does not take, the module is exactly BatchNorm2d + leaky_relu.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from . import _lib
+from . import _ext, _lib
 
 
 def _launch(fn_name, x, *args):
@@ -73,8 +75,14 @@ class _BnLreluFunction(Function):
 MIN_FUSED_NUMEL = 1 << 20
 
 
+# ... with the C++ binding (ffwm_amd/_ext.py) the host cost no longer decides; measured on the train step, floors of
+# 0 / 256 K / 1 M elements give 60.1 / 59.1 / 59.0 ms: tiny planes are better off in the vendor's two kernels
+MIN_FUSED_NUMEL_EXT = int(os.environ.get("FFWM_BN_MIN_NUMEL", str(1 << 20)))
+
+
 def _kernel_ok(x):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() >= MIN_FUSED_NUMEL and x.is_contiguous()
+    floor = MIN_FUSED_NUMEL if (MIN_FUSED_NUMEL == 0 or _ext.get() is None) else MIN_FUSED_NUMEL_EXT
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() >= floor and x.is_contiguous()
             and x.data_ptr() % 16 == 0)
 
 
@@ -93,6 +101,9 @@ class BatchNormLeakyReLU2d(nn.BatchNorm2d):
                 self._pending_batches += 1
             rm = self.running_mean if self.track_running_stats else None
             rv = self.running_var if self.track_running_stats else None
+            ext = _ext.get()
+            if ext is not None:                # C++ autograd binding: same kernels, a fraction of the host cost
+                return ext.bn_lrelu(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, self.negative_slope)
             return _BnLreluFunction.apply(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, self.negative_slope)
         return F.leaky_relu(super().forward(x), self.negative_slope)
 

@@ -16,11 +16,12 @@ __global__ void __launch_bounds__(256) k(float* out, float* gbuf, int iters) {
     float* G = gbuf + (size_t)blockIdx.x * N;
     float v = 1.0f + (threadIdx.x & 63);
     float acc = 0;
+    if (MODE == 10) __builtin_amdgcn_s_setreg(1 | (4 << 6) | (1 << 11), 0);     // MODE.FP_DENORM[5:4] = 0: flush fp32 denormals (in and out)
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int idx = (threadIdx.x + u * 256) & (N - 1);      // conflict-free, consecutive per wave
-            if (MODE == 0) __hip_atomic_fetch_add(&A[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (MODE == 0 || MODE == 10) __hip_atomic_fetch_add(&A[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (MODE == 1) acc += __hip_atomic_fetch_add(&A[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (MODE == 2) __hip_atomic_fetch_add(&D[idx & (N / 2 - 1)], (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (MODE == 3) {   // CAS loop
@@ -74,6 +75,7 @@ int main() {
     run<7>("lds ds_add_u32", B, 2000);
     run<9>("lds ds_max_i32", B, 2000);
     run<0>("lds ds_add_f32", B, 200);
+    run<10>("lds ds_add_f32, MODE.FP_DENORM f32 = flush", B, 200);
     run<1>("lds ds_add_rtn_f32", B, 200);
     run<2>("lds ds_add_f64", B, 200);
     run<3>("lds CAS loop f32", B, 200);
