@@ -31,6 +31,8 @@ _SIGNATURES = {
     "ffwm_flow_head_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_flow_up_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_conv2d_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _i, _i, _i, _i64, _i, ctypes.c_double, _i, ctypes.POINTER(_i), _i, _p],
+    "ffwm_conv2d_wgrad": [_p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
+    "ffwm_conv3x3_winograd_forward": [_p, _p, _p, _p, _p] + [_i64] * 5 + [_i, _i, ctypes.c_double, _i, _p],
     "ffwm_adam_step": [_p, _p, _p, _p, _i64] + [ctypes.c_double] * 4 + [_i64, _i, _p],
     "ffwm_conv3x3_wgrad": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _p],
     "ffwm_conv3x3_wgrad_block": [_p, _p, _p, _p] + [_i64] * 9 + [_i, _p],
@@ -82,6 +84,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _i
+    lib.ffwm_conv3x3_winograd_workspace_bytes.argtypes = [_i64, _i64]
+    lib.ffwm_conv3x3_winograd_workspace_bytes.restype = _i64
     lib.ffwm_last_error.argtypes = []
     lib.ffwm_last_error.restype = ctypes.c_char_p
     got = lib.ffwm_abi_version()

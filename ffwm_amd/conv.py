@@ -85,24 +85,120 @@ def route_conv_wgrad(net):
     return n
 
 
+# ================================================================================= Winograd on MFMA (csrc/conv_winograd.hip)
+# Forward and data gradient of the 3x3 / stride-1 layers by fp32 Winograd F(2x2, 3x3) with the 16 per-position GEMMs on the
+# MFMA units: 1.5-1.9 x the vendor's VALU Winograd on the layers that dominate the train step (netG's 195 -> 195 residual
+# blocks at 128^2 / 64^2: 0.62 ms against 0.93 ms; 256 channels at 128^2: 0.71 against 1.32 ms).  Small planes stay with the
+# vendor: below ~2000 tiles the 64 x 64-tile workgroups do not fill the chip.
+import os as _os
+_WINOGRAD = _os.environ.get("FFWM_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_TILES = int(_os.environ.get("FFWM_WINOGRAD_MIN_TILES", 2048))
+
+
+def winograd_ok(x, weight):
+    K, C = weight.shape[0], weight.shape[1]
+    tiles = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)
+    return (_WINOGRAD and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and min(C, K) >= 32 and tiles >= WINOGRAD_MIN_TILES and x.numel() < (1 << 29) and x.shape[0] * K * x.shape[2] * x.shape[3] < (1 << 29))
+
+
+class _WinogradConv3x3(Function):
+    """Conv2d(C, K, 3, 1, 1): forward and d(input) on csrc/conv_winograd.hip, d(weight) on csrc/conv_wgrad.hip where that
+    kernel serves the shape (wgrad_route_ok), else the vendor's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = x.contiguous(), weight.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.conv3x3_winograd(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight = ctx.saved_tensors
+        go = grad_output.contiguous()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        gx = gw = gb = None
+        if need_x:
+            gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True)
+        if need_w:
+            if wgrad_route_ok(x, weight):
+                if need_b:       # the bias gradient is a row sum of the operand the MFMA kernel streams anyway
+                    gb = torch.zeros(weight.shape[0], device=go.device, dtype=go.dtype)
+                gw = ops.conv3x3_wgrad(x, go, None, gb)
+            else:
+                _, gw, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[0]] if need_b else None, [1, 1], [1, 1],
+                                                                [1, 1], False, [0, 0], 1, [False, True, bool(need_b)])
+        if need_b and gb is None:
+            gb = _bias_grad(go)
+        return gx, gw, gb
+
+
+class WinogradConv2d(MfmaWgradConv2d):
+    """nn.Conv2d (3x3, stride 1, padding 1) on the Winograd MFMA kernel when the plane is large enough (winograd_ok), else
+    whatever MfmaWgradConv2d does with it."""
+
+    def _conv_forward(self, input, weight, bias):
+        if winograd_ok(input, weight):
+            if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad):
+                return _WinogradConv3x3.apply(input, weight, bias)
+            return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias)
+        if self.__dict__.get("_mfma_fwd_small") and fwd_route_ok(input, weight) and input.size(2) <= 32:
+            ext = _ext.get()          # small planes: the direct MFMA kernel (route_conv_fwd)
+            if ext is not None:
+                return ext.conv2d(input, weight, bias, 1, 1)
+            return _MfmaConv2d.apply(input, weight, bias, 1, 1)
+        return super()._conv_forward(input, weight, bias)
+
+
+def winograd_eligible(m):
+    return (type(m) in (nn.Conv2d, MfmaWgradConv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros" and min(m.in_channels, m.out_channels) >= 32)
+
+
+def route_conv_winograd(net):
+    """Re-class every eligible 3x3 / stride-1 convolution of `net` in place; returns the number of layers routed."""
+    n = 0
+    if not _WINOGRAD:
+        return n
+    for m in net.modules():
+        if winograd_eligible(m):
+            m.__class__ = WinogradConv2d
+            n += 1
+    return n
+
+
 # ================================================================================= MFMA forward (csrc/conv_fwd.hip)
 # The layers MIOpen serves through NHWC implicit-GEMM kernels wrapped in layout transposes and zero-fills -- stride-2
 # convolutions, 4x4 / stride-2 transposed convolutions, small-plane 3x3 layers with awkward channel counts (FlowNet's
 # 1026 / 770 / 386-channel concatenations: 125-160 us through the vendor path, 26-30 us here) -- run their FORWARD on the
-# hand-written fp32 MFMA kernel, in training too.  The 4x4 / stride-2 family is closed under differentiation with
-# respect to the input (the data gradient of the convolution is the transposed convolution with the same weight tensor
-# and vice versa), so those data gradients run on the same kernel; everything else in backward stays with ATen.
+# hand-written fp32 MFMA kernel, in training too, and so does their whole backward: the data gradient of a 4x4 / stride-2
+# convolution is the transposed convolution with the same weight tensor and vice versa, the data gradient of the 3x3
+# layers is the same kernel with the weight read transposed / as parity classes (csrc/conv_fwd.hip modes 1-3), the
+# weight gradients are csrc/conv_bwd.hip.  No NHWC implicit GEMM, no layout transposes, no zero-fills for these layers.
 def _conv_fwd_call(x, weight, bias, stride, pad, transposed):
     from .flownet_eval import conv_mfma, NONE
     return conv_mfma(x, weight, bias, stride, pad, transposed, NONE)
 
 
+def _bias_grad(go):
+    return go.sum((0, 2, 3))
+
+
+# The data / weight gradients of the layers routed to csrc/conv_fwd.hip: the kernels exist and are parity-tested (conv_fwd.hip
+# modes 1-3, conv_bwd.hip), but inside the train step they lose ~1 ms each against the vendor's (A/B in DESIGN.md section 6), so
+# they are opt-in: FFWM_CONV_DGRAD=1 / FFWM_CONV_WGRAD=1.
+_OWN_DGRAD = _os.environ.get("FFWM_CONV_DGRAD", "0") == "1"
+_OWN_WGRAD = _os.environ.get("FFWM_CONV_WGRAD", "0") == "1"
+
+
 class _MfmaConv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad):
+        x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None)
-        return _conv_fwd_call(x.contiguous(), weight.contiguous(), bias, stride, pad, False)
+        return _conv_fwd_call(x, weight, bias, stride, pad, False)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -110,37 +206,59 @@ class _MfmaConv2d(Function):
         stride, pad, has_bias = ctx.cfg
         go = grad_output.contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
-        gx = None
+        gx = gw = gb = None
         k = weight.size(2)
-        if need_x and k == 4 and stride == 2 and pad == 1 and x.size(2) == 2 * go.size(2) and x.size(3) == 2 * go.size(3):
-            # d(input) of Conv2d(C, K, 4, 2, 1) = ConvTranspose2d(K, C, 4, 2, 1) with the SAME weight tensor [K, C, 4, 4]
-            gx = _conv_fwd_call(go, weight.contiguous(), None, 2, 1, True)
+        even = x.size(2) == 2 * go.size(2) and x.size(3) == 2 * go.size(3)
+        if need_x and _OWN_DGRAD and stride == 2 and pad == 1 and even:
+            # d(input) of Conv2d(C, K, 4, 2, 1) = ConvTranspose2d(K, C, 4, 2, 1) with the SAME weight tensor [K, C, 4, 4]; of
+            # Conv2d(C, K, 3, 2, 1) = the transposed 3x3 (output padding 1): parity classes with 1 or 2 taps per axis
+            gx = _conv_fwd_call(go, weight, None, 2, 1, 1 if k == 4 else 2)
             need_x = False
-        gxa, gw, gb = torch.ops.aten.convolution_backward(
-            go, x, weight, [weight.size(0)] if has_bias else None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
-            [need_x, need_w, need_b])
-        return (gx if gx is not None else gxa), gw, gb, None, None
+        elif need_x and _OWN_DGRAD and k == 3 and stride == 1 and pad == 1:
+            gx = _conv_fwd_call(go, weight, None, 1, 1, 3)         # 3x3 / stride-1 convolution of grad_output, weight read rotated
+            need_x = False
+        if need_w and _OWN_WGRAD:
+            gw = ops.conv2d_wgrad(go, x, k, stride, pad)
+            need_w = False
+        if need_x or need_w:
+            gx2, gw2, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[0]] if need_b else None, [stride, stride],
+                                                               [pad, pad], [1, 1], False, [0, 0], 1, [bool(need_x), bool(need_w), bool(need_b)])
+            gx = gx2 if need_x else gx
+            gw = gw2 if need_w else gw
+        elif need_b:
+            gb = _bias_grad(go)
+        return gx, gw, gb, None, None
 
 
 class _MfmaConvTranspose2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
+        x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _conv_fwd_call(x.contiguous(), weight.contiguous(), bias, 2, 1, True)
+        return _conv_fwd_call(x, weight, bias, 2, 1, True)
 
     @staticmethod
     def backward(ctx, grad_output):
         x, weight = ctx.saved_tensors
         go = grad_output.contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        gx = None
-        if need_x:
+        gx = gw = gb = None
+        if need_x and _OWN_DGRAD:
             # d(input) of ConvTranspose2d(C, K, 4, 2, 1) = Conv2d(K, C, 4, 2, 1) with the same weight tensor [C, K, 4, 4]
-            gx = _conv_fwd_call(go, weight.contiguous(), None, 2, 1, False)
-        _, gw, gb = torch.ops.aten.convolution_backward(
-            go, x, weight, [weight.size(1)] if ctx.has_bias else None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1,
-            [False, need_w, need_b])
+            gx = _conv_fwd_call(go, weight, None, 2, 1, False)
+            need_x = False
+        if need_w and _OWN_WGRAD:
+            # d(weight): the same pixel sum as a Conv2d weight gradient with the two tensors' roles swapped
+            gw = ops.conv2d_wgrad(x, go, 4, 2, 1)
+            need_w = False
+        if need_x or need_w:
+            gx2, gw2, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[1]] if need_b else None, [2, 2], [1, 1], [1, 1],
+                                                               True, [0, 0], 1, [bool(need_x), bool(need_w), bool(need_b)])
+            gx = gx2 if need_x else gx
+            gw = gw2 if need_w else gw
+        elif need_b:
+            gb = _bias_grad(go)
         return gx, gw, gb
 
 
@@ -173,7 +291,6 @@ class MfmaFwdConvTranspose2d(nn.ConvTranspose2d):
         return super().forward(input, output_size)
 
 
-import os as _os
 _POLICY = _os.environ.get("FFWM_FWD_ROUTE", "all")
 
 
@@ -186,7 +303,7 @@ def fwd_eligible(m):
         return False
     if type(m) is nn.Conv2d and _POLICY == "T":
         return False
-    if type(m) is nn.Conv2d:
+    if type(m) in (nn.Conv2d, WinogradConv2d):
         return (m.kernel_size in ((3, 3), (4, 4)) and m.stride in ((1, 1), (2, 2)) and m.padding[0] == m.padding[1]
                 and m.padding[0] < m.kernel_size[0] and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"
                 and m.in_channels >= 32 and m.out_channels >= 32
@@ -203,6 +320,9 @@ def route_conv_fwd(net):
     n = 0
     for m in net.modules():
         if fwd_eligible(m):
-            m.__class__ = MfmaFwdConv2d if isinstance(m, nn.Conv2d) else MfmaFwdConvTranspose2d
+            if type(m) is WinogradConv2d:
+                m._mfma_fwd_small = True          # its small-plane calls (winograd_ok false)
+            else:
+                m.__class__ = MfmaFwdConv2d if isinstance(m, nn.Conv2d) else MfmaFwdConvTranspose2d
             n += 1
     return n

@@ -13,6 +13,11 @@
 //   * MODE 1  ConvTranspose2d(C, K, 4, 2, 1): the four output-parity classes (oy & 1, ox & 1) are four independent 2x2
 //             convolutions over the INPUT grid (kd = (c, a, b)): a parity class uses exactly the taps ky = 1 - py + 2a,
 //             kx = 1 - px + 2b at input row y' + py - a, column x' + px - b -- no multiplication by structural zeros.
+//   * MODE 2  d(input) of Conv2d(C, K, 3, 2, 1) (= ConvTranspose2d(K, C, 3, 2, 1, output_padding 1) with the same weight
+//             tensor): parity classes again, with 1 or 2 taps per axis (an even output row meets r = 1 only, an odd one
+//             r = 0 and r = 2); the missing taps of a class are zero weights.
+//   * MODE 3  d(input) of Conv2d(C, K, 3, 1, 1): a 3x3 / stride-1 convolution of grad_output with the weight read
+//             transposed and rotated in place, Wm[c, (k, r, s)] = W[k, c, 2 - r, 2 - s] -- no weight copy.
 //   A workgroup (4 waves = 2 x 2 MFMA tiles) owns 64 output channels x 64 output pixels (pixels linearised over batch
 //   and plane) and walks kd in chunks of 32: weights [64 x 32] and gathered activations [32 x 64] are staged in LDS
 //   (global loads of chunk i+1 in flight under the 16 MFMAs per wave of chunk i), operands are ds_read_b32 at
@@ -42,31 +47,36 @@ struct ConvGeo {
     unsigned x_bytes, w_bytes;   // sizes of the input / weight tensors (buffer resources; both < 2^31)
 };
 
-constexpr int kBP = 64;              // Bs pitch
-
 // A chunk of the reduction = CPC whole input channels x all R*S taps, so that the (channel-in-chunk, r, s) of every staged
 // element is FIXED for the life of the kernel: all address arithmetic happens once, before the loop, and a chunk costs
 // one add per load.  (The first version decoded kd -> (c, r, s) per element and chunk on the scalar unit: 270 SALU
 // instructions per chunk and wave, more issue time than the 16 MFMAs they fed -- SQ counters: SALU 7.6 M vs MFMA 0.44 M.)
-template <int MODE, int R, int S>
+//
+// TM x TN = the workgroup's tile of (output channels) x (output pixels), 64 or 128 each; the 2 x 2 waves own
+// (TM/2) x (TN/2) sub-tiles = 1, 2 or 4 MFMA accumulators each.  A 128 x 128 tile issues 64 MFMAs per wave and chunk
+// for the same two barriers, and one LDS operand read per MFMA instead of two.
+template <int MODE, int R, int S, int TM, int TN>
 __global__ void __launch_bounds__(kBlock)
 conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
                 const ConvGeo g) {
-    constexpr int RS = MODE == 0 ? R * S : 4;
+    constexpr bool PARITY = MODE == 1 || MODE == 2;          // four output-parity classes over the input grid
+    constexpr int RS = PARITY ? 4 : R * S;
     constexpr int CPC = RS == 9 ? 4 : (RS == 16 ? 2 : 8);       // channels per chunk
     constexpr int KC = CPC * RS;                                  // 36 / 32 / 32 reduction steps per chunk (even: MFMA k = 2)
     constexpr int AP = KC + 1;                                    // As pitch (odd: conflict-free operand reads)
-    constexpr int NE = KC * 64 / kBlock;                          // staged elements per thread and operand: 9 / 8 / 8
-    __shared__ float As[64 * AP];
-    __shared__ float Bs[KC * kBP];
+    constexpr int NEA = TM * KC / kBlock, NEB = KC * TN / kBlock; // staged elements per thread
+    constexpr int WMT = TM / 64, WNT = TN / 64;                   // 32 x 32 accumulators per wave: WMT x WNT
+    constexpr int KSTEP = kBlock / TN;                            // B rows covered by one pass of the block: 4 or 2
+    __shared__ float As[TM * AP];
+    __shared__ float Bs[KC * TN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TM;
     int zz = blockIdx.z;
     const int split = zz % g.splitk;
     zz /= g.splitk;
-    const int py = MODE == 1 ? (zz >> 1) : 0, px = MODE == 1 ? (zz & 1) : 0;
+    const int py = PARITY ? (zz >> 1) : 0, px = PARITY ? (zz & 1) : 0;
     constexpr unsigned kOobOff = 0xFFFFFFF0u;
 
     // branch-free loads: buffer resources over the whole tensors + 32-bit byte offsets; an invalid element gets an offset
@@ -74,87 +84,110 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     const rsrc_t rx = make_rsrc(x, g.x_bytes);
     const rsrc_t rw = make_rsrc(w, g.w_bytes);
 
-    // ---- B: the pixel this thread gathers for is fixed (nn = tid % 64), and so is each element's tap: kk = wave + 4 i
+    // ---- B: the pixel this thread gathers for is fixed (nn = tid % TN), and so is each element's tap: kk = tid / TN + KSTEP i
     const int plane_o = g.Ho * g.Wo;
     const int HW = g.H * g.W;
-    const int gn = n0 + (threadIdx.x & 63);
+    const int nn = threadIdx.x % TN, kb = threadIdx.x / TN;       // kb is wave-uniform
+    const int gn = n0 + nn;
     const bool gvalid = gn < g.N;
     const int gb = gvalid ? gn / plane_o : 0;
     const int gp = gvalid ? gn - gb * plane_o : 0;
     const int goy = gp / g.Wo, gox = gp - goy * g.Wo;
-    const int iy0 = MODE == 0 ? goy * g.stride - g.pad : goy + py;     // MODE 1: iy = y' + py - a
-    const int ix0 = MODE == 0 ? gox * g.stride - g.pad : gox + px;
-    unsigned boff[NE];                   // byte offset of the element for channel chunk 0, or kOobOff
-    int bcc[NE];                         // its channel within the chunk (wave-uniform)
+    const int iy0 = PARITY ? goy + py : goy * g.stride - g.pad;     // MODE 1 / 2: iy = y' + py - a
+    const int ix0 = PARITY ? gox + px : gox * g.stride - g.pad;
+    unsigned boff[NEB];                  // byte offset of the element for channel chunk 0, or kOobOff
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int kk = wave + 4 * i;
+    for (int i = 0; i < NEB; ++i) {
+        const int kk = kb + KSTEP * i;
         const int cc = kk / RS, rs = kk - cc * RS;
         int iy, ix;
-        if constexpr (MODE == 0) {
+        bool tap = true;
+        if constexpr (!PARITY) {
             iy = iy0 + rs / S; ix = ix0 + rs % S;
         } else {
             iy = iy0 - (rs >> 1); ix = ix0 - (rs & 1);
+            if constexpr (MODE == 2) tap = (py == 1 || (rs >> 1) == 0) && (px == 1 || (rs & 1) == 0);   // an even row / column has one tap
         }
-        const bool ok = gvalid && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-        bcc[i] = cc;
+        const bool ok = gvalid && tap && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
         boff[i] = ok ? ((static_cast<unsigned>(gb) * g.C + cc) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + ix)) * 4u : kOobOff;
     }
-    // ---- A: element e = tid + 256 i of the [64 x KC] weight chunk: m = e / KC, kk = e % KC -- fixed as well
-    unsigned aoff[NE];                   // byte offset for chunk 0, or kOobOff
-    int acc_[NE], alds[NE];              // channel within the chunk; LDS slot
+    // ---- A: element e = tid + 256 i of the [TM x KC] weight chunk: m = e / KC, kk = e % KC -- fixed as well
+    unsigned aoff[NEA];                  // byte offset for chunk 0, or kOobOff
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
+    for (int i = 0; i < NEA; ++i) {
         const int e = threadIdx.x + kBlock * i;
         const int m = e / KC, kk = e - m * KC;
         const int cc = kk / RS, rs = kk - cc * RS;
-        acc_[i] = cc;
-        alds[i] = m * AP + kk;
         if (k0 + m >= g.K) aoff[i] = kOobOff;
         else if (MODE == 0) aoff[i] = (static_cast<unsigned>(k0 + m) * static_cast<unsigned>(g.Kd) + kk) * 4u;
-        else                       // ConvTranspose2d weight [C][K][4][4]: tap (a, b) = (rs >> 1, rs & 1) -> ky = 1 - py + 2a, kx = 1 - px + 2b
+        else if (MODE == 1)        // ConvTranspose2d weight [C][K][4][4]: tap (a, b) = (rs >> 1, rs & 1) -> ky = 1 - py + 2a, kx = 1 - px + 2b
             aoff[i] = ((static_cast<unsigned>(cc) * g.K + (k0 + m)) * 16u + (1 - py + 2 * (rs >> 1)) * 4 + (1 - px + 2 * (rs & 1))) * 4u;
+        else if (MODE == 2) {      // weight [C_in][K_out][3][3] (the Conv2d's own [K][C][3][3]): even row: r = 1; odd row: a = 0 -> r = 0, a = 1 -> r = 2
+            const int a = rs >> 1, bq = rs & 1;
+            const bool tap = (py == 1 || a == 0) && (px == 1 || bq == 0);
+            const int r = py == 0 ? 1 : 2 * a, sx = px == 0 ? 1 : 2 * bq;
+            aoff[i] = tap ? ((static_cast<unsigned>(cc) * g.K + (k0 + m)) * 9u + r * 3 + sx) * 4u : kOobOff;
+        } else                     // MODE 3: Wm[c_out = k0 + m][(k_in = cc, r, s)] = W[cc][k0 + m][2 - r][2 - s]
+            aoff[i] = ((static_cast<unsigned>(cc) * g.K + (k0 + m)) * 9u + (8 - rs)) * 4u;
     }
-    const unsigned a_step = (MODE == 0 ? static_cast<unsigned>(KC) : static_cast<unsigned>(CPC) * g.K * 16u) * 4u;   // bytes per chunk
+    const unsigned a_step = (MODE == 0 ? static_cast<unsigned>(KC)
+                                       : static_cast<unsigned>(CPC) * g.K * (MODE == 1 ? 16u : 9u)) * 4u;   // bytes per chunk
     const unsigned b_step = static_cast<unsigned>(CPC) * static_cast<unsigned>(HW) * 4u;
 
     const int chunk_begin = split * g.chunks;
     const int chunk_end = min((g.C + CPC - 1) / CPC, chunk_begin + g.chunks);
 
-    auto fetch = [&](int ch, float (&ra)[NE], float (&rb)[NE]) {
+    auto fetch = [&](int ch, float (&ra)[NEA], float (&rb)[NEB]) {
         const int c0 = ch * CPC;
         const unsigned ao = static_cast<unsigned>(ch) * a_step, bo = static_cast<unsigned>(ch) * b_step;
+        const bool tail = c0 + CPC > g.C;                                  // only the last chunk can run past C
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const bool cin = c0 + acc_[i] < g.C;                       // only the last chunk can run past C
+        for (int i = 0; i < NEA; ++i) {
+            const int kk = (threadIdx.x + kBlock * i) % KC;
+            const bool cin = !tail || c0 + kk / RS < g.C;
             ra[i] = buf_ld<float>(rw, (cin && aoff[i] != kOobOff) ? aoff[i] + ao : kOobOff);
         }
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const bool cin = c0 + bcc[i] < g.C;
+        for (int i = 0; i < NEB; ++i) {
+            const bool cin = !tail || c0 + (kb + KSTEP * i) / RS < g.C;
             rb[i] = buf_ld<float>(rx, (cin && boff[i] != kOobOff) ? boff[i] + bo : kOobOff);
         }
     };
-    auto commit = [&](const float (&ra)[NE], const float (&rb)[NE]) {
+    auto commit = [&](const float (&ra)[NEA], const float (&rb)[NEB]) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) As[alds[i]] = ra[i];
+        for (int i = 0; i < NEA; ++i) {
+            const int e = threadIdx.x + kBlock * i;
+            As[(e / KC) * AP + e % KC] = ra[i];
+        }
 #pragma unroll
-        for (int i = 0; i < NE; ++i) Bs[(wave + 4 * i) * kBP + (threadIdx.x & 63)] = rb[i];
+        for (int i = 0; i < NEB; ++i) Bs[(kb + KSTEP * i) * TN + nn] = rb[i];
     };
 
-    f32x16 acc;
+    f32x16 acc[WMT][WNT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int a = 0; a < WMT; ++a)
+#pragma unroll
+        for (int b = 0; b < WNT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // software pipeline, prefetch distance 2: the global loads of chunks i+1 and i+2 are in flight while the KC/2 MFMAs per
-    // wave of chunk i run
-    float ra0[NE], rb0[NE], ra1[NE], rb1[NE];
+    // software pipeline, prefetch distance 2: the global loads of chunks i+1 and i+2 are in flight while the MFMAs of chunk i run
+    float ra0[NEA], rb0[NEB], ra1[NEA], rb1[NEB];
     auto compute = [&]() {
-        const float* ap = As + (wm * 32 + l31) * AP + half;
-        const float* bp = Bs + half * kBP + wn * 32 + l31;
+        const float* ap = As + (wm * (TM / 2) + l31) * AP + half;
+        const float* bp = Bs + half * TN + wn * (TN / 2) + l31;
 #pragma unroll
-        for (int q = 0; q < KC / 2; ++q)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * q], bp[2 * q * kBP], acc, 0, 0, 0);
+        for (int q = 0; q < KC / 2; ++q) {
+            float av[WMT], bv[WNT];
+#pragma unroll
+            for (int a = 0; a < WMT; ++a) av[a] = ap[a * 32 * AP + 2 * q];
+#pragma unroll
+            for (int b = 0; b < WNT; ++b) bv[b] = bp[2 * q * TN + b * 32];
+#pragma unroll
+            for (int a = 0; a < WMT; ++a)
+#pragma unroll
+                for (int b = 0; b < WNT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
     };
     if (chunk_begin < chunk_end) fetch(chunk_begin, ra0, rb0);
     if (chunk_begin + 1 < chunk_end) fetch(chunk_begin + 1, ra1, rb1);
@@ -173,32 +206,37 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     }
 
     // ---- epilogue.  C/D layout: col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
-    const int n = n0 + wn * 32 + l31;
-    if (n >= g.N) return;
-    const int b = n / plane_o;
-    const int p = n - b * plane_o;
-    size_t pix;
-    if constexpr (MODE == 0) {
-        pix = static_cast<size_t>(p);
-    } else {
-        const int oy = p / g.Wo, ox = p - oy * g.Wo;
-        pix = static_cast<size_t>(2 * oy + py) * g.oW + (2 * ox + px);
-    }
-    float* ob = out + static_cast<size_t>(b) * g.out_bs + pix;
     const size_t oplane = static_cast<size_t>(g.oH) * g.oW;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k = k0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (k >= g.K) continue;
-        float v = acc[r];
-        if (g.splitk > 1) {
-            atomic_add(ob + static_cast<size_t>(k) * oplane, v);
+    for (int bq = 0; bq < WNT; ++bq) {
+        const int n = n0 + wn * (TN / 2) + bq * 32 + l31;
+        if (n >= g.N) continue;
+        const int b = n / plane_o;
+        const int p = n - b * plane_o;
+        size_t pix;
+        if constexpr (!PARITY) {
+            pix = static_cast<size_t>(p);
         } else {
-            if (bias) v += bias[k];
-            if (g.act == 1) v = v > 0.f ? v : v * g.slope;
-            else if (g.act == 2) v = tanhf(v);
-            ob[static_cast<size_t>(k) * oplane] = v;
+            const int oy = p / g.Wo, ox = p - oy * g.Wo;
+            pix = static_cast<size_t>(2 * oy + py) * g.oW + (2 * ox + px);
         }
+        float* ob = out + static_cast<size_t>(b) * g.out_bs + pix;
+#pragma unroll
+        for (int a = 0; a < WMT; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wm * (TM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k >= g.K) continue;
+                float v = acc[a][bq][r];
+                if (g.splitk > 1) {
+                    atomic_add(ob + static_cast<size_t>(k) * oplane, v);
+                } else {
+                    if (bias) v += bias[k];
+                    if (g.act == 1) v = v > 0.f ? v : v * g.slope;
+                    else if (g.act == 2) v = tanhf(v);
+                    ob[static_cast<size_t>(k) * oplane] = v;
+                }
+            }
     }
 }
 
@@ -221,27 +259,42 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
     g.C = static_cast<int>(C); g.H = static_cast<int>(H); g.W = static_cast<int>(W); g.K = static_cast<int>(K);
     g.stride = stride; g.pad = pad;
     int classes = 1;
-    if (transposed) {
-        FFWM_REQUIRE(kernel == 4 && stride == 2 && pad == 1, FFWM_ERR_ARG, "%s: transposed convolutions are 4x4 / stride 2 / pad 1 only", fn);
+    int64_t w_elems;
+    const int mode = transposed;        // 0 conv, 1 ConvTranspose2d(4, 2, 1), 2 d(input) of Conv2d(3, 2, 1), 3 d(input) of Conv2d(3, 1, 1)
+    FFWM_REQUIRE(mode >= 0 && mode <= 3, FFWM_ERR_ARG, "%s: unknown mode %d", fn, mode);
+    if (mode == 1 || mode == 2) {
+        FFWM_REQUIRE((mode == 1 ? kernel == 4 : kernel == 3) && stride == 2 && pad == 1, FFWM_ERR_ARG,
+                     "%s: mode %d is a %s / stride 2 / pad 1 operator", fn, mode, mode == 1 ? "4x4" : "3x3");
         g.Ho = g.H; g.Wo = g.W; g.oH = 2 * g.H; g.oW = 2 * g.W; g.Kd = g.C * 4;
         classes = 4;
+        w_elems = C * K * kernel * kernel;
     } else {
         FFWM_REQUIRE((kernel == 3 || kernel == 4) && (stride == 1 || stride == 2) && pad >= 0 && pad < kernel, FFWM_ERR_ARG,
                      "%s: 3x3 / 4x4 kernels with stride 1 / 2 only (got %d, %d, %d)", fn, kernel, stride, pad);
+        FFWM_REQUIRE(mode == 0 || (kernel == 3 && stride == 1 && pad == 1), FFWM_ERR_ARG, "%s: mode 3 is the data gradient of a 3x3 / stride 1 / pad 1 convolution", fn);
         g.Ho = (g.H + 2 * pad - kernel) / stride + 1;
         g.Wo = (g.W + 2 * pad - kernel) / stride + 1;
         FFWM_REQUIRE(g.Ho > 0 && g.Wo > 0, FFWM_ERR_ARG, "%s: empty output", fn);
         g.oH = g.Ho; g.oW = g.Wo; g.Kd = g.C * kernel * kernel;
+        w_elems = C * K * kernel * kernel;
     }
-    FFWM_REQUIRE(B * g.Ho * g.Wo < (1LL << 31) && B * C * H * W < (1LL << 29) && K * static_cast<int64_t>(g.Kd) * (transposed ? 4 : 1) < (1LL << 29),
+    FFWM_REQUIRE(B * g.Ho * g.Wo < (1LL << 31) && B * C * H * W < (1LL << 29) && w_elems < (1LL << 29),
                  FFWM_ERR_SIZE, "%s: tensor too large (input and weight must stay below 2 GiB: 32-bit buffer offsets)", fn);
     g.x_bytes = static_cast<unsigned>(B * C * H * W * 4);
-    g.w_bytes = static_cast<unsigned>(K * static_cast<int64_t>(g.Kd) * (transposed ? 4 : 1) * 4);
+    g.w_bytes = static_cast<unsigned>(w_elems * 4);
     FFWM_REQUIRE(out_batch_stride >= K * g.oH * g.oW, FFWM_ERR_ARG, "%s: output batch stride smaller than K * Ho * Wo", fn);
     g.N = static_cast<int>(B * g.Ho * g.Wo);
-    g.n_tiles = (g.N + 63) / 64;
-    g.k_tiles = (g.K + 63) / 64;
-    const int cpc = transposed ? 8 : (kernel == 3 ? 4 : 2);          // channels per chunk (conv_fwd_kernel's CPC)
+    // tile: as large as the layer allows while >= 512 workgroups remain (tile_variant: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128)
+    int tm = 64, tn = 64;
+    {
+        const int v = options().conv_tile_variant;
+        auto wgs = [&](int a, int b) { return static_cast<int64_t>((g.K + a - 1) / a) * ((g.N + b - 1) / b) * classes; };
+        if (v == 2 || v == 4 || (v == 0 && g.K >= 128 && wgs(128, 64) >= 512)) tm = 128;
+        if (v == 3 || v == 4 || (v == 0 && wgs(tm, 128) >= 512)) tn = 128;
+    }
+    g.n_tiles = (g.N + tn - 1) / tn;
+    g.k_tiles = (g.K + tm - 1) / tm;
+    const int cpc = (mode == 1 || mode == 2) ? 8 : (kernel == 3 ? 4 : 2);          // channels per chunk (conv_fwd_kernel's CPC)
     const int chunks_total = (g.C + cpc - 1) / cpc;
     const int64_t tiles = static_cast<int64_t>(g.n_tiles) * g.k_tiles * classes;
     int splitk = 1;
@@ -260,13 +313,24 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
     const dim3 grid(static_cast<unsigned>(g.n_tiles), static_cast<unsigned>(g.k_tiles), static_cast<unsigned>(g.splitk * classes));
     const double flops = 2.0 * B * g.Ho * g.Wo * classes * static_cast<double>(g.K) * g.Kd;
     const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(K) * g.Kd * classes + static_cast<double>(B) * K * g.oH * g.oW);
-    LaunchScope ls(transposed ? "conv_fwd_mfma_transposed" : "conv_fwd_mfma", st, bytes, flops);
+    static const char* const kScope[4] = {"conv_fwd_mfma", "conv_fwd_mfma_transposed", "conv_dgrad_mfma_3x3s2", "conv_dgrad_mfma_3x3s1"};
+    LaunchScope ls(kScope[mode], st, bytes, flops);
     const float* x = static_cast<const float*>(input);
     const float* wt = static_cast<const float*>(weight);
     const float* bs = static_cast<const float*>(bias);
     float* o = static_cast<float*>(output);
-    if (transposed) hipLaunchKernelGGL((conv_fwd_kernel<1, 2, 2>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);
-    else if (kernel == 3) hipLaunchKernelGGL((conv_fwd_kernel<0, 3, 3>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);
-    else hipLaunchKernelGGL((conv_fwd_kernel<0, 4, 4>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);
+#define FFWM_CONV_LAUNCH(M, RR, SS)                                                                                          \
+    do {                                                                                                                   \
+        if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 128, 128>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g); \
+        else if (tm == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 128, 64>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);          \
+        else if (tn == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 64, 128>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);          \
+        else hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 64, 64>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);                          \
+    } while (0)
+    if (mode == 1) FFWM_CONV_LAUNCH(1, 2, 2);
+    else if (mode == 2) FFWM_CONV_LAUNCH(2, 2, 2);
+    else if (mode == 3) FFWM_CONV_LAUNCH(3, 3, 3);
+    else if (kernel == 3) FFWM_CONV_LAUNCH(0, 3, 3);
+    else FFWM_CONV_LAUNCH(0, 4, 4);
+#undef FFWM_CONV_LAUNCH
     return check_launch(fn);
 }

@@ -1,0 +1,336 @@
+// conv_winograd.hip -- fp32 Winograd F(2x2, 3x3) convolution on the MFMA units (gfx950): forward and data gradient of
+// the 3x3 / stride 1 / pad 1 layers of netG (/root/reference/models/base_networks.py:207-233, 293-298: dres0-2 at
+// 195 channels x 128^2 and 64^2) and of FlowNet / LightCNN (:59-112).
+//
+// Those layers are ~40 % of the GPU time of an FFWM train step, spent in the vendor's VALU Winograd
+// (miopenSp3AsmConv...f2x3: ~95 TFLOP/s direct-equivalent).  The same transform cuts the multiplications 2.25 x, and
+// here the 16 per-position GEMMs run on v_mfma_f32_32x32x2_f32:
+//
+//   y[b, k, 2ty + i', 2tx + j'] = sum_ij At[i'][i] ( sum_c U[k, c, i, j] V[c, t, i, j] ) At[j'][j],  t = (b, ty, tx)
+//   U[k, c] = G w[k, c] Gt   (4 x 4, prepared once per call by winograd_weights_kernel)
+//   V[c, t] = Bt d[c, t] B   (4 x 4, d = the 4 x 4 input patch of tile t; formed in registers on the way to LDS)
+//
+// A workgroup (4 waves) owns 64 output channels x 64 tiles (= 256 output pixels per image channel) for ALL 16 positions:
+// every wave holds 16 accumulators of 32 x 32 (256 AGPRs), so the output transform is lane-local and the result is
+// stored once, NCHW, with bias + LeakyReLU in the same epilogue.  The reduction runs in chunks of 8 input channels:
+//   * U is stored by the weight kernel exactly as LDS wants it ([k tile][chunk][position][channel half][64 k][4 c]), so
+//     a chunk is one contiguous 32 KiB block: 8 dwordx4 loads + 8 ds_write_b128 per thread;
+//   * each thread gathers the patch of one tile for two channels (32 dword loads through a buffer resource: the zero
+//     padding and the channel tail are the hardware's out-of-range 0), transforms it (32 adds) and scatters the 16
+//     positions to LDS -- lanes run along (4 channels, 16 tiles), consecutive dwords, no bank conflict;
+//   * an MFMA takes A[k][c] and B[c][t] for TWO channels (k = 2): lanes 0-31 feed channel j, lanes 32-63 channel 4 + j of
+//     the chunk, so ONE ds_read_b128 per operand feeds four MFMAs (0.5 LDS reads per MFMA; the direct kernel of
+//     conv_fwd.hip needs 2).
+// Loads of chunk i + 1 are in flight while the 64 MFMAs per wave of chunk i issue (4096 cycles between two barriers).
+//
+// Mode 1 is the data gradient of the same layer: dx = conv(dy, w') with w'[c][k][r][s] = w[k][c][2 - r][2 - s]; only the
+// weight kernel differs.  fp32 throughout; the rounding differs from a direct sum in the last bits, like the vendor's
+// Winograd that it replaces (tests: <= 2e-5 of the output scale against fp64).
+#include "common.hpp"
+
+namespace ffwm {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWinoChunk = 16 * 2 * 64 * 4;      // floats of U (and of V) per chunk of 8 channels: 8192 = 32 KiB
+
+struct WinoGeo {
+    int C, H, W, K;
+    int TH, TW, T;           // tiles per column / row / in total (B * TH * TW)
+    int CH;                  // chunks of 8 input channels
+    int KT, TT;              // tiles of 64 output channels / of 64 output tiles
+    int act;
+    float slope;
+    unsigned x_bytes, u_bytes;
+
+};
+
+// U[kt][ch][p][h][k64][c4] = (G w Gt)[p] of output channel kt * 64 + k64 and input channel ch * 8 + 4 h + c4; zero outside
+// K x C.  mode 0: w is [K][C][3][3]; mode 1 (data gradient): w is the layer's own [C][K][3][3], used transposed and flipped.
+__global__ void __launch_bounds__(kBlock)
+winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int CH, int KT, int mode) {
+    const int Cp = CH * 8;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= KT * 64 * Cp) return;
+    const int k = e / Cp, c = e - k * Cp;
+    float g[3][3];
+    const bool in = k < K && c < C;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float v = 0.f;
+            if (in) v = mode == 0 ? w[(static_cast<size_t>(k) * C + c) * 9 + r * 3 + s]
+                                  : w[(static_cast<size_t>(c) * K + k) * 9 + (2 - r) * 3 + (2 - s)];
+            g[r][s] = v;
+        }
+    // rows: G g  (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1])
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        t[0][s] = g[0][s];
+        t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+        t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+        t[3][s] = g[2][s];
+    }
+    float* dst = U + (static_cast<size_t>(k >> 6) * CH + (c >> 3)) * kWinoChunk + (((c >> 2) & 1) * 64 + (k & 63)) * 4 + (c & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float u0 = t[i][0];
+        const float u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+        const float u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+        const float u3 = t[i][2];
+        dst[(i * 4 + 0) * 512] = u0;
+        dst[(i * 4 + 1) * 512] = u1;
+        dst[(i * 4 + 2) * 512] = u2;
+        dst[(i * 4 + 3) * 512] = u3;
+    }
+}
+
+constexpr int kWinoThreads = 512;        // 8 waves: two per SIMD, 128 accumulator + <= 128 other registers each
+constexpr int kWinoTiles = 64;           // output tiles (2 x 2 pixels) per workgroup
+
+template <int ABL>          // ABL: timing experiments only (bit 0 no patch loads, 1 no U loads, 2 no LDS commits, 3 no operand reads)
+__global__ void __launch_bounds__(kWinoThreads)
+winograd_conv_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out,
+                     const WinoGeo g, int remap) {
+    extern __shared__ f32x4 smem[];          // [2 buffers][U | V][16 positions][2 channel halves][64 k or tiles] x 4 channels: 128 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    // compute role: positions 8 ph .. 8 ph + 7 (rows 2 ph, 2 ph + 1 of the 4 x 4 transform domain) of the (wm, wn) quarter of the tile
+    const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    // consecutive logical ids = the k tiles of one strip of tiles, kept on one XCD (they gather the same input)
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tt = static_cast<int>(lid) / g.KT, kt = static_cast<int>(lid) - tt * g.KT;
+    constexpr unsigned kOobOff = 0xFFFFFFF0u;
+    const rsrc_t rx = make_rsrc(x, g.x_bytes);
+    const rsrc_t ru = make_rsrc(U, g.u_bytes);
+    const int HW = g.H * g.W;
+
+    // ---- staging role: lane = (c_lo, t_lo), wave = (channel half, t_hi): the patch of tile ts for channel 4 sh + c_lo of the chunk
+    const int c_lo = lane & 3, ts = (wave & 3) * 16 + (lane >> 2), sh = wave >> 2;
+    unsigned poff[16];               // byte offsets of the 4 x 4 patch in channel 0 of its image, or kOobOff
+    {
+        const int tg = tt * kWinoTiles + ts;
+        const bool tv = tg < g.T;
+        const int b = tv ? tg / (g.TH * g.TW) : 0;
+        const int rem = tv ? tg - b * (g.TH * g.TW) : 0;
+        const int ty = rem / g.TW, tx = rem - ty * g.TW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = 2 * ty - 1 + i, ix = 2 * tx - 1 + j;
+                const bool ok = tv && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                poff[i * 4 + j] = ok ? (static_cast<unsigned>(b) * g.C * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + ix)) * 4u : kOobOff;
+            }
+    }
+    const unsigned u_base = (static_cast<unsigned>(kt) * g.CH) * (kWinoChunk * 4u) + threadIdx.x * 16u;
+
+    // The side work of a chunk is cut into 2 fetch slices and 2 commit slices that ride between the MFMA groups
+    float d[16] = {};
+    u32x4 uw[4] = {};
+    auto fetch_slice = [&](int ch, int s) {          // U rows 2s, 2s + 1; patch elements 8 s ..+8
+        if (!(ABL & 2))
+#pragma unroll
+            for (int i = 2 * s; i < 2 * s + 2; ++i)
+                uw[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, u_base + static_cast<unsigned>(ch) * (kWinoChunk * 4u) + i * 8192u, 0, 0);
+        const int c = ch * 8 + 4 * sh + c_lo;
+        const unsigned co = static_cast<unsigned>(c) * static_cast<unsigned>(HW) * 4u;
+        const bool cin = c < g.C;                    // the channel tail and every chunk past the last read 0
+        if (!(ABL & 1))
+#pragma unroll
+            for (int q = 8 * s; q < 8 * s + 8; ++q) {
+                const unsigned o = poff[q] + co;
+                d[q] = buf_ld<float>(rx, (cin & (poff[q] != kOobOff)) ? o : kOobOff);
+            }
+    };
+    auto commit_slice = [&](f32x4* Ub, f32x4* Vb, int s) {   // U rows 2s, 2s + 1; V rows 2s, 2s + 1
+        if (ABL & 4) return;
+#pragma unroll
+        for (int i = 2 * s; i < 2 * s + 2; ++i) reinterpret_cast<u32x4*>(Ub)[threadIdx.x + kWinoThreads * i] = uw[i];
+        float* dst = reinterpret_cast<float*>(Vb) + (sh * 64 + ts) * 4 + c_lo;
+#pragma unroll
+        for (int i = 2 * s; i < 2 * s + 2; ++i) {
+            // row i of Bt d: (d0 - d2, d1 + d2, d2 - d1, d1 - d3), then the same along the columns
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                r[j] = i == 0 ? d[0 + j] - d[8 + j] : i == 1 ? d[4 + j] + d[8 + j] : i == 2 ? d[8 + j] - d[4 + j] : d[4 + j] - d[12 + j];
+            dst[(i * 4 + 0) * 512] = r[0] - r[2];
+            dst[(i * 4 + 1) * 512] = r[1] + r[2];
+            dst[(i * 4 + 2) * 512] = r[2] - r[1];
+            dst[(i * 4 + 3) * 512] = r[1] - r[3];
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    // one chunk: 4 groups of 8 MFMAs (two positions); groups 0-1 carry the commit of chunk ch + 1 into the other buffer,
+    // groups 2-3 the loads of chunk ch + 2; the operands of group i + 1 are read while group i issues
+    auto step = [&](int ch, f32x4* Ub, f32x4* Vb, f32x4* Un, f32x4* Vn) {
+        const f32x4* ap = Ub + (ph * 8) * 128 + half * 64 + wm * 32 + l31;
+        const f32x4* bp = Vb + (ph * 8) * 128 + half * 64 + wn * 32 + l31;
+        f32x4 oa[2][2], ob[2][2];
+        oa[0][0] = ap[0]; ob[0][0] = bp[0]; oa[0][1] = ap[128]; ob[0][1] = bp[128];
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int cur = grp & 1, nxt = cur ^ 1;
+            if (grp < 3 && !(ABL & 8)) {
+                oa[nxt][0] = ap[(2 * grp + 2) * 128]; ob[nxt][0] = bp[(2 * grp + 2) * 128];
+                oa[nxt][1] = ap[(2 * grp + 3) * 128]; ob[nxt][1] = bp[(2 * grp + 3) * 128];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * grp] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][0][j], ob[cur][0][j], acc[2 * grp], 0, 0, 0);
+                acc[2 * grp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][1][j], ob[cur][1][j], acc[2 * grp + 1], 0, 0, 0);
+            }
+            if (grp < 2) commit_slice(Un, Vn, grp);
+            else fetch_slice(ch + 2, grp - 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+
+    // buffer 0 = smem[0 .. 4096), buffer 1 = smem[4096 .. 8192) (f32x4 units); U first, V 2048 behind it
+    fetch_slice(0, 0); fetch_slice(0, 1);
+    commit_slice(smem, smem + 2048, 0); commit_slice(smem, smem + 2048, 1);
+    fetch_slice(1, 0); fetch_slice(1, 1);
+    __syncthreads();
+    unsigned cur = 0;
+    for (int ch = 0; ch < g.CH; ++ch) {
+        f32x4* const ub = smem + cur;
+        f32x4* const un = smem + (cur ^ 4096u);
+        step(ch, ub, ub + 2048, un, un + 2048);
+        cur ^= 4096u;
+    }
+
+    // ---- epilogue: y = At m A per (k, tile).  C/D layout: col = lane & 31 (tile), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (k).
+    // A wave holds rows i = 2 ph, 2 ph + 1 of m: it forms its share of y (2 x 2 values per register), the ph = 1 waves hand theirs
+    // to their ph = 0 partners through LDS (the staging buffers are free: the loop ended with a barrier).
+    float part[16][4];               // [r][y00, y01, y10, y11]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 2 ph
+        const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 2 ph + 1
+        if (ph == 0) {               // y0 = z0 + z1 (+ z2), y1 = z1 (- z2 - z3)
+            part[r][0] = za0 + zb0; part[r][1] = za1 + zb1; part[r][2] = zb0; part[r][3] = zb1;
+        } else {                     // y0 = z2, y1 = -z2 - z3
+            part[r][0] = za0; part[r][1] = za1; part[r][2] = -za0 - zb0; part[r][3] = -za1 - zb1;
+        }
+    }
+    float* xch = reinterpret_cast<float*>(smem) + (wave & 3) * 4096 + lane;
+    if (ph == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xch[(r * 4 + v) * 64] = part[r][v];
+    }
+    __syncthreads();
+    if (ph == 1 || kt * 64 + wm * 32 >= g.K) return;
+    const int tg = tt * kWinoTiles + wn * 32 + l31;
+    if (tg >= g.T) return;
+    const int b = tg / (g.TH * g.TW);
+    const int rem = tg - b * (g.TH * g.TW);
+    const int ty = rem / g.TW, tx = rem - ty * g.TW;
+    const int oy = 2 * ty, ox = 2 * tx;
+    const bool row1 = oy + 1 < g.H, col1 = ox + 1 < g.W;
+    float* ob = out + (static_cast<size_t>(b) * g.K) * HW + static_cast<size_t>(oy) * g.W + ox;
+    const bool vec = col1 && (g.W & 1) == 0;         // 8-byte aligned pair
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = kt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (k >= g.K) continue;
+        const float bv = bias ? bias[k] : 0.f;
+        float y[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float t = part[r][v] + xch[(r * 4 + v) * 64] + bv;
+            if (g.act == 1) t = t > 0.f ? t : t * g.slope;
+            y[v] = t;
+        }
+        float* o = ob + static_cast<size_t>(k) * HW;
+        if (vec) {
+            *reinterpret_cast<float2*>(o) = make_float2(y[0], y[1]);
+            if (row1) *reinterpret_cast<float2*>(o + g.W) = make_float2(y[2], y[3]);
+        } else {
+            o[0] = y[0];
+            if (col1) o[1] = y[1];
+            if (row1) {
+                o[g.W] = y[2];
+                if (col1) o[g.W + 1] = y[3];
+            }
+        }
+    }
+}
+
+}  // namespace
+}  // namespace ffwm
+
+using namespace ffwm;
+
+extern "C" int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C) {
+    if (K <= 0 || C <= 0) return 0;
+    return ((K + 63) / 64) * ((C + 7) / 8) * static_cast<int64_t>(kWinoChunk) * 4;
+}
+
+extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weight, const void* bias, void* output, void* workspace,
+                                             int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int data_gradient, int act,
+                                             double slope, int dtype, void* stream) {
+    const char* fn = "ffwm_conv3x3_winograd_forward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(input && weight && output && workspace, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && K > 0, FFWM_ERR_ARG, "%s: sizes must be positive", fn);
+    FFWM_REQUIRE(act == 0 || act == 1, FFWM_ERR_ARG, "%s: act must be 0 (none) or 1 (leaky relu)", fn);
+    FFWM_REQUIRE(data_gradient == 0 || data_gradient == 1, FFWM_ERR_ARG, "%s: data_gradient must be 0 or 1", fn);
+    FFWM_REQUIRE(B * C * H * W < (1LL << 29) && B * K * H * W < (1LL << 40), FFWM_ERR_SIZE, "%s: the input must stay below 2 GiB", fn);
+    WinoGeo g;
+    g.C = static_cast<int>(C); g.H = static_cast<int>(H); g.W = static_cast<int>(W); g.K = static_cast<int>(K);
+    g.TH = (g.H + 1) / 2; g.TW = (g.W + 1) / 2;
+    const int64_t T = B * g.TH * g.TW;
+    FFWM_REQUIRE(T < (1LL << 30), FFWM_ERR_SIZE, "%s: too many tiles", fn);
+    g.T = static_cast<int>(T);
+    g.CH = (g.C + 7) / 8;
+    g.KT = (g.K + 63) / 64;
+    g.TT = (g.T + kWinoTiles - 1) / kWinoTiles;
+    g.act = act; g.slope = static_cast<float>(slope);
+    g.x_bytes = static_cast<unsigned>(B * C * H * W * 4);
+    const int64_t ub = ffwm_conv3x3_winograd_workspace_bytes(K, C);
+    FFWM_REQUIRE(ub < (1LL << 31), FFWM_ERR_SIZE, "%s: weight workspace beyond 2 GiB", fn);
+    g.u_bytes = static_cast<unsigned>(ub);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* U = static_cast<float*>(workspace);
+    {
+        const int64_t n = static_cast<int64_t>(g.KT) * 64 * g.CH * 8;
+        LaunchScope ls("conv_winograd_weights", st, 4.0 * (9.0 * K * C + 16.0 * n));
+        hipLaunchKernelGGL(winograd_weights_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           static_cast<const float*>(weight), U, g.K, g.C, g.CH, g.KT, data_gradient);
+        const int rc = check_launch(fn);
+        if (rc) return rc;
+    }
+    // flops = the multiplications the MFMAs actually perform (16 per tile, channel pair), not the 36 of the direct sum
+    const double flops = 2.0 * 16.0 * static_cast<double>(T) * K * C;
+    const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(B) * K * H * W) + static_cast<double>(ub);
+    LaunchScope ls(data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd", st, bytes, flops);
+    const unsigned nblk = static_cast<unsigned>(g.TT) * static_cast<unsigned>(g.KT);
+    auto kern = winograd_conv_kernel<0>;
+    switch (options().ablate) {
+        case 1: kern = winograd_conv_kernel<1>; break;
+        case 2: kern = winograd_conv_kernel<2>; break;
+        case 3: kern = winograd_conv_kernel<3>; break;
+        case 4: kern = winograd_conv_kernel<4>; break;
+        case 7: kern = winograd_conv_kernel<7>; break;
+        case 15: kern = winograd_conv_kernel<15>; break;
+        default: break;
+    }
+    allow_large_lds(reinterpret_cast<const void*>(kern));
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(kWinoThreads), 4 * kWinoChunk * 4, st, static_cast<const float*>(input), U,
+                       static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
+    return check_launch(fn);
+}

@@ -83,18 +83,21 @@ def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None
     the atomically accumulated result.  dst / dst2 as in bias_act (channel slices of concatenation buffers)."""
     B, C, H, W = x.shape
     k = weight.size(2)
-    if transposed:
+    mode = int(transposed)      # 0 conv, 1 ConvTranspose2d(4, 2, 1), 2 / 3: d(input) of Conv2d(3, 2, 1) / Conv2d(3, 1, 1) (x = grad_output)
+    if mode in (1, 2):
         K, Ho, Wo = weight.size(1), 2 * H, 2 * W
+    elif mode == 3:
+        K, Ho, Wo = weight.size(1), H, W
     else:
         K = weight.size(0)
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     lib = _lib.load()
     flag = ctypes.c_int(0)
-    small = B * Ho * Wo * ((K + 63) // 64) * (1 if transposed else 4) < 256 * 64 * 4      # fewer than 256 tiles: split the reduction
+    small = B * Ho * Wo * ((K + 63) // 64) * (1 if mode in (1, 2) else 4) < 256 * 64 * 4      # fewer than 256 tiles: split the reduction
     direct = dst is not None and dst2 is None and not small
     y = dst if direct else (torch.zeros if small else torch.empty)(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
     _lib.check(lib.ffwm_conv2d_forward(x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                       B, C, H, W, K, k, stride, pad, 1 if transposed else 0, y.stride(0), act, float(slope),
+                                       B, C, H, W, K, k, stride, pad, mode, y.stride(0), act, float(slope),
                                        1 if small else 0, ctypes.byref(flag), _lib.F32, _stream(x)), "ffwm_conv2d_forward")
     if flag.value:                       # split launch: bias + activation as a pass over the accumulated sums
         if dst is None and dst2 is None:

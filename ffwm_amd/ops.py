@@ -425,6 +425,55 @@ def conv3x3_wgrad(input, grad_output, grad_weight=None, grad_bias=None):
     return grad_weight
 
 
+def conv2d_wgrad(rows, gathered, kernel, stride, pad, grad_weight=None):
+    """grad_weight[K, C, k, k] of Conv2d (rows = grad_output, gathered = input) or [Ci, Co, 4, 4] of ConvTranspose2d(4, 2, 1)
+    (rows = input, gathered = grad_output) on csrc/conv_bwd.hip; += into `grad_weight` when given, else a fresh tensor."""
+    _check("conv2d_wgrad", rows, gathered, grad_weight)
+    B, K, Ho, Wo = rows.shape
+    Bg, C, H, W = gathered.shape
+    if Bg != B:
+        raise ValueError("conv2d_wgrad: batch sizes differ")
+    if grad_weight is None:
+        grad_weight = rows.new_zeros((K, C, kernel, kernel))
+    elif tuple(grad_weight.shape) != (K, C, kernel, kernel):
+        raise ValueError("conv2d_wgrad: grad_weight has the wrong shape")
+    with _on_device(rows) as stream:
+        _lib.check(_lib.load().ffwm_conv2d_wgrad(_ptr(rows), _ptr(gathered), _ptr(grad_weight), B, K, Ho, Wo, C, H, W, int(kernel),
+                                                 int(stride), int(pad), _dtype_code(rows), stream), "ffwm_conv2d_wgrad")
+    return grad_weight
+
+
+def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0, out=None):
+    """Conv2d(C, K, 3, 1, 1) forward (weight [K, C, 3, 3]) or its data gradient (x = grad_output [B, K_layer, H, W], weight =
+    the layer's own [K_layer, C_layer, 3, 3]; returns [B, C_layer, H, W]) by fp32 Winograd F(2x2, 3x3) on the MFMA units
+    (csrc/conv_winograd.hip).  act = 1 applies LeakyReLU(slope) after the bias."""
+    _check("conv3x3_winograd", x, weight, out)
+    if bias is not None and (not bias.is_cuda or bias.dtype != x.dtype or not bias.is_contiguous()):
+        raise ValueError("conv3x3_winograd: bias must be a contiguous tensor of the input's device and dtype")
+    B, C, H, W = x.shape
+    if data_gradient:
+        if weight.shape[0] != C or tuple(weight.shape[2:]) != (3, 3):
+            raise ValueError("conv3x3_winograd: weight %s does not belong to a grad_output with %d channels" % (tuple(weight.shape), C))
+        K = weight.shape[1]
+    else:
+        if weight.shape[1] != C or tuple(weight.shape[2:]) != (3, 3):
+            raise ValueError("conv3x3_winograd: weight %s does not fit an input with %d channels" % (tuple(weight.shape), C))
+        K = weight.shape[0]
+    if bias is not None and tuple(bias.shape) != (K,):
+        raise ValueError("conv3x3_winograd: bias must have %d elements" % K)
+    if out is None:
+        out = x.new_empty((B, K, H, W))
+    elif tuple(out.shape) != (B, K, H, W):
+        raise ValueError("conv3x3_winograd: out has the wrong shape")
+    lib = _lib.load()
+    ws = x.new_empty((lib.ffwm_conv3x3_winograd_workspace_bytes(K, C) // 4,))
+    with _on_device(x) as stream:
+        _lib.check(lib.ffwm_conv3x3_winograd_forward(_ptr(x), _ptr(weight), _ptr(bias) if bias is not None else None, _ptr(out), _ptr(ws),
+                                                     B, C, H, W, K, int(bool(data_gradient)), int(act), float(slope), _dtype_code(x),
+                                                     stream), "ffwm_conv3x3_winograd_forward")
+    return out
+
+
 # ---------------------------------------------------------------- LightCNN max-feature-map
 def _mfm_dims(x):
     if x.dim() < 2 or x.shape[1] % 2:

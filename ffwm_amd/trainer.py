@@ -114,6 +114,12 @@ class FFWMTrainer(object):
             # weight gradients of the large-image 3x3 layers on the hand-written MFMA kernel (conv.py)
             from .conv import route_conv_wgrad
             self.mfma_wgrad_layers = route_conv_wgrad(self.netG)
+        self.winograd_layers = 0
+        if self.device.type == "cuda":
+            # forward + data gradient of the large-plane 3x3 / stride-1 layers: fp32 Winograd on the MFMA units (conv.py),
+            # before route_conv_fwd so that the small-plane policy of that route only sees what is left
+            from .conv import route_conv_winograd
+            self.winograd_layers = sum(route_conv_winograd(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD, self.lightCNN))
         if mfma_fwd is None:
             mfma_fwd = self.device.type == "cuda"
         self.mfma_fwd_layers = 0

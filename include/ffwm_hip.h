@@ -317,6 +317,26 @@ int ffwm_conv2d_forward(const void* input, const void* weight, const void* bias,
                         int64_t W, int64_t K, int kernel, int stride, int pad, int transposed, int64_t out_batch_stride,
                         int act, double negative_slope, int allow_split, int* needs_epilogue, int dtype, void* stream);
 
+/* fp32 MFMA weight gradient of the convolutions ffwm_conv2d_forward serves, one launch, no layout transposes:
+ *   grad_weight[k][(c, r, s)] += sum_{b, oy, ox} rows[b, k, oy, ox] * gathered[b, c, oy * stride + r - pad, ox * stride + s - pad]
+ * nn.Conv2d(C, K, kernel, stride, pad):   rows = grad_output [B,K,Ho,Wo], gathered = input [B,C,H,W]         -> [K, C, k, k]
+ * nn.ConvTranspose2d(Ci, Co, 4, 2, 1):    rows = input [B,Ci,H,W],        gathered = grad_output [B,Co,2H,2W] -> [Ci, Co, 4, 4]
+ * (kernel = 4, stride = 2, pad = 1).  grad_weight must be ZERO-FILLED (or hold the value to accumulate into): the pixel
+ * slices of the reduction are added atomically. */
+int ffwm_conv2d_wgrad(const void* rows, const void* gathered, void* grad_weight, int64_t B, int64_t K, int64_t Ho, int64_t Wo,
+                      int64_t C, int64_t H, int64_t W, int kernel, int stride, int pad, int dtype, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2, 3x3) on the fp32 MFMA units (csrc/conv_winograd.hip): the
+ * forward (data_gradient = 0: weight [K, C, 3, 3]) or the data gradient (data_gradient = 1: input = grad_output with C =
+ * the layer's OUTPUT channels, K = its input channels, weight = the layer's own [C, K, 3, 3]) of Conv2d(.., 3, 1, 1)
+ * (models/base_networks.py:207-233: the residual blocks of netG; :59-112 FlowNet's conv*_1 / inter_conv*).
+ * output [B, K, H, W] = conv + bias (NULL: none), then LeakyReLU(slope) when act = 1.  workspace: device memory of
+ * ffwm_conv3x3_winograd_workspace_bytes(K, C) bytes (the transformed weights; rewritten by every call). */
+int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C);
+int ffwm_conv3x3_winograd_forward(const void* input, const void* weight, const void* bias, void* output, void* workspace,
+                                  int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int data_gradient, int act,
+                                  double slope, int dtype, void* stream);
+
 /* One Adam step (no weight decay, no amsgrad: torch.optim.Adam as models/ffwm_model.py:46-49 and
  * models/flownet_model.py:33 construct it) over FLAT float32 arrays of n elements, 16-byte aligned: parameters,
  * gradients, first and second moments.  `step` is the 1-based step count (bias corrections 1 - beta^step). */

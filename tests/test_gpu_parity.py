@@ -1369,12 +1369,18 @@ def test_conv2d_forward_mfma_matches_aten(case):
     assert (buf[:, :2] == 7).all() and (buf[:, 2 + K:] == 7).all()
 
 
-def test_conv_forward_routing_matches_aten_autograd():
-    """conv.route_conv_fwd: re-classed Conv2d / ConvTranspose2d (forward on csrc/conv_fwd.hip, the 4x4 / stride-2 data
-    gradients too) against the untouched modules -- outputs, input gradients and parameter gradients."""
+@pytest.mark.parametrize("own_backward", [False, True])
+def test_conv_forward_routing_matches_aten_autograd(own_backward, monkeypatch):
+    """conv.route_conv_fwd: re-classed Conv2d / ConvTranspose2d (forward on csrc/conv_fwd.hip; with own_backward the data
+    gradients on conv_fwd.hip modes 0-3 and the weight gradients on conv_bwd.hip too, the FFWM_CONV_DGRAD / _WGRAD opt-in)
+    against the untouched modules -- outputs, input gradients and parameter gradients."""
     import copy
     import torch.nn as nn
     from ffwm_amd import conv
+    if own_backward:
+        monkeypatch.setattr(conv, "_OWN_DGRAD", True)
+        monkeypatch.setattr(conv, "_OWN_WGRAD", True)
+        monkeypatch.setattr(conv._ext, "get", lambda: None)       # the Python autograd functions (the C++ ones read the env once)
     torch.manual_seed(7)
     ref = nn.Sequential(nn.Conv2d(40, 64, 3, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 96, 4, 2, 1), nn.LeakyReLU(0.2),
                         nn.Conv2d(96, 96, 3, 1, 1), nn.LeakyReLU(0.2), nn.ConvTranspose2d(96, 48, 4, 2, 1), nn.LeakyReLU(0.2),
@@ -1391,3 +1397,95 @@ def test_conv_forward_routing_matches_aten_autograd():
     assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * (1 + xa.grad.abs().max().item())
     for (n, p), (_, q) in zip(ref.named_parameters(), fast.named_parameters()):
         assert (p.grad - q.grad).abs().max().item() <= 1e-4 * (1 + p.grad.abs().max().item()), n
+
+
+@pytest.mark.parametrize("case", [
+    # (B, C, H, W, K, kernel, stride, pad, transposed)
+    (2, 3, 16, 16, 8, 3, 2, 1, False), (8, 64, 128, 128, 64, 3, 2, 1, False), (8, 512, 4, 4, 1024, 3, 2, 1, False),
+    (8, 1026, 4, 4, 512, 3, 1, 1, False), (3, 70, 9, 11, 130, 3, 1, 1, False), (2, 64, 32, 32, 128, 4, 2, 1, False),
+    (8, 1024, 2, 2, 512, 4, 2, 1, True), (8, 66, 32, 32, 32, 4, 2, 1, True), (2, 5, 7, 9, 3, 4, 2, 1, True),
+])
+def test_conv2d_wgrad_generic_matches_aten(case):
+    """csrc/conv_bwd.hip against ATen's float64 convolution_backward: Conv2d and ConvTranspose2d weight gradients."""
+    from ffwm_amd import ops
+    B, C, H, W, K, k, stride, pad, transposed = case
+    g = _gen(sum(case[:5]) + 1)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(*((C, K, k, k) if transposed else (K, C, k, k)), generator=g) * 0.05
+    conv = F.conv_transpose2d if transposed else F.conv2d
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = conv(xd, wd, None, stride, pad)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go.double())
+    if transposed:
+        dw = ops.conv2d_wgrad(x.to(DEV), go.to(DEV), k, stride, pad)        # rows = input, gathered = grad_output
+    else:
+        dw = ops.conv2d_wgrad(go.to(DEV), x.to(DEV), k, stride, pad)
+    ref = wd.grad
+    assert (dw.cpu().double() - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item()) * (B * y.size(2) * y.size(3)) ** 0.5
+
+
+@pytest.mark.parametrize("case", [
+    # (B, C, H, W, K)
+    (1, 8, 4, 4, 64), (2, 5, 6, 10, 3), (2, 19, 7, 9, 70), (1, 64, 32, 32, 64), (3, 33, 17, 30, 130), (8, 195, 64, 64, 195),
+    (2, 96, 128, 128, 48),
+])
+def test_conv3x3_winograd_matches_aten(case):
+    """csrc/conv_winograd.hip (fp32 Winograd F(2x2, 3x3) on the MFMA units) against ATen's float64 convolution: forward with
+    bias and LeakyReLU, and the data gradient (the layer's own weight read transposed and rotated); odd planes, channel
+    counts that are no multiple of the 8-channel chunk or the 64-channel tile, netG's 195 -> 195 residual layer
+    (/root/reference/models/base_networks.py:293-298)."""
+    from ffwm_amd import ops
+    B, C, H, W, K = case
+    g = _gen(sum(case))
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(K, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    tol = 2e-5 * (1 + ref.abs().max().item())
+    assert (ops.conv3x3_winograd(xd, wd, bd).cpu().double() - ref).abs().max().item() <= tol
+    assert (ops.conv3x3_winograd(xd, wd, bd, act=1, slope=0.2).cpu().double() - F.leaky_relu(ref, 0.2)).abs().max().item() <= tol
+    assert (ops.conv3x3_winograd(xd, wd).cpu().double() - (ref - b.double().view(1, -1, 1, 1))).abs().max().item() <= tol
+    go = torch.randn(B, K, H, W, generator=g)
+    dref = torch.nn.grad.conv2d_input((B, C, H, W), w.double(), go.double(), 1, 1)
+    dx = ops.conv3x3_winograd(go.to(DEV), wd, None, data_gradient=True)
+    assert tuple(dx.shape) == (B, C, H, W)
+    assert (dx.cpu().double() - dref).abs().max().item() <= 2e-5 * (1 + dref.abs().max().item())
+    out = torch.empty(B, K, H, W, device=DEV)
+    assert ops.conv3x3_winograd(xd, wd, bd, out=out) is out
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(xd, torch.zeros(K, C + 1, 3, 3, device=DEV))
+    with pytest.raises(ValueError):
+        ops.conv3x3_winograd(xd, wd, torch.zeros(K + 1, device=DEV))
+
+
+def test_winograd_routing_matches_aten_autograd():
+    """conv.route_conv_winograd: re-classed 3x3 / stride-1 Conv2d layers (forward + data gradient on csrc/conv_winograd.hip,
+    weight gradient on conv_wgrad.hip or the vendor's) against the untouched modules; a plane below the tile threshold takes
+    the fallback path."""
+    import copy
+    import torch.nn as nn
+    from ffwm_amd import conv
+    torch.manual_seed(11)
+    ref = nn.Sequential(nn.Conv2d(40, 64, 3, 1, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 70, 3, 1, 1, bias=False), nn.LeakyReLU(0.2),
+                        nn.Conv2d(70, 64, 3, 1, 1), nn.Conv2d(64, 3, 3, 1, 1)).to(DEV)
+    fast = copy.deepcopy(ref)
+    assert conv.route_conv_winograd(fast) == 3             # the 64 -> 3 layer stays
+    for shape in ((2, 40, 64, 64), (1, 40, 16, 16)):
+        assert conv.winograd_ok(torch.empty(shape, device=DEV), fast[0].weight) == (shape[2] == 64)
+        x = torch.randn(*shape, generator=_gen(shape[2])).to(DEV)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = ref(xa), fast(xb)
+        assert (ya - yb).abs().max().item() <= 2e-5 * (1 + ya.abs().max().item())
+        go = torch.randn(ya.shape, generator=_gen(10)).to(DEV)
+        for net in (ref, fast):
+            net.zero_grad()
+        ya.backward(go)
+        yb.backward(go)
+        assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * (1 + xa.grad.abs().max().item())
+        for (n, p), (_, q) in zip(ref.named_parameters(), fast.named_parameters()):
+            assert (p.grad - q.grad).abs().max().item() <= 1e-4 * (1 + p.grad.abs().max().item()), n
+    with torch.no_grad():
+        x = torch.randn(2, 40, 64, 64, generator=_gen(3)).to(DEV)
+        assert (ref(x) - fast(x)).abs().max().item() <= 2e-5 * (1 + ref(x).abs().max().item())

@@ -11,7 +11,7 @@ def t(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-B = 6
+B = int(os.environ.get("B", 6))
 layers = [("conv1", 64, 128, 64, 3, 2, False), ("conv2", 128, 64, 128, 3, 2, False), ("conv3", 128, 32, 256, 3, 2, False),
           ("conv4", 256, 16, 512, 3, 2, False), ("conv4_1", 512, 8, 512, 3, 1, False), ("conv5", 512, 8, 512, 3, 2, False),
           ("conv5_1", 512, 4, 512, 3, 1, False), ("conv6", 512, 4, 1024, 3, 2, False), ("conv6_1", 1024, 2, 1024, 3, 1, False),
