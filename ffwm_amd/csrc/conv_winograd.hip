@@ -34,10 +34,12 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kThinStride = 36;           // floats per input channel of the thin tail's weights: up to 4 output channels x 9 taps
 constexpr int kWinoChunk = 16 * 2 * 64 * 4;      // floats of U (and of V) per chunk of 8 channels: 8192 = 32 KiB
 
 struct WinoGeo {
-    int C, H, W, K;
+    int C, H, W, K;          // K = the output channels THIS launch computes (a multiple of 64 when a thin tail follows)
+    int Kout;                // channels of the output tensor
     int TH, TW, T;           // tiles per column / row / in total (B * TH * TW)
     int CH;                  // chunks of 8 input channels
     int KT, TT;              // tiles of 64 output channels / of 64 output tiles
@@ -50,10 +52,20 @@ struct WinoGeo {
 // U[kt][ch][p][h][k64][c4] = (G w Gt)[p] of output channel kt * 64 + k64 and input channel ch * 8 + 4 h + c4; zero outside
 // K x C.  mode 0: w is [K][C][3][3]; mode 1 (data gradient): w is the layer's own [C][K][3][3], used transposed and flipped.
 __global__ void __launch_bounds__(kBlock)
-winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C, int CH, int KT, int mode) {
+winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int Kw, int C, int CH, int KT, int mode, int tail) {
     const int Cp = CH * 8;
     const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= KT * 64 * Cp) return;
+    if (e >= KT * 64 * Cp) {
+        // the thin tail's weights (output channels K .. K + tail): Wt[c][36] = (k, tap) -> w, rotated for the data gradient,
+        // in the slot of the k tile the Winograd kernel no longer computes
+        const int t = e - KT * 64 * Cp;
+        if (t >= C * kThinStride) return;
+        const int c = t / kThinStride, q = t - c * kThinStride, k = q / 9, tap = q - k * 9;
+        float v = 0.f;
+        if (k < tail) v = mode == 0 ? w[(static_cast<size_t>(K + k) * C + c) * 9 + tap] : w[(static_cast<size_t>(c) * Kw + K + k) * 9 + (8 - tap)];
+        U[static_cast<size_t>(KT) * CH * kWinoChunk + t] = v;
+        return;
+    }
     const int k = e / Cp, c = e - k * Cp;
     float g[3][3];
     const bool in = k < K && c < C;
@@ -63,7 +75,7 @@ winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int 
         for (int s = 0; s < 3; ++s) {
             float v = 0.f;
             if (in) v = mode == 0 ? w[(static_cast<size_t>(k) * C + c) * 9 + r * 3 + s]
-                                  : w[(static_cast<size_t>(c) * K + k) * 9 + (2 - r) * 3 + (2 - s)];
+                                  : w[(static_cast<size_t>(c) * Kw + k) * 9 + (2 - r) * 3 + (2 - s)];
             g[r][s] = v;
         }
     // rows: G g  (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1])
@@ -241,7 +253,7 @@ winograd_conv_kernel(const float* __restrict__ x, const float* __restrict__ U, c
     const int ty = rem / g.TW, tx = rem - ty * g.TW;
     const int oy = 2 * ty, ox = 2 * tx;
     const bool row1 = oy + 1 < g.H, col1 = ox + 1 < g.W;
-    float* ob = out + (static_cast<size_t>(b) * g.K) * HW + static_cast<size_t>(oy) * g.W + ox;
+    float* ob = out + (static_cast<size_t>(b) * g.Kout) * HW + static_cast<size_t>(oy) * g.W + ox;
     const bool vec = col1 && (g.W & 1) == 0;         // 8-byte aligned pair
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -270,6 +282,110 @@ winograd_conv_kernel(const float* __restrict__ x, const float* __restrict__ U, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- thin tail
+// The last 1-4 output channels of a layer whose channel count is just past a multiple of 64 (netG's residual blocks: 195 =
+// 3 * 64 + 3) would cost a whole 64-channel tile of the Winograd kernel (a quarter of the launch).  They are a direct sum
+// on the vector ALUs instead: a lane owns 4 consecutive pixels of a row and all KN channels, the 4 waves of a workgroup
+// split the input channels (weights are wave-uniform: scalar loads feeding the FMAs) and meet in LDS.
+struct ThinGeo {
+    int C, H, W, Kout, k_off;
+    int strips;              // B * H * W / 4
+    int act;
+    float slope;
+    unsigned x_bytes;
+};
+
+constexpr int kThinWaves = 8;
+
+template <int KN>
+__global__ void __launch_bounds__(64 * kThinWaves)
+conv3x3_thin_kernel(const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias, float* __restrict__ out,
+                    const ThinGeo g) {
+    __shared__ float red[kThinWaves - 1][KN * 4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x * 64 + lane;
+    const bool sv = strip < g.strips;
+    const int W4 = g.W >> 2, HW = g.H * g.W;
+    const int row = sv ? strip / W4 : 0;                 // b * H + y
+    const int x0 = sv ? (strip - row * W4) * 4 : 0;
+    const int b = row / g.H, y = row - b * g.H;
+    constexpr unsigned kOobOff = 0xFFFFFFF0u;
+    const rsrc_t rx = make_rsrc(x, g.x_bytes);
+    unsigned offm[3], off4[3], offp[3];                 // per input row: pixel x0 - 1, the aligned four, pixel x0 + 4 (channel 0)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y - 1 + r;
+        const bool rv = sv && yy >= 0 && yy < g.H;
+        const unsigned base = (static_cast<unsigned>(b) * g.C * static_cast<unsigned>(HW) + static_cast<unsigned>(yy * g.W + x0)) * 4u;
+        off4[r] = rv ? base : kOobOff;
+        offm[r] = (rv && x0 > 0) ? base - 4u : kOobOff;
+        offp[r] = (rv && x0 + 4 < g.W) ? base + 16u : kOobOff;
+    }
+    float acc[KN][4];
+#pragma unroll
+    for (int k = 0; k < KN; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+    auto load = [&](int c, float (&in)[3][6]) {          // a channel past the last reads 0
+        const unsigned co = static_cast<unsigned>(c) * static_cast<unsigned>(HW) * 4u;
+        const bool cv = c < g.C;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            in[r][0] = buf_ld<float>(rx, (cv & (offm[r] != kOobOff)) ? offm[r] + co : kOobOff);
+            unsigned q[4];           // (never __builtin_bit_cast a vector ELEMENT: clang reads the vector's first lane for each)
+            buf_load_dwords<4>(rx, (cv & (off4[r] != kOobOff)) ? off4[r] + co : kOobOff, q);
+            in[r][1] = __uint_as_float(q[0]); in[r][2] = __uint_as_float(q[1]);
+            in[r][3] = __uint_as_float(q[2]); in[r][4] = __uint_as_float(q[3]);
+            in[r][5] = buf_ld<float>(rx, (cv & (offp[r] != kOobOff)) ? offp[r] + co : kOobOff);
+        }
+    };
+    auto fma_all = [&](int c, const float (&in)[3][6]) {
+        const float* wp = wt + static_cast<size_t>(c) * kThinStride;          // wave-uniform: scalar loads
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float wv = wp[k * 9 + t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(wv, in[t / 3][j + t % 3], acc[k][j]);
+            }
+    };
+    // channels wave, wave + 8, ...: the next channel's window is in flight while this one's 36 KN FMAs issue
+    float in0[3][6], in1[3][6];
+    load(wave, in0);
+    for (int c = wave; c < g.C; c += 2 * kThinWaves) {
+        load(c + kThinWaves, in1);
+        fma_all(c, in0);
+        if (c + kThinWaves >= g.C) break;
+        load(c + 2 * kThinWaves, in0);
+        fma_all(c + kThinWaves, in1);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < KN; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave - 1][k * 4 + j][lane] = acc[k][j];
+    }
+    __syncthreads();
+    if (wave > 0 || !sv) return;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+        const float bv = bias ? bias[g.k_off + k] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = acc[k][j];
+#pragma unroll
+            for (int q = 0; q < kThinWaves - 1; ++q) t += red[q][k * 4 + j][lane];
+            t += bv;
+            if (g.act == 1) t = t > 0.f ? t : t * g.slope;
+            v[j] = t;
+        }
+        *reinterpret_cast<float4*>(out + (static_cast<size_t>(b) * g.Kout + g.k_off + k) * HW + static_cast<size_t>(y) * g.W + x0) =
+            make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 }  // namespace
 }  // namespace ffwm
 
@@ -290,8 +406,13 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
     FFWM_REQUIRE(act == 0 || act == 1, FFWM_ERR_ARG, "%s: act must be 0 (none) or 1 (leaky relu)", fn);
     FFWM_REQUIRE(data_gradient == 0 || data_gradient == 1, FFWM_ERR_ARG, "%s: data_gradient must be 0 or 1", fn);
     FFWM_REQUIRE(B * C * H * W < (1LL << 29) && B * K * H * W < (1LL << 40), FFWM_ERR_SIZE, "%s: the input must stay below 2 GiB", fn);
+    // a tail of 1-4 channels past a multiple of 64 goes to the thin kernel instead of costing a 64-channel tile
+    const int tail = static_cast<int>(K % 64);
+    const bool thin = K > 64 && tail >= 1 && tail <= 4 && W % 4 == 0 && options().conv_thin_tail;
     WinoGeo g;
-    g.C = static_cast<int>(C); g.H = static_cast<int>(H); g.W = static_cast<int>(W); g.K = static_cast<int>(K);
+    g.C = static_cast<int>(C); g.H = static_cast<int>(H); g.W = static_cast<int>(W);
+    g.K = static_cast<int>(thin ? K - tail : K);
+    g.Kout = static_cast<int>(K);
     g.TH = (g.H + 1) / 2; g.TW = (g.W + 1) / 2;
     const int64_t T = B * g.TH * g.TW;
     FFWM_REQUIRE(T < (1LL << 30), FFWM_ERR_SIZE, "%s: too many tiles", fn);
@@ -307,30 +428,51 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* U = static_cast<float*>(workspace);
     {
-        const int64_t n = static_cast<int64_t>(g.KT) * 64 * g.CH * 8;
+        const int64_t n = static_cast<int64_t>(g.KT) * 64 * g.CH * 8 + (thin ? C * kThinStride : 0);
         LaunchScope ls("conv_winograd_weights", st, 4.0 * (9.0 * K * C + 16.0 * n));
         hipLaunchKernelGGL(winograd_weights_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           static_cast<const float*>(weight), U, g.K, g.C, g.CH, g.KT, data_gradient);
+                           static_cast<const float*>(weight), U, g.K, static_cast<int>(K), g.C, g.CH, g.KT, data_gradient, thin ? tail : 0);
         const int rc = check_launch(fn);
         if (rc) return rc;
     }
-    // flops = the multiplications the MFMAs actually perform (16 per tile, channel pair), not the 36 of the direct sum
-    const double flops = 2.0 * 16.0 * static_cast<double>(T) * K * C;
-    const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(B) * K * H * W) + static_cast<double>(ub);
-    LaunchScope ls(data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd", st, bytes, flops);
-    const unsigned nblk = static_cast<unsigned>(g.TT) * static_cast<unsigned>(g.KT);
-    auto kern = winograd_conv_kernel<0>;
-    switch (options().ablate) {
-        case 1: kern = winograd_conv_kernel<1>; break;
-        case 2: kern = winograd_conv_kernel<2>; break;
-        case 3: kern = winograd_conv_kernel<3>; break;
-        case 4: kern = winograd_conv_kernel<4>; break;
-        case 7: kern = winograd_conv_kernel<7>; break;
-        case 15: kern = winograd_conv_kernel<15>; break;
-        default: break;
+    {
+        // flops = the multiplications the MFMAs actually perform (16 per tile, channel pair), not the 36 of the direct sum
+        const double flops = 2.0 * 16.0 * static_cast<double>(T) * g.K * C;
+        const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(B) * g.K * H * W) + static_cast<double>(ub);
+        LaunchScope ls(data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd", st, bytes, flops);
+        const unsigned nblk = static_cast<unsigned>(g.TT) * static_cast<unsigned>(g.KT);
+        auto kern = winograd_conv_kernel<0>;
+        switch (options().ablate) {
+            case 1: kern = winograd_conv_kernel<1>; break;
+            case 2: kern = winograd_conv_kernel<2>; break;
+            case 3: kern = winograd_conv_kernel<3>; break;
+            case 4: kern = winograd_conv_kernel<4>; break;
+            case 7: kern = winograd_conv_kernel<7>; break;
+            case 15: kern = winograd_conv_kernel<15>; break;
+            default: break;
+        }
+        allow_large_lds(reinterpret_cast<const void*>(kern));
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(kWinoThreads), 4 * kWinoChunk * 4, st, static_cast<const float*>(input), U,
+                           static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
+        const int rc = check_launch(fn);
+        if (rc || !thin) return rc;
     }
-    allow_large_lds(reinterpret_cast<const void*>(kern));
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(kWinoThreads), 4 * kWinoChunk * 4, st, static_cast<const float*>(input), U,
-                       static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
+    ThinGeo t;
+    t.C = g.C; t.H = g.H; t.W = g.W; t.Kout = g.Kout; t.k_off = g.K;
+    t.strips = static_cast<int>(B * H * W / 4);
+    t.act = act; t.slope = static_cast<float>(slope);
+    t.x_bytes = g.x_bytes;
+    LaunchScope ls("conv3x3_thin_tail", st, 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(B) * tail * H * W));
+    const dim3 grid(static_cast<unsigned>((t.strips + 63) / 64)), block(64 * kThinWaves);
+    const float* xin = static_cast<const float*>(input);
+    const float* wt = U + static_cast<size_t>(g.KT) * g.CH * kWinoChunk;
+    const float* bs = static_cast<const float*>(bias);
+    float* o = static_cast<float*>(output);
+    switch (tail) {
+        case 1: hipLaunchKernelGGL(conv3x3_thin_kernel<1>, grid, block, 0, st, xin, wt, bs, o, t); break;
+        case 2: hipLaunchKernelGGL(conv3x3_thin_kernel<2>, grid, block, 0, st, xin, wt, bs, o, t); break;
+        case 3: hipLaunchKernelGGL(conv3x3_thin_kernel<3>, grid, block, 0, st, xin, wt, bs, o, t); break;
+        default: hipLaunchKernelGGL(conv3x3_thin_kernel<4>, grid, block, 0, st, xin, wt, bs, o, t); break;
+    }
     return check_launch(fn);
 }
