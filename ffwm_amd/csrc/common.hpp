@@ -32,6 +32,7 @@ struct Options {
     int rs_fwd_variant = 0;   // resample2d forward: 0 = auto, 1 = direct gathers, LDS-staged tiles 64 x 16 / 4 / 8: 2 / 3 / 4 (two buffers), 6 / 7 / 5 (one)
     int rs_bwd1_variant = 0;  // resample2d d_input1: 0 = auto (plane kernel when a plane fits LDS, else tile kernel), 2 = tile kernel
     int conv_tile_variant = 0; // conv_fwd.hip workgroup tile: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128
+    int conv_wino_raw = 1;     // conv_winograd.hip: stage the input window through LDS when a workgroup covers whole tile rows
     int conv_thin_tail = 1;    // conv_winograd.hip: 1-4 output channels past a multiple of 64 on the thin direct kernel
     int ablate = 0;           // bench-only ablation bits (1 = skip source fetch, 2 = skip stores)
 };

@@ -27,6 +27,7 @@
 // weight kernel differs.  fp32 throughout; the rounding differs from a direct sum in the last bits, like the vendor's
 // Winograd that it replaces (tests: <= 2e-5 of the output scale against fp64).
 #include "common.hpp"
+#include <type_traits>
 
 namespace ffwm {
 namespace {
@@ -46,6 +47,7 @@ struct WinoGeo {
     int act;
     float slope;
     unsigned x_bytes, u_bytes;
+    int R, ROWS;             // raw-staged variant: tile rows per workgroup (64 / TW) and input rows it stages (2 R + 2)
 
 };
 
@@ -103,6 +105,71 @@ winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int 
 
 constexpr int kWinoThreads = 512;        // 8 waves: two per SIMD, 128 accumulator + <= 128 other registers each
 constexpr int kWinoTiles = 64;           // output tiles (2 x 2 pixels) per workgroup
+
+// ---- epilogue: y = At m A per (k, tile).  C/D layout: col = lane & 31 (tile), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (k).
+// A wave holds rows i = 2 ph, 2 ph + 1 of m: it forms its share of y (2 x 2 values per register), the ph = 1 waves hand theirs
+// to their ph = 0 partners through LDS (the staging buffers are free: the loop ended with a barrier).
+__device__ __forceinline__ void winograd_epilogue(const f32x16 (&acc)[8], f32x4* smem, const float* __restrict__ bias, float* __restrict__ out,
+                                                  const WinoGeo& g, int tt, int kt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int HW = g.H * g.W;
+    float part[16][4];               // [r][y00, y01, y10, y11]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 2 ph
+        const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 2 ph + 1
+        if (ph == 0) {               // y0 = z0 + z1 (+ z2), y1 = z1 (- z2 - z3)
+            part[r][0] = za0 + zb0; part[r][1] = za1 + zb1; part[r][2] = zb0; part[r][3] = zb1;
+        } else {                     // y0 = z2, y1 = -z2 - z3
+            part[r][0] = za0; part[r][1] = za1; part[r][2] = -za0 - zb0; part[r][3] = -za1 - zb1;
+        }
+    }
+    float* xch = reinterpret_cast<float*>(smem) + (wave & 3) * 4096 + lane;
+    if (ph == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xch[(r * 4 + v) * 64] = part[r][v];
+    }
+    __syncthreads();
+    if (ph == 1 || kt * 64 + wm * 32 >= g.K) return;
+    const int tg = tt * kWinoTiles + wn * 32 + l31;
+    if (tg >= g.T) return;
+    const int b = tg / (g.TH * g.TW);
+    const int rem = tg - b * (g.TH * g.TW);
+    const int ty = rem / g.TW, tx = rem - ty * g.TW;
+    const int oy = 2 * ty, ox = 2 * tx;
+    const bool row1 = oy + 1 < g.H, col1 = ox + 1 < g.W;
+    float* ob = out + (static_cast<size_t>(b) * g.Kout) * HW + static_cast<size_t>(oy) * g.W + ox;
+    const bool vec = col1 && (g.W & 1) == 0;         // 8-byte aligned pair
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = kt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (k >= g.K) continue;
+        const float bv = bias ? bias[k] : 0.f;
+        float y[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float t = part[r][v] + xch[(r * 4 + v) * 64] + bv;
+            if (g.act == 1) t = t > 0.f ? t : t * g.slope;
+            y[v] = t;
+        }
+        float* o = ob + static_cast<size_t>(k) * HW;
+        if (vec) {
+            *reinterpret_cast<float2*>(o) = make_float2(y[0], y[1]);
+            if (row1) *reinterpret_cast<float2*>(o + g.W) = make_float2(y[2], y[3]);
+        } else {
+            o[0] = y[0];
+            if (col1) o[1] = y[1];
+            if (row1) {
+                o[g.W] = y[2];
+                if (col1) o[g.W + 1] = y[3];
+            }
+        }
+    }
+}
 
 template <int ABL>          // ABL: timing experiments only (bit 0 no patch loads, 1 no U loads, 2 no LDS commits, 3 no operand reads)
 __global__ void __launch_bounds__(kWinoThreads)
@@ -223,63 +290,173 @@ winograd_conv_kernel(const float* __restrict__ x, const float* __restrict__ U, c
         cur ^= 4096u;
     }
 
-    // ---- epilogue: y = At m A per (k, tile).  C/D layout: col = lane & 31 (tile), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (k).
-    // A wave holds rows i = 2 ph, 2 ph + 1 of m: it forms its share of y (2 x 2 values per register), the ph = 1 waves hand theirs
-    // to their ph = 0 partners through LDS (the staging buffers are free: the loop ended with a barrier).
-    float part[16][4];               // [r][y00, y01, y10, y11]
+    winograd_epilogue(acc, smem, bias, out, g, tt, kt);
+}
+
+// ---------------------------------------------------------------------------------------------------- raw-staged variant
+// The gathers above cost the texture addresser 16 scattered dword loads per thread and chunk (TA busy 45 %, each input element
+// fetched ~4 x through L1) next to the MFMAs' 60 %.  When the 64 tiles of a workgroup are whole tile rows of one image (W in
+// {16, 32, 64, 128}: R = 64 / TW tile rows, 2 R + 2 input rows of W pixels, no horizontal halo -- it is all zero padding) the
+// input window of a chunk is copied ONCE, row-contiguous dwordx4 -> LDS (2 loads per thread instead of 16), and the 4 x 4
+// patches are read back from LDS (3 reads per row: the patch starts at an odd column; the border columns are masked).
+//
+// Pipeline of chunk n, one barrier per step: L(n) global -> registers in step n - 3, W(n) registers -> raw[n & 1] in step
+// n - 2, T(n) raw -> Bt d B -> V[n & 1] and U(n) -> LDS in step n - 1, MFMAs in step n.  LDS: 128 KiB of operands + 2 x 16 KiB
+// raw = the CU's 160 KiB exactly.
+constexpr int kWinoRawFloats = 8 * 4 * 128;      // 8 channels x (2 R + 2) rows x W <= 4096 floats for every supported W
+
+template <int ABL>
+__global__ void __launch_bounds__(kWinoThreads)
+winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out,
+                         const WinoGeo g, int remap) {
+    extern __shared__ f32x4 smem[];          // operands as above (8192 f32x4), then raw[2][kWinoRawFloats]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tt = static_cast<int>(lid) / g.KT, kt = static_cast<int>(lid) - tt * g.KT;
+    constexpr unsigned kOobOff = 0xFFFFFFF0u;
+    const rsrc_t rx = make_rsrc(x, g.x_bytes);
+    const rsrc_t ru = make_rsrc(U, g.u_bytes);
+    const int HW = g.H * g.W;
+    float* const raw0 = reinterpret_cast<float*>(smem + 8192);
+
+    // the workgroup's tiles: rows ty0 .. ty0 + R of image b
+    const int strips_per_img = g.TH / g.R;
+    const int b = tt / strips_per_img, ty0 = (tt - b * strips_per_img) * g.R;
+    // ---- W stage role: quads q = tid, tid + 512 of the [8 channels][ROWS][W / 4] window
+    const int W4 = g.W >> 2, nquads = 8 * g.ROWS * W4;
+    unsigned qoff[2];                // byte offset of the quad in channel 0 of the chunk, or kOobOff
+    int qc[2], qlds[2];              // its channel within the chunk; its float index in the raw buffer
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 2 ph
-        const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 2 ph + 1
-        if (ph == 0) {               // y0 = z0 + z1 (+ z2), y1 = z1 (- z2 - z3)
-            part[r][0] = za0 + zb0; part[r][1] = za1 + zb1; part[r][2] = zb0; part[r][3] = zb1;
-        } else {                     // y0 = z2, y1 = -z2 - z3
-            part[r][0] = za0; part[r][1] = za1; part[r][2] = -za0 - zb0; part[r][3] = -za1 - zb1;
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + kWinoThreads * i;
+        const int c = q / (g.ROWS * W4), rem = q - c * (g.ROWS * W4);
+        const int rr = rem / W4, xq = rem - rr * W4;
+        const int iy = 2 * ty0 - 1 + rr;
+        const bool ok = q < nquads && iy >= 0 && iy < g.H;
+        qc[i] = q < nquads ? c : 8;
+        qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + c) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + 4 * xq)) * 4u : kOobOff;
+        qlds[i] = q < nquads ? q * 4 : -1;
     }
-    float* xch = reinterpret_cast<float*>(smem) + (wave & 3) * 4096 + lane;
-    if (ph == 1) {
+    // ---- T stage role: lane = (c_lo, t_lo), wave = (channel half, t_hi): the patch of tile ts for channel 4 sh + c_lo of the chunk
+    const int c_lo = lane & 3, ts = (wave & 3) * 16 + (lane >> 2), sh = wave >> 2;
+    const int tr = ts / g.TW, tx = ts - tr * g.TW;
+    const int pbase = ((4 * sh + c_lo) * g.ROWS + 2 * tr) * g.W + 2 * tx;         // float index of patch element (0, 1)
+    const bool lcol = tx > 0, rcol = tx < g.TW - 1;
+    const unsigned u_base = (static_cast<unsigned>(kt) * g.CH) * (kWinoChunk * 4u) + threadIdx.x * 16u;
+
+    // two register sets each, alternating with the chunk's parity: a load has ~1.5 steps (6000+ cycles) to land
+    u32x4 rq[2][2] = {};
+    u32x4 uw[2][4] = {};
+    float d[16];
+    auto load_raw = [&](int ch, u32x4 (&q)[2]) {     // L(ch)
+        if (ABL & 1) return;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) xch[(r * 4 + v) * 64] = part[r][v];
-    }
-    __syncthreads();
-    if (ph == 1 || kt * 64 + wm * 32 >= g.K) return;
-    const int tg = tt * kWinoTiles + wn * 32 + l31;
-    if (tg >= g.T) return;
-    const int b = tg / (g.TH * g.TW);
-    const int rem = tg - b * (g.TH * g.TW);
-    const int ty = rem / g.TW, tx = rem - ty * g.TW;
-    const int oy = 2 * ty, ox = 2 * tx;
-    const bool row1 = oy + 1 < g.H, col1 = ox + 1 < g.W;
-    float* ob = out + (static_cast<size_t>(b) * g.Kout) * HW + static_cast<size_t>(oy) * g.W + ox;
-    const bool vec = col1 && (g.W & 1) == 0;         // 8-byte aligned pair
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int k = kt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (k >= g.K) continue;
-        const float bv = bias ? bias[k] : 0.f;
-        float y[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            float t = part[r][v] + xch[(r * 4 + v) * 64] + bv;
-            if (g.act == 1) t = t > 0.f ? t : t * g.slope;
-            y[v] = t;
+        for (int i = 0; i < 2; ++i) {
+            const bool cin = ch * 8 + qc[i] < g.C && qc[i] < 8;
+            q[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (cin & (qoff[i] != kOobOff)) ? qoff[i] + static_cast<unsigned>(ch) * (32u * HW) : kOobOff, 0, 0);
         }
-        float* o = ob + static_cast<size_t>(k) * HW;
-        if (vec) {
-            *reinterpret_cast<float2*>(o) = make_float2(y[0], y[1]);
-            if (row1) *reinterpret_cast<float2*>(o + g.W) = make_float2(y[2], y[3]);
-        } else {
-            o[0] = y[0];
-            if (col1) o[1] = y[1];
-            if (row1) {
-                o[g.W] = y[2];
-                if (col1) o[g.W + 1] = y[3];
+    };
+    auto write_raw = [&](float* raw, const u32x4 (&q)[2]) {      // W: registers -> raw window
+        if (ABL & 4) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (qlds[i] >= 0) *reinterpret_cast<u32x4*>(raw + qlds[i]) = q[i];
+    };
+    auto load_u = [&](int ch, u32x4 (&u)[4], int s) {            // U rows 2s, 2s + 1
+        if (ABL & 2) return;
+#pragma unroll
+        for (int i = 2 * s; i < 2 * s + 2; ++i)
+            u[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, u_base + static_cast<unsigned>(ch) * (kWinoChunk * 4u) + i * 8192u, 0, 0);
+    };
+    auto read_patch = [&](const float* raw) {        // 3 reads per row: columns 2tx - 1 | 2tx, 2tx + 1 | 2tx + 2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* rp = raw + pbase + i * g.W;
+            const float a = rp[-1], e = rp[2];
+            const float2 m = *reinterpret_cast<const float2*>(rp);
+            d[i * 4 + 0] = lcol ? a : 0.f;
+            d[i * 4 + 1] = m.x;
+            d[i * 4 + 2] = m.y;
+            d[i * 4 + 3] = rcol ? e : 0.f;
+        }
+    };
+    auto commit_slice = [&](f32x4* Ub, f32x4* Vb, const u32x4 (&u)[4], int s) {   // U rows 2s, 2s + 1; V rows 2s, 2s + 1
+        if (ABL & 4) return;
+#pragma unroll
+        for (int i = 2 * s; i < 2 * s + 2; ++i) reinterpret_cast<u32x4*>(Ub)[threadIdx.x + kWinoThreads * i] = u[i];
+        float* dst = reinterpret_cast<float*>(Vb) + (sh * 64 + ts) * 4 + c_lo;
+#pragma unroll
+        for (int i = 2 * s; i < 2 * s + 2; ++i) {
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                r[j] = i == 0 ? d[0 + j] - d[8 + j] : i == 1 ? d[4 + j] + d[8 + j] : i == 2 ? d[8 + j] - d[4 + j] : d[4 + j] - d[12 + j];
+            dst[(i * 4 + 0) * 512] = r[0] - r[2];
+            dst[(i * 4 + 1) * 512] = r[1] + r[2];
+            dst[(i * 4 + 2) * 512] = r[2] - r[1];
+            dst[(i * 4 + 3) * 512] = r[1] - r[3];
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    float* const raw1 = raw0 + kWinoRawFloats;
+    // step of chunk ch (parity P): MFMAs on buffers P; T(ch + 1), U(ch + 1) into buffers 1 - P; W(ch + 2) into raw[P];
+    // loads of U(ch + 3) and raw chunk ch + 4 into the register sets just emptied
+    auto step = [&](auto parity, int ch) {
+        constexpr int P = decltype(parity)::value, Q = 1 - P;
+        f32x4* const Ub = smem + P * 4096;
+        f32x4* const Vb = Ub + 2048;
+        f32x4* const Un = smem + Q * 4096;
+        f32x4* const Vn = Un + 2048;
+        const f32x4* ap = Ub + (ph * 8) * 128 + half * 64 + wm * 32 + l31;
+        const f32x4* bp = Vb + (ph * 8) * 128 + half * 64 + wn * 32 + l31;
+        f32x4 oa[2][2], ob[2][2];
+        oa[0][0] = ap[0]; ob[0][0] = bp[0]; oa[0][1] = ap[128]; ob[0][1] = bp[128];
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int cur = grp & 1, nxt = cur ^ 1;
+            if (grp < 3 && !(ABL & 8)) {
+                oa[nxt][0] = ap[(2 * grp + 2) * 128]; ob[nxt][0] = bp[(2 * grp + 2) * 128];
+                oa[nxt][1] = ap[(2 * grp + 3) * 128]; ob[nxt][1] = bp[(2 * grp + 3) * 128];
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * grp] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][0][j], ob[cur][0][j], acc[2 * grp], 0, 0, 0);
+                acc[2 * grp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][1][j], ob[cur][1][j], acc[2 * grp + 1], 0, 0, 0);
+            }
+            if (grp == 0) { if (!(ABL & 4)) read_patch(Q ? raw1 : raw0); commit_slice(Un, Vn, uw[Q], 0); }
+            else if (grp == 1) commit_slice(Un, Vn, uw[Q], 1);
+            else if (grp == 2) { write_raw(P ? raw1 : raw0, rq[P]); load_u(ch + 3, uw[Q], 0); }
+            else { load_u(ch + 3, uw[Q], 1); load_raw(ch + 4, rq[P]); }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
+    };
+
+    // prologue: chunk 0 staged and transformed, chunk 1 in raw[1], U(1), U(2) and raw chunks 2, 3 in flight
+    load_raw(0, rq[0]); load_u(0, uw[0], 0); load_u(0, uw[0], 1);
+    load_raw(1, rq[1]); load_u(1, uw[1], 0); load_u(1, uw[1], 1);
+    write_raw(raw0, rq[0]);
+    __syncthreads();
+    read_patch(raw0);
+    commit_slice(smem, smem + 2048, uw[0], 0); commit_slice(smem, smem + 2048, uw[0], 1);
+    write_raw(raw1, rq[1]);
+    load_raw(2, rq[0]); load_raw(3, rq[1]);
+    load_u(2, uw[0], 0); load_u(2, uw[0], 1);
+    __syncthreads();
+    // pairs of chunks; an odd count ends with one step over a chunk of zeros (every channel past C reads 0)
+    for (int ch = 0; ch < g.CH; ch += 2) {
+        step(std::integral_constant<int, 0>(), ch);
+        step(std::integral_constant<int, 1>(), ch + 1);
     }
+    winograd_epilogue(acc, smem, bias, out, g, tt, kt);
 }
 
 // ---------------------------------------------------------------------------------------------------- thin tail
@@ -441,6 +618,26 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
         const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(B) * g.K * H * W) + static_cast<double>(ub);
         LaunchScope ls(data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd", st, bytes, flops);
         const unsigned nblk = static_cast<unsigned>(g.TT) * static_cast<unsigned>(g.KT);
+        // whole tile rows of one image per workgroup -> the raw-staged variant
+        const bool rawv = options().conv_wino_raw && (W == 16 || W == 32 || W == 64 || W == 128) && g.TW <= 64 && 64 % g.TW == 0 &&
+                          g.TH % (64 / g.TW) == 0 && (2 * (64 / g.TW) + 2) * g.W * 8 <= kWinoRawFloats;
+        g.R = rawv ? 64 / g.TW : 0;
+        g.ROWS = 2 * g.R + 2;
+        if (rawv) {
+            auto kern = winograd_conv_raw_kernel<0>;
+            switch (options().ablate) {
+                case 1: kern = winograd_conv_raw_kernel<1>; break;
+                case 2: kern = winograd_conv_raw_kernel<2>; break;
+                case 3: kern = winograd_conv_raw_kernel<3>; break;
+                case 7: kern = winograd_conv_raw_kernel<7>; break;
+                default: break;
+            }
+            allow_large_lds(reinterpret_cast<const void*>(kern));
+            hipLaunchKernelGGL(kern, dim3(nblk), dim3(kWinoThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st, static_cast<const float*>(input), U,
+                               static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
+            const int rc = check_launch(fn);
+            if (rc || !thin) return rc;
+        } else {
         auto kern = winograd_conv_kernel<0>;
         switch (options().ablate) {
             case 1: kern = winograd_conv_kernel<1>; break;
@@ -456,6 +653,7 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
                            static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
         const int rc = check_launch(fn);
         if (rc || !thin) return rc;
+        }
     }
     ThinGeo t;
     t.C = g.C; t.H = g.H; t.W = g.W; t.Kout = g.Kout; t.k_off = g.K;

@@ -217,6 +217,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "rs_bwd1_variant")) slot = &o.rs_bwd1_variant;
     else if (!strcmp(key, "conv_tile_variant")) slot = &o.conv_tile_variant;
     else if (!strcmp(key, "conv_thin_tail")) slot = &o.conv_thin_tail;
+    else if (!strcmp(key, "conv_wino_raw")) slot = &o.conv_wino_raw;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;

@@ -1429,14 +1429,19 @@ def test_conv2d_wgrad_generic_matches_aten(case):
     # (B, C, H, W, K)
     (1, 8, 4, 4, 64), (2, 5, 6, 10, 3), (2, 19, 7, 9, 70), (1, 64, 32, 32, 64), (3, 33, 17, 30, 130), (8, 195, 64, 64, 195),
     (2, 96, 128, 128, 48), (1, 66, 8, 12, 65), (2, 68, 9, 16, 131),          # 1-4 channels past 64: the thin tail kernel
+    (3, 20, 16, 16, 40),
 ])
-def test_conv3x3_winograd_matches_aten(case):
+@pytest.mark.parametrize("raw_staging", [1, 0])
+def test_conv3x3_winograd_matches_aten(case, raw_staging):
     """csrc/conv_winograd.hip (fp32 Winograd F(2x2, 3x3) on the MFMA units) against ATen's float64 convolution: forward with
     bias and LeakyReLU, and the data gradient (the layer's own weight read transposed and rotated); odd planes, channel
     counts that are no multiple of the 8-channel chunk or the 64-channel tile, netG's 195 -> 195 residual layer
     (/root/reference/models/base_networks.py:293-298)."""
-    from ffwm_amd import ops
+    from ffwm_amd import ops, _lib
     B, C, H, W, K = case
+    # square planes of 16 / 32 / 64 / 128 pixels stage the input window through LDS (raw_staging = 1), everything else and
+    # raw_staging = 0 gathers the patches from memory
+    _lib.set_option("conv_wino_raw", raw_staging)
     g = _gen(sum(case))
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
@@ -1458,6 +1463,7 @@ def test_conv3x3_winograd_matches_aten(case):
         ops.conv3x3_winograd(xd, torch.zeros(K, C + 1, 3, 3, device=DEV))
     with pytest.raises(ValueError):
         ops.conv3x3_winograd(xd, wd, torch.zeros(K + 1, device=DEV))
+    _lib.set_option("conv_wino_raw", 1)
 
 
 def test_winograd_routing_matches_aten_autograd():

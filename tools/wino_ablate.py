@@ -4,7 +4,7 @@ import torch
 from ffwm_amd import ops, _lib
 B, C, H, K = 8, 256, 128, 256
 x = torch.randn(B, C, H, H, device="cuda"); w = torch.randn(K, C, 3, 3, device="cuda") * 0.05; b = torch.randn(K, device="cuda")
-for ab in [0, 1, 2, 3, 4, 7, 15]:
+for ab in [0, 0, 1, 2, 3, 7]:
     _lib.set_option("ablate", ab)
     for _ in range(3): ops.conv3x3_winograd(x, w, b)
     _lib.prof_reset(); _lib.prof_enable(True)
