@@ -14,7 +14,7 @@ on one batch resident in HBM.  fp32 throughout (the reference's dtype).  Rank 0 
                       launch duration (HIP events on its launch stream, ffwm_prof_*) vs the 8 TB/s HBM peak;
                       traffic = PMC-measured HBM bytes per launch (profiles/r02_pmc_traffic.json, rocprofv3 FETCH_SIZE /
                       WRITE_SIZE passes of this same command) or null when no valid measurement is committed
-  roofline_mfma     : the hand-written MFMA kernel with the largest share of the step (conv weight gradients)
+  roofline_mfma     : the hand-written MFMA kernel with the largest share of the step (conv weight gradient / Winograd conv)
   kernels           : the same figures for every hand-written kernel seen in the timed region and for the stand-alone
                       operator shapes of configs[0] / [4] (cfg-1 resample2d, cfg-5 block_extractor / local_attn_reshape)
   subpaths          : (N = 1) the other scopes SURVEY 8(d) asks for, each timed the same way on a few steps:
@@ -191,6 +191,15 @@ def standalone_kernels(reps=10):
     gi = torch.empty_like(attn)
     run("cfg5/GPU local_attn_reshape k=3 [4,9,256,256]", lambda: ops.local_attn_reshape_forward(attn, 3, out=o))
     run("cfg5/GPU local_attn_reshape k=3 backward", lambda: ops.local_attn_reshape_backward(o, 3, gi))
+    # netG's residual layer (base_networks.py:293-298): 195 -> 195 channels at 128 x 128, batch 8 -- forward and data gradient on
+    # csrc/conv_winograd.hip (TFLOPs = the MFMA flops executed; the direct sum it replaces has 2.25 x as many)
+    xw = torch.randn(8, 195, 128, 128, generator=g).to(dev)
+    ww = (torch.randn(195, 195, 3, 3, generator=g) * 0.02).to(dev)
+    bw = torch.randn(195, generator=g).to(dev)
+    ow = torch.empty_like(xw)
+    run("netG dres conv3x3 195->195 [8,195,128,128] winograd forward", lambda: ops.conv3x3_winograd(xw, ww, bw, out=ow))
+    run("netG dres conv3x3 195->195 [8,195,128,128] winograd data gradient", lambda: ops.conv3x3_winograd(xw, ww, None, data_gradient=True, out=ow))
+    del xw, ww, bw, ow
     in1 = torch.rand(1, 64, 128, 128, generator=g).to(dev)
     in2 = torch.cat((torch.rand(1, 2, 128, 128, generator=g) * 6 - 3, torch.full((1, 1, 128, 128), 2.0)), 1).to(dev)
     o = torch.empty_like(in1)
@@ -412,6 +421,11 @@ def main():
                                   "miopen": "immediate mode%s" % (" + in-tree find-db (ffwm_amd/miopen_db)" if miopen_db else ", heuristic solver choice"),
                                   "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))
                                   if args.mfma_wgrad == "on" else "vendor library",
+                                  "conv_fwd_dgrad": "fp32 Winograd F(2x2,3x3) on MFMA (csrc/conv_winograd.hip) for the 3x3/stride-1 calls of %d layers "
+                                                    "with >= %d tiles; direct MFMA kernel (csrc/conv_fwd.hip) forward for %d stride-2 / transposed / "
+                                                    "small-plane layers; vendor library for the rest" % (
+                                                        getattr(t, "winograd_layers", 0), __import__("ffwm_amd.conv", fromlist=["x"]).WINOGRAD_MIN_TILES,
+                                                        getattr(t, "mfma_fwd_layers", 0)),
                                   "titers_branch": "<20000" if args.titers < 20000 else ">=20000",
                                   "weights": "seeded random init (no pretrained VGG19/LightCNN/FlowNet offline)",
                                   "flow_nets": ("fitted to the identity grid for 80 untimed steps (stand-in for the reference's "

@@ -63,7 +63,7 @@ _SIGNATURES = {
     "ffwm_abi_version": [],
 }
 
-EXPORTS = sorted(list(_SIGNATURES) + ["ffwm_last_error"])
+EXPORTS = sorted(list(_SIGNATURES) + ["ffwm_last_error", "ffwm_conv3x3_winograd_workspace_bytes"])
 
 
 class FFWMError(RuntimeError):

@@ -21,8 +21,14 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "block_extractor_bwd_far": "be_bwd_far2_kernel<float, 3, false>",
     "block_extractor_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, false>",
     "block_extractor_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 0>",
+    "conv3x3_thin_tail": "conv3x3_thin_kernel<3>",
     "conv3x3_wgrad": "conv3x3_wgrad_kernel<false>",
     "conv3x3_wgrad_packed": "conv3x3_wgrad_kernel<true>",
+    "conv_fwd_mfma": "conv_fwd_kernel<0,",
+    "conv_fwd_mfma_transposed": "conv_fwd_kernel<1,",
+    "conv_winograd_dgrad": "winograd_conv_raw_kernel<0>",
+    "conv_winograd_fwd": "winograd_conv_raw_kernel<0>",
+    "conv_winograd_weights": "winograd_weights_kernel",
     "guided_filter_bwd": "gf_backward_kernel<float>",
     "guided_filter_fwd": "gf_forward_kernel<float>",
     "mfm_bwd": "mfm_bwd4_kernel",
@@ -31,6 +37,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "local_attn_reshape_fwd": "lar_fwd_kernel<float, 3>",
     "resample2d_bwd_input1_plane": "rs_bwd1_plane_kernel<float, 2>",
     "resample2d_bwd_input2": "rs_bwd2_kernel<float, 2>",
+    "resample2d_bwd_input2_lds": "rs_bwd2_lds_kernel<2,",
     "resample2d_fwd_lds": "rs_fwd_lds_kernel<2,",
     "spectral_norm_bwd_apply": "sn_bwd_apply_kernel<float>",
     "spectral_norm_bwd_dot": "sn_bwd_dot_kernel<float>",
