@@ -305,6 +305,12 @@ winograd_conv_kernel(const float* __restrict__ x, const float* __restrict__ U, c
 // raw = the CU's 160 KiB exactly.
 constexpr int kWinoRawFloats = 8 * 4 * 128;      // 8 channels x (2 R + 2) rows x W <= 4096 floats for every supported W
 
+// The kernel is PERSISTENT: one workgroup per CU walks a contiguous range of (tile strip, k tile) pairs and the chunk
+// pipeline runs straight through the boundaries -- the loads of the next pair's first chunks are in flight under the last
+// MFMAs of this one.  Launched one workgroup per pair, every pair paid ~15 us of dead time (dispatch, two dependent load round
+// trips before the first MFMA, the epilogue, uneven dynamic distribution) next to 2.3 us per chunk: 45 % of a 64-channel
+// layer, 17 % of a 256-channel one.  Here the epilogue of a pair costs two barriers: the ph = 1 waves park their share of the
+// output transform in the operand buffers the last step just finished with.
 template <int ABL>
 __global__ void __launch_bounds__(kWinoThreads)
 winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out,
@@ -313,50 +319,91 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x, remap);
-    const int tt = static_cast<int>(lid) / g.KT, kt = static_cast<int>(lid) - tt * g.KT;
     constexpr unsigned kOobOff = 0xFFFFFFF0u;
     const rsrc_t rx = make_rsrc(x, g.x_bytes);
     const rsrc_t ru = make_rsrc(U, g.u_bytes);
     const int HW = g.H * g.W;
     float* const raw0 = reinterpret_cast<float*>(smem + 8192);
+    float* const raw1 = raw0 + kWinoRawFloats;
 
-    // the workgroup's tiles: rows ty0 .. ty0 + R of image b
-    const int strips_per_img = g.TH / g.R;
-    const int b = tt / strips_per_img, ty0 = (tt - b * strips_per_img) * g.R;
+    // this workgroup's pairs: [pair_begin, pair_begin + pair_cnt) of the tt-major list (the k tiles of a strip are consecutive:
+    // the same CU re-reads the strip's input from L2); each XCD gets a contiguous range of the list
+    const int npairs = g.TT * g.KT;
+    const int L = static_cast<int>(xcd_remap(blockIdx.x, gridDim.x, remap));
+    const int per = npairs / static_cast<int>(gridDim.x), extra = npairs - per * static_cast<int>(gridDim.x);
+    const int pair_begin = L * per + min(L, extra), pair_cnt = per + (L < extra ? 1 : 0);
+    const int pair_end = pair_begin + pair_cnt;
+    if (pair_cnt == 0) return;
+    const int CHp = (g.CH + 1) & ~1;         // chunks per pair, even: an odd count ends with a chunk of zeros (channels >= C read 0)
+
     // ---- W stage role: quads q = tid, tid + 512 of the [8 channels][ROWS][W / 4] window
     const int W4 = g.W >> 2, nquads = 8 * g.ROWS * W4;
-    unsigned qoff[2];                // byte offset of the quad in channel 0 of the chunk, or kOobOff
-    int qc[2], qlds[2];              // its channel within the chunk; its float index in the raw buffer
+    const int strips_per_img = g.TH / g.R;
+    int qc[2], qlds[2], qrow[2], qcol[2];      // channel within the chunk; float index in the raw buffer; window row; pixel column
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = threadIdx.x + kWinoThreads * i;
         const int c = q / (g.ROWS * W4), rem = q - c * (g.ROWS * W4);
-        const int rr = rem / W4, xq = rem - rr * W4;
-        const int iy = 2 * ty0 - 1 + rr;
-        const bool ok = q < nquads && iy >= 0 && iy < g.H;
+        const int rr = rem / W4;
         qc[i] = q < nquads ? c : 8;
-        qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + c) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + 4 * xq)) * 4u : kOobOff;
+        qrow[i] = rr;
+        qcol[i] = 4 * (rem - rr * W4);
         qlds[i] = q < nquads ? q * 4 : -1;
     }
+    // a load cursor: the (pair, chunk) a stream of loads has reached, and what depends on the pair
+    struct Cursor {
+        int pair, ch;
+        unsigned qoff[2];            // byte offset of the quad in channel 0, or kOobOff
+        unsigned u_base;             // byte offset of this thread's first U quad of chunk 0, or kOobOff past the last pair
+    };
+    auto seat = [&](Cursor& c) {
+        if (c.pair >= pair_end) {
+            c.qoff[0] = c.qoff[1] = kOobOff;
+            c.u_base = kOobOff;
+            return;
+        }
+        const int tt = c.pair / g.KT, kt = c.pair - tt * g.KT;
+        const int b = tt / strips_per_img, ty0 = (tt - b * strips_per_img) * g.R;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = 2 * ty0 - 1 + qrow[i];
+            const bool ok = qc[i] < 8 && iy >= 0 && iy < g.H;
+            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + qc[i]) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol[i])) * 4u : kOobOff;
+        }
+        c.u_base = (static_cast<unsigned>(kt) * g.CH) * (kWinoChunk * 4u) + threadIdx.x * 16u;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.ch == CHp) {
+            c.ch = 0;
+            ++c.pair;
+            seat(c);
+        }
+    };
+    Cursor cr, cu;
+    cr.pair = cu.pair = pair_begin;
+    cr.ch = cu.ch = 0;
+    seat(cr);
+    cu = cr;
+
     // ---- T stage role: lane = (c_lo, t_lo), wave = (channel half, t_hi): the patch of tile ts for channel 4 sh + c_lo of the chunk
     const int c_lo = lane & 3, ts = (wave & 3) * 16 + (lane >> 2), sh = wave >> 2;
     const int tr = ts / g.TW, tx = ts - tr * g.TW;
     const int pbase = ((4 * sh + c_lo) * g.ROWS + 2 * tr) * g.W + 2 * tx;         // float index of patch element (0, 1)
     const bool lcol = tx > 0, rcol = tx < g.TW - 1;
-    const unsigned u_base = (static_cast<unsigned>(kt) * g.CH) * (kWinoChunk * 4u) + threadIdx.x * 16u;
 
     // two register sets each, alternating with the chunk's parity: a load has ~1.5 steps (6000+ cycles) to land
     u32x4 rq[2][2] = {};
     u32x4 uw[2][4] = {};
     float d[16];
-    auto load_raw = [&](int ch, u32x4 (&q)[2]) {     // L(ch)
-        if (ABL & 1) return;
+    auto load_raw = [&](u32x4 (&q)[2]) {             // L: the cursor's chunk, then the cursor moves on
+        if (!(ABL & 1)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool cin = ch * 8 + qc[i] < g.C && qc[i] < 8;
-            q[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (cin & (qoff[i] != kOobOff)) ? qoff[i] + static_cast<unsigned>(ch) * (32u * HW) : kOobOff, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                const bool cin = cr.ch * 8 + qc[i] < g.C;
+                q[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (cin & (cr.qoff[i] != kOobOff)) ? cr.qoff[i] + static_cast<unsigned>(cr.ch) * (32u * HW) : kOobOff, 0, 0);
+            }
         }
+        advance(cr);
     };
     auto write_raw = [&](float* raw, const u32x4 (&q)[2]) {      // W: registers -> raw window
         if (ABL & 4) return;
@@ -364,11 +411,13 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         for (int i = 0; i < 2; ++i)
             if (qlds[i] >= 0) *reinterpret_cast<u32x4*>(raw + qlds[i]) = q[i];
     };
-    auto load_u = [&](int ch, u32x4 (&u)[4], int s) {            // U rows 2s, 2s + 1
-        if (ABL & 2) return;
+    auto load_u = [&](u32x4 (&u)[4], int s) {        // U rows 2s, 2s + 1 of the cursor's chunk; the cursor moves on after s = 1
+        if (!(ABL & 2)) {
 #pragma unroll
-        for (int i = 2 * s; i < 2 * s + 2; ++i)
-            u[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, u_base + static_cast<unsigned>(ch) * (kWinoChunk * 4u) + i * 8192u, 0, 0);
+            for (int i = 2 * s; i < 2 * s + 2; ++i)
+                u[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, cu.u_base != kOobOff ? cu.u_base + static_cast<unsigned>(cu.ch) * (kWinoChunk * 4u) + i * 8192u : kOobOff, 0, 0);
+        }
+        if (s == 1) advance(cu);
     };
     auto read_patch = [&](const float* raw) {        // 3 reads per row: columns 2tx - 1 | 2tx, 2tx + 1 | 2tx + 2
 #pragma unroll
@@ -406,10 +455,9 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    float* const raw1 = raw0 + kWinoRawFloats;
-    // step of chunk ch (parity P): MFMAs on buffers P; T(ch + 1), U(ch + 1) into buffers 1 - P; W(ch + 2) into raw[P];
-    // loads of U(ch + 3) and raw chunk ch + 4 into the register sets just emptied
-    auto step = [&](auto parity, int ch) {
+    // step of chunk n (parity P): MFMAs on buffers P; T(n + 1), U(n + 1) into buffers 1 - P; W(n + 2) into raw[P];
+    // loads of U(n + 3) and raw chunk n + 4 into the register sets just emptied
+    auto step = [&](auto parity) {
         constexpr int P = decltype(parity)::value, Q = 1 - P;
         f32x4* const Ub = smem + P * 4096;
         f32x4* const Vb = Ub + 2048;
@@ -433,30 +481,86 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
             }
             if (grp == 0) { if (!(ABL & 4)) read_patch(Q ? raw1 : raw0); commit_slice(Un, Vn, uw[Q], 0); }
             else if (grp == 1) commit_slice(Un, Vn, uw[Q], 1);
-            else if (grp == 2) { write_raw(P ? raw1 : raw0, rq[P]); load_u(ch + 3, uw[Q], 0); }
-            else { load_u(ch + 3, uw[Q], 1); load_raw(ch + 4, rq[P]); }
+            else if (grp == 2) { write_raw(P ? raw1 : raw0, rq[P]); load_u(uw[Q], 0); }
+            else { load_u(uw[Q], 1); load_raw(rq[P]); }
+            #pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // up to 4 VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // up to 2 LDS writes
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one VMEM read
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     };
 
-    // prologue: chunk 0 staged and transformed, chunk 1 in raw[1], U(1), U(2) and raw chunks 2, 3 in flight
-    load_raw(0, rq[0]); load_u(0, uw[0], 0); load_u(0, uw[0], 1);
-    load_raw(1, rq[1]); load_u(1, uw[1], 0); load_u(1, uw[1], 1);
+    // prologue of the stream: chunk 0 staged and transformed, chunk 1 in raw[1], U(1), U(2) and raw chunks 2, 3 in flight
+    load_raw(rq[0]); load_u(uw[0], 0); load_u(uw[0], 1);
+    load_raw(rq[1]); load_u(uw[1], 0); load_u(uw[1], 1);
     write_raw(raw0, rq[0]);
     __syncthreads();
     read_patch(raw0);
     commit_slice(smem, smem + 2048, uw[0], 0); commit_slice(smem, smem + 2048, uw[0], 1);
     write_raw(raw1, rq[1]);
-    load_raw(2, rq[0]); load_raw(3, rq[1]);
-    load_u(2, uw[0], 0); load_u(2, uw[0], 1);
+    load_raw(rq[0]); load_raw(rq[1]);
+    load_u(uw[0], 0); load_u(uw[0], 1);
     __syncthreads();
-    // pairs of chunks; an odd count ends with one step over a chunk of zeros (every channel past C reads 0)
-    for (int ch = 0; ch < g.CH; ch += 2) {
-        step(std::integral_constant<int, 0>(), ch);
-        step(std::integral_constant<int, 1>(), ch + 1);
+
+    // C/D layout: col = lane & 31 (tile), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (k).  A wave holds rows i = 2 ph, 2 ph + 1
+    // of the 4 x 4 products m; y = At m A: the ph = 1 waves park their share in the parity-1 operand buffers (consumed by the
+    // step that just ended, next written by the commits of the step after next... of the NEXT step: hence the second barrier)
+    float* const xch = reinterpret_cast<float*>(smem + 4096) + (wave & 3) * 4096 + lane;
+    for (int pair = pair_begin; pair < pair_end; ++pair) {
+        for (int ch = 0; ch < CHp; ch += 2) {
+            step(std::integral_constant<int, 0>());
+            step(std::integral_constant<int, 1>());
+        }
+        const int tt = pair / g.KT, kt = pair - tt * g.KT;
+        if (ph == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 2
+                const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 3
+                xch[(r * 4 + 0) * 64] = za0;             // y0 += z2, y1 += -z2 - z3
+                xch[(r * 4 + 1) * 64] = za1;
+                xch[(r * 4 + 2) * 64] = -za0 - zb0;
+                xch[(r * 4 + 3) * 64] = -za1 - zb1;
+            }
+        }
+        __syncthreads();
+        const int tg = tt * kWinoTiles + wn * 32 + l31;
+        if (ph == 0 && kt * 64 + wm * 32 < g.K && tg < g.T) {
+            const int b = tg / (g.TH * g.TW);
+            const int rem = tg - b * (g.TH * g.TW);
+            const int ty = rem / g.TW, txo = rem - ty * g.TW;
+            float* ob = out + (static_cast<size_t>(b) * g.Kout) * HW + static_cast<size_t>(2 * ty) * g.W + 2 * txo;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k >= g.K) continue;
+                const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 0
+                const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 1
+                const float bv = bias ? bias[k] : 0.f;
+                float y[4] = {za0 + zb0, za1 + zb1, zb0, zb1};   // y0 = z0 + z1 (+ z2), y1 = z1 (- z2 - z3)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float t = y[v] + xch[(r * 4 + v) * 64] + bv;
+                    if (g.act == 1) t = t > 0.f ? t : t * g.slope;
+                    y[v] = t;
+                }
+                float* o = ob + static_cast<size_t>(k) * HW;         // W and H are even here: whole 2 x 2 tiles, 8-byte aligned pairs
+                *reinterpret_cast<float2*>(o) = make_float2(y[0], y[1]);
+                *reinterpret_cast<float2*>(o + g.W) = make_float2(y[2], y[3]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+        __syncthreads();                 // the exchange is read before the next step's commits overwrite it
     }
-    winograd_epilogue(acc, smem, bias, out, g, tt, kt);
 }
 
 // ---------------------------------------------------------------------------------------------------- thin tail
@@ -633,7 +737,13 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
                 default: break;
             }
             allow_large_lds(reinterpret_cast<const void*>(kern));
-            hipLaunchKernelGGL(kern, dim3(nblk), dim3(kWinoThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st, static_cast<const float*>(input), U,
+            static const int cus = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                return n;
+            }();
+            const unsigned pgrid = nblk < static_cast<unsigned>(cus) ? nblk : static_cast<unsigned>(cus);     // persistent: one workgroup per CU
+            hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kWinoThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st, static_cast<const float*>(input), U,
                                static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
             const int rc = check_launch(fn);
             if (rc || !thin) return rc;
