@@ -111,7 +111,7 @@ class _WinogradConv3x3(Function):
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return ops.conv3x3_winograd(x, weight, bias)
+        return ops.conv3x3_winograd(x, weight, bias, frozen=not weight.requires_grad)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -120,7 +120,7 @@ class _WinogradConv3x3(Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         gx = gw = gb = None
         if need_x:
-            gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True)
+            gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True, frozen=not weight.requires_grad)
         if need_w:
             if wgrad_route_ok(x, weight):
                 if need_b:       # the bias gradient is a row sum of the operand the MFMA kernel streams anyway
@@ -134,6 +134,31 @@ class _WinogradConv3x3(Function):
         return gx, gw, gb
 
 
+class _WinogradConvBiasReLU(Function):
+    """relu(Conv2d(C, K, 3, 1, 1)(x) + bias) of a FROZEN layer (VGG19: models/losses.py:398-519) as one launch: the bias and the
+    activation are the Winograd kernel's epilogue, the transformed weights are kept between calls; backward = the mask from
+    the saved output, then the data gradient on the same kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = ops.conv3x3_winograd(x.contiguous(), weight, bias, act=1, slope=0.0, frozen=True)
+        ctx.save_for_backward(weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        weight, y = ctx.saved_tensors
+        gh = torch.ops.aten.threshold_backward(grad_y.contiguous(), y, 0)
+        return ops.conv3x3_winograd(gh, weight, None, data_gradient=True, frozen=True), None, None
+
+
+def winograd_bias_relu(x, weight, bias):
+    """relu(conv3x3(x, weight) + bias) for a frozen layer; the caller has checked winograd_ok(x, weight)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _WinogradConvBiasReLU.apply(x, weight, bias)
+    return ops.conv3x3_winograd(x.contiguous(), weight, bias, act=1, slope=0.0, frozen=True)
+
+
 class WinogradConv2d(MfmaWgradConv2d):
     """nn.Conv2d (3x3, stride 1, padding 1) on the Winograd MFMA kernel when the plane is large enough (winograd_ok), else
     whatever MfmaWgradConv2d does with it."""
@@ -142,7 +167,7 @@ class WinogradConv2d(MfmaWgradConv2d):
         if winograd_ok(input, weight):
             if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad):
                 return _WinogradConv3x3.apply(input, weight, bias)
-            return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias)
+            return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=not weight.requires_grad)
         if self.__dict__.get("_mfma_fwd_small") and fwd_route_ok(input, weight) and input.size(2) <= 32:
             ext = _ext.get()          # small planes: the direct MFMA kernel (route_conv_fwd)
             if ext is not None:

@@ -685,7 +685,9 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
     FFWM_REQUIRE(input && weight && output && workspace, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
     FFWM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && K > 0, FFWM_ERR_ARG, "%s: sizes must be positive", fn);
     FFWM_REQUIRE(act == 0 || act == 1, FFWM_ERR_ARG, "%s: act must be 0 (none) or 1 (leaky relu)", fn);
-    FFWM_REQUIRE(data_gradient == 0 || data_gradient == 1, FFWM_ERR_ARG, "%s: data_gradient must be 0 or 1", fn);
+    FFWM_REQUIRE(data_gradient >= 0 && data_gradient <= 3, FFWM_ERR_ARG, "%s: data_gradient must be 0 or 1, + 2 to reuse the workspace", fn);
+    const bool reuse = (data_gradient & 2) != 0;         // the workspace holds the transformed weights of an earlier, identical call
+    data_gradient &= 1;
     FFWM_REQUIRE(B * C * H * W < (1LL << 29) && B * K * H * W < (1LL << 40), FFWM_ERR_SIZE, "%s: the input must stay below 2 GiB", fn);
     // a tail of 1-4 channels past a multiple of 64 goes to the thin kernel instead of costing a 64-channel tile
     const int tail = static_cast<int>(K % 64);
@@ -708,7 +710,7 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
     g.u_bytes = static_cast<unsigned>(ub);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* U = static_cast<float*>(workspace);
-    {
+    if (!reuse) {
         const int64_t n = static_cast<int64_t>(g.KT) * 64 * g.CH * 8 + (thin ? C * kThinStride : 0);
         LaunchScope ls("conv_winograd_weights", st, 4.0 * (9.0 * K * C + 16.0 * n));
         hipLaunchKernelGGL(winograd_weights_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
 from . import _ext
+from . import conv as _conv
 from .external_function import WarpFlipCat, WarpNet, warp_many
 
 LRELU = 0.2
@@ -406,6 +407,11 @@ class VGG19(nn.Module):
                 while i < len(mods):
                     m = mods[i]
                     if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and m.bias is not None:
+                        if not m.weight.requires_grad and _conv.winograd_ok(x, m.weight):
+                            # large planes: conv + bias + ReLU as ONE launch of the Winograd MFMA kernel (csrc/conv_winograd.hip)
+                            x = _conv.winograd_bias_relu(x, m.weight, m.bias)
+                            i += 2
+                            continue
                         h = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
                         ext = _ext.get()
                         x = ext.bias_relu(h, m.bias) if ext is not None else BiasReLUFunction.apply(h, m.bias)

@@ -330,8 +330,10 @@ int ffwm_conv2d_wgrad(const void* rows, const void* gathered, void* grad_weight,
  * forward (data_gradient = 0: weight [K, C, 3, 3]) or the data gradient (data_gradient = 1: input = grad_output with C =
  * the layer's OUTPUT channels, K = its input channels, weight = the layer's own [C, K, 3, 3]) of Conv2d(.., 3, 1, 1)
  * (models/base_networks.py:207-233: the residual blocks of netG; :59-112 FlowNet's conv*_1 / inter_conv*).
- * output [B, K, H, W] = conv + bias (NULL: none), then LeakyReLU(slope) when act = 1.  workspace: device memory of
- * ffwm_conv3x3_winograd_workspace_bytes(K, C) bytes (the transformed weights; rewritten by every call). */
+ * output [B, K, H, W] = conv + bias (NULL: none), then LeakyReLU(slope) when act = 1 (slope 0: ReLU).  workspace: device
+ * memory of ffwm_conv3x3_winograd_workspace_bytes(K, C) bytes (the transformed weights; rewritten by every call).
+ * data_gradient + 2: the workspace still holds the transformed weights of an earlier call with the same weight values,
+ * direction, K, C and (W % 4 == 0) -- frozen networks (VGG19, LightCNN: models/losses.py:398-519) skip the transform. */
 int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C);
 int ffwm_conv3x3_winograd_forward(const void* input, const void* weight, const void* bias, void* output, void* workspace,
                                   int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int data_gradient, int act,

@@ -1495,3 +1495,26 @@ def test_winograd_routing_matches_aten_autograd():
     with torch.no_grad():
         x = torch.randn(2, 40, 64, 64, generator=_gen(3)).to(DEV)
         assert (ref(x) - fast(x)).abs().max().item() <= 2e-5 * (1 + ref(x).abs().max().item())
+
+
+def test_vgg_winograd_bias_relu_matches_the_module_path():
+    """nets.VGG19 on the GPU: the large-plane layers run conv + bias + ReLU as one Winograd launch with the transformed weights
+    of the frozen layers kept between calls (conv.winograd_bias_relu); features and the gradient with respect to the image
+    against the same network evaluated layer by layer in float64."""
+    from ffwm_amd import nets, ops
+    torch.manual_seed(3)
+    vgg = nets.VGG19("relu3_1").to(DEV).eval()
+    ref = nets.VGG19("relu3_1").double().eval()
+    ref.load_state_dict({k: v.double().cpu() for k, v in vgg.state_dict().items()})
+    x = torch.rand(8, 3, 64, 64, generator=_gen(5))
+    xa = x.to(DEV).requires_grad_(True)
+    xb = x.double().requires_grad_(True)
+    for _ in range(2):                    # the second pass runs on the kept transforms
+        fa, fb = vgg(xa), ref(xb)
+        for name in fb:
+            assert (fa[name].cpu().double() - fb[name]).abs().max().item() <= 5e-5 * (1 + fb[name].abs().max().item()), name
+    assert any(k[2] == 0 for k in ops._WINOGRAD_FROZEN) and any(k[2] == 1 for k in ops._WINOGRAD_FROZEN) is False
+    sum(f.square().mean() for f in fa.values()).backward()
+    sum(f.square().mean() for f in fb.values()).backward()
+    assert (xa.grad.cpu().double() - xb.grad).abs().max().item() <= 1e-4 * (1 + xb.grad.abs().max().item())
+    assert any(k[2] == 1 for k in ops._WINOGRAD_FROZEN)
