@@ -14,6 +14,10 @@ from torch.autograd import Function
 from . import _ext, ops
 
 
+import os as _os0
+_WGRAD_W64 = _os0.environ.get("FFWM_WGRAD_W64", "0") == "1"
+
+
 class _Conv3x3MfmaWgrad(Function):
     """F.conv2d(x, w, b, stride 1, padding 1) whose backward takes grad_weight from the MFMA kernel."""
 
@@ -50,7 +54,7 @@ def wgrad_route_ok(x, weight):
     layers between an RGB image and >= 64 feature channels at 128 x 128 (3 channels x 9 taps fit one MFMA tile)."""
     K, C = weight.shape[0], weight.shape[1]
     W = x.shape[3]
-    wide = min(C, K) >= 64 and (W >= 128 or C % 64 != 0 or K % 64 != 0)
+    wide = min(C, K) >= 64 and (W >= 128 or C % 64 != 0 or K % 64 != 0 or _WGRAD_W64)
     rgb = min(C, K) <= 3 and max(C, K) >= 64 and W >= 128          # image <-> features: the packed-tap variant alone
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and W % 64 == 0 and (wide or rgb) and ops.conv3x3_wgrad_supported(x, x))
