@@ -111,11 +111,12 @@ class _WinogradConv3x3(Function):
     kernel serves the shape (wgrad_route_ok), else the vendor's."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, frozen=None):
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return ops.conv3x3_winograd(x, weight, bias, frozen=not weight.requires_grad)
+        ctx.frozen = frozen
+        return ops.conv3x3_winograd(x, weight, bias, frozen=frozen)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -124,7 +125,7 @@ class _WinogradConv3x3(Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         gx = gw = gb = None
         if need_x:
-            gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True, frozen=not weight.requires_grad)
+            gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True, frozen=ctx.frozen)
         if need_w:
             if wgrad_route_ok(x, weight):
                 if need_b:       # the bias gradient is a row sum of the operand the MFMA kernel streams anyway
@@ -135,7 +136,15 @@ class _WinogradConv3x3(Function):
                                                                 [1, 1], False, [0, 0], 1, [False, True, bool(need_b)])
         if need_b and gb is None:
             gb = _bias_grad(go)
-        return gx, gw, gb
+        return gx, gw, gb, None
+
+
+def frozen_cache(owner, weight):
+    """The dict in which a layer with frozen weights keeps its transformed weights (None for a trainable layer): it lives on
+    the module, so it dies with it -- a cache keyed by the storage address alone would outlive the tensor."""
+    if weight.requires_grad:
+        return None
+    return owner.__dict__.setdefault("_winograd_frozen", {})
 
 
 class _WinogradConvBiasReLU(Function):
@@ -144,23 +153,34 @@ class _WinogradConvBiasReLU(Function):
     the saved output, then the data gradient on the same kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        y = ops.conv3x3_winograd(x.contiguous(), weight, bias, act=1, slope=0.0, frozen=True)
+    def forward(ctx, x, weight, bias, frozen):
+        y = ops.conv3x3_winograd(x.contiguous(), weight, bias, act=1, slope=0.0, frozen=frozen)
         ctx.save_for_backward(weight, y)
+        ctx.frozen = frozen
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
         weight, y = ctx.saved_tensors
         gh = torch.ops.aten.threshold_backward(grad_y.contiguous(), y, 0)
-        return ops.conv3x3_winograd(gh, weight, None, data_gradient=True, frozen=True), None, None
+        return ops.conv3x3_winograd(gh, weight, None, data_gradient=True, frozen=ctx.frozen), None, None, None
 
 
-def winograd_bias_relu(x, weight, bias):
-    """relu(conv3x3(x, weight) + bias) for a frozen layer; the caller has checked winograd_ok(x, weight)."""
+def winograd_bias_relu(x, layer):
+    """relu(layer(x)) for a FROZEN nn.Conv2d(C, K, 3, 1, 1) with a bias; the caller has checked winograd_ok(x, layer.weight)."""
+    cache = frozen_cache(layer, layer.weight)
     if torch.is_grad_enabled() and x.requires_grad:
-        return _WinogradConvBiasReLU.apply(x, weight, bias)
-    return ops.conv3x3_winograd(x.contiguous(), weight, bias, act=1, slope=0.0, frozen=True)
+        return _WinogradConvBiasReLU.apply(x, layer.weight, layer.bias, cache)
+    return ops.conv3x3_winograd(x.contiguous(), layer.weight, layer.bias, act=1, slope=0.0, frozen=cache)
+
+
+def winograd_conv(x, layer, bias=None):
+    """conv3x3(x, layer.weight) + bias on the Winograd kernel with autograd; the caller has checked winograd_ok(x, layer.weight)."""
+    weight = layer.weight
+    cache = frozen_cache(layer, weight)
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return _WinogradConv3x3.apply(x, weight, bias, cache)
+    return ops.conv3x3_winograd(x.contiguous(), weight.contiguous(), bias, frozen=cache)
 
 
 class WinogradConv2d(MfmaWgradConv2d):
@@ -169,9 +189,11 @@ class WinogradConv2d(MfmaWgradConv2d):
 
     def _conv_forward(self, input, weight, bias):
         if winograd_ok(input, weight):
+            # (weight may be a spectral-norm product, not self.weight: only a frozen PARAMETER keeps its transform)
+            cache = frozen_cache(self, weight) if weight is self.weight else None
             if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad):
-                return _WinogradConv3x3.apply(input, weight, bias)
-            return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=not weight.requires_grad)
+                return _WinogradConv3x3.apply(input, weight, bias, cache)
+            return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=cache)
         if self.__dict__.get("_mfma_fwd_small") and fwd_route_ok(input, weight) and input.size(2) <= 32:
             ext = _ext.get()          # small planes: the direct MFMA kernel (route_conv_fwd)
             if ext is not None:

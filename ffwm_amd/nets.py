@@ -288,6 +288,9 @@ FUSED_ACTIVATIONS = os.environ.get("FFWM_FUSED_ACT", "1") != "0"
 
 
 # =============================================================================== LightCNN-29
+_WINOGRAD_MFM = os.environ.get("FFWM_WINOGRAD_MFM", "0") == "1"      # LightCNN's 48 / 96-channel layers: measured 0.4 ms per step slower than the vendor
+
+
 class mfm(nn.Module):
     """max-feature-map: conv/linear to 2*out channels, elementwise max of the halves."""
 
@@ -302,7 +305,11 @@ class mfm(nn.Module):
             # the layer without its bias, then bias + max-feature-map as one kernel per direction (csrc/mfm.hip)
             from .external_function import MaxFeatureMapFunction
             if isinstance(f, nn.Conv2d):
-                h = F.conv2d(x, f.weight, None, f.stride, f.padding, f.dilation, f.groups)
+                if (f.kernel_size == (3, 3) and f.stride == (1, 1) and f.padding == (1, 1) and f.dilation == (1, 1) and f.groups == 1
+                        and _WINOGRAD_MFM and _conv.winograd_ok(x, f.weight)):
+                    h = _conv.winograd_conv(x, f)          # large planes: csrc/conv_winograd.hip
+                else:
+                    h = F.conv2d(x, f.weight, None, f.stride, f.padding, f.dilation, f.groups)
             else:
                 h = F.linear(x, f.weight, None)
             ext = _ext.get()
@@ -409,7 +416,7 @@ class VGG19(nn.Module):
                     if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and m.bias is not None:
                         if not m.weight.requires_grad and _conv.winograd_ok(x, m.weight):
                             # large planes: conv + bias + ReLU as ONE launch of the Winograd MFMA kernel (csrc/conv_winograd.hip)
-                            x = _conv.winograd_bias_relu(x, m.weight, m.bias)
+                            x = _conv.winograd_bias_relu(x, m)
                             i += 2
                             continue
                         h = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)

@@ -443,14 +443,12 @@ def conv2d_wgrad(rows, gathered, kernel, stride, pad, grad_weight=None):
     return grad_weight
 
 
-_WINOGRAD_FROZEN = {}     # (weight ptr, version, direction, W % 4 == 0) -> transformed weights of a frozen layer
-
-
-def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0, out=None, frozen=False):
+def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0, out=None, frozen=None):
     """Conv2d(C, K, 3, 1, 1) forward (weight [K, C, 3, 3]) or its data gradient (x = grad_output [B, K_layer, H, W], weight =
     the layer's own [K_layer, C_layer, 3, 3]; returns [B, C_layer, H, W]) by fp32 Winograd F(2x2, 3x3) on the MFMA units
-    (csrc/conv_winograd.hip).  act = 1 applies LeakyReLU(slope) after the bias (slope 0 = ReLU).  frozen: the weight never
-    changes in place without a version bump (a frozen feature network): its transformed copy is kept between calls."""
+    (csrc/conv_winograd.hip).  act = 1 applies LeakyReLU(slope) after the bias (slope 0 = ReLU).  frozen: a dict OWNED BY THE
+    LAYER (it must die with the weight tensor) in which the transformed weights of a frozen layer are kept between calls,
+    keyed by direction, layout and the weight's version counter."""
     _check("conv3x3_winograd", x, weight, out)
     if bias is not None and (not bias.is_cuda or bias.dtype != x.dtype or not bias.is_contiguous()):
         raise ValueError("conv3x3_winograd: bias must be a contiguous tensor of the input's device and dtype")
@@ -472,17 +470,18 @@ def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0
     lib = _lib.load()
     mode = int(bool(data_gradient))
     ws = None
-    if frozen:
-        key = (weight.data_ptr(), weight._version, mode, W % 4 == 0, x.device.index)
-        ws = _WINOGRAD_FROZEN.get(key)
+    if frozen is not None and frozen is not False:
+        key = (mode, W % 4 == 0, weight._version, weight.data_ptr())
+        ws = frozen.get(key)
         if ws is not None:
             mode |= 2
-        elif len(_WINOGRAD_FROZEN) > 512:
-            _WINOGRAD_FROZEN.clear()
+        else:
+            for k in [k for k in frozen if k[2:] != key[2:]]:
+                del frozen[k]         # transforms of an older version of the weights
     if ws is None:
         ws = x.new_empty((lib.ffwm_conv3x3_winograd_workspace_bytes(K, C) // 4,))
-        if frozen:
-            _WINOGRAD_FROZEN[key] = ws
+        if frozen is not None and frozen is not False:
+            frozen[key] = ws
     with _on_device(x) as stream:
         _lib.check(lib.ffwm_conv3x3_winograd_forward(_ptr(x), _ptr(weight), _ptr(bias) if bias is not None else None, _ptr(out), _ptr(ws),
                                                      B, C, H, W, K, mode, int(act), float(slope), _dtype_code(x),

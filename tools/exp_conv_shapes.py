@@ -37,7 +37,7 @@ def main():
             dt = e.cuda_time_total
         rows.append((dt, e.key, e.count, str(e.input_shapes)))
     rows.sort(reverse=True)
-    for dt, key, n, shapes in rows[:40]:
+    for dt, key, n, shapes in rows[:90]:
         print("%10.1f us  x%-3d %-40s %s" % (dt, n, key, shapes))
     # kernel-level attribution: which kernels serve which conv op
     agg = {}
