@@ -97,13 +97,27 @@ def route_conv_wgrad(net):
 import os as _os
 _WINOGRAD = _os.environ.get("FFWM_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_TILES = int(_os.environ.get("FFWM_WINOGRAD_MIN_TILES", 2048))
+# (strips of 64 tiles) x (tiles of 64 output channels) a call must offer the 256 persistent workgroups: measured per shape of
+# the train step (tools/wino_layers.py), below ~160 pairs the vendor's kernel is as fast or faster (128 -> 128 @32²: 52 vs 30 us)
+WINOGRAD_MIN_PAIRS = int(_os.environ.get("FFWM_WINOGRAD_MIN_PAIRS", 160))
+
+
+def _winograd_dir_ok(x, c_red, k_out):
+    tiles = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)
+    return (min(c_red, k_out) >= 32 and tiles >= WINOGRAD_MIN_TILES and ((tiles + 63) // 64) * ((k_out + 63) // 64) >= WINOGRAD_MIN_PAIRS
+            and x.shape[0] * max(c_red, k_out) * x.shape[2] * x.shape[3] < (1 << 29))
+
+
+def winograd_dirs(x, weight):
+    """(forward, data gradient): which directions of Conv2d(C, K, 3, 1, 1) on this input run on the Winograd kernel."""
+    if not (_WINOGRAD and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4):
+        return False, False
+    K, C = weight.shape[0], weight.shape[1]
+    return _winograd_dir_ok(x, C, K), _winograd_dir_ok(x, K, C)
 
 
 def winograd_ok(x, weight):
-    K, C = weight.shape[0], weight.shape[1]
-    tiles = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)
-    return (_WINOGRAD and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
-            and min(C, K) >= 32 and tiles >= WINOGRAD_MIN_TILES and x.numel() < (1 << 29) and x.shape[0] * K * x.shape[2] * x.shape[3] < (1 << 29))
+    return winograd_dirs(x, weight)[0]
 
 
 class _WinogradConv3x3(Function):
@@ -111,12 +125,15 @@ class _WinogradConv3x3(Function):
     kernel serves the shape (wgrad_route_ok), else the vendor's."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, frozen=None):
+    def forward(ctx, x, weight, bias, frozen=None, dirs=(True, True)):
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.frozen = frozen
-        return ops.conv3x3_winograd(x, weight, bias, frozen=frozen)
+        ctx.own_dgrad = dirs[1]
+        if dirs[0]:
+            return ops.conv3x3_winograd(x, weight, bias, frozen=frozen)
+        return torch.ops.aten.convolution(x, weight, bias, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -124,8 +141,10 @@ class _WinogradConv3x3(Function):
         go = grad_output.contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         gx = gw = gb = None
-        if need_x:
+        if need_x and ctx.own_dgrad:
             gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True, frozen=ctx.frozen)
+        elif need_x:
+            gx = torch.ops.aten.convolution_backward(go, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if need_w:
             if wgrad_route_ok(x, weight):
                 if need_b:       # the bias gradient is a row sum of the operand the MFMA kernel streams anyway
@@ -136,7 +155,7 @@ class _WinogradConv3x3(Function):
                                                                 [1, 1], False, [0, 0], 1, [False, True, bool(need_b)])
         if need_b and gb is None:
             gb = _bias_grad(go)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def frozen_cache(owner, weight):
@@ -153,24 +172,29 @@ class _WinogradConvBiasReLU(Function):
     the saved output, then the data gradient on the same kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, frozen):
-        y = ops.conv3x3_winograd(x.contiguous(), weight, bias, act=1, slope=0.0, frozen=frozen)
-        ctx.save_for_backward(weight, y)
+    def forward(ctx, x, weight, bias, frozen, own_dgrad):
+        x = x.contiguous()
+        y = ops.conv3x3_winograd(x, weight, bias, act=1, slope=0.0, frozen=frozen)
+        ctx.save_for_backward(weight, y, x if not own_dgrad else None)
         ctx.frozen = frozen
+        ctx.own_dgrad = own_dgrad
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        weight, y = ctx.saved_tensors
+        weight, y, x = ctx.saved_tensors
         gh = torch.ops.aten.threshold_backward(grad_y.contiguous(), y, 0)
-        return ops.conv3x3_winograd(gh, weight, None, data_gradient=True, frozen=ctx.frozen), None, None, None
+        if ctx.own_dgrad:
+            return ops.conv3x3_winograd(gh, weight, None, data_gradient=True, frozen=ctx.frozen), None, None, None, None
+        gx = torch.ops.aten.convolution_backward(gh, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        return gx, None, None, None, None
 
 
 def winograd_bias_relu(x, layer):
     """relu(layer(x)) for a FROZEN nn.Conv2d(C, K, 3, 1, 1) with a bias; the caller has checked winograd_ok(x, layer.weight)."""
     cache = frozen_cache(layer, layer.weight)
     if torch.is_grad_enabled() and x.requires_grad:
-        return _WinogradConvBiasReLU.apply(x, layer.weight, layer.bias, cache)
+        return _WinogradConvBiasReLU.apply(x, layer.weight, layer.bias, cache, winograd_dirs(x, layer.weight)[1])
     return ops.conv3x3_winograd(x.contiguous(), layer.weight, layer.bias, act=1, slope=0.0, frozen=cache)
 
 
@@ -179,7 +203,7 @@ def winograd_conv(x, layer, bias=None):
     weight = layer.weight
     cache = frozen_cache(layer, weight)
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-        return _WinogradConv3x3.apply(x, weight, bias, cache)
+        return _WinogradConv3x3.apply(x, weight, bias, cache, winograd_dirs(x, weight))
     return ops.conv3x3_winograd(x.contiguous(), weight.contiguous(), bias, frozen=cache)
 
 
@@ -188,11 +212,13 @@ class WinogradConv2d(MfmaWgradConv2d):
     whatever MfmaWgradConv2d does with it."""
 
     def _conv_forward(self, input, weight, bias):
-        if winograd_ok(input, weight):
+        dirs = winograd_dirs(input, weight)
+        grad = torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad)
+        if dirs[0] or (grad and dirs[1] and input.requires_grad):
             # (weight may be a spectral-norm product, not self.weight: only a frozen PARAMETER keeps its transform)
             cache = frozen_cache(self, weight) if weight is self.weight else None
-            if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad):
-                return _WinogradConv3x3.apply(input, weight, bias, cache)
+            if grad:
+                return _WinogradConv3x3.apply(input, weight, bias, cache, dirs)
             return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=cache)
         if self.__dict__.get("_mfma_fwd_small") and fwd_route_ok(input, weight) and input.size(2) <= 32:
             ext = _ext.get()          # small planes: the direct MFMA kernel (route_conv_fwd)

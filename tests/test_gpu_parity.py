@@ -1466,7 +1466,8 @@ def test_conv3x3_winograd_matches_aten(case, raw_staging):
     _lib.set_option("conv_wino_raw", 1)
 
 
-def test_winograd_routing_matches_aten_autograd():
+@pytest.mark.parametrize("min_pairs", [1, 64])
+def test_winograd_routing_matches_aten_autograd(min_pairs, monkeypatch):
     """conv.route_conv_winograd: re-classed 3x3 / stride-1 Conv2d layers (forward + data gradient on csrc/conv_winograd.hip,
     weight gradient on conv_wgrad.hip or the vendor's) against the untouched modules; a plane below the tile threshold takes
     the fallback path."""
@@ -1478,8 +1479,10 @@ def test_winograd_routing_matches_aten_autograd():
                         nn.Conv2d(70, 64, 3, 1, 1), nn.Conv2d(64, 3, 3, 1, 1)).to(DEV)
     fast = copy.deepcopy(ref)
     assert conv.route_conv_winograd(fast) == 3             # the 64 -> 3 layer stays
+    monkeypatch.setattr(conv, "WINOGRAD_MIN_PAIRS", min_pairs)         # 64 here: 70 -> 64 forward and 64 -> 70 data gradient stay with ATen
     for shape in ((2, 40, 64, 64), (1, 40, 16, 16)):
-        assert conv.winograd_ok(torch.empty(shape, device=DEV), fast[0].weight) == (shape[2] == 64)
+        assert conv.winograd_ok(torch.empty(shape, device=DEV), fast[0].weight) == (shape[2] == 64 and min_pairs == 1)
+        assert conv.winograd_dirs(torch.empty((shape[0], 64) + shape[2:], device=DEV), fast[2].weight) == ((shape[2] == 64, shape[2] == 64 and min_pairs == 1))
         x = torch.randn(*shape, generator=_gen(shape[2])).to(DEV)
         xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
         ya, yb = ref(xa), fast(xb)
@@ -1497,11 +1500,12 @@ def test_winograd_routing_matches_aten_autograd():
         assert (ref(x) - fast(x)).abs().max().item() <= 2e-5 * (1 + ref(x).abs().max().item())
 
 
-def test_vgg_winograd_bias_relu_matches_the_module_path():
+def test_vgg_winograd_bias_relu_matches_the_module_path(monkeypatch):
     """nets.VGG19 on the GPU: the large-plane layers run conv + bias + ReLU as one Winograd launch with the transformed weights
     of the frozen layers kept between calls (conv.winograd_bias_relu); features and the gradient with respect to the image
     against the same network evaluated layer by layer in float64."""
-    from ffwm_amd import nets, ops
+    from ffwm_amd import conv, nets
+    monkeypatch.setattr(conv, "WINOGRAD_MIN_PAIRS", 1)          # route every >= 2048-tile layer of this small input
     torch.manual_seed(3)
     vgg = nets.VGG19("relu3_1").to(DEV).eval()
     ref = nets.VGG19("relu3_1").double().eval()
