@@ -348,7 +348,9 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         qc[i] = q < nquads ? c : 8;
         qrow[i] = rr;
         qcol[i] = 4 * (rem - rr * W4);
-        qlds[i] = q < nquads ? q * 4 : -1;
+        // the rows of channel c are stored rotated by 16 c pixels: the 4 channels a wave reads patches from sit 0 (mod 64) dwords
+        // apart, unrotated they would share their banks (35 % of the LDS cycles were conflicts)
+        qlds[i] = q < nquads ? (c * g.ROWS + rr) * g.W + ((qcol[i] + 16 * c) & (g.W - 1)) : -1;
     }
     // a load cursor: the (pair, chunk) a stream of loads has reached, and what depends on the pair
     struct Cursor {
@@ -388,7 +390,9 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     // ---- T stage role: lane = (c_lo, t_lo), wave = (channel half, t_hi): the patch of tile ts for channel 4 sh + c_lo of the chunk
     const int c_lo = lane & 3, ts = (wave & 3) * 16 + (lane >> 2), sh = wave >> 2;
     const int tr = ts / g.TW, tx = ts - tr * g.TW;
-    const int pbase = ((4 * sh + c_lo) * g.ROWS + 2 * tr) * g.W + 2 * tx;         // float index of patch element (0, 1)
+    const int prow = ((4 * sh + c_lo) * g.ROWS + 2 * tr) * g.W;                   // float index of the patch's first row
+    const int prot = 16 * (4 * sh + c_lo);                                        // that channel's rotation
+    const int pcm = (2 * tx - 1 + prot) & (g.W - 1), pc0 = (2 * tx + prot) & (g.W - 1), pcp = (2 * tx + 2 + prot) & (g.W - 1);
     const bool lcol = tx > 0, rcol = tx < g.TW - 1;
 
     // two register sets each, alternating with the chunk's parity: a load has ~1.5 steps (6000+ cycles) to land
@@ -422,9 +426,9 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     auto read_patch = [&](const float* raw) {        // 3 reads per row: columns 2tx - 1 | 2tx, 2tx + 1 | 2tx + 2
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float* rp = raw + pbase + i * g.W;
-            const float a = rp[-1], e = rp[2];
-            const float2 m = *reinterpret_cast<const float2*>(rp);
+            const float* rp = raw + prow + i * g.W;
+            const float a = rp[pcm], e = rp[pcp];
+            const float2 m = *reinterpret_cast<const float2*>(rp + pc0);
             d[i * 4 + 0] = lcol ? a : 0.f;
             d[i * 4 + 1] = m.x;
             d[i * 4 + 2] = m.y;

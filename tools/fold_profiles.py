@@ -109,7 +109,10 @@ def main():
               ("flowtrain_kernel_stats.csv", "_flowtrain_kernel_stats.csv"), ("ops_kernel_stats.csv", "_ops_kernel_stats.csv"),
               ("ffwm_kernels_whole_run.csv", "_ffwm_kernels_rocprofv3.csv"), ("bench_default.json", "_bench_default.json"),
               ("warpatt_bench.json", "_bench_warpatt.json"), ("flownet_bench.json", "_bench_flownet.json"),
-              ("flowtrain_bench.json", "_bench_flowtrain.json"), ("ops_bench.json", "_bench_ops.json")]
+              ("flowtrain_bench.json", "_bench_flowtrain.json"), ("ops_bench.json", "_bench_ops.json"),
+              ("winograd_sq_192.txt", "_winograd_sq_counters_192.txt"), ("winograd_sq_256.txt", "_winograd_sq_counters_256.txt"),
+              ("winograd_mem_192.txt", "_winograd_mem_counters_192.txt"), ("winograd_mem_256.txt", "_winograd_mem_counters_256.txt"),
+              ("winograd_vs_vendor.txt", "_winograd_vs_vendor.txt"), ("winograd_layers_of_the_step.txt", "_winograd_layers_of_the_step.txt")]
     for a, b in copies:
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p) > 0:

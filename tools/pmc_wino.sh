@@ -6,4 +6,4 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/p_$i -- python $R/tools/wino_one.py > /tmp/p_$i.log 2>&1 || { echo "pass $i failed"; tail -3 /tmp/p_$i.log; }
   i=$((i+1))
 done
-python $R/tools/pmc_fold.py /tmp/conv1.json /tmp/p_0 /tmp/p_1 /tmp/p_2 /tmp/p_3 | grep -A1 winograd_conv
+python $R/tools/pmc_fold.py /tmp/conv1.json /tmp/p_0 /tmp/p_1 /tmp/p_2 /tmp/p_3 | grep -A1 winograd_conv_raw

@@ -57,3 +57,10 @@ done
 python $R/tools/pmc_fold.py $OUT/bench_pmc_raw.json /tmp/pmc_0 /tmp/pmc_1 /tmp/pmc_2 /tmp/pmc_3 > $OUT/pmc_fold.txt 2>&1
 timeout 1200 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 400 $OUT/bench_default.json
+# SQ / memory counters of the Winograd convolution kernel alone (netG's 192 -> 192 and 256 -> 256 layers at 128 x 128, batch 8)
+for CK in 192 256; do
+  CV_C=$CK CV_K=$CK bash $R/tools/pmc_wino.sh > $OUT/winograd_sq_$CK.txt 2>&1
+  CV_C=$CK CV_K=$CK bash $R/tools/pmc_wino2.sh > $OUT/winograd_mem_$CK.txt 2>&1
+done
+python $R/tools/wino_check.py > $OUT/winograd_vs_vendor.txt 2>&1
+python $R/tools/wino_layers.py > $OUT/winograd_layers_of_the_step.txt 2>/dev/null
