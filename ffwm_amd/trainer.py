@@ -411,6 +411,11 @@ class FFWMTrainer(object):
                 self._seg_stepG()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        # the fused BatchNorm + LeakyReLU modules count their batches on the host (norm.py): a replay runs no Python, so the
+        # calls of ONE captured step are recorded here and added per replay (num_batches_tracked stays what nn.BatchNorm2d's is)
+        from .norm import BatchNormLeakyReLU2d
+        fused = [m for net in (self.flowNetF, self.flowNetB, self.netG, self.netD) for m in net.modules() if isinstance(m, BatchNormLeakyReLU2d)]
+        before = [m._pending_batches for m in fused]
         graphs = []
         if self.world_size == 1:
             g = torch.cuda.CUDAGraph()
@@ -431,6 +436,9 @@ class FFWMTrainer(object):
                 self._seg_stepG()
             graphs = [g1, g2, g3]
         self.losses["D"] = self.loss_D
+        self._bn_calls_per_replay = [(m, m._pending_batches - n0) for m, n0 in zip(fused, before) if m._pending_batches != n0]
+        for m, n in self._bn_calls_per_replay:
+            m._pending_batches -= n          # the capture pass itself executed nothing
         self._graphs = graphs
         self._frozen_branch = self.titers < 20000
         return self
@@ -449,6 +457,8 @@ class FFWMTrainer(object):
             self._graphs[1].replay()
             self.red_G.finish()
             self._graphs[2].replay()
+        for m, n in self._bn_calls_per_replay:
+            m._pending_batches += n
         self.titers += batch_increment if batch_increment is not None else b["img_S"].size(0)
         return self.losses
 

@@ -758,10 +758,13 @@ def test_launches_follow_the_current_stream():
 
 # ------------------------------------------------------------------------- hipGraph replay of the train step
 @pytest.mark.parametrize("split", [False, True])
-def test_train_step_graph_replay_matches_eager(split):
+def test_train_step_graph_replay_matches_eager(split, monkeypatch):
     """Two trainers with identical seeds: one eager, one replaying captured graphs (single graph, and
-    the three-graph split used under data parallelism) -- same losses and same weights after 3 steps (within atomics noise)."""
-    from ffwm_amd import trainer
+    the three-graph split used under data parallelism) -- same losses and same weights after 3 steps (within atomics noise),
+    and the same BatchNorm batch counters in the state dict (the fused BatchNorm + LeakyReLU modules, forced for every pair
+    here, count on the host: a replay runs no Python, capture() records the calls of one step)."""
+    from ffwm_amd import norm, trainer
+    monkeypatch.setattr(norm, "MIN_FUSED_NUMEL", 0)
     torch.backends.cudnn.benchmark = False
     batch = trainer.synthetic_batch(2, DEV, seed=3)
     te = trainer.FFWMTrainer(DEV, seed=0, ngf=16)
@@ -783,6 +786,16 @@ def test_train_step_graph_replay_matches_eager(split):
     pe = torch.cat([p.detach().flatten() for p in te.netG.parameters()])
     pg = torch.cat([p.detach().flatten() for p in tg.netG.parameters()])
     assert (pe - pg).abs().max().item() <= 5e-3
+    lg = tg.step(batch)
+    le = te.step(batch)
+    counted = 0
+    for net in ("flowNetF", "netG", "netD"):
+        se, sg = getattr(te, net).state_dict(), getattr(tg, net).state_dict()
+        for k in se:
+            if k.endswith("num_batches_tracked"):
+                assert int(se[k]) == int(sg[k]), (net, k, int(se[k]), int(sg[k]))
+                counted += int(se[k]) == 4           # (FlowNet's never-used inter_conv_occ* stay at 0)
+    assert counted > 10
 
 
 def test_train_step_fast_paths_match_the_plain_pytorch_paths():
