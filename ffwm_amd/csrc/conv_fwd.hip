@@ -284,13 +284,16 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
     g.w_bytes = static_cast<unsigned>(w_elems * 4);
     FFWM_REQUIRE(out_batch_stride >= K * g.oH * g.oW, FFWM_ERR_ARG, "%s: output batch stride smaller than K * Ho * Wo", fn);
     g.N = static_cast<int>(B * g.Ho * g.Wo);
-    // tile: as large as the layer allows while >= 512 workgroups remain (tile_variant: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128)
+    // tile (conv_tile_variant: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128).  Measured per layer at batch 32
+    // (tools/conv_layers.py): 64 x 128 pixels wins where >= 512 workgroups remain and on the transposed convolutions with >= 2048
+    // pixels per parity class (the weight chunk is shared by twice the pixels); 128 output channels per workgroup never does
+    // (128 x 128: 256 + 144 registers, one wave per SIMD)
     int tm = 64, tn = 64;
     {
         const int v = options().conv_tile_variant;
         auto wgs = [&](int a, int b) { return static_cast<int64_t>((g.K + a - 1) / a) * ((g.N + b - 1) / b) * classes; };
-        if (v == 2 || v == 4 || (v == 0 && g.K >= 128 && wgs(128, 64) >= 512)) tm = 128;
-        if (v == 3 || v == 4 || (v == 0 && wgs(tm, 128) >= 512)) tn = 128;
+        if (v == 2 || v == 4) tm = 128;
+        if (v == 3 || v == 4 || (v == 0 && (wgs(64, 128) >= 512 || (mode == 1 && g.N >= 2048)))) tn = 128;
     }
     g.n_tiles = (g.N + tn - 1) / tn;
     g.k_tiles = (g.K + tm - 1) / tm;
