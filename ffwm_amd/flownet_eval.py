@@ -77,7 +77,37 @@ def flow_up(flow, weight, bias, out):
     return out
 
 
-def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None, dst2=None):
+class ZeroArena(object):
+    """The zero-filled accumulation buffers of one forward pass as slices of ONE tensor cleared by one fill: the layers with so few
+    output pixels that the convolution kernel splits its reduction add partial tiles atomically into a zeroed output, and a
+    `torch.zeros` per layer was 17 of the 121 launches of FlowNet's eval forward (85 of 920 us).  The first pass measures, later
+    passes carve; a slice is valid until the next begin()."""
+
+    def __init__(self):
+        self.buf, self.need, self.pos, self.used = None, 0, 0, 0
+
+    def begin(self, device):
+        self.need = max(self.need, self.used)
+        if self.need and (self.buf is None or self.buf.numel() < self.need or self.buf.device != device):
+            self.buf = torch.empty(self.need, device=device, dtype=torch.float32)
+        if self.buf is not None:
+            self.buf.zero_()
+        self.pos = self.used = 0
+
+    def take(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        padded = (n + 63) // 64 * 64            # 256-byte aligned slices
+        self.used += padded
+        if self.buf is not None and self.pos + padded <= self.buf.numel():
+            v = self.buf[self.pos:self.pos + n].view(*shape)
+            self.pos += padded
+            return v
+        return torch.zeros(*shape, device=self.buf.device if self.buf is not None else None, dtype=torch.float32)
+
+
+def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None, dst2=None, arena=None):
     """The hand-written fp32 MFMA convolution (csrc/conv_fwd.hip) with its bias + activation epilogue: fused in the kernel,
     or -- when the layer has so few output pixels that the launch is cut along the reduction -- as a bias_act pass over
     the atomically accumulated result.  dst / dst2 as in bias_act (channel slices of concatenation buffers)."""
@@ -95,7 +125,16 @@ def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None
     flag = ctypes.c_int(0)
     small = B * Ho * Wo * ((K + 63) // 64) * (1 if mode in (1, 2) else 4) < 256 * 64 * 4      # fewer than 256 tiles: split the reduction
     direct = dst is not None and dst2 is None and not small
-    y = dst if direct else (torch.zeros if small else torch.empty)(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
+    if direct:
+        y = dst
+    elif not small:
+        y = torch.empty(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
+    elif arena is not None and arena.buf is not None:
+        y = arena.take(B, K, Ho, Wo)
+    else:
+        if arena is not None:
+            arena.take(B, K, Ho, Wo)             # measuring pass
+        y = torch.zeros(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
     _lib.check(lib.ffwm_conv2d_forward(x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
                                        B, C, H, W, K, k, stride, pad, mode, y.stride(0), act, float(slope),
                                        1 if small else 0, ctypes.byref(flag), _lib.F32, _stream(x)), "ffwm_conv2d_forward")
@@ -114,6 +153,7 @@ def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None
 class FoldedFlowNet(object):
     def __init__(self, net, graph=False, mfma_conv=True):
         self.mfma_conv = bool(mfma_conv)
+        self.arena = ZeroArena()
         if net.training:
             raise ValueError("FoldedFlowNet folds eval-mode BatchNorm statistics: call net.eval() first")
         p = next(net.parameters())
@@ -144,7 +184,7 @@ class FoldedFlowNet(object):
             # weight-streaming 2 x 2 ... 8 x 8 tail and the 16 x 16 / 32 x 32 stride-1 layers (measured per layer,
             # tools/conv_layers.py: faster than the vendor kernel + epilogue everywhere except the >= 64 x 64 stride-1
             # layers and the thin 18 / 34-channel ones): hand-written MFMA kernel with the epilogue fused
-            return conv_mfma(x, w, b, stride[0], padding[0], transposed, LRELU, slope, dst=dst, dst2=dst2)
+            return conv_mfma(x, w, b, stride[0], padding[0], transposed, LRELU, slope, dst=dst, dst2=dst2, arena=self.arena)
         h = F.conv_transpose2d(x, w, None, stride, padding) if transposed else F.conv2d(x, w, None, stride, padding)
         if dst is None and dst2 is None:
             return bias_act(h, b, LRELU, slope=slope)
@@ -153,6 +193,7 @@ class FoldedFlowNet(object):
 
     def _forward(self, x):
         B = x.size(0)
+        self.arena.begin(x.device)
         f = self._block("conv0", x)
         skips = {}
         cats = {}
