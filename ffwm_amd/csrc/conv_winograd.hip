@@ -729,7 +729,7 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
         LaunchScope ls(data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd", st, bytes, flops);
         const unsigned nblk = static_cast<unsigned>(g.TT) * static_cast<unsigned>(g.KT);
         // whole tile rows of one image per workgroup -> the raw-staged variant
-        const bool rawv = options().conv_wino_raw && (W == 16 || W == 32 || W == 64 || W == 128) && g.TW <= 64 && 64 % g.TW == 0 &&
+        const bool rawv = options().conv_wino_raw && (W == 16 || W == 32 || W == 64 || W == 128) && H % 2 == 0 && g.TW <= 64 && 64 % g.TW == 0 &&
                           g.TH % (64 / g.TW) == 0 && (2 * (64 / g.TW) + 2) * g.W * 8 <= kWinoRawFloats;
         g.R = rawv ? 64 / g.TW : 0;
         g.ROWS = 2 * g.R + 2;

@@ -1442,7 +1442,7 @@ def test_conv2d_wgrad_generic_matches_aten(case):
     # (B, C, H, W, K)
     (1, 8, 4, 4, 64), (2, 5, 6, 10, 3), (2, 19, 7, 9, 70), (1, 64, 32, 32, 64), (3, 33, 17, 30, 130), (8, 195, 64, 64, 195),
     (2, 96, 128, 128, 48), (1, 66, 8, 12, 65), (2, 68, 9, 16, 131),          # 1-4 channels past 64: the thin tail kernel
-    (3, 20, 16, 16, 40),
+    (3, 20, 16, 16, 40), (2, 40, 15, 16, 64), (1, 24, 30, 32, 33),        # odd heights with a raw-staging width: the gather variant
 ])
 @pytest.mark.parametrize("raw_staging", [1, 0])
 def test_conv3x3_winograd_matches_aten(case, raw_staging):
