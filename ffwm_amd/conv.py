@@ -113,6 +113,10 @@ def winograd_dirs(x, weight):
     if not (_WINOGRAD and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4):
         return False, False
     K, C = weight.shape[0], weight.shape[1]
+    if K <= 4 and C >= 32:
+        # an image head (netG's 195 -> 3 output layer): the forward is the thin direct kernel of conv_winograd.hip alone (a lane
+        # owns 4 pixels x K channels), measured 50 us against the vendor's 137 at 128 x 128, batch 8; its data gradient stays
+        return x.shape[3] % 4 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 65536 and x.numel() < (1 << 29), False
     return _winograd_dir_ok(x, C, K), _winograd_dir_ok(x, K, C)
 
 
@@ -230,7 +234,8 @@ class WinogradConv2d(MfmaWgradConv2d):
 
 def winograd_eligible(m):
     return (type(m) in (nn.Conv2d, MfmaWgradConv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
-            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros" and min(m.in_channels, m.out_channels) >= 32)
+            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"
+            and (min(m.in_channels, m.out_channels) >= 32 or (m.out_channels <= 4 and m.in_channels >= 32)))
 
 
 def route_conv_winograd(net):

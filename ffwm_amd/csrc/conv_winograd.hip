@@ -695,7 +695,8 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
     FFWM_REQUIRE(B * C * H * W < (1LL << 29) && B * K * H * W < (1LL << 40), FFWM_ERR_SIZE, "%s: the input must stay below 2 GiB", fn);
     // a tail of 1-4 channels past a multiple of 64 goes to the thin kernel instead of costing a 64-channel tile
     const int tail = static_cast<int>(K % 64);
-    const bool thin = K > 64 && tail >= 1 && tail <= 4 && W % 4 == 0 && options().conv_thin_tail;
+    // (K <= 4 altogether -- netG's 195 -> 3 output layer, base_networks.py:312 -- is the thin kernel alone)
+    const bool thin = (K > 64 || K <= 4) && tail >= 1 && tail <= 4 && W % 4 == 0 && options().conv_thin_tail;
     WinoGeo g;
     g.C = static_cast<int>(C); g.H = static_cast<int>(H); g.W = static_cast<int>(W);
     g.K = static_cast<int>(thin ? K - tail : K);
@@ -722,7 +723,7 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
         const int rc = check_launch(fn);
         if (rc) return rc;
     }
-    {
+    if (g.KT > 0) {
         // flops = the multiplications the MFMAs actually perform (16 per tile, channel pair), not the 36 of the direct sum
         const double flops = 2.0 * 16.0 * static_cast<double>(T) * g.K * C;
         const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(B) * g.K * H * W) + static_cast<double>(ub);

@@ -71,8 +71,21 @@ class AffineRegularizationLoss(nn.Module):
         grid_y = grid[:, 1, :, :].unsqueeze(1)
         return self.calculate_loss(grid_x, weights) + self.calculate_loss(grid_y, weights)
 
+    @staticmethod
+    def _patch_products(grid, weights):
+        """F.conv2d(grid, weights) of the reference (models/losses.py:196: ONE input channel, kz^2 output channels) as im2col +
+        matmul on the GPU: with one input channel the vendor library's heuristics pick an NHWC implicit-GEMM data-gradient kernel
+        (igemm_bwd_gtcx35_nhwc_fp32 ... bt256x32x4) that reads out of bounds -- a GPU memory fault whenever the neighbouring
+        page is unmapped (seen under rocgdb after a trainer had shaped the allocator).  Same sums, rocBLAS instead."""
+        if not grid.is_cuda:
+            return F.conv2d(grid, weights)
+        b, _, h, w = grid.shape
+        kz = weights.shape[-1]
+        cols = F.unfold(grid, kz)                                    # [b, kz*kz, (h - kz + 1) (w - kz + 1)]
+        return torch.matmul(weights.reshape(weights.shape[0], -1), cols).view(b, weights.shape[0], h - kz + 1, w - kz + 1)
+
     def calculate_loss(self, grid, weights):
-        results = F.conv2d(grid, weights)                            # K^T K patch: [b, kz*kz, h, w]
+        results = self._patch_products(grid, weights)                # K^T K patch: [b, kz*kz, h, w]
         b, c, h, w = results.size()
         kernels_new = self.reshape(results, self.kz)                 # HIP local_attn_reshape
         f = torch.full((b, 2, h, w), float(int(self.kz / 2)), dtype=kernels_new.dtype, device=kernels_new.device)

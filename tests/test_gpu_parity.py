@@ -1443,6 +1443,7 @@ def test_conv2d_wgrad_generic_matches_aten(case):
     (1, 8, 4, 4, 64), (2, 5, 6, 10, 3), (2, 19, 7, 9, 70), (1, 64, 32, 32, 64), (3, 33, 17, 30, 130), (8, 195, 64, 64, 195),
     (2, 96, 128, 128, 48), (1, 66, 8, 12, 65), (2, 68, 9, 16, 131),          # 1-4 channels past 64: the thin tail kernel
     (3, 20, 16, 16, 40), (2, 40, 15, 16, 64), (1, 24, 30, 32, 33),        # odd heights with a raw-staging width: the gather variant
+    (2, 70, 32, 32, 3), (1, 33, 8, 12, 1),                                # an image head: the thin kernel alone
 ])
 @pytest.mark.parametrize("raw_staging", [1, 0])
 def test_conv3x3_winograd_matches_aten(case, raw_staging):
@@ -1491,7 +1492,7 @@ def test_winograd_routing_matches_aten_autograd(min_pairs, monkeypatch):
     ref = nn.Sequential(nn.Conv2d(40, 64, 3, 1, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 70, 3, 1, 1, bias=False), nn.LeakyReLU(0.2),
                         nn.Conv2d(70, 64, 3, 1, 1), nn.Conv2d(64, 3, 3, 1, 1)).to(DEV)
     fast = copy.deepcopy(ref)
-    assert conv.route_conv_winograd(fast) == 3             # the 64 -> 3 layer stays
+    assert conv.route_conv_winograd(fast) == 4             # the 64 -> 3 image head too (thin kernel, forward only, >= 65536 pixels)
     monkeypatch.setattr(conv, "WINOGRAD_MIN_PAIRS", min_pairs)         # 64 here: 70 -> 64 forward and 64 -> 70 data gradient stay with ATen
     for shape in ((2, 40, 64, 64), (1, 40, 16, 16)):
         assert conv.winograd_ok(torch.empty(shape, device=DEV), fast[0].weight) == (shape[2] == 64 and min_pairs == 1)
