@@ -183,6 +183,14 @@ def standalone_kernels(reps=10):
     run("cfg5/GPU block_extractor k=3 src[4,128,256,256] flow~U[-2,2)", lambda: ops.block_extractor_forward(src, flow, 3, out=out))
     gs, gf = torch.zeros_like(src), torch.zeros_like(flow)
     run("cfg5/GPU block_extractor k=3 backward", lambda: ops.block_extractor_backward(src, flow, out, 3, gs, gf))
+    # a SMOOTH flow of the same amplitude (what a trained flow net produces): no LDS bank / same-cell collisions in the backward's
+    # scatter; its extrema sit next to integers, so a few pixels take the per-tap paths (fallback block / far kernel)
+    yy, xx = torch.meshgrid(torch.arange(256.0), torch.arange(256.0), indexing="ij")
+    smooth = torch.stack([2 * torch.sin(xx / 41.0 + yy / 67.0), 2 * torch.cos(xx / 53.0 - yy / 37.0)]).unsqueeze(0).repeat(4, 1, 1, 1).to(dev)
+    run("cfg5/GPU block_extractor k=3 smooth flow, amplitude 2 px", lambda: ops.block_extractor_forward(src, smooth, 3, out=out))
+    gs.zero_(); gf.zero_()
+    run("cfg5/GPU block_extractor k=3 backward, smooth flow", lambda: ops.block_extractor_backward(src, smooth, out, 3, gs, gf))
+    del smooth
     wide = (torch.rand(4, 2, 256, 256, generator=g) * 128 - 64).to(dev)
     run("cfg5/GPU block_extractor k=3 flow~U[-64,64) (gather fallback)", lambda: ops.block_extractor_forward(src, wide, 3, out=out), 3)
     del src, out, gs, gf, wide

@@ -516,11 +516,14 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
         return;
     }
 
-    // ---- fallback: direct global gathers, every tap formed per element like the reference
+    // ---- fallback: direct global gathers, every tap formed per element like the reference.  Four channels per trip share
+    // the taps and keep 16 K loads in flight per lane: ONE block that falls back (a single irregular pixel among its 64 x 4 RPT
+    // is enough) used to walk its slab channel by channel with a dependent load group per tap row -- a 340 us tail on a
+    // 230 us launch for a smooth flow whose extrema sit next to integers.
     if (!inx) return;
-    for (int c = c0; c < c1; ++c, sp += splane, op += (MODE == 2 ? 0 : oplane)) {
-        const rsrc_t rs = make_rsrc(sp, sbytes);
-        const rsrc_t ro = make_rsrc(op, obytes);
+    constexpr int CB = MODE == 0 ? 4 : 1;          // (the attention modes sit at a register-count step: one more VGPR costs a wave)
+    for (int c = c0; c < c1; c += CB, sp += CB * splane, op += (MODE == 2 ? 0 : CB * oplane)) {
+        const int nb = (c1 - c) < CB ? (c1 - c) : CB;
 #pragma unroll 1
         for (int r = 0; r < RPT; ++r) {
             if (!iny[r]) continue;
@@ -528,31 +531,60 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
             const size_t pix = static_cast<size_t>(yf) * Wf + xf;
             const T fx0 = fb[pix], fy0 = fb[fplane + pix];
             const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
-            T osum = 0;
-            T gd = 0;
-            if constexpr (MODE == 2) gd = gb[static_cast<size_t>(c - c0) * fplane + pix] / kK2;
+            T osum[CB], gd[CB];
+#pragma unroll
+            for (int q = 0; q < CB; ++q) {
+                osum[q] = 0;
+                gd[q] = 0;
+                if constexpr (MODE == 2)
+                    if (q < nb) gd[q] = gb[static_cast<size_t>(c - c0 + q) * fplane + pix] / kK2;
+            }
+            Tap1<T> tx1[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) tx1[j] = make_tap<T>(fx0, j - K / 2, xf, Ws);
 #pragma unroll 1
             for (int i = 0; i < K; ++i) {
                 const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
                 const unsigned rT = ty1.lo * static_cast<unsigned>(Ws), rB = ty1.hi * static_cast<unsigned>(Ws);
-                ElemRow<T, K> row;
+                T v[CB][K][4];
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
-                    T s = (tx1.wlo * ty1.wlo) * buf_ld<T>(rs, (rT + tx1.lo) * E);
-                    s = fma_t<T>(tx1.whi * ty1.wlo, buf_ld<T>(rs, (rT + tx1.hi) * E), s);
-                    s = fma_t<T>(tx1.wlo * ty1.whi, buf_ld<T>(rs, (rB + tx1.lo) * E), s);
-                    s = fma_t<T>(tx1.whi * ty1.whi, buf_ld<T>(rs, (rB + tx1.hi) * E), s);
-                    row.v[j] = s;
-                    if constexpr (MODE == 1) osum = add_rn(osum, mul_rn(s, wb[(i * K + j) * fplane + pix]));
-                    if constexpr (MODE == 2) atomic_add(op + (i * K + j) * fplane + pix, gd * s);
+                for (int q = 0; q < CB; ++q) {
+                    if (q >= nb) break;
+                    const rsrc_t rs = make_rsrc(sp + static_cast<size_t>(q) * splane, sbytes);
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        v[q][j][0] = buf_ld<T>(rs, (rT + tx1[j].lo) * E);
+                        v[q][j][1] = buf_ld<T>(rs, (rT + tx1[j].hi) * E);
+                        v[q][j][2] = buf_ld<T>(rs, (rB + tx1[j].lo) * E);
+                        v[q][j][3] = buf_ld<T>(rs, (rB + tx1[j].hi) * E);
+                    }
                 }
-                if constexpr (MODE == 0) buf_store_row<T, K>(ro, ob + i * orow, row);
+#pragma unroll
+                for (int q = 0; q < CB; ++q) {
+                    if (q >= nb) break;
+                    ElemRow<T, K> row;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        T s = (tx1[j].wlo * ty1.wlo) * v[q][j][0];
+                        s = fma_t<T>(tx1[j].whi * ty1.wlo, v[q][j][1], s);
+                        s = fma_t<T>(tx1[j].wlo * ty1.whi, v[q][j][2], s);
+                        s = fma_t<T>(tx1[j].whi * ty1.whi, v[q][j][3], s);
+                        row.v[j] = s;
+                        if constexpr (MODE == 1) osum[q] = add_rn(osum[q], mul_rn(s, wb[(i * K + j) * fplane + pix]));
+                        if constexpr (MODE == 2) atomic_add(op + (i * K + j) * fplane + pix, gd[q] * s);
+                    }
+                    if constexpr (MODE == 0)
+                        buf_store_row<T, K>(make_rsrc(op + static_cast<size_t>(q) * oplane, obytes), ob + i * orow, row);
+                }
             }
             if constexpr (MODE == 1) {
-                ElemRow<T, 1> o;
-                o.v[0] = osum / kK2;
-                buf_store_row<T, 1>(ro, static_cast<unsigned>(pix) * E, o);
+#pragma unroll
+                for (int q = 0; q < CB; ++q) {
+                    if (q >= nb) break;
+                    ElemRow<T, 1> o;
+                    o.v[0] = osum[q] / kK2;
+                    buf_store_row<T, 1>(make_rsrc(op + static_cast<size_t>(q) * oplane, obytes), static_cast<unsigned>(pix) * E, o);
+                }
             }
         }
     }
@@ -1465,10 +1497,11 @@ be_bwd_far2_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __
                    int Ws, int Hf, int Wf, int tiles_x, int tiles_y, int cslabs, int cs, TileGeo geo,
                    const T* __restrict__ attn = nullptr) {
     const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, 0);
-    if (tc.xf >= Wf || tc.yf >= Hf) return;
+    if (tc.yf >= Hf) return;                            // (wave-uniform: a wave is one row)
+    const bool live = tc.xf < Wf;                       // lanes past the row's end stay: they share the unfit pixels' work below
     constexpr unsigned E = sizeof(T);
     const size_t fplane = static_cast<size_t>(Hf) * Wf;
-    const size_t foff = static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(tc.yf) * Wf + tc.xf;
+    const size_t foff = static_cast<size_t>(tc.b) * 2 * fplane + static_cast<size_t>(tc.yf) * Wf + (live ? tc.xf : 0);
     const T fx0 = flow[foff], fy0 = flow[foff + fplane];
     // the tile kernel's `fit` predicate, same arithmetic
     T flx0 = 0, fly0 = 0;
@@ -1489,36 +1522,43 @@ be_bwd_far2_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __
     const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;
     const bool fit = inside & regular & (static_cast<unsigned>(u0 - ax0) <= static_cast<unsigned>(AP - 1 - K)) &
                      (static_cast<unsigned>(v0 - ay0) <= static_cast<unsigned>(AH - 1 - K));
-    if (fit) return;
+    // Unfit pixels are rare (a flow value within an ulp of a cell boundary, a NaN, a wide flow) -- but ONE thread walking its
+    // slab's channels x K x K taps with a dependent load each is a 200 us tail on a launch that otherwise ends in 7 us (seen
+    // with a smooth field whose extrema sit next to integers).  The wave shares them instead: for every unfit lane in turn, the
+    // 64 lanes split that pixel's (channel, tap) pairs, one load + four atomics per pair, all independent.
     const int c0 = tc.slab * cs;
     const int c1 = (c0 + cs < C) ? c0 + cs : C;
     const int W = K * Wf;
     const size_t oplane = FUSED ? fplane : static_cast<size_t>(K) * Hf * W;
     const size_t splane = static_cast<size_t>(Hs) * Ws;
     const unsigned obytes = static_cast<unsigned>(oplane * E);
-    T* gp = gsrc + (static_cast<size_t>(tc.b) * C + c0) * splane;
-    const T* op = gout + (static_cast<size_t>(tc.b) * C + c0) * oplane;
-    const unsigned obase = (static_cast<unsigned>(tc.yf) * K * W + static_cast<unsigned>(tc.xf) * K) * E;
     const unsigned orow = static_cast<unsigned>(W) * E;
-    for (int c = c0; c < c1; ++c, op += oplane, gp += splane) {
-        const rsrc_t rg = make_rsrc(op, obytes);
-#pragma unroll 1
-        for (int i = 0; i < K; ++i) {
-            const Tap1<T> ty = make_tap<T>(fy0, i - K / 2, tc.yf, Hs);
-#pragma unroll 1
-            for (int j = 0; j < K; ++j) {
-                const Tap1<T> tx = make_tap<T>(fx0, j - K / 2, tc.xf, Ws);
-                const unsigned pix = (static_cast<unsigned>(tc.yf) * Wf + tc.xf) * E;
-                const T gv = FUSED ? (buf_ld<T>(rg, pix) / static_cast<T>(K * K)) *
-                                         attn[(static_cast<size_t>(tc.b) * K * K + i * K + j) * fplane + pix / E]
-                                   : buf_ld<T>(rg, obase + i * orow + j * E);
-                const unsigned rT = ty.lo * static_cast<unsigned>(Ws) * E, rB = ty.hi * static_cast<unsigned>(Ws) * E;
-                const unsigned cL = tx.lo * E, cR = tx.hi * E;
-                atomic_add_off(gp, rT + cL, gv * tx.wlo * ty.wlo);
-                atomic_add_off(gp, rT + cR, gv * tx.whi * ty.wlo);
-                atomic_add_off(gp, rB + cL, gv * tx.wlo * ty.whi);
-                atomic_add_off(gp, rB + cR, gv * tx.whi * ty.whi);
-            }
+    const int lane = threadIdx.x & (kWave - 1);
+    unsigned long long todo = __ballot(live && !fit);
+    while (todo) {
+        const int src = __ffsll(static_cast<long long>(todo)) - 1;
+        todo &= todo - 1;
+        const T pfx = __shfl(fx0, src, kWave), pfy = __shfl(fy0, src, kWave);
+        const int px = __shfl(tc.xf, src, kWave), py = tc.yf;          // (a wave is 64 consecutive x of one row)
+        const unsigned obase = (static_cast<unsigned>(py) * K * W + static_cast<unsigned>(px) * K) * E;
+        const unsigned pix = (static_cast<unsigned>(py) * Wf + px) * E;
+        for (int e = lane; e < (c1 - c0) * K * K; e += kWave) {
+            const int cc = e / (K * K), t = e - cc * (K * K);
+            const int i = t / K, j = t - i * K;
+            T* gp = gsrc + (static_cast<size_t>(tc.b) * C + c0 + cc) * splane;
+            const T* op = gout + (static_cast<size_t>(tc.b) * C + c0 + cc) * oplane;
+            const rsrc_t rg = make_rsrc(op, obytes);
+            const Tap1<T> ty = make_tap<T>(pfy, i - K / 2, py, Hs);
+            const Tap1<T> tx = make_tap<T>(pfx, j - K / 2, px, Ws);
+            const T gv = FUSED ? (buf_ld<T>(rg, pix) / static_cast<T>(K * K)) *
+                                     attn[(static_cast<size_t>(tc.b) * K * K + i * K + j) * fplane + pix / E]
+                               : buf_ld<T>(rg, obase + i * orow + j * E);
+            const unsigned rT = ty.lo * static_cast<unsigned>(Ws) * E, rB = ty.hi * static_cast<unsigned>(Ws) * E;
+            const unsigned cL = tx.lo * E, cR = tx.hi * E;
+            atomic_add_off(gp, rT + cL, gv * tx.wlo * ty.wlo);
+            atomic_add_off(gp, rT + cR, gv * tx.whi * ty.wlo);
+            atomic_add_off(gp, rB + cL, gv * tx.wlo * ty.whi);
+            atomic_add_off(gp, rB + cR, gv * tx.whi * ty.whi);
         }
     }
 }
