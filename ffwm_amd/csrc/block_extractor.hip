@@ -241,9 +241,14 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
             const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
             const T fxl = floor_t(dx), fyl = floor_t(dy);
             if (j == 0) { flx0 = fxl; fly0 = fyl; }
-            regular = regular && (fxl == flx0 + static_cast<T>(j)) && (fyl == fly0 + static_cast<T>(j));
-            wxr[r][j] = dx - fxl; wxl[r][j] = 1 - (dx - fxl);
-            wyb[r][j] = dy - fyl; wyt[r][j] = 1 - (dy - fyl);
+            // tap j sits j cells after tap 0 -- or its coordinate was rounded up onto the next integer exactly (dx == floor(dx)
+            // == that cell + 1: a flow value within an ulp of a cell boundary): then cell + j with the weights (0, 1) is the
+            // reference's cell + j + 1 with (1, 0), the same sample bit for bit, and the pixel stays on the LDS path.  (Without
+            // this a smooth field whose extrema sit next to integers sent whole blocks to the per-tap fallback.)
+            const T cx = flx0 + static_cast<T>(j), cy = fly0 + static_cast<T>(j);
+            regular = regular && (fxl == cx || (fxl == cx + 1 && dx == fxl)) && (fyl == cy || (fyl == cy + 1 && dy == fyl));
+            wxr[r][j] = dx - cx; wxl[r][j] = 1 - (dx - cx);
+            wyb[r][j] = dy - cy; wyt[r][j] = 1 - (dy - cy);
         }
         const T lim = static_cast<T>(1 << 20);
         const bool ok = (flx0 > -lim) && (flx0 < lim) && (fly0 > -lim) && (fly0 < lim);   // also rejects NaN
@@ -521,7 +526,7 @@ be_fwd_lds_kernel(const T* __restrict__ src, const T* __restrict__ flow, T* __re
     // is enough) used to walk its slab channel by channel with a dependent load group per tap row -- a 340 us tail on a
     // 230 us launch for a smooth flow whose extrema sit next to integers.
     if (!inx) return;
-    constexpr int CB = MODE == 0 ? 4 : 1;          // (the attention modes sit at a register-count step: one more VGPR costs a wave)
+    constexpr int CB = MODE == 0 ? 4 : 2;          // (the attention modes sit at a register-count step: one more VGPR costs a wave)
     for (int c = c0; c < c1; c += CB, sp += CB * splane, op += (MODE == 2 ? 0 : CB * oplane)) {
         const int nb = (c1 - c) < CB ? (c1 - c) : CB;
 #pragma unroll 1

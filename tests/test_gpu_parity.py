@@ -70,6 +70,32 @@ def test_block_extractor_forward(oracle, case, dtype):
     _close(out, ref, FWD_TOL[dtype])
 
 
+def test_block_extractor_smooth_flow_with_extrema_next_to_integers(oracle):
+    """A smooth flow whose extrema sit within an ulp of integers (2 sin / 2 cos: what a saturating flow net can emit): the tap
+    coordinates of a few pixels round up ONTO a cell boundary.  Forward: those pixels stay on the LDS path with the weights
+    (0, 1) on the previous cell pair -- bit-exact against the oracle's per-tap arithmetic; backward: they go to the far kernel,
+    shared by the wave -- same tolerance as everywhere."""
+    from ffwm_amd import ops
+    H = W = 192
+    yy, xx = torch.meshgrid(torch.arange(float(H)), torch.arange(float(W)), indexing="ij")
+    flow = torch.stack([2 * torch.sin(xx / 41.0 + yy / 67.0), 2 * torch.cos(xx / 53.0 - yy / 37.0)]).unsqueeze(0).contiguous()
+    g = _gen(77)
+    src = torch.rand(1, 5, H, W, generator=g)
+    go = torch.rand(1, 5, 3 * H, 3 * W, generator=g)
+    # the case really occurs in this field: a tap coordinate that is an exact integer one past the expected cell
+    dx0 = (flow[0, 0] - 1) + xx
+    dx2 = (flow[0, 0] + 1) + xx
+    assert ((torch.floor(dx2) == torch.floor(dx0) + 3) & (dx2 == torch.floor(dx2))).any()
+    ref = oracle.block_extractor_forward(src, flow, 3)
+    out = ops.block_extractor_forward(src.to(DEV), flow.to(DEV), 3)
+    assert torch.equal(out.cpu(), ref)
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, 3)
+    gs, gf = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV)
+    ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), 3, gs, gf)
+    _close(gs, gs_ref, BWD_TOL[torch.float32], relative=True)
+    _close(gf, gf_ref, BWD_TOL[torch.float32], relative=True)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("case", BE_CASES)
 def test_block_extractor_backward(oracle, case, dtype):
