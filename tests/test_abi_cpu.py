@@ -55,6 +55,18 @@ def test_argument_errors_are_reported_before_launch(hiplib):
     rc = hiplib.ffwm_warp_forward(p, p, p, 1, 1, 1 << 15, 1 << 15, 4, 4, 0, 0, None)
     assert rc == -3
     assert hiplib.ffwm_set_option(b"no_such_key", 1) == -1
+    # the convolution entry points: argument checks come before any launch
+    rc = hiplib.ffwm_conv3x3_winograd_forward(None, None, None, None, None, 1, 8, 4, 4, 8, 0, 0, 0.0, 0, None)
+    assert rc == -1 and b"NULL" in hiplib.ffwm_last_error()
+    rc = hiplib.ffwm_conv3x3_winograd_forward(p, p, None, p, p, 1, 8, 4, 4, 8, 5, 0, 0.0, 0, None)
+    assert rc == -1 and b"data_gradient" in hiplib.ffwm_last_error()
+    rc = hiplib.ffwm_conv3x3_winograd_forward(p, p, None, p, p, 1, 8, 4, 4, 8, 0, 0, 0.0, 1, None)
+    assert rc == -2
+    # transformed weights: 16 positions x 64-channel tiles x 8-channel chunks, fp32
+    assert hiplib.ffwm_conv3x3_winograd_workspace_bytes(195, 195) == 4 * 25 * 16 * 2 * 64 * 4 * 4
+    assert hiplib.ffwm_conv3x3_winograd_workspace_bytes(0, 5) == 0
+    rc = hiplib.ffwm_conv2d_wgrad(None, None, None, 1, 8, 4, 4, 8, 4, 4, 3, 1, 1, 0, None)
+    assert rc == -1
 
 
 def test_cpu_tensors_are_refused_like_the_reference():
