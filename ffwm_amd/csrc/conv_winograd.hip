@@ -490,10 +490,10 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
             #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // up to 4 VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to 6 VALU
                 __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // up to 2 LDS writes
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // up to 2 VMEM reads
             }
             __builtin_amdgcn_sched_barrier(0);
         }
