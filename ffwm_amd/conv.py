@@ -164,9 +164,13 @@ class _WinogradConv3x3(Function):
 
 def frozen_cache(owner, weight):
     """The dict in which a layer with frozen weights keeps its transformed weights (None for a trainable layer): it lives on
-    the module, so it dies with it -- a cache keyed by the storage address alone would outlive the tensor."""
-    if weight.requires_grad:
+    the module, so it dies with it -- a cache keyed by the storage address alone would outlive the tensor.  Only a frozen
+    nn.Parameter qualifies: a spectral-norm product is a fresh plain tensor per forward (requires_grad False under no_grad,
+    version counter 0, an address the caching allocator hands out again), so its transform must never be kept."""
+    if (not isinstance(weight, nn.Parameter)) or weight.requires_grad or hasattr(owner, "weight_orig"):
         return None
+    if torch.cuda.is_current_stream_capturing():
+        return None      # a transform kernel that was only captured, not run, must not be recorded as valid
     return owner.__dict__.setdefault("_winograd_frozen", {})
 
 
@@ -220,7 +224,7 @@ class WinogradConv2d(MfmaWgradConv2d):
         grad = torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad)
         if dirs[0] or (grad and dirs[1] and input.requires_grad):
             # (weight may be a spectral-norm product, not self.weight: only a frozen PARAMETER keeps its transform)
-            cache = frozen_cache(self, weight) if weight is self.weight else None
+            cache = frozen_cache(self, weight) if weight is self._parameters.get("weight") else None
             if grad:
                 return _WinogradConv3x3.apply(input, weight, bias, cache, dirs)
             return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=cache)

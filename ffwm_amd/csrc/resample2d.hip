@@ -689,11 +689,15 @@ rs_bwd2_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
 #pragma unroll
     for (int r = 0; r < RPT; ++r) poffb[r] = (static_cast<unsigned>(ys[r]) * W + static_cast<unsigned>(x)) * 4u;
 
-    float acc[RPT][NA];                      // reference order: k = 4 * (fy * HALF + fx) + {TL, TR, BL, BR}
+    // sum over the channels of gO * in1[tap], per tap, in DOUBLE: the quotient rule below subtracts two nearly equal sums of
+    // these (a narrow sigma makes the derivative weights large), so fp32 rounding of a running sum over the channels was
+    // amplified to 1.5e-4 of the result against the reference's own kernels; a group of four channels is summed in fp32 from
+    // zero (error relative to the GROUP's value) and added to the double accumulator
+    double acc[RPT][NA];                     // reference order: k = 4 * (fy * HALF + fx) + {TL, TR, BL, BR}
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
 #pragma unroll
-        for (int k = 0; k < NA; ++k) acc[r][k] = 0.f;
+        for (int k = 0; k < NA; ++k) acc[r][k] = 0.0;
 
     // visit the taps in the reference's order, handing the body (k, row position, column position)
     auto for_each_tap = [&](auto&& body) {
@@ -763,12 +767,11 @@ rs_bwd2_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
                 const f32x4* nb = tb + lbase[r];
                 for_each_tap([&](int k, int pr, int pc) {
                     const f32x4 v = nb[pr * kRsBoxW + pc];
-                    float a = acc[r][k];
-                    a = __builtin_fmaf(gx, v.x, a);
+                    float a = gx * v.x;
                     a = __builtin_fmaf(gy, v.y, a);
                     a = __builtin_fmaf(gz, v.z, a);
                     a = __builtin_fmaf(gw, v.w, a);
-                    acc[r][k] = a;
+                    acc[r][k] += static_cast<double>(a);
                 });
             }
             if (more) {
@@ -787,53 +790,47 @@ rs_bwd2_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
                 for_each_tap([&](int k, int pr, int pc) {
                     const int fyq = pr < HALF ? 2 * (HALF - 1 - pr) : 2 * (pr - HALF) + 1;      // position -> RsTaps entry
                     const int fxq = pc < HALF ? 2 * (HALF - 1 - pc) : 2 * (pc - HALF) + 1;
-                    acc[r][k] = __builtin_fmaf(g, buf_ld<float>(rs, t[r].row[fyq] + t[r].col[fxq]), acc[r][k]);
+                    acc[r][k] += static_cast<double>(g) * static_cast<double>(buf_ld<float>(rs, t[r].row[fyq] + t[r].col[fxq]));
                 });
             }
         }
     }
 
-    // quotient rule, resample2d_kernel.cu:252-328, with sum_ch(gO * in1[tap]) factored out (as rs_bwd2_kernel)
+    // quotient rule, resample2d_kernel.cu:252-328, with sum_ch(gO * in1[tap]) factored out (as rs_bwd2_kernel), evaluated in
+    // double from the fp32 weights (SAFE_DIV's zero tests on the values the reference's fp32 code would test)
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
         if (!(inx && iny[r])) continue;
         const float sigma = sg[r];
-        const float ns2 = -sigma * sigma, s3 = sigma * sigma * sigma;
-        float g1x = 0, g1y = 0, g1s = 0, sgx = 0, sgy = 0, sgs = 0, S = 0;
+        const float ns2f = -sigma * sigma, s3f = sigma * sigma * sigma;
+        const double ns2 = (ns2f == 0.f) ? 1e-8 : -static_cast<double>(sigma) * sigma;
+        const double s3 = (s3f == 0.f) ? 1e-8 : static_cast<double>(sigma) * sigma * sigma;
+        double g1x = 0, g1y = 0, g1s = 0, sgx = 0, sgy = 0, sgs = 0, S = 0;
 #pragma unroll
         for (int fy = 0; fy < HALF; ++fy)
 #pragma unroll
             for (int fx = 0; fx < HALF; ++fx) {
-                const float yT = t[r].wy[2 * fy], yB = t[r].wy[2 * fy + 1], xL = t[r].wx[2 * fx], xR = t[r].wx[2 * fx + 1];
-                const float yT_ = t[r].dy_[2 * fy], yB_ = t[r].dy_[2 * fy + 1], xL_ = t[r].dx_[2 * fx], xR_ = t[r].dx_[2 * fx + 1];
-                const float* a = acc[r] + 4 * (fy * HALF + fx);
-                g1x += static_cast<float>(safe_div<float>(xL_ * yT * xL * a[0], ns2));
-                g1x -= static_cast<float>(safe_div<float>(xR_ * yT * xR * a[1], ns2));
-                g1x += static_cast<float>(safe_div<float>(xL_ * yB * xL * a[2], ns2));
-                g1x -= static_cast<float>(safe_div<float>(xR_ * yB * xR * a[3], ns2));
-                sgx += static_cast<float>(safe_div<float>(xL_ * yT * xL - xR_ * yT * xR + xL_ * yB * xL - xR_ * yB * xR, ns2));
-                g1y += static_cast<float>(safe_div<float>(yT_ * yT * xL * a[0], ns2));
-                g1y += static_cast<float>(safe_div<float>(yT_ * yT * xR * a[1], ns2));
-                g1y -= static_cast<float>(safe_div<float>(yB_ * yB * xL * a[2], ns2));
-                g1y -= static_cast<float>(safe_div<float>(yB_ * yB * xR * a[3], ns2));
-                sgy += static_cast<float>(safe_div<float>(yT_ * yT * xL + yT_ * yT * xR - yB_ * yB * xL - yB_ * yB * xR, ns2));
-                const float dTL = yT_ * yT_ + xL_ * xL_, dTR = yT_ * yT_ + xR_ * xR_;
-                const float dBL = yB_ * yB_ + xL_ * xL_, dBR = yB_ * yB_ + xR_ * xR_;
-                g1s += static_cast<float>(safe_div<float>(dTL * yT * xL * a[0], s3));
-                g1s += static_cast<float>(safe_div<float>(dTR * yT * xR * a[1], s3));
-                g1s += static_cast<float>(safe_div<float>(dBL * yB * xL * a[2], s3));
-                g1s += static_cast<float>(safe_div<float>(dBR * yB * xR * a[3], s3));
-                sgs += static_cast<float>(safe_div<float>(dTL * yT * xL + dTR * yT * xR + dBL * yB * xL + dBR * yB * xR, s3));
-                S += yT * xL * a[0];
-                S += yT * xR * a[1];
-                S += yB * xL * a[2];
-                S += yB * xR * a[3];
+                const double yT = t[r].wy[2 * fy], yB = t[r].wy[2 * fy + 1], xL = t[r].wx[2 * fx], xR = t[r].wx[2 * fx + 1];
+                const double yT_ = t[r].dy_[2 * fy], yB_ = t[r].dy_[2 * fy + 1], xL_ = t[r].dx_[2 * fx], xR_ = t[r].dx_[2 * fx + 1];
+                const double* a = acc[r] + 4 * (fy * HALF + fx);
+                const double wTL = yT * xL, wTR = yT * xR, wBL = yB * xL, wBR = yB * xR;
+                g1x += (xL_ * wTL * a[0] - xR_ * wTR * a[1] + xL_ * wBL * a[2] - xR_ * wBR * a[3]) / ns2;
+                sgx += (xL_ * wTL - xR_ * wTR + xL_ * wBL - xR_ * wBR) / ns2;
+                g1y += (yT_ * wTL * a[0] + yT_ * wTR * a[1] - yB_ * wBL * a[2] - yB_ * wBR * a[3]) / ns2;
+                sgy += (yT_ * wTL + yT_ * wTR - yB_ * wBL - yB_ * wBR) / ns2;
+                const double dTL = yT_ * yT_ + xL_ * xL_, dTR = yT_ * yT_ + xR_ * xR_;
+                const double dBL = yB_ * yB_ + xL_ * xL_, dBR = yB_ * yB_ + xR_ * xR_;
+                g1s += (dTL * wTL * a[0] + dTR * wTR * a[1] + dBL * wBL * a[2] + dBR * wBR * a[3]) / s3;
+                sgs += (dTL * wTL + dTR * wTR + dBL * wBL + dBR * wBR) / s3;
+                S += wTL * a[0] + wTR * a[1] + wBL * a[2] + wBR * a[3];
             }
-        const float sum = t[r].sum;
+        const float sumf = t[r].sum;
+        const double sum = (sumf == 0.f) ? 1e-8 : static_cast<double>(sumf);
+        const double sum2 = (sumf * sumf == 0.f) ? 1e-8 : static_cast<double>(sumf) * sumf;
         float* op = gin2 + static_cast<size_t>(b) * 3 * plane + poffb[r] / 4u;
-        const float rx = static_cast<float>(safe_div<float>(g1x, sum) - safe_div<float>(sgx * S, sum * sum));
-        const float ry = static_cast<float>(safe_div<float>(g1y, sum) - safe_div<float>(sgy * S, sum * sum));
-        const float rs_ = static_cast<float>(safe_div<float>(g1s, sum) - safe_div<float>(sgs * S, sum * sum));
+        const float rx = static_cast<float>(g1x / sum - sgx * S / sum2);
+        const float ry = static_cast<float>(g1y / sum - sgy * S / sum2);
+        const float rs_ = static_cast<float>(g1s / sum - sgs * S / sum2);
         if (cslabs == 1) {
             op[0] = rx; op[plane] = ry; op[2 * plane] = rs_;
         } else {                              // linear in the accumulators: the slabs' partial results add up (buffer zero-filled by the host)

@@ -62,6 +62,7 @@ class BucketedGradReducer(object):
             base = self._seal(plist, base)
         self.overlap = True
         self.gather = False
+        self.launch_log = []       # (bucket index, "hook" | "finish") of the current step, in launch order
         self.set_gather(gather)
         self._hooks = []
         if self.world > 1:
@@ -82,7 +83,7 @@ class BucketedGradReducer(object):
             self._view[p] = view
             self.offset[p] = (base + off, base + off + n)
             off += _pad4(n)
-        b = {"flat": flat, "params": plist, "pending": len(plist), "launched": False, "handle": None}
+        b = {"flat": flat, "params": plist, "pending": len(plist), "launched": False, "handle": None, "index": len(self.buckets)}
         for p in plist:
             self._bucket_of[p] = b
         self.buckets.append(b)
@@ -93,6 +94,7 @@ class BucketedGradReducer(object):
         """Replaces optimizer.zero_grad(): keeps the bucket views alive."""
         if self.flat is not None:
             self.flat.zero_()
+        self.launch_log = []
         for b in self.buckets:
             if self.flat is None:
                 b["flat"].zero_()
@@ -128,8 +130,11 @@ class BucketedGradReducer(object):
         if src:
             torch._foreach_copy_(dst, src)
 
-    def _launch(self, b):
+    def _launch(self, b, where="hook"):
         b["launched"] = True
+        # (bucket index, who launched it): what the dry-run tests assert the overlap on -- a bucket reduced from an autograd
+        # hook went out DURING backward, one reduced from finish() did not
+        self.launch_log.append((b["index"], where))
         b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def set_overlap(self, on):
@@ -168,11 +173,40 @@ class BucketedGradReducer(object):
             return
         for b in self.buckets:
             if not b["launched"] or not self.overlap:
-                self._launch(b)       # parameters without a gradient this step still take part
+                self._launch(b, "finish")       # parameters without a gradient this step still take part
         for b in self.buckets:
             b["handle"].wait()
             if self.average:
                 b["flat"].div_(self.world)
+
+    def time_buckets(self, reps=3):
+        """Stand-alone duration of every bucket's all-reduce (ms, max over `reps` excluded: the median), measured OUTSIDE a step with
+        the device idle: what the collective costs when nothing overlaps it.  -> list of dicts (bucket MiB, ms, algorithm
+        bandwidth and ring bus bandwidth 2 (n - 1) / n x bytes / time in GB/s).  The flat arrays are summed in place `reps` times:
+        call it after the measurement, or zero_grad() afterwards."""
+        out = []
+        if self.world == 1:
+            return out
+        cuda = self.buckets[0]["flat"].is_cuda
+        import time
+        for i, b in enumerate(self.buckets):
+            ts = []
+            for _ in range(reps + 1):
+                if cuda:
+                    torch.cuda.synchronize()
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
+                if cuda:
+                    torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            ts = sorted(ts[1:])
+            t = ts[len(ts) // 2]
+            nbytes = b["flat"].numel() * b["flat"].element_size()
+            out.append({"bucket": i, "MiB": round(nbytes / 2 ** 20, 2), "ms": round(t * 1e3, 3),
+                        "algbw_GBps": round(nbytes / t / 1e9, 1),
+                        "busbw_GBps": round(2.0 * (self.world - 1) / self.world * nbytes / t / 1e9, 1)})
+        return out
 
     def grad_bytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)

@@ -151,8 +151,11 @@ def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None
 
 
 class FoldedFlowNet(object):
-    def __init__(self, net, graph=False, mfma_conv=True):
+    def __init__(self, net, graph=False, mfma_conv=True, mfma_min_channels=32):
         self.mfma_conv = bool(mfma_conv)
+        # layers thinner than this stay with the vendor kernel (measured slower on csrc/conv_fwd.hip); the fixture test lowers it
+        # to 1 so that EVERY stride-2 / transposed / small-plane layer of a narrow FlowNet runs on the hand-written kernel
+        self.mfma_min_channels = int(mfma_min_channels)
         self.arena = ZeroArena()
         if net.training:
             raise ValueError("FoldedFlowNet folds eval-mode BatchNorm statistics: call net.eval() first")
@@ -179,7 +182,7 @@ class FoldedFlowNet(object):
     # conv (no bias: it is added by the epilogue) -> bias + LeakyReLU, in place and / or into a cat slice
     def _block(self, name, x, dst=None, dst2=None):
         transposed, w, b, stride, padding, slope = self.blocks[name]
-        if self.mfma_conv and (transposed or stride[0] == 2 or x.size(2) <= 32) and x.size(1) >= 32:
+        if self.mfma_conv and (transposed or stride[0] == 2 or x.size(2) <= 32) and x.size(1) >= self.mfma_min_channels:
             # the layers MIOpen wraps in layout transposes (stride-2 convolutions, transposed convolutions), the
             # weight-streaming 2 x 2 ... 8 x 8 tail and the 16 x 16 / 32 x 32 stride-1 layers (measured per layer,
             # tools/conv_layers.py: faster than the vendor kernel + epilogue everywhere except the >= 64 x 64 stride-1

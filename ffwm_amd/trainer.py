@@ -154,8 +154,6 @@ class FFWMTrainer(object):
         # foreach implementation (1275 extra launches per step, measured)
         kw = {"fused": True, "capturable": cap} if self.device.type == "cuda" else {}
         self.world_size = world_size
-        self.side_stream = (torch.cuda.Stream(self.device) if self.device.type == "cuda" and not capturable
-                            and os.environ.get("FFWM_TWO_STREAMS", "0") == "1" else None)
         self.batched_losses = batched_losses
         self._graphs = None
         self._static = None
@@ -285,19 +283,8 @@ class FFWMTrainer(object):
     # ------------------------------------------------------------------ one optimisation step
     def forward(self, b):
         img_S, img_F = b["img_S"], b["img_F"]
-        if self.side_stream is not None:
-            # the two flow nets are independent: flowNetB runs (forward, and with it its backward: autograd replays a node on
-            # the stream its forward ran on) on a second stream, so the dispatch gaps between one net's dependent kernels --
-            # the step spends ~13 ms in them, tools/host_sync_probe.py -- are filled by the other net's kernels
-            cur = torch.cuda.current_stream(self.device)
-            self.side_stream.wait_stream(cur)
-            with torch.cuda.stream(self.side_stream):
-                self.flows_B = self.flowNetB(img_S)
-            flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
-            cur.wait_stream(self.side_stream)
-        else:
-            flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
-            self.flows_B = self.flowNetB(img_S)
+        flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
+        self.flows_B = self.flowNetB(img_S)
         self.img_S_warp, self.img_S_rec = self.warp_many([img_S, img_F], [flow_F128, self.flows_B[0]])
         self.fake32, self.fake64, self.fake128 = self.netG(img_S, flow=[flow_F32, flow_F64, flow_F128])
         self.img_GF128 = self.gf[128](self.fake128, img_F)

@@ -127,3 +127,73 @@ def test_reducer_is_a_noop_without_process_group():
     red.finish()
     assert torch.allclose(net.weight.grad, torch.full((3, 4), 2.0))
     assert red.grad_bytes() == (12 + 4) * 4          # every parameter starts on a 16-byte boundary: the 3-element bias takes 4
+
+
+# ------------------------------------------------------------------------------------------------ 8 ranks (BASELINE configs[3]'s world size)
+def _worker8(rank, world, port, ret):
+    """The reducer at the world size of BASELINE configs[3] (8 ranks, gloo on CPU): buckets go out from the autograd hooks in
+    the order backward completes them (overlap), finish() launches only what got no gradient, every rank ends with the
+    global-batch gradient and -- after ten SGD steps on per-rank data -- bit-identical weights."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ffwm_amd.dp import BucketedGradReducer, broadcast_module_state
+        torch.set_num_threads(1)
+        g, d, unused = _toy(300 + rank)
+        broadcast_module_state([g, d, unused])
+        gparams = list(g.parameters()) + list(unused.parameters())
+        red_g = BucketedGradReducer(gparams, bucket_bytes=512, gather=True)
+        red_d = BucketedGradReducer(d.parameters(), bucket_bytes=64, gather=True)
+        nb = len(red_g.buckets)
+        assert nb >= 3 and len(red_d.buckets) >= 2
+        # buckets holding a never-used parameter cannot complete from the hooks: finish() reduces them
+        dead = [i for i, b in enumerate(red_g.buckets) if any(any(p is q for q in unused.parameters()) for p in b["params"])]
+        live = [i for i in range(nb) if i not in dead]
+        opt = torch.optim.SGD(list(g.parameters()) + list(d.parameters()), lr=0.05)
+        gen = torch.Generator().manual_seed(1000 + rank)
+        for step in range(10):
+            x, y = torch.rand(2, 3, 8, 8, generator=gen), torch.rand(2, 3, 8, 8, generator=gen)
+            fake = g(x)
+            for p in d.parameters():
+                p.requires_grad = True
+            red_d.zero_grad()
+            (0.5 * ((d(fake.detach()) ** 2).mean() + ((d(y) - 1) ** 2).mean())).backward()
+            log_before_finish = list(red_d.launch_log)
+            red_d.finish()
+            assert [w for _, w in log_before_finish] == ["hook"] * len(red_d.buckets), log_before_finish      # all during backward
+            for p in d.parameters():
+                p.requires_grad = False
+            red_g.zero_grad()
+            ((fake - y).abs().mean() + 0.1 * ((d(fake) - 1) ** 2).mean()).backward()
+            before = list(red_g.launch_log)
+            red_g.finish()
+            after = list(red_g.launch_log)
+            # overlap: every bucket whose parameters all get gradients was reduced from a hook, i.e. DURING backward and before
+            # finish(), in the order backward completed them; finish() launches exactly the rest
+            assert sorted(i for i, _ in before) == live and all(w == "hook" for _, w in before), (before, live)
+            assert sorted(i for i, w in after[len(before):]) == dead and all(w == "finish" for _, w in after[len(before):]), after
+            assert len(live) >= 2
+            for p in d.parameters():
+                p.requires_grad = True
+            opt.step()
+        flat = torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())])
+        got = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(got, flat)
+        assert all(torch.equal(t, got[0]) for t in got), "weights diverged across the 8 ranks"
+        times = red_g.time_buckets(reps=1)
+        assert len(times) == nb and all(t["ms"] > 0 for t in times)
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "FAIL: %s\n%s" % (e, traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_reducer_world8_gloo_launch_order_overlap_and_lockstep():
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)

@@ -66,6 +66,67 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _worker8(rank, world, port, ret):
+    """BASELINE configs[3]'s world size as a dry run: 8 gloo ranks sharing this box's GPU, narrow nets (ngf 16), batch 1 per
+    rank.  Asserted per step: the G buckets completed by backward went out from the autograd hooks (overlap) and finish()
+    launched the rest; after ten steps: weights in lock-step (<= 1e-6), and the spectral-norm power-iteration vectors -- which
+    evolve per rank, dp.py -- within 1e-4 of rank 0's (they depend on the weights alone, so identical weights keep them together;
+    BatchNorm running statistics are data-dependent and do differ)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ffwm_amd import trainer
+        torch.backends.cudnn.benchmark = False
+        dev = torch.device("cuda", 0)
+        t = trainer.FFWMTrainer(dev, world_size=world, seed=20 + rank, ngf=16, bucket_bytes=2 << 20)
+        nb = len(t.red_G.buckets)
+        assert t.red_G.world == world and nb >= 4
+
+        def gathered(v):
+            got = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(got, v)
+            return got
+
+        def flat(ts):
+            return torch.cat([p.detach().flatten().float() for p in ts])
+        params = [p for m in (t.flowNetF, t.flowNetB, t.netG, t.netD) for p in m.parameters()]
+        sn_u = [b for m in (t.netG, t.netD) for n, b in m.named_buffers() if n.endswith("weight_u")]
+        assert len(sn_u) >= 50
+        hooked = 0
+        for i in range(10):
+            t.step(trainer.synthetic_batch(1, dev, seed=500 + 10 * i + rank))
+            log = t.red_G.launch_log
+            assert sorted(b for b, _ in log) == list(range(nb)), log            # every bucket reduced exactly once
+            hooked += sum(1 for _, w in log if w == "hook")
+            # the hook launches come first (during backward), finish() only adds what backward could not complete
+            first_finish = next((k for k, (_, w) in enumerate(log) if w == "finish"), len(log))
+            assert all(w == "finish" for _, w in log[first_finish:]), log
+        assert hooked >= 10 * (nb - 2), (hooked, nb)                             # nearly all buckets overlap with backward
+        torch.cuda.synchronize()
+        got = gathered(flat(params))
+        assert all((g - got[0]).abs().max().item() <= 1e-6 for g in got), "weights diverged across the 8 ranks"
+        gu = gathered(flat(sn_u))
+        drift = max((g - gu[0]).abs().max().item() for g in gu)
+        assert drift <= 1e-4, "spectral-norm u drifted by %.3e across ranks" % drift
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "FAIL: %s\n%s" % (e, traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_train_step_eight_ranks_dry_run_on_one_gpu():
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
 def test_dp_train_step_two_ranks_on_one_gpu():
     world = 2
     mgr = mp.Manager()

@@ -157,3 +157,130 @@ def test_ffwm_train_step_batch8_full_size_properties():
         assert abs(a - b) <= 2e-3 * (1 + abs(a)), (k, a, b)
     for p in fast.netG.parameters():
         assert torch.isfinite(p).all()
+
+
+# ------------------------------------------------------------------------------------------------ the product's OWN conv kernels
+def _launch_counts(fn):
+    """run fn with the library's launch profiler on; -> {scope name: launches}"""
+    from ffwm_amd import _lib
+    torch.cuda.synchronize()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        _lib.prof_enable(False)
+    return out, {k: v["launches"] for k, v in _lib.prof_collect().items()}
+
+
+def _route_all(net, monkeypatch):
+    """every route the trainer applies (trainer.py:111-130), with the size gates of the Winograd route lifted so that the
+    small fixture batch takes the hand-written kernels wherever a production batch would"""
+    from ffwm_amd import conv
+    monkeypatch.setattr(conv, "WINOGRAD_MIN_PAIRS", 1)
+    monkeypatch.setattr(conv, "WINOGRAD_MIN_TILES", 64)
+    n_w = conv.route_conv_wgrad(net)
+    n_wino = conv.route_conv_winograd(net)
+    n_fwd = conv.route_conv_fwd(net)
+    return n_w, n_wino, n_fwd
+
+
+def test_ffwm_generator_on_the_routed_conv_kernels_matches_reference_fixture(gold, monkeypatch):
+    """Row a8 DIRECTLY: nets.FFWM(sn=True) with route_conv_wgrad + route_conv_winograd + route_conv_fwd applied -- the
+    Winograd MFMA kernel (csrc/conv_winograd.hip), the direct MFMA kernel (csrc/conv_fwd.hip), the HIP warp and the batched
+    spectral norm -- against the reference module's outputs (`ffwm_eval`, base_networks.py:274-347), <= 1e-4."""
+    from ffwm_amd import nets
+    from ffwm_amd.spectral_norm import fuse_spectral_norm
+    netG = fill.fill_module(nets.FFWM(sn=True)).to(DEV).eval()
+    n_w, n_wino, n_fwd = _route_all(netG, monkeypatch)
+    assert n_wino >= 30 and n_fwd >= 3, (n_w, n_wino, n_fwd)
+    fuse_spectral_norm(netG)
+    img = fill.image(1, 3, 128, 128, "netG_in").to(DEV)
+    flows = [fill.flow_field(1, s, s, "netG_flow%d" % s).to(DEV) for s in (32, 64, 128)]
+
+    def run():
+        with torch.no_grad():
+            return netG(img, flow=flows, return_att=True)
+    (r32, r64, r128, att), launches = _launch_counts(run)
+    # the hand-written kernels really ran: Winograd forward for the 3x3 / stride-1 layers, conv_fwd for e1-e3
+    assert launches.get("conv_winograd_fwd", 0) >= 25, launches
+    assert sum(v for k, v in launches.items() if k.startswith("conv_fwd")) >= 3, launches
+    g = gold["ffwm_eval"]
+    _close(r32, g["rec32"])
+    _close(r64, g["rec64"])
+    _close(_sub(r128, 2), g["rec128_s2"])
+    _close(_sub(att, 8), g["att_s8"])
+    assert abs(r128.double().sum().item() - g["sum128"].item()) < 0.2
+
+
+def test_ffwm_generator_routed_gradients_match_the_vendor_path(monkeypatch):
+    """forward + backward of netG through the routed kernels (Winograd forward / data gradient, MFMA weight gradients, conv_fwd /
+    conv_bwd) against the same network on ATen's convolutions in float64: parameter gradients within 1e-4 of the largest
+    gradient of the tensor, i.e. fp32 rounding."""
+    import copy
+    from ffwm_amd import nets
+    plain = fill.fill_module(nets.FFWM(sn=True)).to(DEV).train()         # (torch's own spectral-norm hooks on all three copies)
+    fast = copy.deepcopy(plain)
+    _route_all(fast, monkeypatch)
+    ref = copy.deepcopy(plain).double()
+    img = fill.image(2, 3, 128, 128, "netG_in").to(DEV)
+    flows = [fill.flow_field(2, s, s, "netG_flow%d" % s).to(DEV) for s in (32, 64, 128)]
+    gos = [fill.wave((2, 3, s, s), "go%d" % s).to(DEV) for s in (32, 64, 128)]
+
+    def grads(net, dt):
+        outs = net(img.to(dt), flow=[f.to(dt) for f in flows])
+        torch.autograd.backward(list(outs), [g.to(dt) for g in gos])
+        return {n: p.grad.detach().double().cpu() for n, p in net.named_parameters() if p.grad is not None}
+    (gf, launches) = _launch_counts(lambda: grads(fast, torch.float32))
+    assert launches.get("conv_winograd_dgrad", 0) >= 20, launches
+    gp, gr = grads(plain, torch.float32), grads(ref, torch.float64)
+    worst = 0.0
+    for n in gr:
+        scale = gr[n].abs().max().item() + 1e-12
+        e_fast = (gf[n] - gr[n]).abs().max().item() / scale
+        e_plain = (gp[n] - gr[n]).abs().max().item() / scale
+        worst = max(worst, e_fast)
+        assert e_fast <= max(1e-4, 3 * e_plain), (n, e_fast, e_plain)
+    assert worst > 0            # the comparison really ran on different code paths
+
+
+def test_folded_flownet4_on_the_conv_fwd_kernel_matches_reference_fixture(gold):
+    """Row a7 DIRECTLY: the launch-lean eval path (BatchNorm folded, bias + LeakyReLU epilogues, HIP flow heads / upsamplers) with
+    EVERY stride-2 / transposed / small-plane convolution on csrc/conv_fwd.hip (channel gate lifted: FlowNet(4) is 4-64
+    channels wide) against the reference module's outputs (`flownet4_eval`, base_networks.py:116-165)."""
+    from ffwm_amd import flownet_eval, nets
+    net = fill.fill_module(nets.FlowNet(4)).to(DEV).eval()
+    lean = flownet_eval.FoldedFlowNet(net, mfma_min_channels=1)
+    x = fill.image(2, 3, 128, 128, "flownet_in").to(DEV)
+    (f128, f64, f32), launches = _launch_counts(lambda: lean(x))
+    assert sum(v for k, v in launches.items() if k.startswith("conv_fwd")) >= 15, launches
+    g = gold["flownet4_eval"]
+    _close(_sub(f128, 2), g["flow128_s2"])
+    _close(f64, g["flow64"])
+    _close(f32, g["flow32"])
+    assert abs(f128.double().sum().item() - g["sum128"].item()) < 5e-2
+
+
+def test_spectral_norm_product_never_keeps_a_stale_winograd_transform(monkeypatch):
+    """a spectral-normalised layer under no_grad hands the Winograd route a fresh plain tensor per forward (version 0,
+    recycled address); its transformed weights must not be cached across an update of weight_orig."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch.nn.utils import spectral_norm
+    from ffwm_amd import conv
+    monkeypatch.setattr(conv, "WINOGRAD_MIN_PAIRS", 1)
+    monkeypatch.setattr(conv, "WINOGRAD_MIN_TILES", 64)
+    torch.manual_seed(0)
+    layer = spectral_norm(nn.Conv2d(64, 64, 3, 1, 1)).to(DEV).eval()
+    conv.route_conv_winograd(layer)
+    assert type(layer) is conv.WinogradConv2d
+    x = torch.randn(2, 64, 32, 32, device=DEV)
+    with torch.no_grad():
+        for it in range(3):
+            y = layer(x)
+            w = layer.weight.detach().clone()
+            ref = F.conv2d(x.double(), w.double(), layer.bias.double(), 1, 1).float()
+            assert (y - ref).abs().max().item() <= 1e-4 * (1 + ref.abs().max().item()), it
+            layer.weight_orig.mul_(1.5).add_(0.01 * torch.randn_like(layer.weight_orig))      # a training update in between
+    assert "_winograd_frozen" not in layer.__dict__ or not layer.__dict__["_winograd_frozen"]

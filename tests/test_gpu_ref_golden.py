@@ -9,8 +9,9 @@
 Tolerances, relative to 1 + max|reference| (north_star: <= 1e-4 max abs diff vs the reference resample2d, fp32):
   forward                 fp32 1e-6          fp64 1e-13
   d_input1 / d_source     fp32 4e-6          fp64 1e-12   (both sides accumulate in a different order)
-  d_input2 / d_flow       fp32 5e-4          fp64 1e-11   (C-channel sums + a quotient-rule difference of O(100)
-                                                           terms at sigma = 0.3: measured 1.5e-4 worst, fp64 2e-13)
+  d_input2 / d_flow       fp32 2e-4          fp64 1e-11   (C-channel sums + a quotient-rule difference of O(100)
+                                                           terms at sigma = 0.3; since round 3 the tap sums over the channels
+                                                           and the quotient rule are accumulated in double, fp64 2e-13)
 """
 import os
 import sys
@@ -28,7 +29,7 @@ DEV = "cuda:0"
 GOLDEN = os.path.join(HERE, "golden", "reference_ops_gfx950.pt")
 FWD = {"f32": 1e-6, "f64": 1e-13}
 G1 = {"f32": 4e-6, "f64": 1e-12}
-G2 = {"f32": 5e-4, "f64": 1e-11}
+G2 = {"f32": 2e-4, "f64": 1e-11}
 
 
 @pytest.fixture(scope="module")
