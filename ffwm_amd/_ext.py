@@ -20,6 +20,19 @@ def get():
     if os.environ.get("FFWM_TORCH_EXT", "1") == "0" or not os.path.exists(EXT_PATH):
         return None
     import torch  # noqa: F401  (libtorch must be loaded first)
+    # a module built from another version of the source / the C ABI header / PyTorch would be called with mismatched signatures:
+    # it is only loaded when its build stamp matches what `build.build_ext` would produce now (else: the ctypes Functions)
+    from . import build
+    try:
+        with open(EXT_PATH + ".digest") as f:
+            stamp = f.read()
+    except OSError:
+        stamp = None
+    if stamp != build.ext_digest():
+        import warnings
+        warnings.warn("ffwm_torch_ext.so is stale (source, header or PyTorch changed since it was built): using the ctypes bindings; "
+                      "rebuild with `python -m ffwm_amd.build`")
+        return None
     from . import _lib
     _lib.load()                               # libffwm_hip.so: fail loudly if the kernels themselves are missing
     spec = importlib.util.spec_from_file_location("ffwm_torch_ext", EXT_PATH)

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libffwm_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -32,6 +32,7 @@ _SIGNATURES = {
     "ffwm_flow_up_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_conv2d_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _i, _i, _i, _i64, _i, ctypes.c_double, _i, ctypes.POINTER(_i), _i, _p],
     "ffwm_conv2d_wgrad": [_p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
+    "ffwm_conv2d_wgrad_tiled": [_p, _p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
     "ffwm_conv3x3_winograd_forward": [_p, _p, _p, _p, _p] + [_i64] * 5 + [_i, _i, ctypes.c_double, _i, _p],
     "ffwm_adam_step": [_p, _p, _p, _p, _i64] + [ctypes.c_double] * 4 + [_i64, _i, _p],
     "ffwm_conv3x3_wgrad": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _p],
@@ -53,6 +54,7 @@ _SIGNATURES = {
     "ffwm_affine_regularization": [_p, _p, _p, _p, _i64, _i64, _i64, _i, ctypes.c_double, _i, _p],
     "ffwm_correlation_colmax": [_p, _p, _p, _i64, _i64, _i64, _i, _p],
     "ffwm_guided_filter_backward": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
+    "ffwm_l1_multi": [_p, _i, _p, _p, _i, _i, _p],          # (array of ffwm_l1_problem, n, out, grad_out, n_slots, dtype, stream)
     "ffwm_prof_enable": [_i],
     "ffwm_prof_collect": [],
     "ffwm_prof_get": [_i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),

@@ -96,6 +96,17 @@ EXT_SRC = os.path.join(HERE, "csrc_ext", "ffwm_torch.cpp")
 EXT_LIB = os.path.join(LIBDIR, "ffwm_torch_ext.so")
 
 
+def ext_digest():
+    """Build stamp of the torch extension: its source, the C ABI header and the PyTorch version it is compiled against."""
+    import torch
+    h = hashlib.sha256()
+    for p in (EXT_SRC, os.path.join(HERE, "..", "include", "ffwm_hip.h")):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    return h.hexdigest()
+
+
 def build_ext(force=False, verbose=False):
     """The C++ autograd bindings (csrc_ext/ffwm_torch.cpp, a pybind11 torch extension linked against libffwm_hip.so):
     g++ against the PyTorch-ROCm headers, in-tree, no GPU needed.  Returns the path of the module."""
@@ -103,12 +114,7 @@ def build_ext(force=False, verbose=False):
     import torch
     build()
     stamp = EXT_LIB + ".digest"
-    h = hashlib.sha256()
-    for p in (EXT_SRC, os.path.join(HERE, "..", "include", "ffwm_hip.h")):
-        with open(p, "rb") as f:
-            h.update(f.read())
-    h.update(torch.__version__.encode())
-    digest = h.hexdigest()
+    digest = ext_digest()
     if not force and os.path.exists(EXT_LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
         return EXT_LIB
     tdir = os.path.dirname(torch.__file__)

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from . import _ext, ops
+from . import ops
 
 
 import os as _os0
@@ -28,6 +28,7 @@ class _Conv3x3MfmaWgrad(Function):
         return torch.ops.aten.convolution(x, weight, bias, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         x, weight = ctx.saved_tensors
         go = grad_output.contiguous()
@@ -56,7 +57,7 @@ def wgrad_route_ok(x, weight):
     W = x.shape[3]
     wide = min(C, K) >= 64 and (W >= 128 or C % 64 != 0 or K % 64 != 0 or _WGRAD_W64)
     rgb = min(C, K) <= 3 and max(C, K) >= 64 and W >= 128          # image <-> features: the packed-tap variant alone
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()
             and W % 64 == 0 and (wide or rgb) and ops.conv3x3_wgrad_supported(x, x))
 
 
@@ -65,11 +66,16 @@ class MfmaWgradConv2d(nn.Conv2d):
 
     def _conv_forward(self, input, weight, bias):
         if torch.is_grad_enabled() and weight.requires_grad and wgrad_route_ok(input, weight):
-            ext = _ext.get()
-            if ext is not None:
-                return ext.conv3x3_mfma_wgrad(input, weight, bias)
             return _Conv3x3MfmaWgrad.apply(input, weight, bias)
+        if (torch.is_grad_enabled() and weight.requires_grad and _tiled_wgrad_layer_ok(self)
+                and input.is_cuda and input.dtype == torch.float32 and not torch.is_autocast_enabled()):
+            return _MfmaConv2d.apply(input, weight, bias, self.stride[0], self.padding[0], False)      # vendor forward, own weight gradient
         return super()._conv_forward(input, weight, bias)
+
+
+def _tiled_wgrad_layer_ok(m):
+    return (_TILED_WGRAD and m.kernel_size in ((3, 3), (4, 4)) and m.stride in ((1, 1), (2, 2)) and m.padding[0] == m.padding[1]
+            and m.padding[0] < m.kernel_size[0] and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros")
 
 
 def eligible(m):
@@ -87,6 +93,51 @@ def route_conv_wgrad(net):
             m.__class__ = MfmaWgradConv2d
             n += 1
     return n
+
+
+# ================================================================================= weight gradients: one chooser for every routed layer
+# Measured per layer of the FFWM train step on an MI355X (tools/bwd_layers.py, profiles/r03_bwd_layers.txt), the whole aten op --
+# NHWC implicit GEMM + its layout transposes and fills -- against the hand-written kernels:
+#   * csrc/conv_wgrad.hip (3x3 / stride 1, 64-pixel rows): 2-5 x the vendor on the 128-pixel layers (wgrad_route_ok);
+#   * csrc/conv_bwd.hip, tiled variant: faster than or level with the vendor on every other 3x3 / 4x4 layer of the step (2-3 x on
+#     FlowNet's 2 x 2 ... 8 x 8 tail and on the thin heads, level on the 256-384 channel layers at 32 x 32), one launch + at most
+#     one memset instead of five to eight launches, and the bias gradient comes out of the same pass;
+#   * left with the vendor: image heads (<= 4 output channels) on large planes, where a 64-row MFMA tile is mostly empty.
+import os as _os1
+_TILED_WGRAD = _os1.environ.get("FFWM_TILED_WGRAD", "1") != "0"
+
+
+def _tiled_wgrad_wins(rows, gathered, kernel):
+    K, P = rows.shape[1], rows.shape[2] * rows.shape[3]
+    if not (_TILED_WGRAD and kernel in (3, 4) and ops.conv2d_wgrad_tiled_ok(rows) and gathered.numel() < (1 << 29)):
+        return False
+    if K <= 4 and (P >= 16384 or (P >= 4096 and gathered.shape[1] >= 128)):
+        return False
+    return True
+
+
+def conv_weight_grad(x, go, weight, stride, pad, need_b):
+    """-> (grad_weight, grad_bias or None) of Conv2d(C, K, k, stride, pad) from its input and grad_output."""
+    k = weight.shape[2]
+    if k == 3 and stride == 1 and pad == 1 and wgrad_route_ok(x, weight):
+        gb = torch.zeros(weight.shape[0], device=go.device, dtype=go.dtype) if need_b else None     # a row sum of the operand the kernel streams anyway
+        return ops.conv3x3_wgrad(x, go, None, gb), gb
+    if _tiled_wgrad_wins(go, x, k) and weight.shape[2] == weight.shape[3]:
+        return ops.conv2d_wgrad_tiled(go, x, k, stride, pad, want_bias=bool(need_b))
+    _, gw, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[0]] if need_b else None, [stride, stride], [pad, pad],
+                                                    [1, 1], False, [0, 0], 1, [False, True, bool(need_b)])
+    return gw, gb
+
+
+def conv_transpose_weight_grad(x, go, weight, need_b):
+    """-> (grad_weight [Ci, Co, 4, 4], grad_bias or None) of ConvTranspose2d(Ci, Co, 4, 2, 1): the same pixel sum as a Conv2d weight
+    gradient with the two tensors' roles swapped."""
+    if _tiled_wgrad_wins(x, go, 4):
+        gw, _ = ops.conv2d_wgrad_tiled(x, go, 4, 2, 1)
+        return gw, (_bias_grad(go) if need_b else None)
+    _, gw, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[1]] if need_b else None, [2, 2], [1, 1], [1, 1], True,
+                                                    [0, 0], 1, [False, True, bool(need_b)])
+    return gw, gb
 
 
 # ================================================================================= Winograd on MFMA (csrc/conv_winograd.hip)
@@ -110,7 +161,8 @@ def _winograd_dir_ok(x, c_red, k_out):
 
 def winograd_dirs(x, weight):
     """(forward, data gradient): which directions of Conv2d(C, K, 3, 1, 1) on this input run on the Winograd kernel."""
-    if not (_WINOGRAD and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4):
+    if not (_WINOGRAD and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+            and not torch.is_autocast_enabled()):          # (under autocast the fp32 kernels stand aside: the vendor path casts)
         return False, False
     K, C = weight.shape[0], weight.shape[1]
     if K <= 4 and C >= 32:
@@ -140,6 +192,7 @@ class _WinogradConv3x3(Function):
         return torch.ops.aten.convolution(x, weight, bias, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         x, weight = ctx.saved_tensors
         go = grad_output.contiguous()
@@ -150,13 +203,7 @@ class _WinogradConv3x3(Function):
         elif need_x:
             gx = torch.ops.aten.convolution_backward(go, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if need_w:
-            if wgrad_route_ok(x, weight):
-                if need_b:       # the bias gradient is a row sum of the operand the MFMA kernel streams anyway
-                    gb = torch.zeros(weight.shape[0], device=go.device, dtype=go.dtype)
-                gw = ops.conv3x3_wgrad(x, go, None, gb)
-            else:
-                _, gw, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[0]] if need_b else None, [1, 1], [1, 1],
-                                                                [1, 1], False, [0, 0], 1, [False, True, bool(need_b)])
+            gw, gb = conv_weight_grad(x, go, weight, 1, 1, need_b)
         if need_b and gb is None:
             gb = _bias_grad(go)
         return gx, gw, gb, None, None
@@ -189,6 +236,7 @@ class _WinogradConvBiasReLU(Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_y):
         weight, y, x = ctx.saved_tensors
         gh = torch.ops.aten.threshold_backward(grad_y.contiguous(), y, 0)
@@ -229,10 +277,7 @@ class WinogradConv2d(MfmaWgradConv2d):
                 return _WinogradConv3x3.apply(input, weight, bias, cache, dirs)
             return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=cache)
         if self.__dict__.get("_mfma_fwd_small") and fwd_route_ok(input, weight) and input.size(2) <= 32:
-            ext = _ext.get()          # small planes: the direct MFMA kernel (route_conv_fwd)
-            if ext is not None:
-                return ext.conv2d(input, weight, bias, 1, 1)
-            return _MfmaConv2d.apply(input, weight, bias, 1, 1)
+            return _MfmaConv2d.apply(input, weight, bias, 1, 1)          # small planes: the direct MFMA kernel (route_conv_fwd)
         return super()._conv_forward(input, weight, bias)
 
 
@@ -274,19 +319,27 @@ def _bias_grad(go):
 # The data / weight gradients of the layers routed to csrc/conv_fwd.hip: the kernels exist and are parity-tested (conv_fwd.hip
 # modes 1-3, conv_bwd.hip), but inside the train step they lose ~1 ms each against the vendor's (A/B in DESIGN.md section 6), so
 # they are opt-in: FFWM_CONV_DGRAD=1 / FFWM_CONV_WGRAD=1.
-_OWN_DGRAD = _os.environ.get("FFWM_CONV_DGRAD", "0") == "1"
-_OWN_WGRAD = _os.environ.get("FFWM_CONV_WGRAD", "0") == "1"
+_OWN_DGRAD = _os.environ.get("FFWM_CONV_DGRAD", "0") == "1"            # stride-2 / every 3x3 stride-1 data gradient on conv_fwd.hip: opt-in (slower)
+_OWN_DGRAD_T = _os.environ.get("FFWM_CONVT_DGRAD", "1") != "0"        # transposed convolutions' data gradient: measured faster, on
 
 
 class _MfmaConv2d(Function):
+    """Conv2d (3x3 / 4x4, stride 1 / 2): forward on csrc/conv_fwd.hip (own_fwd) or the vendor library; backward per direction by
+    measurement (tools/bwd_layers.py): weight gradient through conv_weight_grad, data gradient on csrc/conv_fwd.hip for the
+    3x3 / stride-1 layers on planes of <= 64 pixels (FlowNet's conv5_1 / conv6_1 / inter_conv5 / inter_conv4: 24-48 us against the
+    vendor's 32-53), with the vendor for the stride-2 layers (its NHWC kernel + transposes is still 5-20 us faster than mode 1 / 2)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad):
+    def forward(ctx, x, weight, bias, stride, pad, own_fwd=True):
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, bias is not None)
-        return _conv_fwd_call(x, weight, bias, stride, pad, False)
+        if own_fwd:
+            return _conv_fwd_call(x, weight, bias, stride, pad, False)
+        return torch.ops.aten.convolution(x, weight, bias, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         x, weight = ctx.saved_tensors
         stride, pad, has_bias = ctx.cfg
@@ -295,61 +348,61 @@ class _MfmaConv2d(Function):
         gx = gw = gb = None
         k = weight.size(2)
         even = x.size(2) == 2 * go.size(2) and x.size(3) == 2 * go.size(3)
-        if need_x and _OWN_DGRAD and stride == 2 and pad == 1 and even:
+        if need_x and _OWN_DGRAD and stride == 2 and pad == 1 and even and min(weight.shape[0], weight.shape[1]) >= 32:
             # d(input) of Conv2d(C, K, 4, 2, 1) = ConvTranspose2d(K, C, 4, 2, 1) with the SAME weight tensor [K, C, 4, 4]; of
             # Conv2d(C, K, 3, 2, 1) = the transposed 3x3 (output padding 1): parity classes with 1 or 2 taps per axis
             gx = _conv_fwd_call(go, weight, None, 2, 1, 1 if k == 4 else 2)
             need_x = False
-        elif need_x and _OWN_DGRAD and k == 3 and stride == 1 and pad == 1:
+        elif (need_x and k == 3 and stride == 1 and pad == 1 and min(weight.shape[0], weight.shape[1]) >= 32
+              and (_OWN_DGRAD or x.size(2) * x.size(3) <= 64)):
             gx = _conv_fwd_call(go, weight, None, 1, 1, 3)         # 3x3 / stride-1 convolution of grad_output, weight read rotated
             need_x = False
-        if need_w and _OWN_WGRAD:
-            gw = ops.conv2d_wgrad(go, x, k, stride, pad)
-            need_w = False
-        if need_x or need_w:
-            gx2, gw2, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[0]] if need_b else None, [stride, stride],
-                                                               [pad, pad], [1, 1], False, [0, 0], 1, [bool(need_x), bool(need_w), bool(need_b)])
-            gx = gx2 if need_x else gx
-            gw = gw2 if need_w else gw
-        elif need_b:
+        if need_w:
+            gw, gb = conv_weight_grad(x, go, weight, stride, pad, need_b)
+        if need_x:
+            gx = torch.ops.aten.convolution_backward(go, x, weight, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if need_b and gb is None:
             gb = _bias_grad(go)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 class _MfmaConvTranspose2d(Function):
+    """ConvTranspose2d(Ci, Co, 4, 2, 1): forward on csrc/conv_fwd.hip (own_fwd) or the vendor library; data gradient = Conv2d(Co, Ci,
+    4, 2, 1) with the same weight tensor on csrc/conv_fwd.hip (20-38 us against the vendor's 25-58 on every deconv of FlowNet);
+    weight gradient through conv_transpose_weight_grad."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, own_fwd=True):
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _conv_fwd_call(x, weight, bias, 2, 1, True)
+        if own_fwd:
+            return _conv_fwd_call(x, weight, bias, 2, 1, True)
+        return torch.ops.aten.convolution(x, weight, bias, [2, 2], [1, 1], [1, 1], True, [0, 0], 1)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         x, weight = ctx.saved_tensors
         go = grad_output.contiguous()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         gx = gw = gb = None
-        if need_x and _OWN_DGRAD:
+        if need_x and _OWN_DGRAD_T and min(weight.shape[0], weight.shape[1]) >= 16:
             # d(input) of ConvTranspose2d(C, K, 4, 2, 1) = Conv2d(K, C, 4, 2, 1) with the same weight tensor [C, K, 4, 4]
             gx = _conv_fwd_call(go, weight, None, 2, 1, False)
             need_x = False
-        if need_w and _OWN_WGRAD:
-            # d(weight): the same pixel sum as a Conv2d weight gradient with the two tensors' roles swapped
-            gw = ops.conv2d_wgrad(x, go, 4, 2, 1)
-            need_w = False
-        if need_x or need_w:
-            gx2, gw2, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[1]] if need_b else None, [2, 2], [1, 1], [1, 1],
-                                                               True, [0, 0], 1, [bool(need_x), bool(need_w), bool(need_b)])
-            gx = gx2 if need_x else gx
-            gw = gw2 if need_w else gw
-        elif need_b:
+        if need_w:
+            gw, gb = conv_transpose_weight_grad(x, go, weight, need_b)
+        if need_x:
+            gx = torch.ops.aten.convolution_backward(go, x, weight, None, [2, 2], [1, 1], [1, 1], True, [0, 0], 1, [True, False, False])[0]
+        if need_b and gb is None:
             gb = _bias_grad(go)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def fwd_route_ok(x, weight):
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()
             and x.numel() < (1 << 29) and weight.numel() < (1 << 29))
 
 
@@ -358,9 +411,6 @@ class MfmaFwdConv2d(nn.Conv2d):
 
     def _conv_forward(self, input, weight, bias):
         if fwd_route_ok(input, weight) and (self.stride[0] == 2 or input.size(2) <= 32):
-            ext = _ext.get()
-            if ext is not None:
-                return ext.conv2d(input, weight, bias, self.stride[0], self.padding[0])
             return _MfmaConv2d.apply(input, weight, bias, self.stride[0], self.padding[0])
         return super()._conv_forward(input, weight, bias)
 
@@ -370,9 +420,6 @@ class MfmaFwdConvTranspose2d(nn.ConvTranspose2d):
 
     def forward(self, input, output_size=None):
         if output_size is None and fwd_route_ok(input, self.weight):
-            ext = _ext.get()
-            if ext is not None:
-                return ext.conv_transpose2d(input, self.weight, self.bias)
             return _MfmaConvTranspose2d.apply(input, self.weight, self.bias)
         return super().forward(input, output_size)
 
@@ -410,5 +457,41 @@ def route_conv_fwd(net):
                 m._mfma_fwd_small = True          # its small-plane calls (winograd_ok false)
             else:
                 m.__class__ = MfmaFwdConv2d if isinstance(m, nn.Conv2d) else MfmaFwdConvTranspose2d
+            n += 1
+    return n
+
+
+# ================================================================================= the rest: vendor forward, own backward
+# What none of the routes above takes -- FlowNet's thin decoder layers (18 / 34 channels), its seven two-channel flow heads and six
+# 2 -> 2 flow upsamplers, netD's image layers -- keeps the vendor's forward (launch-bound either way) but gets its weight gradient
+# from the tiled kernel: the vendor's path is an NHWC implicit GEMM behind two or three layout transposes and a fill per call.
+class OwnBwdConv2d(nn.Conv2d):
+    def _conv_forward(self, input, weight, bias):
+        if (torch.is_grad_enabled() and weight.requires_grad and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+                and not torch.is_autocast_enabled()):
+            return _MfmaConv2d.apply(input, weight, bias, self.stride[0], self.padding[0], False)
+        return super()._conv_forward(input, weight, bias)
+
+
+class OwnBwdConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, input, output_size=None):
+        if (output_size is None and torch.is_grad_enabled() and self.weight.requires_grad and input.is_cuda
+                and input.dtype == torch.float32 and input.dim() == 4 and not torch.is_autocast_enabled()):
+            return _MfmaConvTranspose2d.apply(input, self.weight, self.bias, False)
+        return super().forward(input, output_size)
+
+
+def route_conv_bwd(net):
+    """Re-class every convolution no other route has taken whose weight gradient the tiled kernel serves; returns the number."""
+    n = 0
+    if not _TILED_WGRAD:
+        return n
+    for m in net.modules():
+        if type(m) is nn.Conv2d and _tiled_wgrad_layer_ok(m):
+            m.__class__ = OwnBwdConv2d
+            n += 1
+        elif (type(m) is nn.ConvTranspose2d and m.kernel_size == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1)
+              and m.output_padding == (0, 0) and m.dilation == (1, 1) and m.groups == 1):
+            m.__class__ = OwnBwdConvTranspose2d
             n += 1
     return n

@@ -130,162 +130,6 @@ struct Mfm : public torch::autograd::Function<Mfm> {
     }
 };
 
-// ---------------------------------------------------------------- MFMA convolution forward  (conv.py, flownet_eval.conv_mfma)
-// y = conv(x, w) [+ bias]; a layer with few output pixels is cut along its reduction and finished by the bias pass.
-// mode: 0 conv, 1 ConvTranspose2d(4, 2, 1), 2 / 3: d(input) of Conv2d(3, 2, 1) / Conv2d(3, 1, 1) (x = grad_output)
-Tensor conv_fwd_raw(const Tensor& x, const Tensor& w, const Tensor& bias, int64_t stride, int64_t pad, int mode) {
-    const c10::DeviceGuard guard(x.device());
-    const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
-    const int64_t k = w.size(2);
-    const bool parity = mode == 1 || mode == 2;
-    const int64_t K = mode == 0 ? w.size(0) : w.size(1);
-    const int64_t Ho = parity ? 2 * H : (mode == 3 ? H : (H + 2 * pad - k) / stride + 1);
-    const int64_t Wo = parity ? 2 * W : (mode == 3 ? W : (W + 2 * pad - k) / stride + 1);
-    const bool small = B * Ho * Wo * ((K + 63) / 64) * (parity ? 1 : 4) < 256 * 64 * 4;
-    Tensor y = small ? torch::zeros({B, K, Ho, Wo}, x.options()) : torch::empty({B, K, Ho, Wo}, x.options());
-    int flag = 0;
-    check(ffwm_conv2d_forward(x.data_ptr(), w.data_ptr(), cptr(bias), y.data_ptr(), B, C, H, W, K, static_cast<int>(k),
-                              static_cast<int>(stride), static_cast<int>(pad), mode, K * Ho * Wo, 0, 0.0, small ? 1 : 0,
-                              &flag, FFWM_F32, stream_of(x)), "ffwm_conv2d_forward");
-    if (flag && has(bias))
-        check(ffwm_bias_act_forward(y.data_ptr(), bias.data_ptr(), y.data_ptr(), nullptr, B, K, Ho * Wo, K * Ho * Wo, 0, 0, 0.0, FFWM_F32,
-                                    stream_of(x)), "ffwm_bias_act_forward");
-    return y;
-}
-
-// Which parts of the routed convolutions' backward run on the hand-written kernels (the rest goes to ATen / MIOpen):
-// FFWM_CONV_DGRAD / FFWM_CONV_WGRAD = 1 | 0, read once.
-bool env_flag(const char* name, bool dflt) {
-    const char* v = std::getenv(name);
-    return v ? (v[0] == '1') : dflt;
-}
-bool use_dgrad() { static const bool v = env_flag("FFWM_CONV_DGRAD", false); return v; }
-bool use_wgrad() { static const bool v = env_flag("FFWM_CONV_WGRAD", false); return v; }
-
-// grad_weight [K, C, k, k] (rows = grad_output, gathered = input) or, for the transposed convolution, [Ci, Co, 4, 4]
-Tensor wgrad_raw(const Tensor& rows, const Tensor& gathered, int64_t k, int64_t stride, int64_t pad) {
-    const c10::DeviceGuard guard(rows.device());
-    Tensor gw = torch::zeros({rows.size(1), gathered.size(1), k, k}, rows.options());
-    check(ffwm_conv2d_wgrad(rows.data_ptr(), gathered.data_ptr(), gw.data_ptr(), rows.size(0), rows.size(1), rows.size(2), rows.size(3),
-                            gathered.size(1), gathered.size(2), gathered.size(3), static_cast<int>(k), static_cast<int>(stride),
-                            static_cast<int>(pad), FFWM_F32, stream_of(rows)), "ffwm_conv2d_wgrad");
-    return gw;
-}
-
-struct MfmaConv2d : public torch::autograd::Function<MfmaConv2d> {
-    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& weight, const Tensor& bias, int64_t stride, int64_t pad) {
-        Tensor xc = x.contiguous(), wc = weight.contiguous();
-        ctx->save_for_backward({xc, wc});
-        ctx->saved_data["stride"] = stride;
-        ctx->saved_data["pad"] = pad;
-        ctx->saved_data["has_bias"] = has(bias);
-        return conv_fwd_raw(xc, wc, bias, stride, pad, 0);
-    }
-    static variable_list backward(AutogradContext* ctx, variable_list grads) {
-        auto saved = ctx->get_saved_variables();
-        const Tensor &x = saved[0], &weight = saved[1];
-        const int64_t stride = ctx->saved_data["stride"].toInt(), pad = ctx->saved_data["pad"].toInt();
-        const bool has_bias = ctx->saved_data["has_bias"].toBool();
-        Tensor go = grads[0].contiguous();
-        bool need_x = ctx->needs_input_grad(0);
-        const bool need_w = ctx->needs_input_grad(1), need_b = has_bias && ctx->needs_input_grad(2);
-        Tensor gx, gxa, gw, gb;
-        const int64_t k = weight.size(2);
-        const bool even = x.size(2) == 2 * go.size(2) && x.size(3) == 2 * go.size(3);
-        const Tensor none = torch::empty({0}, go.options());
-        if (need_x && use_dgrad() && stride == 2 && pad == 1 && even) {
-            // d(input) of Conv2d(C, K, 4, 2, 1) = ConvTranspose2d(K, C, 4, 2, 1) with the SAME weight tensor; of Conv2d(C, K, 3, 2, 1)
-            // = the transposed 3x3 with output padding 1 (parity classes with 1 or 2 taps per axis)
-            gx = conv_fwd_raw(go, weight, none, 2, 1, k == 4 ? 1 : 2);
-            need_x = false;
-        } else if (need_x && use_dgrad() && k == 3 && stride == 1 && pad == 1) {
-            gx = conv_fwd_raw(go, weight, none, 1, 1, 3);
-            need_x = false;
-        }
-        bool aten_w = false;
-        if (need_w && use_wgrad()) gw = wgrad_raw(go, x, k, stride, pad);
-        else aten_w = need_w;
-        if (need_b) gb = go.sum(std::vector<int64_t>{0, 2, 3});
-        if (need_x || aten_w) {
-            Tensor gw2, gb2;
-            std::tie(gxa, gw2, gb2) = at::convolution_backward(go, x, weight, c10::nullopt, {stride, stride}, {pad, pad}, {1, 1}, false,
-                                                               {0, 0}, 1, {need_x, aten_w, false});
-            if (aten_w) gw = gw2;
-        }
-        return {gx.defined() ? gx : gxa, gw, gb, Tensor(), Tensor()};
-    }
-};
-
-struct MfmaConvTranspose2d : public torch::autograd::Function<MfmaConvTranspose2d> {
-    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& weight, const Tensor& bias) {
-        Tensor xc = x.contiguous(), wc = weight.contiguous();
-        ctx->save_for_backward({xc, wc});
-        ctx->saved_data["has_bias"] = has(bias);
-        return conv_fwd_raw(xc, wc, bias, 2, 1, 1);
-    }
-    static variable_list backward(AutogradContext* ctx, variable_list grads) {
-        auto saved = ctx->get_saved_variables();
-        const Tensor &x = saved[0], &weight = saved[1];
-        const bool has_bias = ctx->saved_data["has_bias"].toBool();
-        Tensor go = grads[0].contiguous();
-        const bool need_w = ctx->needs_input_grad(1), need_b = has_bias && ctx->needs_input_grad(2);
-        Tensor gx, gw, gb;
-        // d(input) of ConvTranspose2d(C, K, 4, 2, 1) = Conv2d(K, C, 4, 2, 1) with the same weight tensor [C, K, 4, 4]
-        bool aten_x = false, aten_w = false;
-        if (ctx->needs_input_grad(0) && use_dgrad()) gx = conv_fwd_raw(go, weight, torch::empty({0}, go.options()), 2, 1, 0);
-        else aten_x = ctx->needs_input_grad(0);
-        // d(weight): a Conv2d weight gradient with the two tensors' roles swapped (rows = input, gathered = grad_output)
-        if (need_w && use_wgrad()) gw = wgrad_raw(x, go, 4, 2, 1);
-        else aten_w = need_w;
-        if (need_b) gb = go.sum(std::vector<int64_t>{0, 2, 3});
-        if (aten_x || aten_w) {
-            Tensor gx2, gw2, gb2;
-            std::tie(gx2, gw2, gb2) = at::convolution_backward(go, x, weight, c10::nullopt, {2, 2}, {1, 1}, {1, 1}, true, {0, 0}, 1,
-                                                               {aten_x, aten_w, false});
-            if (aten_x) gx = gx2;
-            if (aten_w) gw = gw2;
-        }
-        return {gx, gw, gb};
-    }
-};
-
-// ---------------------------------------------------------------- conv2d (3x3 / s1 / p1) with the MFMA weight gradient  (conv.py)
-struct Conv3x3MfmaWgrad : public torch::autograd::Function<Conv3x3MfmaWgrad> {
-    static Tensor forward(AutogradContext* ctx, const Tensor& x, const Tensor& weight, const Tensor& bias) {
-        ctx->save_for_backward({x, weight});
-        ctx->saved_data["has_bias"] = has(bias);
-        return at::convolution(x, weight, has(bias) ? c10::optional<Tensor>(bias) : c10::nullopt, {1, 1}, {1, 1}, {1, 1}, false, {0, 0}, 1);
-    }
-    static variable_list backward(AutogradContext* ctx, variable_list grads) {
-        auto saved = ctx->get_saved_variables();
-        const Tensor &x = saved[0], &weight = saved[1];
-        const bool has_bias = ctx->saved_data["has_bias"].toBool();
-        Tensor go = grads[0].contiguous();
-        const bool need_x = ctx->needs_input_grad(0), need_w = ctx->needs_input_grad(1), need_b = has_bias && ctx->needs_input_grad(2);
-        Tensor gx, gw, gb;
-        if (need_w) {
-            const c10::DeviceGuard guard(x.device());
-            Tensor xc = x.contiguous();
-            const int64_t B = xc.size(0), C = xc.size(1), H = xc.size(2), W = xc.size(3), K = go.size(1);
-            gw = torch::zeros({K, C, 3, 3}, xc.options());
-            if (need_b) gb = torch::zeros({K}, xc.options());
-            check(ffwm_conv3x3_wgrad(xc.data_ptr(), go.data_ptr(), gw.data_ptr(), mptr(gb), B, C, K, H, W, FFWM_F32, stream_of(xc)),
-                  "ffwm_conv3x3_wgrad");
-        }
-        if (need_x || (need_b && !gb.defined())) {
-            const bool nb = need_b && !gb.defined();
-            c10::optional<c10::IntArrayRef> bias_sizes;
-            std::vector<int64_t> bs{weight.size(0)};
-            if (nb) bias_sizes = c10::IntArrayRef(bs);
-            Tensor gw2, gb2;
-            std::tie(gx, gw2, gb2) = at::convolution_backward(go, x, weight, bias_sizes, {1, 1}, {1, 1}, {1, 1}, false, {0, 0}, 1,
-                                                              {need_x, false, nb});
-            if (nb) gb = gb2;
-        }
-        return {gx, gw, gb};
-    }
-};
-
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -296,13 +140,4 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     });
     m.def("bias_relu", [](const Tensor& h, const Tensor& bias) { return BiasRelu::apply(h, bias); });
     m.def("mfm", [](const Tensor& x, const c10::optional<Tensor>& bias) { return Mfm::apply(x, opt(bias, x)); });
-    m.def("conv2d", [](const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, int64_t stride, int64_t pad) {
-        return MfmaConv2d::apply(x, w, opt(bias, x), stride, pad);
-    });
-    m.def("conv_transpose2d", [](const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias) {
-        return MfmaConvTranspose2d::apply(x, w, opt(bias, x));
-    });
-    m.def("conv3x3_mfma_wgrad", [](const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias) {
-        return Conv3x3MfmaWgrad::apply(x, w, opt(bias, x));
-    });
 }

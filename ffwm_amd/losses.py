@@ -209,3 +209,44 @@ class PerceptualCorrectness(nn.Module):
             return torch.mean(loss_map) - e1
         norm_mask = F.interpolate(norm_mask, size=(h, w)).reshape(-1, h * w)
         return (torch.sum(norm_mask * loss_map) - e1) / (torch.sum(norm_mask) + self.eps)
+
+
+# ================================================================================= fused L1 terms (csrc/l1_loss.hip)
+class _L1Terms(torch.autograd.Function):
+    """out[n_slots] = sum over the terms of weight * mean |x m - y m| (models/ffwm_model.py:107-139: the pixel, perceptual, illumination
+    and identity terms of backward_G), ONE launch forward and ONE backward for all terms instead of 5-7 element-wise / reduction
+    launches per term and direction.  y and the masks are data / detached features in every term of the reference: no gradient."""
+
+    @staticmethod
+    def forward(ctx, n_slots, meta, *xs):
+        from . import ops
+        xs = [x.contiguous() for x in xs]
+        terms = []
+        for x, (y, m, segments) in zip(xs, meta):
+            row = x.numel() // max(x.shape[0], 1)
+            terms.append((x, y.contiguous(), None if m is None else m.contiguous(),
+                          [(x0, y0, rows, w / float(max(rows * row, 1)), slot) for (x0, y0, rows, w, slot) in segments]))
+        ctx.terms = terms
+        return ops.l1_multi_forward(terms, n_slots)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        from . import ops
+        grads = ops.l1_multi_backward(ctx.terms, grad_out, ctx.needs_input_grad[2:])
+        return (None, None) + tuple(grads)
+
+
+def l1_terms(terms, n_slots):
+    """terms: [(x, y, mask or None, weight, slot)] or [(x, y, mask, [(x_row0, y_row0, rows, weight, slot), ...])] -> vector [n_slots]:
+    out[slot] = sum of weight * F.l1_loss(x[rows] * mask, y[rows] * mask) over the terms / segments routed to that slot."""
+    xs, meta = [], []
+    for t in terms:
+        if len(t) == 5:
+            x, y, m, w, slot = t
+            segments = [(0, 0, x.shape[0], float(w), int(slot))]
+        else:
+            x, y, m, segments = t
+        xs.append(x)
+        meta.append((y, m, segments))
+    return _L1Terms.apply(n_slots, meta, *xs)

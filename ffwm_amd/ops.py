@@ -443,6 +443,31 @@ def conv2d_wgrad(rows, gathered, kernel, stride, pad, grad_weight=None):
     return grad_weight
 
 
+def conv2d_wgrad_tiled_ok(rows):
+    """Shapes the tiled weight-gradient kernel takes: a plane of a multiple of 4 pixels, 16-byte aligned float32 rows."""
+    return (rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 4 and (rows.shape[2] * rows.shape[3]) % 4 == 0
+            and rows.data_ptr() % 16 == 0 and rows.numel() < (1 << 29))
+
+
+def conv2d_wgrad_tiled(rows, gathered, kernel, stride, pad, want_bias=False):
+    """-> (grad_weight, grad_bias or None) of Conv2d (rows = grad_output, gathered = input: [K, C, k, k]; grad_bias = the row sums)
+    or grad_weight [Ci, Co, 4, 4] of ConvTranspose2d(4, 2, 1) (rows = input, gathered = grad_output; no bias) on the tiled kernel of
+    csrc/conv_bwd.hip.  Both results are slices of ONE fresh buffer (the library clears it with one memset when it has to)."""
+    _check("conv2d_wgrad_tiled", rows, gathered)
+    B, K, Ho, Wo = rows.shape
+    Bg, C, H, W = gathered.shape
+    if Bg != B:
+        raise ValueError("conv2d_wgrad_tiled: batch sizes differ")
+    n = K * C * kernel * kernel
+    buf = rows.new_empty((n + (K if want_bias else 0),))
+    gw = buf[:n].view(K, C, kernel, kernel)
+    gb = buf[n:] if want_bias else None
+    with _on_device(rows) as stream:
+        _lib.check(_lib.load().ffwm_conv2d_wgrad_tiled(_ptr(rows), _ptr(gathered), _ptr(gw), _ptr(gb), B, K, Ho, Wo, C, H, W, int(kernel),
+                                                       int(stride), int(pad), _dtype_code(rows), stream), "ffwm_conv2d_wgrad_tiled")
+    return gw, gb
+
+
 def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0, out=None, frozen=None):
     """Conv2d(C, K, 3, 1, 1) forward (weight [K, C, 3, 3]) or its data gradient (x = grad_output [B, K_layer, H, W], weight =
     the layer's own [K_layer, C_layer, 3, 3]; returns [B, C_layer, H, W]) by fp32 Winograd F(2x2, 3x3) on the MFMA units
@@ -545,3 +570,68 @@ def bias_relu_forward(h, bias, out=None):
             _lib.check(_lib.load().ffwm_bias_relu_forward(_ptr(h), _ptr(bias), _ptr(y), B, C, HW, _lib.F32, stream),
                        "ffwm_bias_relu_forward")
     return y
+
+
+# ---------------------------------------------------------------- fused L1 terms (csrc/l1_loss.hip)
+class _L1Problem(ctypes.Structure):            # include/ffwm_hip.h: ffwm_l1_problem
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("grad_x", ctypes.c_void_p),
+                ("n", ctypes.c_int64), ("chw", ctypes.c_int64), ("hw", ctypes.c_int64), ("scale", ctypes.c_double),
+                ("slot", ctypes.c_int)]
+
+
+def _l1_table(terms, grads=None):
+    """terms: [(x, y, mask or None, segments)], segments = [(x_row0, y_row0, rows, scale, slot)]: rows x_row0 .. x_row0 + rows of x
+    against rows y_row0 .. of y (and of the mask, indexed like x).  One kernel problem per segment."""
+    segs = []
+    for i, (x, y, m, segments) in enumerate(terms):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous() and y.dtype == x.dtype
+                and y.shape[1:] == x.shape[1:]):
+            raise ValueError("l1_multi: term %d needs contiguous float32 GPU tensors with equal trailing shapes" % i)
+        row = x.numel() // max(x.shape[0], 1)
+        if m is not None:
+            if not (m.is_contiguous() and m.dtype == x.dtype and m.dim() == x.dim() and m.shape[0] == x.shape[0]
+                    and m.shape[2:] == x.shape[2:] and m.shape[1] in (1, x.shape[1])):
+                raise ValueError("l1_multi: term %d: the mask must be [B, 1 or C, ...] over x" % i)
+            mrow = m.numel() // m.shape[0]
+        for (x0, y0, rows, scale, slot) in segments:
+            if x0 < 0 or y0 < 0 or x0 + rows > x.shape[0] or y0 + rows > y.shape[0]:
+                raise ValueError("l1_multi: term %d: segment outside the tensors" % i)
+            segs.append((x.data_ptr() + 4 * x0 * row, y.data_ptr() + 4 * y0 * row, None if m is None else m.data_ptr() + 4 * x0 * mrow,
+                         None if grads is None or grads[i] is None else grads[i].data_ptr() + 4 * x0 * row,
+                         rows * row, row if m is not None else 1, mrow if m is not None else 1, float(scale), int(slot)))
+    arr = (_L1Problem * len(segs))()
+    for a, sg in zip(arr, segs):
+        a.x, a.y, a.mask, a.grad_x, a.n, a.chw, a.hw, a.scale, a.slot = sg
+    return arr, len(segs)
+
+
+def l1_multi_forward(terms, n_slots):
+    """terms as in _l1_table -> out[n_slots] with out[slot] = sum over the segments of scale * sum |x m - y m| (one launch)."""
+    out = torch.zeros(n_slots, device=terms[0][0].device, dtype=torch.float32)
+    arr, n = _l1_table(terms)
+    with _on_device(terms[0][0]) as stream:
+        _lib.check(_lib.load().ffwm_l1_multi(ctypes.cast(arr, ctypes.c_void_p), n, _ptr(out), None, n_slots, _lib.F32, stream),
+                   "ffwm_l1_multi")
+    return out
+
+
+def l1_multi_backward(terms, grad_out, need):
+    """-> [grad_x or None per term]: grad_out[slot] * scale * sign(x m - y m) * m (one launch for all terms)."""
+    sel = [i for i, nd in enumerate(need) if nd]
+    if not sel:
+        return [None] * len(terms)
+    # rows no segment covers get no gradient: such a tensor starts from zeros
+    grads = []
+    for i in sel:
+        x, segments = terms[i][0], terms[i][3]
+        covered = sum(r for (_, _, r, _, _) in segments) == x.shape[0] and len({s0 for (s0, _, _, _, _) in segments}) == len(segments)
+        grads.append(torch.empty_like(x) if covered else torch.zeros_like(x))
+    arr, n = _l1_table([terms[i] for i in sel], grads)
+    go = grad_out.contiguous()
+    with _on_device(go) as stream:
+        _lib.check(_lib.load().ffwm_l1_multi(ctypes.cast(arr, ctypes.c_void_p), n, None, _ptr(go), go.numel(), _lib.F32, stream),
+                   "ffwm_l1_multi")
+    out = [None] * len(terms)
+    for i, g in zip(sel, grads):
+        out[i] = g
+    return out

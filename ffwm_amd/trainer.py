@@ -78,7 +78,7 @@ def part_grids(lm_F, torch15_integer_division=False):
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
                  warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True,
-                 mfma_wgrad=None, flat_adam=None, fused_bn=None, mfma_fwd=None):
+                 mfma_wgrad=None, flat_adam=None, fused_bn=None, mfma_fwd=None, fused_l1=None):
         self.device = torch.device(device)
         self.titers = titers
         torch.manual_seed(seed)
@@ -128,6 +128,11 @@ class FFWMTrainer(object):
             # hand-written MFMA kernel instead of the vendor's NHWC implicit GEMM + layout transposes (conv.py)
             from .conv import route_conv_fwd
             self.mfma_fwd_layers = sum(route_conv_fwd(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD))
+        self.own_bwd_layers = 0
+        if mfma_fwd and self.device.type == "cuda":
+            # what is left (thin layers, flow heads / upsamplers, image layers): vendor forward, weight gradient on the tiled kernel
+            from .conv import route_conv_bwd
+            self.own_bwd_layers = sum(route_conv_bwd(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD))
         if fused_bn is None:
             fused_bn = self.device.type == "cuda"
         if fused_bn:
@@ -155,6 +160,8 @@ class FFWMTrainer(object):
         kw = {"fused": True, "capturable": cap} if self.device.type == "cuda" else {}
         self.world_size = world_size
         self.batched_losses = batched_losses
+        # the ~25 L1 terms of backward_G as one launch per direction (losses.l1_terms, csrc/l1_loss.hip); needs the batched passes
+        self.fused_l1 = (self.device.type == "cuda" and batched_losses) if fused_l1 is None else bool(fused_l1)
         self._graphs = None
         self._static = None
         # eager steps pack the gradients into the flat arrays after backward (no per-parameter accumulation kernel);
@@ -299,7 +306,69 @@ class FFWMTrainer(object):
         self.loss_D = (self.lsgan(fake, False) + self.lsgan(real, True)) * 0.5
         self.loss_D.backward()
 
+    def _backward_G_fused_l1(self, b):
+        """backward_G with every `w * F.l1_loss(x * m, y * m)` term (pixel, perceptual, part crops, illumination, identity:
+        ffwm_model.py:107-139) handed to ONE fused launch per direction; the networks see exactly the inputs they see in
+        backward_G below.  Slots of the result vector: l1, prc, fc, illu, iden."""
+        from .losses import l1_terms
+        img_F, mask_F = b["img_F"], b["mask_F"]
+        img_F64 = F.interpolate(img_F, (64, 64), mode="bilinear")
+        img_F32 = F.interpolate(img_F, (32, 32), mode="bilinear")
+        mask64 = F.interpolate(mask_F, (64, 64), mode="nearest")
+        mask32 = F.interpolate(mask_F, (32, 32), mode="nearest")
+        if self.titers < 20000:
+            gf128, gf64, gf32 = self.fake128, self.fake64, self.fake32
+        else:
+            gf128 = self.img_GF128
+            gf64 = self.gf[64](self.fake64, img_F64)
+            gf32 = self.gf[32](self.fake32, img_F32)
+        L1, PRC, FC, ILLU, IDEN = range(5)
+        B = img_F.size(0)
+        terms = [(gf128, img_F, mask_F, 5.0, L1), (gf64, img_F64, mask64, 5.0, L1), (gf32, img_F32, mask32, 7.5, L1)]
+        # perceptual: the two large scales one VGG pass each, the 32 x 32 scale and the four part crops share one (5 B rows)
+        for x, y, m in ((gf128, img_F, mask_F), (gf64, img_F64, mask64)):
+            fx = self.vgg(x * m)
+            with torch.no_grad():
+                fy = self.vgg(y * m)
+            terms += [(fx[k], fy[k], None, w, PRC) for k, w in zip(PRC_LAYERS, PRC_WEIGHTS)]
+        (el, elt), (er, ert), (no, nog), (mo, mog) = self.parts
+        fx = self.vgg(torch.cat((gf32 * mask32, el, er, mo, no), 0))
+        with torch.no_grad():
+            fy = self.vgg(torch.cat((img_F32 * mask32, elt, ert, mog, nog), 0))
+        for k, w in zip(PRC_LAYERS, PRC_WEIGHTS):
+            terms.append((fx[k], fy[k], None, [(0, 0, B, 1.5 * w, PRC), (B, B, B, 2 * w, FC), (2 * B, 2 * B, B, 2 * w, FC),
+                                               (3 * B, 3 * B, B, w, FC), (4 * B, 4 * B, B, w, FC)]))
+        # illumination (MSL1Loss): the three generated scales warped back with flowNetB (one multi-problem launch)
+        warped = self.warp_many([self.fake128, self.fake64, self.fake32], list(self.flows_B))
+        for w, flow, back in zip((1, 1, 1.5), self.flows_B, warped):
+            size = flow.shape[2:]
+            tgt = F.interpolate(b["img_S"], size, mode="bilinear", align_corners=True)
+            m = F.interpolate(b["mask_S"], size, mode="nearest")
+            terms.append((back, tgt, m, 15.0 * w, ILLU))
+        # identity: ground-truth features once; an output that appears twice (warm-up branch: gf128 IS fake128) runs once
+        uniq, wsum = [], []
+        for o, w in zip((self.fake128, gf128), (0.5, 1.0)):
+            for i, u in enumerate(uniq):
+                if u is o:
+                    wsum[i] += w
+                    break
+            else:
+                uniq.append(o)
+                wsum.append(w)
+        with torch.no_grad():
+            _, fc_g, pool_g = self.lightCNN(img_F.mean(1, keepdim=True))
+        _, fc_o, pool_o = self.lightCNN(torch.cat([u.mean(1, keepdim=True) for u in uniq], 0))
+        terms.append((fc_o, fc_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
+        terms.append((pool_o, pool_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
+        v = l1_terms(terms, 5)
+        loss_adv = self.lsgan(self.netD(self.img_GF128 * mask_F), True) * 0.1
+        self.loss_G = v.sum() + loss_adv
+        self.losses = {"G": self.loss_G, "l1": v[L1], "iden": v[IDEN], "illu": v[ILLU], "adv": loss_adv, "prc": v[PRC], "fc": v[FC]}
+        self.loss_G.backward()
+
     def backward_G(self, b):
+        if self.fused_l1 and self.parts[0][0].shape[2:] == (32, 32):
+            return self._backward_G_fused_l1(b)
         img_F, mask_F = b["img_F"], b["mask_F"]
         img_F64 = F.interpolate(img_F, (64, 64), mode="bilinear")
         img_F32 = F.interpolate(img_F, (32, 32), mode="bilinear")

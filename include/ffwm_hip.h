@@ -25,6 +25,8 @@
  *   ffwm_mfm_*                      <- mfm.forward (split + max)        lightcnn/light_cnn.py
  *   ffwm_bias_relu_forward          <- conv bias add + nn.ReLU of VGG19  models/losses.py:398-519
  *   ffwm_adam_step                  <- torch.optim.Adam.step            models/ffwm_model.py:46-49,151-160
+ *   ffwm_l1_multi                   <- the w * F.l1_loss(x * m, y * m) terms of backward_G   models/ffwm_model.py:107-139
+ *   ffwm_conv2d_wgrad[_tiled]       <- convolution_backward grad_weight of the stride-2 / transposed / small-plane convs
  *
  * Conventions
  *   - dtype: FFWM_F32 or FFWM_F64 (the reference dispatches AT_DISPATCH_FLOATING_TYPES).
@@ -51,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FFWM_ABI_VERSION 1
+#define FFWM_ABI_VERSION 2
 
 typedef enum {
     FFWM_OK = 0,
@@ -142,6 +144,24 @@ typedef struct ffwm_warp_problem {
 } ffwm_warp_problem;
 int ffwm_warp_multi_forward(const ffwm_warp_problem* problems, int n, int flipcat, int dtype, void* stream);
 int ffwm_warp_multi_backward(const ffwm_warp_problem* problems, int n, int flipcat, int dtype, void* stream);
+
+/* ---- the L1 terms of the generator loss in one launch (csrc/l1_loss.hip) ------------------------
+ * models/ffwm_model.py:107-139 (backward_G) sums ~25 terms  w * F.l1_loss(x * m, y * m)  -- pixel loss :112-115, PerceptualLoss
+ * (models/losses.py:293-320), MSL1Loss (:130-157), IdentityLoss (:76-112).  A problem is one term:
+ *     out[slot] += scale * sum_i | x[i] * m[mi] - y[i] * m[mi] |      (scale = w / numel; mask NULL: m = 1)
+ * with the mask broadcast over the channels: x [B, C, H, W] (n = B*chw elements, chw = C*H*W), mask [B, 1, H, W] (hw = H*W).
+ * Forward (grad_out NULL): out[n_slots] is accumulated into (zero-fill it).  Backward (grad_out[n_slots] given):
+ * grad_x = grad_out[slot] * scale * sign(x m - y m) * m is written for every problem (y is data: no gradient). */
+typedef struct ffwm_l1_problem {
+    const void* x;
+    const void* y;
+    const void* mask;       /* may be NULL */
+    void* grad_x;           /* backward only */
+    int64_t n, chw, hw;
+    double scale;
+    int slot;
+} ffwm_l1_problem;
+int ffwm_l1_multi(const ffwm_l1_problem* problems, int n, void* out, const void* grad_out, int n_slots, int dtype, void* stream);
 
 /* ---- batched spectral normalisation of conv weights (netG / netD) -----------------------------
  * Replaces the per-layer hook of torch.nn.utils.spectral_norm that the reference wraps around every
@@ -325,6 +345,15 @@ int ffwm_conv2d_forward(const void* input, const void* weight, const void* bias,
  * slices of the reduction are added atomically. */
 int ffwm_conv2d_wgrad(const void* rows, const void* gathered, void* grad_weight, int64_t B, int64_t K, int64_t Ho, int64_t Wo,
                       int64_t C, int64_t H, int64_t W, int kernel, int stride, int pad, int dtype, void* stream);
+
+/* The same weight gradient on the tiled kernel (128 x 128 tiles of grad_weight, pixels linearised over the batch, one barrier per
+ * 32 pixels; csrc/conv_bwd.hip "tiled variant"): grad_weight is OVERWRITTEN -- the library zero-fills it itself when the pixel
+ * range is cut into slices that meet by atomics -- and grad_bias[K] (NULL: not wanted; Conv2d only: the sum of `rows` over batch
+ * and pixels = convolution_backward's grad_bias) comes out of the same pass.  Needs Ho * Wo % 4 == 0 and a 16-byte aligned `rows`
+ * (status FFWM_ERR_ARG otherwise: use ffwm_conv2d_wgrad). */
+int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, void* grad_weight, void* grad_bias, int64_t B, int64_t K,
+                            int64_t Ho, int64_t Wo, int64_t C, int64_t H, int64_t W, int kernel, int stride, int pad, int dtype,
+                            void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2, 3x3) on the fp32 MFMA units (csrc/conv_winograd.hip): the
  * forward (data_gradient = 0: weight [K, C, 3, 3]) or the data gradient (data_gradient = 1: input = grad_output with C =

@@ -58,24 +58,3 @@ def test_bias_relu_and_mfm(ext):
     x, b2 = torch.randn(4, 96, 16, 16, generator=g).to(DEV), torch.randn(96, generator=g).to(DEV)
     _pair(ext.mfm, MaxFeatureMapFunction.apply, [x, b2])
     _pair(lambda x_: ext.mfm(x_, None), lambda x_: MaxFeatureMapFunction.apply(x_, None), [x])
-
-
-@pytest.mark.parametrize("case", [(3, 40, 32, 64, 3, 2, 1), (2, 64, 16, 128, 4, 2, 1), (6, 96, 8, 96, 3, 1, 1), (6, 512, 4, 256, 3, 1, 1)])
-def test_conv2d_and_conv_transpose2d(ext, case):
-    B, C, H, K, k, s, p = case
-    g = _g(3)
-    x = torch.randn(B, C, H, H, generator=g).to(DEV)
-    w = (torch.randn(K, C, k, k, generator=g) / (C * k * k) ** 0.5).to(DEV)
-    b = torch.randn(K, generator=g).to(DEV)
-    _pair(lambda x_, w_, b_: ext.conv2d(x_, w_, b_, s, p), lambda x_, w_, b_: F.conv2d(x_, w_, b_, s, p), [x, w, b], tol=1e-4)
-    if k == 4:
-        wt = (torch.randn(C, K, 4, 4, generator=g) / (C * 16) ** 0.5).to(DEV)
-        _pair(ext.conv_transpose2d, lambda x_, w_, b_: F.conv_transpose2d(x_, w_, b_, 2, 1), [x, wt, b], tol=1e-4)
-
-
-def test_conv3x3_mfma_wgrad(ext):
-    g = _g(4)
-    x = torch.randn(2, 67, 8, 64, generator=g).to(DEV)
-    w = (torch.randn(70, 67, 3, 3, generator=g) * 0.05).to(DEV)
-    b = torch.randn(70, generator=g).to(DEV)
-    _pair(ext.conv3x3_mfma_wgrad, lambda x_, w_, b_: F.conv2d(x_, w_, b_, 1, 1), [x, w, b], tol=1e-4)

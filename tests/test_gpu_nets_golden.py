@@ -226,7 +226,7 @@ def test_ffwm_generator_routed_gradients_match_the_vendor_path(monkeypatch):
     ref = copy.deepcopy(plain).double()
     img = fill.image(2, 3, 128, 128, "netG_in").to(DEV)
     flows = [fill.flow_field(2, s, s, "netG_flow%d" % s).to(DEV) for s in (32, 64, 128)]
-    gos = [fill.wave((2, 3, s, s), "go%d" % s).to(DEV) for s in (32, 64, 128)]
+    gos = [fill.image(2, 3, s, s, "go%d" % s).to(DEV) for s in (32, 64, 128)]       # in [0, 1]: sums over the pixels do not cancel
 
     def grads(net, dt):
         outs = net(img.to(dt), flow=[f.to(dt) for f in flows])
@@ -235,14 +235,21 @@ def test_ffwm_generator_routed_gradients_match_the_vendor_path(monkeypatch):
     (gf, launches) = _launch_counts(lambda: grads(fast, torch.float32))
     assert launches.get("conv_winograd_dgrad", 0) >= 20, launches
     gp, gr = grads(plain, torch.float32), grads(ref, torch.float64)
-    worst = 0.0
+    worst, checked = 0.0, 0
+    typical = sorted(v.abs().max().item() for v in gr.values())[len(gr) // 2]
     for n in gr:
-        scale = gr[n].abs().max().item() + 1e-12
+        scale = gr[n].abs().max().item()
+        if scale < 1e-6 * typical:
+            # the bias of a convolution in front of a training-mode BatchNorm: its exact gradient is ZERO (the batch mean is
+            # subtracted again), float64 leaves 1e-17, fp32 rounding noise -- nothing to compare but the size of the noise
+            assert gf[n].abs().max().item() <= 1e-3 * typical, (n, gf[n].abs().max().item(), typical)
+            continue
         e_fast = (gf[n] - gr[n]).abs().max().item() / scale
         e_plain = (gp[n] - gr[n]).abs().max().item() / scale
         worst = max(worst, e_fast)
+        checked += 1
         assert e_fast <= max(1e-4, 3 * e_plain), (n, e_fast, e_plain)
-    assert worst > 0            # the comparison really ran on different code paths
+    assert worst > 0 and checked >= 100            # the comparison really ran, on different code paths
 
 
 def test_folded_flownet4_on_the_conv_fwd_kernel_matches_reference_fixture(gold):

@@ -1417,9 +1417,7 @@ def test_conv_forward_routing_matches_aten_autograd(own_backward, monkeypatch):
     import torch.nn as nn
     from ffwm_amd import conv
     if own_backward:
-        monkeypatch.setattr(conv, "_OWN_DGRAD", True)
-        monkeypatch.setattr(conv, "_OWN_WGRAD", True)
-        monkeypatch.setattr(conv._ext, "get", lambda: None)       # the Python autograd functions (the C++ ones read the env once)
+        monkeypatch.setattr(conv, "_OWN_DGRAD", True)              # every data gradient on conv_fwd.hip (the default keeps the stride-2 ones with the vendor)
     torch.manual_seed(7)
     ref = nn.Sequential(nn.Conv2d(40, 64, 3, 2, 1), nn.LeakyReLU(0.2), nn.Conv2d(64, 96, 4, 2, 1), nn.LeakyReLU(0.2),
                         nn.Conv2d(96, 96, 3, 1, 1), nn.LeakyReLU(0.2), nn.ConvTranspose2d(96, 48, 4, 2, 1), nn.LeakyReLU(0.2),
@@ -1461,6 +1459,40 @@ def test_conv2d_wgrad_generic_matches_aten(case):
     else:
         dw = ops.conv2d_wgrad(go.to(DEV), x.to(DEV), k, stride, pad)
     ref = wd.grad
+    assert (dw.cpu().double() - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item()) * (B * y.size(2) * y.size(3)) ** 0.5
+
+
+@pytest.mark.parametrize("case", [
+    # (B, C, H, W, K, kernel, stride, pad, transposed)
+    (2, 3, 16, 16, 8, 3, 2, 1, False), (8, 64, 128, 128, 64, 3, 2, 1, False), (8, 512, 4, 4, 1024, 3, 2, 1, False),
+    (8, 1026, 4, 4, 512, 3, 1, 1, False), (3, 70, 10, 12, 130, 3, 1, 1, False), (2, 64, 32, 32, 128, 4, 2, 1, False),
+    (8, 1024, 2, 2, 512, 4, 2, 1, True), (8, 66, 32, 32, 32, 4, 2, 1, True), (2, 5, 6, 10, 3, 4, 2, 1, True),
+    (8, 1024, 2, 2, 1024, 3, 1, 1, False), (8, 18, 128, 128, 16, 3, 1, 1, False), (8, 16, 128, 128, 2, 3, 1, 1, False),
+    (5, 130, 12, 20, 66, 3, 1, 1, False), (8, 64, 64, 64, 128, 3, 1, 1, False), (8, 2, 16, 16, 2, 4, 2, 1, True),
+    (8, 256, 32, 32, 256, 3, 1, 1, False), (8, 128, 32, 32, 256, 4, 2, 1, False),
+])
+def test_conv2d_wgrad_tiled_matches_aten(case):
+    """csrc/conv_bwd.hip, tiled variant, against ATen's float64 convolution_backward: Conv2d (with the fused bias gradient) and
+    ConvTranspose2d weight gradients -- FlowNet's 2 x 2 ... 8 x 8 tail, odd channel counts, thin heads, sliced and unsliced launches."""
+    from ffwm_amd import ops
+    B, C, H, W, K, k, stride, pad, transposed = case
+    g = _gen(sum(case[:5]) + 2)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(*((C, K, k, k) if transposed else (K, C, k, k)), generator=g) * 0.05
+    bias = torch.randn(K, generator=g)
+    conv = F.conv_transpose2d if transposed else F.conv2d
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    y = conv(xd, wd, bd, stride, pad)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go.double())
+    if transposed:
+        dw, db = ops.conv2d_wgrad_tiled(x.to(DEV), go.to(DEV), k, stride, pad)        # rows = input, gathered = grad_output
+        assert db is None
+    else:
+        dw, db = ops.conv2d_wgrad_tiled(go.to(DEV), x.to(DEV), k, stride, pad, want_bias=True)
+        assert (db.cpu().double() - bd.grad).abs().max().item() <= 2e-5 * (1 + bd.grad.abs().max().item()) * (B * y.size(2) * y.size(3)) ** 0.5
+    ref = wd.grad
+    assert dw.shape == ref.shape
     assert (dw.cpu().double() - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item()) * (B * y.size(2) * y.size(3)) ** 0.5
 
 
@@ -1563,3 +1595,39 @@ def test_vgg_winograd_bias_relu_matches_the_module_path(monkeypatch):
     sum(f.square().mean() for f in fb.values()).backward()
     assert (xa.grad.cpu().double() - xb.grad).abs().max().item() <= 1e-4 * (1 + xb.grad.abs().max().item())
     assert any(k[0] == 1 for c in caches for k in c)          # ... and the data-gradient transforms after the backward
+
+
+# ------------------------------------------------------------------------------------------------ fused L1 terms (csrc/l1_loss.hip)
+def test_l1_terms_match_torch_forward_and_backward():
+    """losses.l1_terms against the w * F.l1_loss(x * m, y * m) sums it replaces (models/ffwm_model.py:107-139): masks broadcast
+    over the channels, row segments with their own weight / slot / partner rows, odd sizes (scalar path), a tensor used twice."""
+    from ffwm_amd.losses import l1_terms
+    g = _gen(77)
+    B = 3
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g).to(DEV)
+    x1, y1, m1 = rnd(B, 3, 16, 16).requires_grad_(True), rnd(B, 3, 16, 16), (torch.rand(B, 1, 16, 16, generator=g) > 0.4).float().to(DEV)
+    x2, y2 = rnd(5 * B, 8, 4, 4).requires_grad_(True), rnd(5 * B, 8, 4, 4)
+    x3, y3 = rnd(2 * B, 7).requires_grad_(True), rnd(B, 7)                      # 7 elements per row: the scalar path
+    x4, y4, m4 = rnd(B, 5, 6, 10).requires_grad_(True), rnd(B, 5, 6, 10), torch.rand(B, 1, 6, 10, generator=g).to(DEV)   # H*W % 4 != 0
+    x5, y5 = rnd(2 * B, 4, 8, 8).requires_grad_(True), rnd(2 * B, 4, 8, 8)      # only the first half takes part: zero gradient behind it
+    terms = [(x1, y1, m1, 5.0, 0), (x2, y2, None, [(0, 0, B, 1.5, 1), (B, B, B, 2.0, 2), (2 * B, 2 * B, B, 2.0, 2), (3 * B, 3 * B, B, 1.0, 2),
+                                                   (4 * B, 4 * B, B, 1.0, 2)]),
+             (x3, y3, None, [(0, 0, B, 0.5, 3), (B, 0, B, 1.0, 3)]), (x4, y4, m4, 0.25, 0), (x5, y5, None, [(0, 0, B, 1.0, 3)]),
+             (x1, y1, None, 0.125, 1)]
+    out = l1_terms(terms, 4)
+    L = torch.nn.functional.l1_loss
+    ref = [5.0 * L(x1 * m1, y1 * m1) + 0.25 * L(x4 * m4, y4 * m4),
+           1.5 * L(x2[:B], y2[:B]) + 0.125 * L(x1, y1),
+           2.0 * (L(x2[B:2 * B], y2[B:2 * B]) + L(x2[2 * B:3 * B], y2[2 * B:3 * B])) + L(x2[3 * B:4 * B], y2[3 * B:4 * B]) + L(x2[4 * B:], y2[4 * B:]),
+           0.5 * L(x3[:B], y3) + L(x3[B:], y3) + L(x5[:B], y5[:B])]
+    for a, b in zip(out, ref):
+        assert abs(float(a) - float(b)) <= 2e-6 * (1 + abs(float(b))), (float(a), float(b))
+    w = torch.tensor([0.7, -1.3, 2.0, 0.4], device=DEV)
+    xs = [x1, x2, x3, x4, x5]
+    ga = torch.autograd.grad((out * w).sum(), xs)
+    gb = torch.autograd.grad(sum(r * wi for r, wi in zip(ref, w)), xs)
+    for a, b in zip(ga, gb):
+        assert (a - b).abs().max().item() <= 1e-6 * (1 + b.abs().max().item())
+    assert float(ga[4][B:].abs().max()) == 0.0
