@@ -602,7 +602,7 @@ rs_bwd2_kernel(const T* __restrict__ in1, const T* __restrict__ in2, const T* __
 // per (channel, tap) in two passes).  The quotient rule (:252-328) is linear in the 4*HALF^2 accumulators, so channel
 // slabs (used when the tiles alone do not fill the chip) combine by atomically adding their partial results.
 //
-// rs_bwd1_tile_kernel (d_input1): the box is an ACCUMULATOR in LDS (double cells, 4 channels interleaved: ds_add_f64
+// rs_bwd1_tile_kernel (d_input1): the box is an ACCUMULATOR in LDS (double cells, one plane per channel of a group of 4: ds_add_f64
 // retires a wave in ~9 clk, ds_add_f32 in ~190 -- tools/ubench/atomics.hip).  Every pixel adds its 4*HALF^2 normalised
 // weights x 4 channel gradients into the box in UNCLAMPED coordinates; after the group's pixels the box is folded onto
 // the clamped image and every non-zero cell goes to grad_input1 with ONE global atomic (~1.8 per pixel and channel
@@ -849,7 +849,10 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
     constexpr int BOXH = TH + 12;
     constexpr int NCELL = BOXH * kRsBoxW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* box = reinterpret_cast<double*>(smem_raw);          // [NCELL][4]
+    // [4][NCELL]: one PLANE per channel of the group.  (Round 2 interleaved the four channels of a cell: a wave's 64 lanes then sat
+    // 32 bytes apart and used 16 of the 64 LDS banks -- an 8-way bank conflict on every ds_add_f64.  Planar, neighbouring lanes are
+    // 8 bytes apart: the 64 lanes of a smooth flow cover all banks twice, the minimum for 512 bytes.)
+    double* box = reinterpret_cast<double*>(smem_raw);
     __shared__ int red[4][NW];
     __shared__ int flag;
 
@@ -930,7 +933,7 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
     if (use_lds) {
         int lbase[RPT];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) lbase[r] = ((v0[r] - vmin) * kRsBoxW + (u0[r] - umin)) * 4;
+        for (int r = 0; r < RPT; ++r) lbase[r] = (v0[r] - vmin) * kRsBoxW + (u0[r] - umin);
         for (int c = c0; c < c1; c += 4) {
             for (int i = threadIdx.x; i < NCELL * 2; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
             __syncthreads();
@@ -950,11 +953,11 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 #pragma unroll
                     for (int pc = 0; pc < NT; ++pc) {
                         const float wq = wn[r][pr * NT + pc];
-                        double* cell = nb + (pr * kRsBoxW + pc) * 4;
-                        lds_add(cell + 0, wq * gx);
-                        lds_add(cell + 1, wq * gy);
-                        lds_add(cell + 2, wq * gz);
-                        lds_add(cell + 3, wq * gw);
+                        double* cell = nb + (pr * kRsBoxW + pc);
+                        lds_add(cell, wq * gx);
+                        lds_add(cell + NCELL, wq * gy);
+                        lds_add(cell + 2 * NCELL, wq * gz);
+                        lds_add(cell + 3 * NCELL, wq * gw);
                     }
             }
             __syncthreads();
@@ -965,10 +968,9 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
                 if (cc >= bw) continue;
                 const int gy = min(max(vmin + r, 0), Hi - 1), gx = min(max(umin + cc, 0), Wi - 1);
                 float* dst = dp + static_cast<size_t>(c - c0) * iplane + static_cast<size_t>(gy) * Wi + gx;
-                const double* cell = box + static_cast<size_t>(i) * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = static_cast<float>(cell[q]);
+                    const float v = static_cast<float>(box[q * NCELL + i]);
                     if (q < nch && v != 0.f) atomic_add(dst + static_cast<size_t>(q) * iplane, v);
                 }
             }

@@ -89,7 +89,30 @@ __device__ __forceinline__ void warp_fwd_body(const T* __restrict__ feat, const 
     const unsigned o_flip = static_cast<unsigned>(y * W + (W - 1 - x)) * static_cast<unsigned>(sizeof(T));
     const size_t flip_planes = static_cast<size_t>(C) * plane;
 
-    for (int c = c0; c < c1; ++c, fp += iplane, op += plane) {
+    // four channels per trip: their sixteen gathers are all in flight before the first product is formed (one channel per trip
+    // left the memory pipeline with four loads per thread between waits)
+    constexpr int U = 4;
+    int c = c0;
+    for (; c + U <= c1; c += U, fp += U * iplane, op += U * plane) {
+        T s[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const rsrc_t rf = make_rsrc(fp + u * iplane, ibytes);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[u][q] = buf_ld<T>(rf, cn.off[q]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            T v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v += s[u][q] * cn.w[q];
+            ElemRow<T, 1> r;
+            r.v[0] = v;
+            buf_store_row<T, 1>(make_rsrc(op + u * plane, obytes), o_direct, r);
+            if (FLIP) buf_store_row<T, 1>(make_rsrc(op + u * plane + flip_planes, obytes), o_flip, r);
+        }
+    }
+    for (; c < c1; ++c, fp += iplane, op += plane) {
         const rsrc_t rf = make_rsrc(fp, ibytes);
         T v = 0;
 #pragma unroll
@@ -389,7 +412,36 @@ __device__ __forceinline__ void warp_bwd_body(const T* __restrict__ feat, const 
     const size_t flip_planes = static_cast<size_t>(C) * plane;
     T gix = 0, giy = 0;
 
-    for (int c = c0; c < c1; ++c, fp += iplane, op += plane) {
+    auto one = [&](const T g, const T s0, const T s1, const T s2, const T s3) {
+        // ATen grid_sampler_2d_backward; invalid corners read 0 and drop out.
+        gix -= s0 * cn.dyw[0] * g;
+        giy -= s0 * cn.dxw[0] * g;
+        gix += s1 * cn.dyw[0] * g;
+        giy -= s1 * cn.dxw[1] * g;
+        gix -= s2 * cn.dyw[1] * g;
+        giy += s2 * cn.dxw[0] * g;
+        gix += s3 * cn.dyw[1] * g;
+        giy += s3 * cn.dxw[1] * g;
+    };
+    int c = c0;
+    if (!gp && gflow) {
+        // d(flow) alone (the plane / tile kernels took d(feat)): four channels per trip, their 24 loads in flight together
+        constexpr int U = 4;
+        for (; c + U <= c1; c += U, fp += U * iplane, op += U * plane) {
+            T g[U], s[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                g[u] = buf_ld<T>(make_rsrc(op + u * plane, obytes), o_direct);
+                if (FLIP) g[u] += buf_ld<T>(make_rsrc(op + u * plane + flip_planes, obytes), o_flip);
+                const rsrc_t rf = make_rsrc(fp + u * iplane, ibytes);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[u][q] = buf_ld<T>(rf, cn.off[q]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) one(g[u], s[u][0], s[u][1], s[u][2], s[u][3]);
+        }
+    }
+    for (; c < c1; ++c, fp += iplane, op += plane) {
         T g = buf_ld<T>(make_rsrc(op, obytes), o_direct);
         if (FLIP) g += buf_ld<T>(make_rsrc(op + flip_planes, obytes), o_flip);
         if (gp) {
@@ -402,15 +454,7 @@ __device__ __forceinline__ void warp_bwd_body(const T* __restrict__ feat, const 
             const rsrc_t rf = make_rsrc(fp, ibytes);
             const T s0 = buf_ld<T>(rf, cn.off[0]), s1 = buf_ld<T>(rf, cn.off[1]);
             const T s2 = buf_ld<T>(rf, cn.off[2]), s3 = buf_ld<T>(rf, cn.off[3]);
-            // ATen grid_sampler_2d_backward; invalid corners read 0 and drop out.
-            gix -= s0 * cn.dyw[0] * g;
-            giy -= s0 * cn.dxw[0] * g;
-            gix += s1 * cn.dyw[0] * g;
-            giy -= s1 * cn.dxw[1] * g;
-            gix -= s2 * cn.dyw[1] * g;
-            giy += s2 * cn.dxw[0] * g;
-            gix += s3 * cn.dyw[1] * g;
-            giy += s3 * cn.dxw[1] * g;
+            one(g, s0, s1, s2, s3);
         }
     }
     if (gflow) {
@@ -523,6 +567,150 @@ warp_bwd_feat_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gou
             const T v = static_cast<T>(acc[i]);
             if (v != 0) atomic_add(dst + i, v);
         }
+    }
+}
+
+// d(feat) for planes BEYOND LDS (Hi * Wi > 20480 cells) when the warp keeps the resolution (Hi == H, Wi == W) and the
+// flow is a displaced identity grid -- what a flow net produces: OWNED TILES, no global atomics on the hot path.
+//   * A 512-thread block owns a 56 x 56 tile of grad_feat for CG channels at a time (LDS accumulators, DOUBLE: ds_add_f64
+//     ~9 clk per wave) and visits the 64 x 64 output pixels of the tile grown by a halo of 4 (a wave per pixel row, eight
+//     rows per wave); the four corners of a pixel are formed ONCE and kept in registers for all channels.  A corner is
+//     added iff its cell lies in the block's own tile -- the neighbouring blocks visit the same halo pixels and keep what
+//     is theirs (x1.31 pixel visits, the re-read grad_output rows come from L2).  The finished tile goes to grad_feat with
+//     plain coalesced read-modify-write rows.
+//   * warp_bwd_feat_far_kernel is the exact complement: a (pixel, corner) pair whose pixel lies OUTSIDE the 64 x 64 region
+//     of the tile that owns the corner's cell (displacement beyond the halo) is scattered with global atomics over all
+//     channels.  For a flow net's field it only reads the flow.
+// Together they replace 4 contended global atomics per pixel and channel (3.2 ms at [32,64,256,256]: 9 % of the HBM peak).
+constexpr int kWtThreads = 512;
+constexpr int kWtWaves = kWtThreads / kWave;
+constexpr int kWtHalo = 4;
+constexpr int kWtRegion = 64;                       // visited pixels per side
+constexpr int kWtTile = kWtRegion - 2 * kWtHalo;    // owned cells per side: 56
+constexpr int kWtRows = kWtRegion / kWtWaves;       // pixel rows per wave: 8
+
+template <bool FLIP, int CG>
+__global__ void __launch_bounds__(kWtThreads)
+warp_bwd_feat_tile_kernel(const float* __restrict__ flow, const float* __restrict__ gout, float* __restrict__ gfeat, int C, int H,
+                          int W, int ntx, int nty, int groups_per_slab, int cslabs) {
+    __shared__ double acc[CG * kWtTile * kWtTile];
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, 1);
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int X0 = tx * kWtTile, Y0 = ty * kWtTile;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int x = X0 - kWtHalo + lane;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fl = flow + static_cast<size_t>(b) * 2 * plane;
+
+    // corners of this lane's eight pixels: cell index inside the own tile (or -1) and weight per corner
+    int cell[kWtRows][4];
+    float wgt[kWtRows][4];
+    unsigned poff[kWtRows], moff[kWtRows];           // byte offsets of the pixel and of its mirror in a grad_output plane (OOB: none)
+#pragma unroll
+    for (int r = 0; r < kWtRows; ++r) {
+        const int y = Y0 - kWtHalo + wave + r * kWtWaves;
+        const bool pin = x >= 0 && x < W && y >= 0 && y < H;
+        poff[r] = pin ? static_cast<unsigned>(y * W + x) * 4u : kOob;
+        moff[r] = pin ? static_cast<unsigned>(y * W + (W - 1 - x)) * 4u : kOob;
+        Corners<float> cn;
+        const size_t fo = static_cast<size_t>(pin ? y : 0) * W + (pin ? x : 0);
+        make_corners<float>(cn, fl[fo], fl[plane + fo], H, W);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = static_cast<int>(cn.off[q] / 4u);          // cy * W + cx when valid
+            const int cy = ci / W, cx = ci - cy * W;
+            const bool mine = pin && cn.valid[q] && cx >= X0 && cx < X0 + kWtTile && cy >= Y0 && cy < Y0 + kWtTile;
+            cell[r][q] = mine ? (cy - Y0) * kWtTile + (cx - X0) : -1;
+            wgt[r][q] = cn.w[q];
+        }
+    }
+    for (int i = threadIdx.x; i < CG * kWtTile * kWtTile; i += kWtThreads) acc[i] = 0.0;
+    __syncthreads();
+
+    const int Co = FLIP ? 2 * C : C;
+    const unsigned obytes = static_cast<unsigned>(plane * 4u);
+    for (int gi = 0; gi < groups_per_slab; ++gi) {
+        const int c0 = (slab * groups_per_slab + gi) * CG;
+        if (c0 >= C) break;
+        const float* g0 = gout + (static_cast<size_t>(b) * Co + c0) * plane;
+        float g[kWtRows][CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const unsigned nb = c0 + c < C ? obytes : 0u;            // a channel past C reads zeros
+            const rsrc_t rd = make_rsrc(g0 + static_cast<size_t>(c) * plane, nb);
+            const rsrc_t rm = make_rsrc(g0 + (static_cast<size_t>(C) + c) * plane, FLIP ? nb : 0u);
+#pragma unroll
+            for (int r = 0; r < kWtRows; ++r) {
+                g[r][c] = buf_ld<float>(rd, poff[r]);
+                if (FLIP) g[r][c] += buf_ld<float>(rm, moff[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kWtRows; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (cell[r][q] >= 0) {
+#pragma unroll
+                    for (int c = 0; c < CG; ++c)
+                        __hip_atomic_fetch_add(acc + c * kWtTile * kWtTile + cell[r][q], static_cast<double>(wgt[r][q] * g[r][c]),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+        __syncthreads();
+        // flush the own tile: coalesced rows of 56 cells, plain read-modify-write (every cell has exactly one owner)
+        for (int i = threadIdx.x; i < CG * kWtTile * kWtTile; i += kWtThreads) {
+            const int c = i / (kWtTile * kWtTile), rem = i - c * kWtTile * kWtTile;
+            const int cy = Y0 + rem / kWtTile, cx = X0 + rem % kWtTile;
+            const double v = acc[i];
+            acc[i] = 0.0;
+            if (c0 + c < C && cx < W && cy < H) {
+                float* d = gfeat + (static_cast<size_t>(b) * C + c0 + c) * plane + static_cast<size_t>(cy) * W + cx;
+                *d += static_cast<float>(v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_bwd_feat_far_kernel(const float* __restrict__ flow, const float* __restrict__ gout, float* __restrict__ gfeat, int C, int H, int W,
+                         int tiles_x, int tiles_y) {
+    unsigned t = blockIdx.x;
+    const int txb = t % tiles_x;
+    t /= tiles_x;
+    const int tyb = t % tiles_y;
+    const int b = t / tiles_y;
+    const int x = txb * kTileX + (threadIdx.x & (kTileX - 1)), y = tyb * kTileY + threadIdx.x / kTileX;
+    if (x >= W || y >= H) return;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const size_t fo = static_cast<size_t>(y) * W + x;
+    Corners<float> cn;
+    make_corners<float>(cn, flow[static_cast<size_t>(b) * 2 * plane + fo], flow[static_cast<size_t>(b) * 2 * plane + plane + fo], H, W);
+    bool far[4];
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ci = static_cast<int>(cn.off[q] / 4u);
+        const int cy = ci / W, cx = ci - cy * W;
+        const int rx0 = (cx / kWtTile) * kWtTile - kWtHalo, ry0 = (cy / kWtTile) * kWtTile - kWtHalo;      // region of the cell's owner
+        far[q] = cn.valid[q] && !(x >= rx0 && x < rx0 + kWtRegion && y >= ry0 && y < ry0 + kWtRegion);
+        any = any || far[q];
+    }
+    if (!any) return;
+    const int Co = FLIP ? 2 * C : C;
+    const float* g0 = gout + static_cast<size_t>(b) * Co * plane;
+    float* gp = gfeat + static_cast<size_t>(b) * C * plane;
+    for (int c = 0; c < C; ++c) {
+        float g = g0[static_cast<size_t>(c) * plane + fo];
+        if (FLIP) g += g0[(static_cast<size_t>(C) + c) * plane + static_cast<size_t>(y) * W + (W - 1 - x)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (far[q]) atomic_add_off(gp + static_cast<size_t>(c) * plane, cn.off[q], cn.w[q] * g);
     }
 }
 
@@ -641,6 +829,35 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
         if (int rc = check_launch("ffwm_warp_backward(feat)")) return rc;
         if (!gflow) return FFWM_OK;
         gfeat = nullptr;   // the pixel-major kernel below now only produces d(flow)
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (gfeat && Hi == H && Wi == W && options().scatter_variant != 1) {
+            // planes beyond LDS, resolution kept: owned tiles + the far complement (no contended global atomics)
+            constexpr int CG = 2;
+            const int ntx = static_cast<int>((W + kWtTile - 1) / kWtTile), nty = static_cast<int>((H + kWtTile - 1) / kWtTile);
+            const int groups = static_cast<int>((C + CG - 1) / CG);
+            int gps = groups;                                       // channel groups per block: split until >= 3 blocks per CU
+            while (gps > 1 && B * ntx * nty * ((groups + gps - 1) / gps) < 768) gps = (gps + 1) / 2;
+            const int cslabs = (groups + gps - 1) / gps;
+            {
+                LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat_far" : "warp_bwd_feat_far", Hi), st, sizeof(T) * static_cast<double>(B) * 2.0 * H * W);
+                const int fx = static_cast<int>((W + kTileX - 1) / kTileX), fy = static_cast<int>((H + kTileY - 1) / kTileY);
+                const unsigned fgrid = static_cast<unsigned>(B * fx * fy);
+                if (flip) hipLaunchKernelGGL((warp_bwd_feat_far_kernel<true>), dim3(fgrid), dim3(kBlock), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, fx, fy);
+                else hipLaunchKernelGGL((warp_bwd_feat_far_kernel<false>), dim3(fgrid), dim3(kBlock), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, fx, fy);
+            }
+            if (int rc = check_launch("ffwm_warp_backward(feat, far)")) return rc;
+            {
+                LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat_tile" : "warp_bwd_feat_tile", Hi), st,
+                               sizeof(T) * static_cast<double>(B) * (2.0 * C * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
+                const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
+                if (flip) hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<true, CG>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs);
+                else hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<false, CG>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs);
+            }
+            if (int rc = check_launch("ffwm_warp_backward(feat, tiles)")) return rc;
+            if (!gflow) return FFWM_OK;
+            gfeat = nullptr;
+        }
     }
     const Geometry g = plan(B, C, H, W, 32);
     LaunchScope ls(scope_at(gfeat ? (flip ? "warp_flipcat_bwd" : "warp_bwd") : (flip ? "warp_flipcat_bwd_flow" : "warp_bwd_flow"), H), st,
