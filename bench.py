@@ -66,8 +66,10 @@ def parse():
                          "sampling grid for 80 untimed Adam steps (default), or leave them randomly initialised")
     ap.add_argument("--mfma-wgrad", default="on", choices=["on", "off"],
                     help="weight gradients of netG's large 3x3 convs on the hand-written MFMA kernel (off: vendor library)")
-    ap.add_argument("--graph", default="off", choices=["on", "off"],
-                    help="train workload: replay the step from captured hipGraphs, or run it eagerly (default: measured faster on ROCm 7.2)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="train workload: replay the step from captured hipGraphs (default on ONE GPU since round 3: 50.3 vs 52.4 ms -- the "
+                         "captured step now runs the same flat Adam / packed-gradient kernels as the eager one) or run it eagerly (default "
+                         "for several ranks: the hook-launched all-reduces overlap with backward only in eager mode)")
     ap.add_argument("--flownet-path", default="lean", choices=["lean", "module"],
                     help="flownet workload: the launch-lean eval path (BatchNorm folded, fused heads, hipGraph) or the nn.Module")
     return ap.parse_args()
@@ -421,6 +423,8 @@ def run_flownet(dev, bs, steps, warmup, world, path, seed=1):
 def main():
     args = parse()
     world, rank, local = init_dist(args)
+    if args.graph == "auto":
+        args.graph = "on" if (world == 1 and args.workload == "train") else "off"
     dev = torch.device("cuda", local)
     # MIOpen ships no gfx950 kernel database in this image: every conv kernel is JIT-compiled on a
     # fresh box.  Exhaustive find mode multiplies that start-up cost by the number of candidate

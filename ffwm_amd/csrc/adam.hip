@@ -48,10 +48,65 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
     if (t < n) adam_one(p[t], g[t], m[t], v[t], beta1, beta2, eps, step_size, bc2_sqrt);
 }
 
+// The step counter on the DEVICE (a step that sits inside a captured hipGraph: a replay runs no host code, so the bias corrections
+// cannot come from a host integer).  state[0] = steps taken so far, state[1] = lr / bc1, state[2] = sqrt(bc2) of the current step.
+__global__ void adam_advance_kernel(double* __restrict__ state, double lr, double beta1, double beta2) {
+    const double step = state[0] + 1.0;
+    state[0] = step;
+    state[1] = lr / (1.0 - pow(beta1, step));
+    state[2] = sqrt(1.0 - pow(beta2, step));
+}
+
+__global__ void __launch_bounds__(kBlock)
+adam_flat_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                     float beta1, float beta2, float eps, const double* __restrict__ state) {
+    const float step_size = static_cast<float>(state[1]), bc2_sqrt = static_cast<float>(state[2]);
+    const int64_t n4 = n >> 2;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n4; i += stride) {
+        const f32x4 p4 = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 g4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        const f32x4 m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+        float pa[4] = {p4.x, p4.y, p4.z, p4.w}, ga[4] = {g4.x, g4.y, g4.z, g4.w};
+        float ma[4] = {m4.x, m4.y, m4.z, m4.w}, va[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) adam_one(pa[q], ga[q], ma[q], va[q], beta1, beta2, eps, step_size, bc2_sqrt);
+        const f32x4 pp = {pa[0], pa[1], pa[2], pa[3]}, mm = {ma[0], ma[1], ma[2], ma[3]}, vv = {va[0], va[1], va[2], va[3]};
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    const int64_t t = (n4 << 2) + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (t < n) adam_one(p[t], g[t], m[t], v[t], beta1, beta2, eps, step_size, bc2_sqrt);
+}
+
 }  // namespace
 }  // namespace ffwm
 
 using namespace ffwm;
+
+// The same step with the step counter in device memory: state = 3 doubles (steps taken so far -- start it at 0 --, then two
+// scratch values).  Two launches (a one-thread advance of the counter, the streaming pass); safe to capture in a hipGraph.
+extern "C" int ffwm_adam_step_device(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr,
+                                     double beta1, double beta2, double eps, void* state, int dtype, void* stream) {
+    const char* fn = "ffwm_adam_step_device";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(params && grads && exp_avg && exp_avg_sq && state, FFWM_ERR_ARG, "%s: NULL pointer", fn);
+    FFWM_REQUIRE(n > 0, FFWM_ERR_ARG, "%s: need n > 0", fn);
+    FFWM_REQUIRE((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+                  reinterpret_cast<uintptr_t>(exp_avg_sq)) % 16 == 0,
+                 FFWM_ERR_ARG, "%s: the four arrays must be 16-byte aligned", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n4 = (n + 3) / 4;
+    int64_t blocks = (n4 + kBlock - 1) / kBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, static_cast<double*>(state), lr, beta1, beta2);
+    LaunchScope ls("adam_flat", st, 28.0 * static_cast<double>(n));
+    hipLaunchKernelGGL(adam_flat_dev_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, (float*)params, (const float*)grads,
+                       (float*)exp_avg, (float*)exp_avg_sq, n, (float)beta1, (float)beta2, (float)eps, static_cast<const double*>(state));
+    return check_launch(fn);
+}
 
 extern "C" int ffwm_adam_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr,
                               double beta1, double beta2, double eps, int64_t step, int dtype, void* stream) {

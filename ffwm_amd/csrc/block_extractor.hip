@@ -1239,46 +1239,6 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
 #pragma unroll
     for (int r = 0; r < PPT; ++r) gxa[r] = gya[r] = 0;
 
-    // Taps once per pixel, NOT once per pixel and channel (round 2 re-derived floor / fractions / fit from two flow loads for every
-    // channel: ~60 of the ~200 vector instructions per pixel and channel of an instruction-issue-bound kernel).  Kept per pixel row:
-    // the fractional weights of the window's CENTRE tap -- on the hot path all K taps of an axis share one floor offset, their
-    // fractions differ from the centre's by fp32 rounding of (flow + j) + x only, 1 ulp of a weight -- and the box position packed
-    // with the fit flag.  Pixels that do not fit are be_bwd_far2_kernel's, which keeps the reference's per-tap arithmetic.
-    T cwx[PPT], cwy[PPT];
-    int cpos[PPT];                       // au | av << 8, or -1: not on the hot path
-    {
-        const int xfc0 = min(max(xf, 0), Wf - 1);
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            const int yf = y0 + wave + r * NW;
-            const int yfc = min(max(yf, 0), Hf - 1);
-            const unsigned fo = (static_cast<unsigned>(yfc) * Wf + xfc0) * E;
-            const T fx0 = buf_ld<T>(rfl, fo), fy0 = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
-            T wxr[K], wyb[K];
-            T flx0 = 0, fly0 = 0;
-            bool regular = true;
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
-                const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
-                const T fxl = floor_t(dx), fyl = floor_t(dy);
-                if (j == 0) { flx0 = fxl; fly0 = fyl; }
-                regular = regular & (fxl == flx0 + static_cast<T>(j)) & (fyl == fly0 + static_cast<T>(j));
-                wxr[j] = dx - fxl;
-                wyb[j] = dy - fyl;
-            }
-            const T lim = static_cast<T>(1 << 20);
-            regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);   // rejects NaN too
-            const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
-            const int au = u0 - ax0, av = v0 - ay0;          // neighbourhood origin in the accumulator box (= the source box)
-            const bool fit = inside & regular & (static_cast<unsigned>(au) <= static_cast<unsigned>(AP - 1 - K)) &
-                             (static_cast<unsigned>(av) <= static_cast<unsigned>(AH - 1 - K)) & xin & (yf >= 0) & (yf < Hf);
-            cwx[r] = wxr[K / 2];
-            cwy[r] = wyb[K / 2];
-            cpos[r] = fit ? (au | (av << 8)) : -1;
-        }
-    }
-
     for (int c = c0; c < c1; ++c, op += oplane) {
         const bool more = c + 1 < c1;
         const rsrc_t rg = make_rsrc(op, obytes);
@@ -1287,7 +1247,7 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
         // requested before row r is processed (their addresses do not depend on the flow), so the
         // ~300 instructions of one row cover the latency of the next one's loads
         struct PixLoad {
-            T gs;                      // FUSED only: the pixel's upstream gradient
+            T fx, fy, gs;              // gs: FUSED only, the pixel's upstream gradient
             ElemRow<T, K> g[K];        // grad_output window (FUSED: the attention weights until `cur` is formed)
         };
         const int xfc = min(max(xf, 0), Wf - 1);
@@ -1295,6 +1255,8 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
             int yfc = y0 + wave + r * NW;
             yfc = min(max(yfc, 0), Hf - 1);                    // rows outside the flow image shadow a valid one
             const unsigned fo = (static_cast<unsigned>(yfc) * Wf + xfc) * E;
+            d.fx = buf_ld<T>(rfl, fo);
+            d.fy = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
             if constexpr (FUSED) {
                 ElemRow<T, 1> gv;
                 buf_load_row_nt<T, 1>(rg, fo, gv);
@@ -1313,8 +1275,6 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
         };
         PixLoad nxt;
         request(0, nxt);
-        // (rolled: r is wave-uniform, the per-row taps are read with an indexed access -- unrolled, the eight rows' windows
-        //  would all be live at once: 212 registers instead of 112)
 #pragma unroll 1
         for (int r = 0; r < PPT; ++r) {
             const int row = wave + r * NW;
@@ -1330,21 +1290,32 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
             }
             const bool row_owned = gflow != nullptr;
             T gx = 0, gy = 0;
-            const int pos = cpos[r];
-            if (pos >= 0) {
+            if (xin && yf >= 0 && yf < Hf) {
                 const bool owned = xown && row_owned;
-                const int au = pos & 255, av = pos >> 8;
-                const int su = au, sv = av;
-                const T wxc = cwx[r], wyc = cwy[r];
+                const T fx0 = cur.fx, fy0 = cur.fy;
+                // taps, the reference's arithmetic (block_extractor_kernel.cu:117-135)
                 T wxr[K], wyb[K];
+                T flx0 = 0, fly0 = 0;
+                bool regular = true;
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
-                    wxr[j] = wxc;
-                    wyb[j] = wyc;
+                    const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
+                    const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
+                    const T fxl = floor_t(dx), fyl = floor_t(dy);
+                    if (j == 0) { flx0 = fxl; fly0 = fyl; }
+                    regular = regular & (fxl == flx0 + static_cast<T>(j)) & (fyl == fly0 + static_cast<T>(j));
+                    wxr[j] = dx - fxl;
+                    wyb[j] = dy - fyl;
                 }
-                const bool fit = true, sfit = true;
+                const T lim = static_cast<T>(1 << 20);
+                regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);   // rejects NaN too
+                const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
+                const int au = u0 - ax0, av = v0 - ay0;          // neighbourhood origin in the accumulator box
+                const int su = au, sv = av;                      // ... which is also the source box
+                const bool fit = inside & regular & (static_cast<unsigned>(au) <= static_cast<unsigned>(AP - 1 - K)) &
+                                 (static_cast<unsigned>(av) <= static_cast<unsigned>(AH - 1 - K));
+                const bool sfit = fit;
                 const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
-                (void)ob;
                 if (fit & (!owned | sfit)) {
                     // hot path: dense (K+1)^2 neighbourhood at one LDS address + immediates, no masks.
                     // A pixel that is not owned reads an arbitrary valid source neighbourhood: its d(flow)
@@ -1406,16 +1377,10 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                             for (int j = 0; j <= K; ++j) sp[j] = sc[j];
                         }
                     }
-                }
-            } else if (xin && yf >= 0 && yf < Hf) {
-                {
+                } else {
                     // a tap outside the accumulator box (flow wider than the halo), a floor that disagrees
                     // between neighbouring taps (fp rounding on an integer boundary), NaN or huge flow:
-                    // every tap on its own like the reference, clamped cells (the scatter itself is be_bwd_far2_kernel's)
-                    const bool owned = xown && row_owned;
-                    const unsigned fo2 = (static_cast<unsigned>(yf) * Wf + static_cast<unsigned>(xf)) * E;
-                    const T fx0 = buf_ld<T>(rfl, fo2), fy0 = buf_ld<T>(rfl, fo2 + static_cast<unsigned>(fplane * E));
-                    const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
+                    // every tap on its own like the reference, clamped cells, ownership tested per cell
 #pragma unroll 1
                     for (int i = 0; i < K; ++i) {
                         const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);

@@ -479,8 +479,10 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     float* dw = static_cast<float*>(grad_weight);
     float* gb = static_cast<float*>(grad_bias);
     if (g.nz > 1) {
-        if (hipMemsetAsync(dw, 0, sizeof(float) * static_cast<size_t>(g.K) * g.N, st) != hipSuccess) return FFWM_ERR_LAUNCH;
-        if (gb && hipMemsetAsync(gb, 0, sizeof(float) * static_cast<size_t>(g.K), st) != hipSuccess) return FFWM_ERR_LAUNCH;
+        const size_t nw = static_cast<size_t>(g.K) * g.N;
+        const bool joined = gb == dw + nw;          // one buffer (ops.conv2d_wgrad_tiled allocates them together): one memset
+        if (hipMemsetAsync(dw, 0, sizeof(float) * (nw + (joined ? static_cast<size_t>(g.K) : 0)), st) != hipSuccess) return FFWM_ERR_LAUNCH;
+        if (gb && !joined && hipMemsetAsync(gb, 0, sizeof(float) * static_cast<size_t>(g.K), st) != hipSuccess) return FFWM_ERR_LAUNCH;
     }
     const double flops = 2.0 * B * g.P * static_cast<double>(g.K) * g.N;
     const double bytes = 4.0 * (static_cast<double>(B) * K * g.P + static_cast<double>(B) * C * H * W + static_cast<double>(K) * g.N);

@@ -12,7 +12,7 @@ from . import _lib
 
 
 class FlatAdam(object):
-    def __init__(self, params, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         params = [p for p in params if p.requires_grad]
         if reducer.flat is None or not params:
             raise ValueError("FlatAdam needs a reducer with one flat gradient array and at least one parameter")
@@ -40,6 +40,10 @@ class FlatAdam(object):
                 p.data = view
         self.n = n
         self.steps = 0
+        # capturable: the step counter lives on the device (ffwm_adam_step_device), so that step() can sit inside a captured hipGraph
+        self.capturable = bool(capturable)
+        self.state = torch.zeros(3, device=dev, dtype=torch.float64) if self.capturable else None
+        self.param_groups = [{"capturable": self.capturable, "lr": self.lr}]
 
     def step(self):
         self.steps += 1
@@ -49,10 +53,16 @@ class FlatAdam(object):
         if cur != dev:
             torch.cuda.set_device(dev)
         try:
-            _lib.check(_lib.load().ffwm_adam_step(self.params.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
-                                                  self.exp_avg_sq.data_ptr(), self.n, self.lr, self.betas[0], self.betas[1],
-                                                  self.eps, self.steps, _lib.F32, torch.cuda.current_stream(dev).cuda_stream),
-                       "ffwm_adam_step")
+            if self.capturable:
+                _lib.check(_lib.load().ffwm_adam_step_device(self.params.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                                                             self.exp_avg_sq.data_ptr(), self.n, self.lr, self.betas[0], self.betas[1],
+                                                             self.eps, self.state.data_ptr(), _lib.F32,
+                                                             torch.cuda.current_stream(dev).cuda_stream), "ffwm_adam_step_device")
+            else:
+                _lib.check(_lib.load().ffwm_adam_step(self.params.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                                                      self.exp_avg_sq.data_ptr(), self.n, self.lr, self.betas[0], self.betas[1],
+                                                      self.eps, self.steps, _lib.F32, torch.cuda.current_stream(dev).cuda_stream),
+                           "ffwm_adam_step")
         finally:
             if cur != dev:
                 torch.cuda.set_device(cur)

@@ -166,18 +166,23 @@ class FFWMTrainer(object):
         self._static = None
         # eager steps pack the gradients into the flat arrays after backward (no per-parameter accumulation kernel);
         # a captured graph needs static gradient addresses: in-place accumulation into the views
+        # (round 3: on ONE GPU the captured step packs too -- inside a capture the fresh gradients come from the graph's private pool,
+        # their addresses are as static as the views'; with several ranks the packing runs between the graphs, in Python, where the
+        # replayed gradients are not visible as new tensors: those keep the in-place accumulation)
+        gather = (not cap) or world_size == 1
         self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
-                                         bucket_bytes=bucket_bytes, gather=not cap)
-        self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes, gather=not cap)
+                                         bucket_bytes=bucket_bytes, gather=gather)
+        self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes, gather=gather)
         if flat_adam is None:
-            flat_adam = self.device.type == "cuda" and not cap
+            flat_adam = self.device.type == "cuda"
         self.flat_adam = bool(flat_adam)
         if self.flat_adam:
-            # parameters, gradients and moments as flat arrays: one streaming kernel per optimizer step (csrc/adam.hip)
+            # parameters, gradients and moments as flat arrays: one streaming kernel per optimizer step (csrc/adam.hip); capturable:
+            # the step counter lives on the device
             from .optim import FlatAdam
-            self.opt_F = FlatAdam(flow_params, self.red_G, lr=0.00005, betas=(0.5, 0.999))
-            self.opt_G = FlatAdam(list(self.netG.parameters()), self.red_G, lr=0.0004, betas=(0.5, 0.999))
-            self.opt_D = FlatAdam(list(self.netD.parameters()), self.red_D, lr=0.0004, betas=(0.5, 0.999))
+            self.opt_F = FlatAdam(flow_params, self.red_G, lr=0.00005, betas=(0.5, 0.999), capturable=cap)
+            self.opt_G = FlatAdam(list(self.netG.parameters()), self.red_G, lr=0.0004, betas=(0.5, 0.999), capturable=cap)
+            self.opt_D = FlatAdam(list(self.netD.parameters()), self.red_D, lr=0.0004, betas=(0.5, 0.999), capturable=cap)
         else:
             self.opt_F = torch.optim.Adam(flow_params, lr=0.00005, betas=(0.5, 0.999), **kw)
             self.opt_G = torch.optim.Adam(self.netG.parameters(), lr=0.0004, betas=(0.5, 0.999), **kw)
@@ -456,6 +461,11 @@ class FFWMTrainer(object):
         sb = self._static
         self.red_D.set_overlap(False)
         self.red_G.set_overlap(False)
+        if self.world_size > 1:
+            # three graphs with the all-reduces between them: the packing of fresh gradients would run in Python between the replays,
+            # where a replayed gradient is not a new tensor -- accumulate in place into the bucket views instead
+            self.red_D.set_gather(False)
+            self.red_G.set_gather(False)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -477,7 +487,9 @@ class FFWMTrainer(object):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._seg_forward_and_D(sb)
+                self.red_D.finish()              # one GPU: packs the D gradients into the flat array (a captured multi-tensor copy)
                 self._seg_stepD_and_G(sb)
+                self.red_G.finish()
                 self._seg_stepG()
             graphs = [g]
         else:
@@ -523,6 +535,8 @@ class FFWMTrainer(object):
         self._static = None
         self.red_D.set_overlap(True)
         self.red_G.set_overlap(True)
+        self.red_D.set_gather(True)
+        self.red_G.set_gather(True)
 
     def loss_values(self):
         return {k: float(v.detach()) for k, v in self.losses.items()}

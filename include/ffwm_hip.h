@@ -374,6 +374,11 @@ int ffwm_conv3x3_winograd_forward(const void* input, const void* weight, const v
 int ffwm_adam_step(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr,
                    double beta1, double beta2, double eps, int64_t step, int dtype, void* stream);
 
+/* The same step with the step counter in DEVICE memory (a step inside a captured hipGraph: a replay runs no host code).  state:
+ * three doubles, state[0] = steps taken so far (start it at 0), the other two are scratch.  Two launches. */
+int ffwm_adam_step_device(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr, double beta1,
+                          double beta2, double eps, void* state, int dtype, void* stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) ---------------------------
  * ffwm_prof_enable(1) brackets every kernel launch of this library with a pair of HIP events
  * recorded on the stream the kernel is launched on.  ffwm_prof_collect() waits for the recorded
