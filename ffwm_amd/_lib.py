@@ -30,6 +30,8 @@ _SIGNATURES = {
     "ffwm_bias_act_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, ctypes.c_double, _i, _p],
     "ffwm_flow_head_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_flow_up_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
+    "ffwm_flow_head_backward": [_p, _p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
+    "ffwm_flow_up_backward": [_p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_conv2d_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _i, _i, _i, _i64, _i, ctypes.c_double, _i, ctypes.POINTER(_i), _i, _p],
     "ffwm_conv2d_wgrad": [_p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
     "ffwm_conv2d_wgrad_tiled": [_p, _p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],

@@ -35,10 +35,7 @@ class _Conv3x3MfmaWgrad(Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         gx = gb = gw = None
         if need_w:
-            # the bias gradient is a row sum of the operand the MFMA kernel streams anyway
-            if need_b:
-                gb = torch.zeros(weight.shape[0], device=go.device, dtype=go.dtype)
-            gw = ops.conv3x3_wgrad(x if x.is_contiguous() else x.contiguous(), go, None, gb)
+            gw, gb = conv_weight_grad(x if x.is_contiguous() else x.contiguous(), go, weight, 1, 1, need_b)
         if need_x or (need_b and gb is None):
             gx, _, gb2 = torch.ops.aten.convolution_backward(
                 go, x, weight, [weight.shape[0]] if (need_b and gb is None) else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
@@ -120,8 +117,12 @@ def conv_weight_grad(x, go, weight, stride, pad, need_b):
     """-> (grad_weight, grad_bias or None) of Conv2d(C, K, k, stride, pad) from its input and grad_output."""
     k = weight.shape[2]
     if k == 3 and stride == 1 and pad == 1 and wgrad_route_ok(x, weight):
-        gb = torch.zeros(weight.shape[0], device=go.device, dtype=go.dtype) if need_b else None     # a row sum of the operand the kernel streams anyway
-        return ops.conv3x3_wgrad(x, go, None, gb), gb
+        # grad_weight and grad_bias (a row sum of the operand the kernel streams anyway) as slices of ONE zero-filled buffer: one fill
+        n = weight.numel()
+        buf = torch.zeros(n + (weight.shape[0] if need_b else 0), device=go.device, dtype=go.dtype)
+        gw, gb = buf[:n].view_as(weight), (buf[n:] if need_b else None)
+        ops.conv3x3_wgrad(x, go, gw, gb)
+        return gw, gb
     if _tiled_wgrad_wins(go, x, k) and weight.shape[2] == weight.shape[3]:
         return ops.conv2d_wgrad_tiled(go, x, k, stride, pad, want_bias=bool(need_b))
     _, gw, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[0]] if need_b else None, [stride, stride], [pad, pad],
@@ -493,5 +494,114 @@ def route_conv_bwd(net):
         elif (type(m) is nn.ConvTranspose2d and m.kernel_size == (4, 4) and m.stride == (2, 2) and m.padding == (1, 1)
               and m.output_padding == (0, 0) and m.dilation == (1, 1) and m.groups == 1):
             m.__class__ = OwnBwdConvTranspose2d
+            n += 1
+    return n
+
+
+# ================================================================================= FlowNet's two-channel layers in training
+# predict_flow* = Conv2d(C, 2, 3, 1, 1) + Tanh and upsampled_flow* = ConvTranspose2d(2, 2, 4, 2, 1) (models/base_networks.py:45-49,
+# 104-109): forward on the launch-lean kernels of the eval path (csrc/flownet_ops.hip: conv + bias + tanh in one launch), data
+# gradient on their new backward twins, weight (and bias) gradient on the tiled kernel.  Through the vendor library each of the
+# 26 layers of the two flow nets costs ~10 launches per step, most of them layout transposes around an implicit GEMM that uses
+# two of its 64 rows.
+class _FlowHead(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .flownet_eval import flow_head
+        x, weight = x.contiguous(), weight.contiguous()
+        y = flow_head(x, weight, bias)
+        ctx.save_for_backward(x, weight, y)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_y):
+        from . import _lib
+        x, weight, y = ctx.saved_tensors
+        go = grad_y.contiguous()
+        B, C, H, W = x.shape
+        gz = torch.empty_like(y)
+        gx = torch.empty_like(x)
+        _lib.check(_lib.load().ffwm_flow_head_backward(y.data_ptr(), go.data_ptr(), weight.data_ptr(), gz.data_ptr(), gx.data_ptr(), B, C, H, W,
+                                                       _lib.F32, torch.cuda.current_stream(x.device).cuda_stream), "ffwm_flow_head_backward")
+        gw = gb = None
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            gw, gb = conv_weight_grad(x, gz, weight, 1, 1, need_b)
+        if need_b and gb is None:
+            gb = _bias_grad(gz)
+        return (gx if ctx.needs_input_grad[0] else None), gw, gb
+
+
+class FlowHead(nn.Sequential):
+    """nn.Sequential(Conv2d(C, 2, 3, 1, 1), Tanh) as ONE launch per direction on the GPU (same parameters, same state-dict keys)."""
+
+    def forward(self, x):
+        conv = self[0]
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.weight.dtype == torch.float32 and conv.bias is not None
+                and not torch.is_autocast_enabled() and x.shape[2] * x.shape[3] < (1 << 28)):
+            return _FlowHead.apply(x, conv.weight, conv.bias)
+        return super().forward(x)
+
+
+class _FlowUp(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .flownet_eval import flow_up
+        x, weight = x.contiguous(), weight.contiguous()
+        B, _, H, W = x.shape
+        out = torch.empty(B, 2, 2 * H, 2 * W, device=x.device, dtype=x.dtype)
+        flow_up(x, weight, bias, out)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        from . import _lib
+        x, weight = ctx.saved_tensors
+        B, _, H, W = x.shape
+        go = grad_out
+        # a channel slice of the decoder concatenation's gradient is read in place (batch stride), anything else is made contiguous
+        if not (go.stride(3) == 1 and go.stride(2) == 2 * W and go.stride(1) == 4 * H * W and go.stride(0) >= 8 * H * W):
+            go = go.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(_lib.load().ffwm_flow_up_backward(go.data_ptr(), weight.data_ptr(), gx.data_ptr(), B, H, W, go.stride(0), _lib.F32,
+                                                         torch.cuda.current_stream(x.device).cuda_stream), "ffwm_flow_up_backward")
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            gw, gb = conv_transpose_weight_grad(x, go.contiguous(), weight, need_b)
+        elif need_b:
+            gb = _bias_grad(go)
+        return gx, gw, gb
+
+
+class FlowUpConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(2, 2, 4, 2, 1) on the direct kernels of csrc/flownet_ops.hip, forward and backward."""
+
+    def forward(self, input, output_size=None):
+        if (output_size is None and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4 and self.bias is not None
+                and not torch.is_autocast_enabled() and input.shape[2] * input.shape[3] < (1 << 26)):
+            return _FlowUp.apply(input, self.weight, self.bias)
+        return super().forward(input, output_size)
+
+
+def route_flow_heads(net):
+    """Re-class the flow heads (Sequential(Conv2d(C, 2, 3, 1, 1), Tanh)) and the 2 -> 2 flow upsamplers of a FlowNet; -> count."""
+    n = 0
+    for m in net.modules():
+        if (type(m) is nn.Sequential and len(m) == 2 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.Tanh)
+                and m[0].out_channels == 2 and m[0].kernel_size == (3, 3) and m[0].stride == (1, 1) and m[0].padding == (1, 1)
+                and m[0].dilation == (1, 1) and m[0].groups == 1 and m[0].bias is not None):
+            m.__class__ = FlowHead
+            n += 1
+        elif (isinstance(m, nn.ConvTranspose2d) and m.in_channels == 2 and m.out_channels == 2 and m.kernel_size == (4, 4)
+              and m.stride == (2, 2) and m.padding == (1, 1) and m.output_padding == (0, 0) and m.dilation == (1, 1) and m.groups == 1
+              and m.bias is not None):
+            m.__class__ = FlowUpConvTranspose2d
             n += 1
     return n

@@ -117,8 +117,24 @@ bn_lrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma
         return;
     }
     if (g.phase == 2) {
-        s = scratch[2 * cc];
-        ss = scratch[2 * cc + 1];
+        // the channel's sums over the slices; the LAST of its S workgroups to have read them clears the two cells and the arrival
+        // counter behind the sums (scratch[2 C ...] as 32-bit counters), so the buffer is zero again for the next call: a
+        // caller keeps ONE zero-filled scratch instead of filling a fresh one per call (60 fill launches per train step)
+        if (threadIdx.x == 0) {
+            red[0] = scratch[2 * cc];
+            red[1] = scratch[2 * cc + 1];
+        }
+        __syncthreads();
+        s = red[0];
+        ss = red[1];
+        if (threadIdx.x == 0) {
+            unsigned* cnt = reinterpret_cast<unsigned*>(scratch + 2 * g.C) + cc;
+            if (atomicAdd(cnt, 1u) == static_cast<unsigned>(g.S) - 1u) {
+                scratch[2 * cc] = 0.0;
+                scratch[2 * cc + 1] = 0.0;
+                *cnt = 0u;
+            }
+        }
     }
     const double n = static_cast<double>(g.B) * g.HW;
     const double mean = s / n;
@@ -242,8 +258,21 @@ bn_lrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, c
         return;
     }
     if (g.phase == 2) {
-        s = scratch[2 * cc];
-        sx = scratch[2 * cc + 1];
+        if (threadIdx.x == 0) {               // as in the forward: read, then the last reader clears for the next call
+            red[0] = scratch[2 * cc];
+            red[1] = scratch[2 * cc + 1];
+        }
+        __syncthreads();
+        s = red[0];
+        sx = red[1];
+        if (threadIdx.x == 0) {
+            unsigned* cnt = reinterpret_cast<unsigned*>(scratch + 2 * g.C) + cc;
+            if (atomicAdd(cnt, 1u) == static_cast<unsigned>(g.S) - 1u) {
+                scratch[2 * cc] = 0.0;
+                scratch[2 * cc + 1] = 0.0;
+                *cnt = 0u;
+            }
+        }
     }
     if (live && t == 0 && blockIdx.y == 0) {
         if (dgamma) dgamma[c] = static_cast<float>(sx);

@@ -132,6 +132,88 @@ flow_up_kernel(const float* __restrict__ in, const float* __restrict__ w, const 
     }
 }
 
+// ---- training: the backward of the two-channel layers (round 3).  Through the vendor library a flow head's data gradient is an
+// NHWC implicit GEMM with two of its 64 output rows in use, wrapped in three layout transposes and a fill, and the 2 -> 2
+// upsampler's is the same again: ~150 launches per train step of the two flow nets for a few MFLOP.
+//
+// flow head, y = tanh(conv3x3(x, w) + b):  gz = go * (1 - y^2)  [B, 2, H, W]  (written out: the weight gradient's row operand)
+//                                          gx[b, c, p] = sum_{k, r, s} gz[b, k, p + (1 - r, 1 - s)] * w[k, c, r, s]
+// P pixels x S = 256 / P channel splits per block: a thread forms the 18 gz values around its pixel once and walks its channels.
+template <int P>
+__global__ void __launch_bounds__(kBlock)
+flow_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ go, const float* __restrict__ w, float* __restrict__ gz,
+                     float* __restrict__ gx, int C, int H, int W, int tiles) {
+    constexpr int S = kBlock / P;
+    const int px_l = threadIdx.x % P, split = threadIdx.x / P;
+    const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
+    const int HW = H * W;
+    const int p = tile * P + px_l;
+    if (p >= HW) return;
+    const int py = p / W, pxx = p - py * W;
+    const float* yb = y + static_cast<int64_t>(b) * 2 * HW;
+    const float* gb = go + static_cast<int64_t>(b) * 2 * HW;
+    float z0[9], z1[9];                 // gz at the pixel that tap (r, s) of the forward reached THIS pixel from: p + (1 - r, 1 - s)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = py + 1 - k / 3, xx = pxx + 1 - k % 3;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const int o = in ? yy * W + xx : 0;
+        const float y0 = yb[o], y1 = yb[HW + o];
+        z0[k] = in ? gb[o] * (1.f - y0 * y0) : 0.f;
+        z1[k] = in ? gb[HW + o] * (1.f - y1 * y1) : 0.f;
+    }
+    if (split == 0) {                   // k = 4 is the pixel itself
+        gz[static_cast<int64_t>(b) * 2 * HW + p] = z0[4];
+        gz[(static_cast<int64_t>(b) * 2 + 1) * HW + p] = z1[4];
+    }
+    float* gxb = gx + static_cast<int64_t>(b) * C * HW + p;
+    for (int c = split; c < C; c += S) {
+        const float* w0 = w + static_cast<int64_t>(c) * 9;
+        const float* w1 = w + (static_cast<int64_t>(C) + c) * 9;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            a = __builtin_fmaf(z0[k], w0[k], a);
+            a = __builtin_fmaf(z1[k], w1[k], a);
+        }
+        gxb[static_cast<int64_t>(c) * HW] = a;
+    }
+}
+
+// 2 -> 2 upsampler, d(input): gx[b, ci, iy, ix] = sum_{co, ky, kx} go[b, co, 2 iy - 1 + ky, 2 ix - 1 + kx] * w[ci, co, ky, kx]
+// (go may be a channel slice of the decoder's concatenation gradient: gobs = its batch stride)
+__global__ void __launch_bounds__(kBlock)
+flow_up_bwd_kernel(const float* __restrict__ go, const float* __restrict__ w, float* __restrict__ gx, int64_t total, int H, int W,
+                   int64_t gobs) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int ix = static_cast<int>(i % W);
+        const int iy = static_cast<int>((i / W) % H);
+        const int64_t b = i / (static_cast<int64_t>(W) * H);
+        const float* gb = go + b * gobs;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int oy = 2 * iy - 1 + ky;
+            if (oy < 0 || oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int ox = 2 * ix - 1 + kx;
+                if (ox < 0 || ox >= Wo) continue;
+                const float g0 = gb[oy * Wo + ox], g1 = gb[static_cast<int64_t>(Ho) * Wo + oy * Wo + ox];
+                const int k = ky * 4 + kx;
+                a0 = __builtin_fmaf(g0, w[k], a0);            // w[ci = 0][co = 0]
+                a0 = __builtin_fmaf(g1, w[16 + k], a0);       // w[0][1]
+                a1 = __builtin_fmaf(g0, w[32 + k], a1);       // w[1][0]
+                a1 = __builtin_fmaf(g1, w[48 + k], a1);       // w[1][1]
+            }
+        }
+        float* ob = gx + b * 2 * H * W + static_cast<int64_t>(iy) * W + ix;
+        ob[0] = a0;
+        ob[static_cast<int64_t>(H) * W] = a1;
+    }
+}
+
 unsigned ew_grid(int64_t n) {
     int64_t blocks = (n + kBlock - 1) / kBlock;
     return static_cast<unsigned>(blocks > 256 * 32 ? 256 * 32 : (blocks < 1 ? 1 : blocks));
@@ -201,5 +283,45 @@ extern "C" int ffwm_flow_up_forward(const void* flow, const void* weight, const 
     LaunchScope ls("flownet_flow_up", st, 4.0 * (B * 2 * H * W + 2.0 * total));
     hipLaunchKernelGGL(flow_up_kernel, dim3(ew_grid(total)), dim3(kBlock), 0, st, (const float*)flow, (const float*)weight,
                        (const float*)bias, (float*)out, total, (int)H, (int)W, out_batch_stride);
+    return check_launch(fn);
+}
+
+// Backward of ffwm_flow_head_forward: y = its output, grad_y [B, 2, H, W] contiguous.  Writes grad_z = grad_y * (1 - y^2) [B, 2, H, W]
+// (the row operand of the weight gradient: ffwm_conv2d_wgrad_tiled(grad_z, x, ...); its sum over batch and pixels is the bias
+// gradient) and grad_x [B, C, H, W].
+extern "C" int ffwm_flow_head_backward(const void* y, const void* grad_y, const void* weight, void* grad_z, void* grad_x, int64_t B,
+                                       int64_t C, int64_t H, int64_t W, int dtype, void* stream) {
+    const char* fn = "ffwm_flow_head_backward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(y && grad_y && weight && grad_z && grad_x, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H * W < (1LL << 28), FFWM_ERR_ARG, "%s: bad sizes", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t HW = H * W;
+    LaunchScope ls("flownet_flow_head_bwd", st, 4.0 * (B * C * HW + 18.0 * C + 6.0 * B * HW));
+#define FFWM_FHB(P)                                                                                                    \
+    do {                                                                                                               \
+        const int tiles = static_cast<int>((HW + P - 1) / P);                                                          \
+        hipLaunchKernelGGL((flow_head_bwd_kernel<P>), dim3(static_cast<unsigned>(B * tiles)), dim3(kBlock), 0, st,     \
+                           (const float*)y, (const float*)grad_y, (const float*)weight, (float*)grad_z, (float*)grad_x, (int)C, (int)H, \
+                           (int)W, tiles);                                                                             \
+    } while (0)
+    if (HW >= 64) FFWM_FHB(64); else if (HW >= 16) FFWM_FHB(16); else FFWM_FHB(4);
+#undef FFWM_FHB
+    return check_launch(fn);
+}
+
+// d(input) of ffwm_flow_up_forward: grad_out [B, 2, 2H, 2W] with batch stride grad_out_batch_stride (a channel slice of a
+// concatenation's gradient is read in place), grad_x [B, 2, H, W] contiguous.
+extern "C" int ffwm_flow_up_backward(const void* grad_out, const void* weight, void* grad_x, int64_t B, int64_t H, int64_t W,
+                                     int64_t grad_out_batch_stride, int dtype, void* stream) {
+    const char* fn = "ffwm_flow_up_backward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(grad_out && weight && grad_x, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(B > 0 && H > 0 && W > 0 && H * W < (1LL << 26) && grad_out_batch_stride >= 8 * H * W, FFWM_ERR_ARG, "%s: bad sizes", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = B * H * W;
+    LaunchScope ls("flownet_flow_up_bwd", st, 4.0 * (B * 10.0 * H * W));
+    hipLaunchKernelGGL(flow_up_bwd_kernel, dim3(ew_grid(total)), dim3(kBlock), 0, st, (const float*)grad_out, (const float*)weight,
+                       (float*)grad_x, total, (int)H, (int)W, grad_out_batch_stride);
     return check_launch(fn);
 }

@@ -13,6 +13,9 @@
 #include <c10/hip/HIPStream.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "../../include/ffwm_hip.h"
@@ -36,10 +39,18 @@ const void* cptr(const Tensor& t) { return has(t) ? t.data_ptr() : nullptr; }
 void* mptr(const Tensor& t) { return has(t) ? t.data_ptr() : nullptr; }
 Tensor opt(const c10::optional<Tensor>& t, const Tensor& like) { return t.has_value() && t->defined() ? *t : torch::empty({0}, like.options()); }
 
+// One zero-filled scratch per (device, C, stream), filled once: the kernels hand it back zero-filled (include/ffwm_hip.h) and the
+// calls that share it are ordered on their stream.  (Round 2 filled a fresh one per call: 60 fill launches per train step.)
 Tensor bn_scratch(const Tensor& x) {
     const int64_t C = x.size(1);
-    if (C < 512 && x.numel() / C >= 32768) return torch::zeros({2 * C}, x.options().dtype(torch::kFloat64));
-    return Tensor();
+    if (!(C < 512 && x.numel() / C >= 32768)) return Tensor();
+    static std::mutex mu;
+    static std::map<std::tuple<int, int64_t, void*>, Tensor> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_tuple(static_cast<int>(x.device().index()), C, stream_of(x));
+    auto it = cache.find(key);
+    if (it == cache.end()) it = cache.emplace(key, torch::zeros({2 * C + (C + 1) / 2}, x.options().dtype(torch::kFloat64))).first;
+    return it->second;
 }
 
 // ---------------------------------------------------------------- BatchNorm2d (training) + LeakyReLU  (norm.py)

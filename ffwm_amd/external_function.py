@@ -271,8 +271,15 @@ class WarpMultiFunction(Function):
         saved = ctx.saved_tensors
         feats, flows = list(saved[:n]), list(saved[n:])
         need = ctx.needs_input_grad[2:]
-        gfe = [torch.zeros_like(feats[i]) if need[i] else None for i in range(n)]
-        gfl = [torch.zeros_like(flows[i]) if need[n + i] else None for i in range(n)]
+        # every wanted gradient is a slice of ONE zero-filled buffer (the kernels accumulate): one fill instead of up to 2 n
+        sizes = [feats[i].numel() if need[i] else 0 for i in range(n)] + [flows[i].numel() if need[n + i] else 0 for i in range(n)]
+        offs, tot = [], 0
+        for sz in sizes:
+            offs.append(tot)
+            tot += (sz + 63) // 64 * 64                    # 256-byte aligned slices
+        buf = torch.zeros(max(tot, 1), device=feats[0].device, dtype=feats[0].dtype)
+        gfe = [buf[offs[i]:offs[i] + sizes[i]].view_as(feats[i]) if need[i] else None for i in range(n)]
+        gfl = [buf[offs[n + i]:offs[n + i] + sizes[n + i]].view_as(flows[i]) if need[n + i] else None for i in range(n)]
         gos = [g.contiguous() if g is not None else torch.zeros(
             (feats[i].size(0), (2 if ctx.flipcat else 1) * feats[i].size(1)) + tuple(flows[i].shape[2:]),
             device=feats[i].device, dtype=feats[i].dtype) for i, g in enumerate(grads)]

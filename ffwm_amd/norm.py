@@ -33,11 +33,20 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_SCRATCH = {}
+
+
 def _scratch(x):
-    """2 C zero-filled doubles when a channel is worth splitting over several workgroups (few channels, large planes)."""
+    """Zero-filled scratch (2 C sums + C arrival counters) when a channel is worth splitting over several workgroups (few channels,
+    large planes).  ONE buffer per (device, C), filled once: the kernels hand it back zero-filled, and the calls that share it
+    are ordered on their stream.  (Other streams get their own buffer.)"""
     C = x.shape[1]
     if C < 512 and x.numel() // C >= 32768:
-        return torch.zeros(2 * C, device=x.device, dtype=torch.float64)
+        key = (x.device, C, torch.cuda.current_stream(x.device).cuda_stream)
+        buf = _SCRATCH.get(key)
+        if buf is None:
+            buf = _SCRATCH[key] = torch.zeros(2 * C + (C + 1) // 2, device=x.device, dtype=torch.float64)
+        return buf
     return None
 
 
@@ -105,7 +114,31 @@ class BatchNormLeakyReLU2d(nn.BatchNorm2d):
             if ext is not None:                # C++ autograd binding: same kernels, a fraction of the host cost
                 return ext.bn_lrelu(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, self.negative_slope)
             return _BnLreluFunction.apply(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, self.negative_slope)
-        return F.leaky_relu(super().forward(x), self.negative_slope)
+        return F.leaky_relu(_bn_host_counted(self, x), self.negative_slope)
+
+    def flush_batch_counter(self):
+        if self._pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked += self._pending_batches
+        self._pending_batches = 0
+
+
+def _bn_host_counted(m, x):
+    """nn.BatchNorm2d.forward with the batch counter on the host: in training mode with a fixed momentum `num_batches_tracked` takes no
+    part in the arithmetic, yet nn.BatchNorm2d spends one tiny kernel per call on `+= 1` (68 launches per FFWM train step for the
+    BatchNorms the fused kernel does not take).  Counted in `_pending_batches`, added when a state dict is taken."""
+    if m.training and m.momentum is not None and m.track_running_stats and m.num_batches_tracked is not None and x.is_cuda:
+        m._pending_batches += 1
+        return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, True, m.momentum, m.eps)
+    return nn.BatchNorm2d.forward(m, x)
+
+
+class HostCountBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d whose batch counter lives on the host between state-dict snapshots (same results, one launch less per call)."""
+
+    _pending_batches = 0
+
+    def forward(self, x):
+        return _bn_host_counted(self, x)
 
     def flush_batch_counter(self):
         if self._pending_batches and self.num_batches_tracked is not None:
@@ -136,4 +169,10 @@ def fuse_bn_lrelu(net):
                 a.register_load_state_dict_pre_hook(_reset_hook)
                 seq._modules[kb] = nn.Identity()
                 n += 1
+    for m in net.modules():                 # the BatchNorms without a LeakyReLU behind them: host-side batch counter only
+        if type(m) is nn.BatchNorm2d:
+            m.__class__ = HostCountBatchNorm2d
+            m._pending_batches = 0
+            m.register_state_dict_pre_hook(_flush_hook)
+            m.register_load_state_dict_pre_hook(_reset_hook)
     return n

@@ -130,6 +130,9 @@ class FFWMTrainer(object):
             self.mfma_fwd_layers = sum(route_conv_fwd(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD))
         self.own_bwd_layers = 0
         if mfma_fwd and self.device.type == "cuda":
+            # FlowNet's two-channel layers (7 flow heads + 6 flow upsamplers per net): direct kernels forward and backward
+            from .conv import route_flow_heads
+            self.flow_head_layers = sum(route_flow_heads(net) for net in (self.flowNetF, self.flowNetB))
             # what is left (thin layers, flow heads / upsamplers, image layers): vendor forward, weight gradient on the tiled kernel
             from .conv import route_conv_bwd
             self.own_bwd_layers = sum(route_conv_bwd(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD))
@@ -479,8 +482,9 @@ class FFWMTrainer(object):
         torch.cuda.synchronize(self.device)
         # the fused BatchNorm + LeakyReLU modules count their batches on the host (norm.py): a replay runs no Python, so the
         # calls of ONE captured step are recorded here and added per replay (num_batches_tracked stays what nn.BatchNorm2d's is)
-        from .norm import BatchNormLeakyReLU2d
-        fused = [m for net in (self.flowNetF, self.flowNetB, self.netG, self.netD) for m in net.modules() if isinstance(m, BatchNormLeakyReLU2d)]
+        from .norm import BatchNormLeakyReLU2d, HostCountBatchNorm2d
+        fused = [m for net in (self.flowNetF, self.flowNetB, self.netG, self.netD) for m in net.modules()
+                 if isinstance(m, (BatchNormLeakyReLU2d, HostCountBatchNorm2d))]
         before = [m._pending_batches for m in fused]
         graphs = []
         if self.world_size == 1:

@@ -283,8 +283,10 @@ int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_output, void* g
  * models/base_networks.py:12-31,207-264,381-413): y = leaky_relu(F.batch_norm(x, running_mean, running_var, weight,
  * bias, training=True, momentum, eps), negative_slope).  x, y [B,C,H,W] contiguous float32 (16-byte aligned),
  * HW = H*W; weight / bias [C] or NULL; running_mean / running_var [C] updated in place (both NULL: not tracked);
- * save_mean / save_invstd [C] are written for the backward pass.  scratch: NULL, or 2*C ZERO-FILLED doubles -- with it a
- * channel with few workgroups' worth of parallelism (C < 1024) is split over several workgroups (two launches). */
+ * save_mean / save_invstd [C] are written for the backward pass.  scratch: NULL, or 2*C + (C+1)/2 ZERO-FILLED doubles (two sums
+ * per channel, then one 32-bit arrival counter per channel) -- with it a channel with few workgroups' worth of parallelism
+ * (C < 1024) is split over several workgroups (two launches).  The kernels leave the scratch ZERO-FILLED again (the last
+ * workgroup of a channel to read the sums clears them): one buffer serves every later call on the same stream. */
 int ffwm_bn_lrelu_forward(const void* x, const void* weight, const void* bias, void* running_mean, void* running_var,
                           void* y, void* save_mean, void* save_invstd, void* scratch, int64_t B, int64_t C, int64_t HW,
                           double eps, double momentum, double negative_slope, int dtype, void* stream);
@@ -325,6 +327,16 @@ int ffwm_flow_head_forward(const void* x, const void* weight, const void* bias, 
  * pad 1) -> [B,2,2H,2W], sample b written at out + b * out_batch_stride (a channel slice of the concatenation buffer). */
 int ffwm_flow_up_forward(const void* flow, const void* weight, const void* bias, void* out, int64_t B, int64_t H, int64_t W,
                          int64_t out_batch_stride, int dtype, void* stream);
+
+/* Training: the backward of the two launch-lean layers above (models/base_networks.py:45-49,104-109).
+ * ffwm_flow_head_backward: y = the head's output, grad_y [B, 2, H, W] contiguous; writes grad_z = grad_y * (1 - y^2) [B, 2, H, W] (the
+ * row operand of the weight gradient, ffwm_conv2d_wgrad_tiled(grad_z, x, ...), whose fused row sum is the bias gradient) and
+ * grad_x [B, C, H, W].  ffwm_flow_up_backward: grad_x [B, 2, H, W] from grad_out [B, 2, 2H, 2W] read with its batch stride (a
+ * channel slice of the decoder concatenation's gradient needs no copy). */
+int ffwm_flow_head_backward(const void* y, const void* grad_y, const void* weight, void* grad_z, void* grad_x, int64_t B, int64_t C,
+                            int64_t H, int64_t W, int dtype, void* stream);
+int ffwm_flow_up_backward(const void* grad_out, const void* weight, void* grad_x, int64_t B, int64_t H, int64_t W,
+                          int64_t grad_out_batch_stride, int dtype, void* stream);
 
 /* fp32 MFMA implicit-GEMM convolution forward, NCHW, for the layers the vendor library wraps in layout transposes:
  * nn.Conv2d(C, K, kernel 3 or 4, stride 1 or 2, pad) or -- transposed != 0 -- nn.ConvTranspose2d(C, K, 4, 2, 1)

@@ -1631,3 +1631,61 @@ def test_l1_terms_match_torch_forward_and_backward():
     for a, b in zip(ga, gb):
         assert (a - b).abs().max().item() <= 1e-6 * (1 + b.abs().max().item())
     assert float(ga[4][B:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ FlowNet's two-channel layers in training
+@pytest.mark.parametrize("case", [(8, 1024, 2, 2), (8, 256, 8, 8), (3, 70, 9, 11), (8, 32, 64, 64), (2, 16, 128, 128)])
+def test_flow_head_training_route_matches_torch(case):
+    """conv.FlowHead (Conv2d(C, 2, 3, 1, 1) + Tanh on csrc/flownet_ops.hip forward and backward, weight gradient on the tiled kernel)
+    against the nn.Sequential it re-classes (base_networks.py:45-49): output, d(input), d(weight), d(bias) in float64."""
+    import copy
+    import torch.nn as nn
+    from ffwm_amd import conv
+    B, C, H, W = case
+    torch.manual_seed(sum(case))
+    ref = nn.Sequential(nn.Conv2d(C, 2, 3, 1, 1), nn.Tanh()).to(DEV)
+    fast = copy.deepcopy(ref)
+    assert conv.route_flow_heads(nn.ModuleList([fast])) == 1 and type(fast) is conv.FlowHead
+    x = torch.randn(B, C, H, W, generator=_gen(5)).to(DEV)
+    go = torch.randn(B, 2, H, W, generator=_gen(6)).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = fast(xa)
+    ya.backward(go)
+    rd = copy.deepcopy(ref).double()
+    xb = x.double().requires_grad_(True)
+    yb = rd(xb)
+    yb.backward(go.double())
+    assert (ya.double() - yb).abs().max().item() <= 2e-6
+    assert (xa.grad.double() - xb.grad).abs().max().item() <= 1e-5 * (1 + xb.grad.abs().max().item())
+    scale = (B * H * W) ** 0.5
+    for p, q in zip(fast.parameters(), rd.parameters()):
+        assert (p.grad.double() - q.grad).abs().max().item() <= 2e-6 * scale * (1 + q.grad.abs().max().item()), tuple(p.shape)
+
+
+@pytest.mark.parametrize("case", [(8, 2, 2), (8, 16, 16), (3, 7, 9), (8, 64, 64)])
+def test_flow_upsampler_training_route_matches_torch(case):
+    """conv.FlowUpConvTranspose2d (ConvTranspose2d(2, 2, 4, 2, 1), base_networks.py:104-109) against the module it re-classes, with
+    the gradient arriving as a channel slice of a concatenation's gradient (read in place through its batch stride)."""
+    import copy
+    import torch.nn as nn
+    from ffwm_amd import conv
+    B, H, W = case
+    torch.manual_seed(sum(case))
+    ref = nn.ConvTranspose2d(2, 2, 4, 2, 1).to(DEV)
+    fast = copy.deepcopy(ref)
+    assert conv.route_flow_heads(nn.ModuleList([fast])) == 1 and type(fast) is conv.FlowUpConvTranspose2d
+    x = torch.randn(B, 2, H, W, generator=_gen(7)).to(DEV)
+    other = torch.randn(B, 5, 2 * H, 2 * W, generator=_gen(8)).to(DEV)
+    gcat = torch.randn(B, 7, 2 * H, 2 * W, generator=_gen(9)).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = fast(xa)
+    torch.cat((other, ya), 1).backward(gcat)                      # the upsampled flow is the LAST block of the decoder's concatenation
+    rd = copy.deepcopy(ref).double()
+    xb = x.double().requires_grad_(True)
+    yb = rd(xb)
+    torch.cat((other.double(), yb), 1).backward(gcat.double())
+    assert (ya.double() - yb).abs().max().item() <= 1e-5 * (1 + yb.abs().max().item())
+    assert (xa.grad.double() - xb.grad).abs().max().item() <= 1e-5 * (1 + xb.grad.abs().max().item())
+    scale = (B * H * W) ** 0.5
+    for p, q in zip(fast.parameters(), rd.parameters()):
+        assert (p.grad.double() - q.grad).abs().max().item() <= 2e-6 * scale * (1 + q.grad.abs().max().item()), tuple(p.shape)
