@@ -103,6 +103,10 @@ def load():
         k, _, v = kv.partition("=")
         if lib.ffwm_set_option(k.strip().encode(), int(v)) < 0:
             raise FFWMError("FFWM_OPTS: unknown option %r" % k)
+        if k.strip() == "ablate" and int(v) != 0:
+            import warnings
+            warnings.warn("FFWM_OPTS: ablate=%s -- timing-only kernel variants are ON: forward / backward RESULTS ARE WRONG "
+                          "(bench experiments only)" % v)
     return lib
 
 

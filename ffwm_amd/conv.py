@@ -217,6 +217,8 @@ def frozen_cache(owner, weight):
     version counter 0, an address the caching allocator hands out again), so its transform must never be kept."""
     if (not isinstance(weight, nn.Parameter)) or weight.requires_grad or hasattr(owner, "weight_orig"):
         return None
+    if getattr(weight, "_ffwm_flat_adam", False):
+        return None      # a parameter of a flat optimizer (netD while the G step freezes it): updated without a version bump
     if torch.cuda.is_current_stream_capturing():
         return None      # a transform kernel that was only captured, not run, must not be recorded as valid
     return owner.__dict__.setdefault("_winograd_frozen", {})

@@ -511,6 +511,10 @@ def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0
         _lib.check(lib.ffwm_conv3x3_winograd_forward(_ptr(x), _ptr(weight), _ptr(bias) if bias is not None else None, _ptr(out), _ptr(ws),
                                                      B, C, H, W, K, mode, int(act), float(slope), _dtype_code(x),
                                                      stream), "ffwm_conv3x3_winograd_forward")
+    if frozen is not None and frozen is not False and not (mode & 2):
+        # a transform that was just written into a layer's cache may be picked up by a call on ANOTHER stream (the trainer runs the
+        # loss networks' passes on side streams): make it visible to every stream, once per frozen layer
+        torch.cuda.current_stream(x.device).synchronize()
     return out
 
 

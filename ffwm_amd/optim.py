@@ -38,6 +38,7 @@ class FlatAdam(object):
                 view = self.params[a - self.lo:b - self.lo].view_as(p)
                 view.copy_(p.data)
                 p.data = view
+                p._ffwm_flat_adam = True       # updated by a raw-pointer kernel: the version counter does not see it (conv.frozen_cache)
         self.n = n
         self.steps = 0
         # capturable: the step counter lives on the device (ffwm_adam_step_device), so that step() can sit inside a captured hipGraph

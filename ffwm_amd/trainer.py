@@ -17,6 +17,7 @@ Deliberate, result-preserving differences from the reference:
   * pretrained VGG19 / LightCNN / FlowNet checkpoints cannot be fetched offline: seeded random
     weights of the same architectures (same FLOPs and bytes; loss values differ).
 """
+import contextlib
 import itertools
 import os
 
@@ -162,6 +163,16 @@ class FFWMTrainer(object):
         # foreach implementation (1275 extra launches per step, measured)
         kw = {"fused": True, "capturable": cap} if self.device.type == "cuda" else {}
         self.world_size = world_size
+        # flowNetB on a second stream (FFWM_FLOW_STREAMS=1): the two flow nets read the same image and share nothing else, and most of
+        # their kernels (2 x 2 ... 16 x 16 planes) fill a fraction of the chip -- under hipGraph replay, where the step is bound by
+        # kernel time alone, the two nets' forward and backward kernels overlap
+        # ... and the loss networks' independent passes (VGG19 on the 64 / 32 px scales, LightCNN) on two more.  Default: on for a
+        # trainer built for capture (FFWM_STREAMS=0 / 1 overrides); in eager mode the host issues the launches one by one and
+        # nothing overlaps (measured: no change).
+        multi = os.environ.get("FFWM_STREAMS", os.environ.get("FFWM_FLOW_STREAMS", "1" if capturable else "0")) == "1"
+        multi = multi and self.device.type == "cuda"
+        self.flow_stream = torch.cuda.Stream(self.device) if multi else None
+        self.loss_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if multi else None
         self.batched_losses = batched_losses
         # the ~25 L1 terms of backward_G as one launch per direction (losses.l1_terms, csrc/l1_loss.hip); needs the batched passes
         self.fused_l1 = (self.device.type == "cuda" and batched_losses) if fused_l1 is None else bool(fused_l1)
@@ -298,8 +309,18 @@ class FFWMTrainer(object):
     # ------------------------------------------------------------------ one optimisation step
     def forward(self, b):
         img_S, img_F = b["img_S"], b["img_F"]
-        flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
-        self.flows_B = self.flowNetB(img_S)
+        if self.flow_stream is not None:
+            cur = torch.cuda.current_stream(self.device)
+            self.flow_stream.wait_stream(cur)                  # fork: img_S and last step's weights are ready
+            with torch.cuda.stream(self.flow_stream):
+                self.flows_B = self.flowNetB(img_S)
+            flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
+            cur.wait_stream(self.flow_stream)                  # join: everything downstream runs on the step's stream
+            for f in self.flows_B:
+                f.record_stream(cur)                           # allocated on the side stream, consumed on this one
+        else:
+            flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
+            self.flows_B = self.flowNetB(img_S)
         self.img_S_warp, self.img_S_rec = self.warp_many([img_S, img_F], [flow_F128, self.flows_B[0]])
         self.fake32, self.fake64, self.fake128 = self.netG(img_S, flow=[flow_F32, flow_F64, flow_F128])
         self.img_GF128 = self.gf[128](self.fake128, img_F)
@@ -333,26 +354,34 @@ class FFWMTrainer(object):
         L1, PRC, FC, ILLU, IDEN = range(5)
         B = img_F.size(0)
         terms = [(gf128, img_F, mask_F, 5.0, L1), (gf64, img_F64, mask64, 5.0, L1), (gf32, img_F32, mask32, 7.5, L1)]
-        # perceptual: the two large scales one VGG pass each, the 32 x 32 scale and the four part crops share one (5 B rows)
-        for x, y, m in ((gf128, img_F, mask_F), (gf64, img_F64, mask64)):
+        # The loss networks' passes are independent of each other until their gradients meet at the generated images: with
+        # `loss_streams` the VGG19 passes of the 64 / 32 px scales and the LightCNN passes run on two side streams beside the 128 px
+        # VGG19 pass (their kernels -- 16 x 16 ... 64 x 64 planes -- fill a fraction of the chip); autograd runs each backward node
+        # on its forward's stream, so the backward overlaps the same way.  Fork here, join in front of the fused L1 launch.
+        cur = torch.cuda.current_stream(self.device) if self.loss_streams else None
+        side_terms = []
+
+        def branch(i):
+            if self.loss_streams is None:
+                return contextlib.nullcontext()
+            self.loss_streams[i].wait_stream(cur)
+            return torch.cuda.stream(self.loss_streams[i])
+
+        def vgg_pair(x, y, m):
             fx = self.vgg(x * m)
             with torch.no_grad():
                 fy = self.vgg(y * m)
-            terms += [(fx[k], fy[k], None, w, PRC) for k, w in zip(PRC_LAYERS, PRC_WEIGHTS)]
-        (el, elt), (er, ert), (no, nog), (mo, mog) = self.parts
-        fx = self.vgg(torch.cat((gf32 * mask32, el, er, mo, no), 0))
-        with torch.no_grad():
-            fy = self.vgg(torch.cat((img_F32 * mask32, elt, ert, mog, nog), 0))
-        for k, w in zip(PRC_LAYERS, PRC_WEIGHTS):
-            terms.append((fx[k], fy[k], None, [(0, 0, B, 1.5 * w, PRC), (B, B, B, 2 * w, FC), (2 * B, 2 * B, B, 2 * w, FC),
-                                               (3 * B, 3 * B, B, w, FC), (4 * B, 4 * B, B, w, FC)]))
-        # illumination (MSL1Loss): the three generated scales warped back with flowNetB (one multi-problem launch)
-        warped = self.warp_many([self.fake128, self.fake64, self.fake32], list(self.flows_B))
-        for w, flow, back in zip((1, 1, 1.5), self.flows_B, warped):
-            size = flow.shape[2:]
-            tgt = F.interpolate(b["img_S"], size, mode="bilinear", align_corners=True)
-            m = F.interpolate(b["mask_S"], size, mode="nearest")
-            terms.append((back, tgt, m, 15.0 * w, ILLU))
+            return [(fx[k], fy[k], None, w, PRC) for k, w in zip(PRC_LAYERS, PRC_WEIGHTS)]
+        # perceptual: the two large scales one VGG pass each, the 32 x 32 scale and the four part crops share one (5 B rows)
+        with branch(0):
+            side_terms += vgg_pair(gf64, img_F64, mask64)
+            (el, elt), (er, ert), (no, nog), (mo, mog) = self.parts
+            fx = self.vgg(torch.cat((gf32 * mask32, el, er, mo, no), 0))
+            with torch.no_grad():
+                fy = self.vgg(torch.cat((img_F32 * mask32, elt, ert, mog, nog), 0))
+            for k, w in zip(PRC_LAYERS, PRC_WEIGHTS):
+                side_terms.append((fx[k], fy[k], None, [(0, 0, B, 1.5 * w, PRC), (B, B, B, 2 * w, FC), (2 * B, 2 * B, B, 2 * w, FC),
+                                                        (3 * B, 3 * B, B, w, FC), (4 * B, 4 * B, B, w, FC)]))
         # identity: ground-truth features once; an output that appears twice (warm-up branch: gf128 IS fake128) runs once
         uniq, wsum = [], []
         for o, w in zip((self.fake128, gf128), (0.5, 1.0)):
@@ -363,11 +392,27 @@ class FFWMTrainer(object):
             else:
                 uniq.append(o)
                 wsum.append(w)
-        with torch.no_grad():
-            _, fc_g, pool_g = self.lightCNN(img_F.mean(1, keepdim=True))
-        _, fc_o, pool_o = self.lightCNN(torch.cat([u.mean(1, keepdim=True) for u in uniq], 0))
-        terms.append((fc_o, fc_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
-        terms.append((pool_o, pool_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
+        with branch(1):
+            with torch.no_grad():
+                _, fc_g, pool_g = self.lightCNN(img_F.mean(1, keepdim=True))
+            _, fc_o, pool_o = self.lightCNN(torch.cat([u.mean(1, keepdim=True) for u in uniq], 0))
+            side_terms.append((fc_o, fc_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
+            side_terms.append((pool_o, pool_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
+        terms += vgg_pair(gf128, img_F, mask_F)
+        # illumination (MSL1Loss): the three generated scales warped back with flowNetB (one multi-problem launch)
+        warped = self.warp_many([self.fake128, self.fake64, self.fake32], list(self.flows_B))
+        for w, flow, back in zip((1, 1, 1.5), self.flows_B, warped):
+            size = flow.shape[2:]
+            tgt = F.interpolate(b["img_S"], size, mode="bilinear", align_corners=True)
+            m = F.interpolate(b["mask_S"], size, mode="nearest")
+            terms.append((back, tgt, m, 15.0 * w, ILLU))
+        if self.loss_streams is not None:
+            for st in self.loss_streams:
+                cur.wait_stream(st)
+            for t in side_terms:                           # allocated on a side stream, read by the fused L1 launch on this one
+                t[0].record_stream(cur)
+                t[1].record_stream(cur)
+        terms += side_terms
         v = l1_terms(terms, 5)
         loss_adv = self.lsgan(self.netD(self.img_GF128 * mask_F), True) * 0.1
         self.loss_G = v.sum() + loss_adv

@@ -1689,3 +1689,29 @@ def test_flow_upsampler_training_route_matches_torch(case):
     scale = (B * H * W) ** 0.5
     for p, q in zip(fast.parameters(), rd.parameters()):
         assert (p.grad.double() - q.grad).abs().max().item() <= 2e-6 * scale * (1 + q.grad.abs().max().item()), tuple(p.shape)
+
+
+def test_multi_stream_step_equals_the_single_stream_step(monkeypatch):
+    """FFWM_STREAMS=1 (flowNetB and the loss networks' side passes on their own HIP streams, the default of the captured step): one
+    eager step from identical weights gives the same losses as the single-stream step -- forward values to fp32 rounding, the
+    backward to the noise of the float atomics (the single-stream step repeated is the yardstick)."""
+    from ffwm_amd import trainer
+    batch = trainer.synthetic_batch(4, DEV, seed=9)
+
+    def one_step(streams):
+        monkeypatch.setenv("FFWM_STREAMS", "1" if streams else "0")
+        t = trainer.FFWMTrainer(DEV, seed=5, ngf=32)
+        assert (t.flow_stream is not None) == streams and (t.loss_streams is not None) == streams
+        t.step(batch, batch_increment=0)
+        torch.cuda.synchronize()
+        return {k: float(v.detach()) for k, v in t.losses.items()}, t.red_G.flat.clone()
+    la, ga = one_step(False)
+    lb, gb = one_step(False)
+    lc, gc = one_step(True)
+    ld, gd = one_step(True)
+    noise = (ga - gb).abs().max().item()
+    for l in (lc, ld):
+        for k in la:
+            assert abs(l[k] - la[k]) <= 1e-5 * (1 + abs(la[k])), (k, l[k], la[k])
+    for g in (gc, gd):
+        assert (g - ga).abs().max().item() <= 4 * noise + 1e-6 * ga.abs().max().item(), ((g - ga).abs().max().item(), noise)

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--top", type=int, default=0, help="also list the N kernels with the most time")
     a = ap.parse_args()
     rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(a.trace)))
-    adam = [i for i, r in enumerate(rows) if "adam_flat_kernel" in r[2]]
+    adam = [i for i, r in enumerate(rows) if "adam_flat_kernel" in r[2] or "adam_flat_dev_kernel" in r[2]]      # eager / captured step
     ends = adam[2::3]                      # index of the last kernel of each step
     if len(ends) < a.steps + 1:
         raise SystemExit("only %d step ends in the trace" % len(ends))
