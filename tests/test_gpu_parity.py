@@ -1710,8 +1710,10 @@ def test_multi_stream_step_equals_the_single_stream_step(monkeypatch):
     lc, gc = one_step(True)
     ld, gd = one_step(True)
     noise = (ga - gb).abs().max().item()
-    for l in (lc, ld):
+    # (the forward itself is not bit-reproducible run to run: the split-K convolutions and the sliced BatchNorm statistics add their
+    #  partial sums with float / double atomics, and netG amplifies the last bit to ~1e-4 of a loss -- with one stream as with several)
+    for l in (lb, lc, ld):
         for k in la:
-            assert abs(l[k] - la[k]) <= 1e-5 * (1 + abs(la[k])), (k, l[k], la[k])
+            assert abs(l[k] - la[k]) <= 3e-4 * (1 + abs(la[k])), (k, l[k], la[k])
     for g in (gc, gd):
         assert (g - ga).abs().max().item() <= 4 * noise + 1e-6 * ga.abs().max().item(), ((g - ga).abs().max().item(), noise)
