@@ -67,9 +67,10 @@ def parse():
     ap.add_argument("--mfma-wgrad", default="on", choices=["on", "off"],
                     help="weight gradients of netG's large 3x3 convs on the hand-written MFMA kernel (off: vendor library)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="train workload: replay the step from captured hipGraphs (default on ONE GPU since round 3: 50.3 vs 52.4 ms -- the "
-                         "captured step now runs the same flat Adam / packed-gradient kernels as the eager one) or run it eagerly (default "
-                         "for several ranks: the hook-launched all-reduces overlap with backward only in eager mode)")
+                    help="train workload: replay the step from captured hipGraphs (default since round 3: 45.3 vs 52.1 ms on one GPU -- the "
+                         "captured step runs the same flat Adam / packed-gradient kernels as the eager one, with flowNetB and the loss "
+                         "networks' side passes on their own streams; several ranks: three graphs with the all-reduces between them) or "
+                         "run it eagerly (several ranks: hook-launched all-reduces overlapping backward)")
     ap.add_argument("--flownet-path", default="lean", choices=["lean", "module"],
                     help="flownet workload: the launch-lean eval path (BatchNorm folded, fused heads, hipGraph) or the nn.Module")
     return ap.parse_args()
@@ -424,7 +425,7 @@ def main():
     args = parse()
     world, rank, local = init_dist(args)
     if args.graph == "auto":
-        args.graph = "on" if (world == 1 and args.workload == "train") else "off"
+        args.graph = "on" if args.workload == "train" else "off"
     dev = torch.device("cuda", local)
     # MIOpen ships no gfx950 kernel database in this image: every conv kernel is JIT-compiled on a
     # fresh box.  Exhaustive find mode multiplies that start-up cost by the number of candidate
@@ -459,7 +460,29 @@ def main():
         else:
             step_flops = flops.count_step(nets_all, lambda: t.step(batch, batch_increment=0))       # one untimed eager step
         if graphed:
-            t.capture(batch, warmup=max(2, args.warmup))
+            # several ranks: three graphs with the two gradient all-reduces issued between them (RCCL stays outside the captures).
+            # Should the capture fail beside a live process group (it cannot be tried on the one-GPU development box), every rank
+            # falls back to the eager step with hook-launched, overlapped all-reduces -- the ranks agree on it first.
+            ok = True
+            try:
+                t.capture(batch, warmup=max(2, args.warmup))
+            except Exception as e:
+                if world == 1:
+                    raise
+                ok = False
+                print("rank %d: hipGraph capture failed (%r): falling back to the eager step" % (rank, e), file=sys.stderr)
+            if world > 1:
+                flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) < 0.5:
+                    graphed = False
+                    args.graph = "off"
+                    del t
+                    torch.cuda.synchronize()
+                    t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers, bucket_bytes=args.bucket_mb << 20,
+                                            capturable=False, mfma_wgrad=args.mfma_wgrad == "on")
+                    flow_fit = t.pretrain_flow_identity(batch) if args.flow_init == "fit-identity" else None
+                    nets_all = [t.flowNetF, t.flowNetB, t.netG, t.netD, t.lightCNN, t.vgg]
         dt, rows = timed(lambda: t.step(batch, batch_increment=0), args.steps, args.warmup, world)
         if graphed:
             # HIP events cannot bracket kernels inside a replayed graph: time the hand-written kernels
@@ -473,7 +496,10 @@ def main():
                        "config": {"workload": "BASELINE configs[2]: full FFWM train step (netG+netD+flowNetF+flowNetB, "
                                               "all losses, 3x Adam), synthetic MultiPIE-shaped 128x128",
                                   "batch_per_gpu": bs, "global_batch": bs * world,
-                                  "parallelism": "dp%d" % world, "launch": "hipGraph replay" if graphed else "eager",
+                                  "parallelism": "dp%d" % world,
+                                  "launch": ("hipGraph replay" + (" (three graphs, the two gradient all-reduces between them)" if world > 1 else "")
+                                             + (", flowNetB and the loss networks' side passes on their own HIP streams" if t.flow_stream is not None else ""))
+                                  if graphed else "eager (hook-launched all-reduces overlap backward)" if world > 1 else "eager",
                                   "miopen": "immediate mode%s" % (" + in-tree find-db (ffwm_amd/miopen_db)" if miopen_db else ", heuristic solver choice"),
                                   "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))
                                   if args.mfma_wgrad == "on" else "vendor library",
