@@ -12,7 +12,7 @@ on one batch resident in HBM.  fp32 throughout (the reference's dtype).  Rank 0 
   roofline          : the SURVEY 8 a1-a6 kernel (warp / resample2d / block_extractor / local_attn_reshape family) that
                       moves the most algorithmic bytes inside the timed region: algorithmic bytes per launch / average
                       launch duration (HIP events on its launch stream, ffwm_prof_*) vs the 8 TB/s HBM peak;
-                      traffic = PMC-measured HBM bytes per launch (profiles/r02_pmc_traffic.json, rocprofv3 FETCH_SIZE /
+                      traffic = PMC-measured HBM bytes per launch (profiles/r03_pmc_traffic.json, rocprofv3 FETCH_SIZE /
                       WRITE_SIZE passes of this same command) or null when no valid measurement is committed
   roofline_mfma     : the hand-written MFMA kernel with the largest share of the step (the Winograd convolution, forward + data
                       gradient scopes together); roofline_mfma_2nd: the next one (the 3x3 weight gradient)
@@ -44,7 +44,9 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP32_PEAK = 157.3e12       # FLOP/s, fp32 vector/MFMA
 REF_TRAIN_FLOP_PER_IMG = 444e9   # the REFERENCE's step, ~222 GMAC per image (quoted for comparison only)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+if not os.path.exists(PMC_FILE):
+    PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 # launch scopes of the SURVEY 8 a1-a6 operators (ffwm_prof_* names)
 HOT_PATH_PREFIXES = ("warp", "resample2d", "block_extractor", "local_attn_reshape", "block_attention")
 
@@ -663,7 +665,7 @@ def main():
             pmc = traffic.get(top["kernel"]) or top.get("_pmc")
             base = {"bound": bound, "kernel": top["kernel"], "avg_us": top["avg_us"], "launches": top["launches"],
                     "traffic": pmc["traffic_bytes"] if pmc else None,
-                    "traffic_source": ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                    "traffic_source": ("profiles/" + os.path.basename(PMC_FILE) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                        "command (--kernel-include-regex ffwm), bytes per launch, FETCH_SIZE x2 per the gfx950 calibration")
                     if pmc else None}
             if bound == "hbm":

@@ -1,4 +1,4 @@
-"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r02_*.
+"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r03_*.
 
     python tools/fold_profiles.py [gpurun_out/refresh]
 
@@ -51,9 +51,25 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "warp_flipcat_bwd_feat@128": "warp_bwd_feat_plane_kernel<float, true, 1>",
     "warp_flipcat_bwd_feat@64": "warp_bwd_feat_plane_kernel<float, true, 2>",
     "warp_flipcat_bwd_feat@32": "warp_bwd_feat_plane_kernel<float, true, 8>",
+    # round 3
+    "conv_wgrad_mfma_tiled": "conv_wgrad_tile_kernel<",
+    "l1_multi_fwd": "l1_multi_kernel<false>",
+    "l1_multi_bwd": "l1_multi_kernel<true>",
+    "flownet_flow_head": "flow_head_kernel<",
+    "flownet_flow_head_bwd": "flow_head_bwd_kernel<",
+    "flownet_flow_up": "flow_up_kernel",
+    "flownet_flow_up_bwd": "flow_up_bwd_kernel",
+    "resample2d_bwd_input1_tile": "rs_bwd1_tile_kernel<2,",
+    "warp_flipcat_fwd@256": "warp_fwd_lds_kernel<true>",
+    "warp_flipcat_bwd_feat_tile@256": "warp_bwd_feat_tile_kernel<true, 2>",
+    "warp_flipcat_bwd_feat_far@256": "warp_bwd_feat_far_kernel<true>",
+    "warp_flipcat_bwd_flow@256": "warp_bwd_kernel<float, true>",
+    "block_attention_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 1>",
+    "block_attention_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, true>",
+    "block_attention_bwd_weights": "be_fwd_lds_kernel<float, 3, 4, 2>",
 }
 FETCH_CORRECTION = 2.0
-ROUND = "r02"
+ROUND = "r03"
 
 
 def main():
@@ -112,7 +128,11 @@ def main():
               ("flowtrain_bench.json", "_bench_flowtrain.json"), ("ops_bench.json", "_bench_ops.json"),
               ("winograd_sq_192.txt", "_winograd_sq_counters_192.txt"), ("winograd_sq_256.txt", "_winograd_sq_counters_256.txt"),
               ("winograd_mem_192.txt", "_winograd_mem_counters_192.txt"), ("winograd_mem_256.txt", "_winograd_mem_counters_256.txt"),
-              ("winograd_vs_vendor.txt", "_winograd_vs_vendor.txt"), ("winograd_layers_of_the_step.txt", "_winograd_layers_of_the_step.txt")]
+              ("winograd_vs_vendor.txt", "_winograd_vs_vendor.txt"), ("winograd_layers_of_the_step.txt", "_winograd_layers_of_the_step.txt"),
+              ("train_step_per_step.txt", "_train_step_per_step.txt"), ("train_step_eager_per_step.txt", "_train_step_eager_per_step.txt"),
+              ("bwd_layers.txt", "_bwd_layers.txt"), ("warp_step_sweep.txt", "_warp_step_sweep.txt"), ("ab_results.txt", "_ab_switches.txt"),
+              ("rs_bwd1.txt", "_resample2d_bwd_input1_variants.txt"), ("host_probe.txt", "_host_issue_vs_drain.txt"),
+              ("two_stream_check.txt", "_multi_stream_check.txt"), ("bench_eager.json", "_bench_eager.json")]
     for a, b in copies:
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p) > 0:

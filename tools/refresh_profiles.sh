@@ -6,7 +6,7 @@
 #      that also instruments MIOpen's kernels aborts with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT): FETCH_SIZE, WRITE_SIZE
 #      and two SQ sets in SEPARATE runs (counters + --kernel-trace only)
 #   4. the default `python bench.py` line
-# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/r02_*.
+# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/r03_*.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh
@@ -21,6 +21,11 @@ trace() {   # tag window-ms bench-args...
   grep -h '^{' $OUT/${TAG}_bench.log | tail -1 > $OUT/${TAG}_bench.json
 }
 trace train_step 200 --steps 6 --warmup 3
+# per-STEP accounting of the same trace (the default = captured step, several streams) and of an eager, single-graph-less run
+python $R/tools/step_trace.py $(find /tmp/kt_train_step -name "*kernel_trace.csv" | head -1) --steps 3 --top 60 > $OUT/train_step_per_step.txt 2>&1
+rm -rf /tmp/kt_eager && mkdir -p /tmp/kt_eager
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_eager -- python $R/bench.py --graph off --steps 6 --warmup 3 --no-cpu-baseline --no-kernels --no-extras > $OUT/train_eager_bench.log 2>&1
+python $R/tools/step_trace.py $(find /tmp/kt_eager -name "*kernel_trace.csv" | head -1) --steps 3 --top 60 > $OUT/train_step_eager_per_step.txt 2>&1
 trace warpatt 30 --workload warpatt --steps 20 --warmup 5
 trace flownet 15 --workload flownet --steps 40 --warmup 10
 trace flownet_module 20 --workload flownet --flownet-path module --steps 40 --warmup 10
@@ -28,7 +33,7 @@ trace flowtrain 60 --workload flowtrain --steps 10 --warmup 3
 trace ops 30 --workload ops --steps 10 --warmup 3
 # whole-run statistics of the hand-written kernels of the default command (train steps + stand-alone cfg-1 / cfg-5 shapes)
 rm -rf /tmp/kt_all && mkdir -p /tmp/kt_all
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_all -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras > $OUT/trace_all.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_all -- python $R/bench.py --graph off --steps 6 --warmup 3 --no-cpu-baseline --no-extras > $OUT/trace_all.log 2>&1
 F=$(find /tmp/kt_all -name "*kernel_trace.csv" | head -1)
 python - "$F" "$OUT/ffwm_kernels_whole_run.csv" <<'PY'
 import collections, csv, sys
@@ -47,7 +52,7 @@ with open(sys.argv[2], "w") as f:
         f.write('"%s",%d,%d,%d\n' % (n, c, t, t // c))
 PY
 # counter passes
-PMC="python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras"
+PMC="python $R/bench.py --graph off --steps 2 --warmup 2 --no-cpu-baseline --no-extras"
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SALU"; do
   rm -rf /tmp/pmc_$i && mkdir -p /tmp/pmc_$i
@@ -64,3 +69,15 @@ for CK in 192 256; do
 done
 python $R/tools/wino_check.py > $OUT/winograd_vs_vendor.txt 2>&1
 python $R/tools/wino_layers.py > $OUT/winograd_layers_of_the_step.txt 2>/dev/null
+
+# round 3: the eager line beside the default (captured) one, every layer's backward vs the vendor's, the in-step warp sweep, switches A/B,
+# host issue time vs drain, the multi-stream check
+timeout 900 python $R/bench.py --graph off --no-cpu-baseline --no-kernels --no-extras > $OUT/bench_eager.json 2>/dev/null
+timeout 900 python $R/tools/bwd_layers.py > $OUT/bwd_layers.txt 2>&1
+timeout 600 python $R/tools/warp_step_sweep.py 2>&1 | grep -v Warn > $OUT/warp_step_sweep.txt
+timeout 600 python $R/tools/rs_bwd1_cfg1.py 2>&1 | grep -v Warn > $OUT/rs_bwd1.txt
+timeout 600 python $R/tools/host_sync_probe.py 2>&1 | grep -E "^host|hip" > $OUT/host_probe.txt
+timeout 900 python $R/tools/two_stream_check.py 2>&1 | grep -v Warn | tail -13 > $OUT/two_stream_check.txt
+rm -f $R/gpurun_out/ab/results.txt
+bash $R/tools/ab_graph.sh "default=X=1" "one_stream=FFWM_STREAMS=0" "tiled_wgrad_off=FFWM_TILED_WGRAD=0" "convT_dgrad_off=FFWM_CONVT_DGRAD=0" "conv_dgrad_all_own=FFWM_CONV_DGRAD=1" "bn_fused_from_0=FFWM_BN_MIN_NUMEL=0" "winograd_pairs_100=FFWM_WINOGRAD_MIN_PAIRS=100" > /dev/null 2>&1
+cp $R/gpurun_out/ab/results.txt $OUT/ab_results.txt

@@ -1,4 +1,4 @@
-"""FFWM_FLOW_STREAMS: flowNetB on a second stream must not change a single number.  The optimizers' learning rates are set to ZERO,
+"""FFWM_STREAMS: flowNetB and the loss networks' side passes on their own streams must not change a single number.  The optimizers' learning rates are set to ZERO,
 so every step (eager or replayed from the captured graph) repeats the same computation from the same weights: the losses of all
 steps of all runs must agree to the noise of the float atomics (~1e-6 relative), with one stream and with two.  A race shows up as
 a run or a step that does not."""
@@ -12,7 +12,7 @@ batch = trainer.synthetic_batch(8, dev, seed=1)
 
 
 def run(two, graph, steps=4):
-    os.environ["FFWM_FLOW_STREAMS"] = "1" if two else "0"
+    os.environ["FFWM_STREAMS"] = "1" if two else "0"
     torch.manual_seed(0)
     t = trainer.FFWMTrainer(dev, seed=0, capturable=graph)
     assert (t.flow_stream is not None) == two
