@@ -636,7 +636,8 @@ def main():
             t.titers = 20000 if keep < 20000 else 0
             dt2, _ = timed(lambda: t.step(batch, batch_increment=0), 5, 3, world)
             extras["train_titers_ge_20000" if keep < 20000 else "train_titers_lt_20000"] = {
-                "img_per_s": round(bs * 5 / dt2, 2), "ms_per_step": round(dt2 / 5 * 1e3, 3), "steps": 5, "warmup": 3}
+                "img_per_s": round(bs * 5 / dt2, 2), "ms_per_step": round(dt2 / 5 * 1e3, 3), "steps": 5, "warmup": 3,
+                "launch": "eager (compare with --graph off: the default line replays a captured step)"}
             t.titers = keep
         except Exception as e:
             extras["train_titers_other_branch"] = {"error": repr(e)}
@@ -649,6 +650,7 @@ def main():
             dt3, _ = timed(lambda: t2.step(batch, batch_increment=0), 5, 3, world)
             extras["train_flow_init_" + other.replace("-", "_")] = {
                 "img_per_s": round(bs * 5 / dt3, 2), "ms_per_step": round(dt3 / 5 * 1e3, 3), "steps": 5, "warmup": 3,
+                "launch": "eager (compare with --graph off)",
                 "note": "an untrained FlowNet outputs tanh(~0): every pixel samples the image centre (all lanes on one cache "
                         "line, all scatter-adds on four cells) -- an access pattern real training never produces"
                         if other == "random" else ""}
