@@ -69,7 +69,7 @@ __device__ __forceinline__ void make_corners(Corners<T>& c, T gx, T gy, int Hi, 
 
 template <typename T, bool FLIP>
 __device__ __forceinline__ void warp_fwd_body(const T* __restrict__ feat, const T* __restrict__ flow, T* __restrict__ out, int C,
-                                              int Hi, int Wi, int H, int W, const TileCoord tc, int cs) {
+                                              int Hi, int Wi, int H, int W, const TileCoord tc, int cs, int nt = 0) {
     const int x = tc.xf, y = tc.yf;
     if (x >= W || y >= H) return;
     const size_t plane = static_cast<size_t>(H) * W;
@@ -108,8 +108,13 @@ __device__ __forceinline__ void warp_fwd_body(const T* __restrict__ feat, const 
             for (int q = 0; q < 4; ++q) v += s[u][q] * cn.w[q];
             ElemRow<T, 1> r;
             r.v[0] = v;
-            buf_store_row<T, 1>(make_rsrc(op + u * plane, obytes), o_direct, r);
-            if (FLIP) buf_store_row<T, 1>(make_rsrc(op + u * plane + flip_planes, obytes), o_flip, r);
+            if (nt) {            // (wave-uniform) streaming stores: the output is read once, by a later kernel
+                buf_store_row_nt<T, 1>(make_rsrc(op + u * plane, obytes), o_direct, r);
+                if (FLIP) buf_store_row_nt<T, 1>(make_rsrc(op + u * plane + flip_planes, obytes), o_flip, r);
+            } else {
+                buf_store_row<T, 1>(make_rsrc(op + u * plane, obytes), o_direct, r);
+                if (FLIP) buf_store_row<T, 1>(make_rsrc(op + u * plane + flip_planes, obytes), o_flip, r);
+            }
         }
     }
     for (; c < c1; ++c, fp += iplane, op += plane) {
@@ -149,6 +154,7 @@ struct WarpProblem {
 };
 struct WarpTable {
     int n;
+    int nt;              // streaming stores (options().warp_nt)
     WarpProblem p[kMaxWarpProblems];
 };
 
@@ -177,7 +183,7 @@ warp_fwd_multi_kernel(const WarpTable tab) {
     const unsigned t = xcd_remap(blockIdx.x - q.begin, (q.nblk + 7u) & ~7u, 1);
     if (t >= q.nblk) return;
     warp_fwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<T*>(q.out), q.C, q.Hi, q.Wi,
-                           q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
+                           q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs, tab.nt);
 }
 
 // ------------------------------------------------------------------------------ forward, LDS-staged
@@ -892,6 +898,7 @@ template <typename T>
 int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_t st) {
     WarpTable tab;
     tab.n = 0;
+    tab.nt = options().warp_nt;
     unsigned blocks = 0;
     double bytes = 0;
     auto flush = [&]() -> int {
@@ -923,6 +930,7 @@ int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
 
 template <typename T>
 int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_t st) {
+    // (the d(flow) table below does not use the store policy)
     // d(feat): one plane launch per problem (the LDS footprint is per plane size; scope names carry the level)
     for (int i = 0; i < n; ++i) {
         const ffwm_warp_problem& pr = probs[i];
@@ -933,6 +941,7 @@ int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
     // d(flow): every problem that wants it, one launch
     WarpTable tab;
     tab.n = 0;
+    tab.nt = 0;
     unsigned blocks = 0;
     double bytes = 0;
     auto flush = [&]() -> int {

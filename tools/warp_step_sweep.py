@@ -46,3 +46,8 @@ for cold in (False, True):
 lib.ffwm_set_option(b"channel_slab", 0); lib.ffwm_set_option(b"xcd_remap", 1)
 lib.ffwm_set_option(b"warp_fwd_variant", 2)
 run("fwd LDS variant", False); run("fwd LDS variant", True)
+lib.ffwm_set_option(b"warp_fwd_variant", 0)
+for nt in (0, 1):
+    lib.ffwm_set_option(b"warp_nt", nt)
+    run("nt stores %d" % nt, False); run("nt stores %d" % nt, True)
+lib.ffwm_set_option(b"warp_nt", 0)
