@@ -500,7 +500,8 @@ def main():
                                   "batch_per_gpu": bs, "global_batch": bs * world,
                                   "parallelism": "dp%d" % world,
                                   "launch": ("hipGraph replay" + (" (three graphs, the two gradient all-reduces between them)" if world > 1 else "")
-                                             + (", flowNetB and the loss networks' side passes on their own HIP streams" if t.flow_stream is not None else ""))
+                                             + (", flowNetB and the loss networks' side passes on their own HIP streams" if t.flow_stream is not None else "")
+                                             + (", the D step on another" if getattr(t, "d_stream", None) is not None else ""))
                                   if graphed else "eager (hook-launched all-reduces overlap backward)" if world > 1 else "eager",
                                   "miopen": "immediate mode%s" % (" + in-tree find-db (ffwm_amd/miopen_db)" if miopen_db else ", heuristic solver choice"),
                                   "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))

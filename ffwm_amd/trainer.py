@@ -173,6 +173,12 @@ class FFWMTrainer(object):
         multi = multi and self.device.type == "cuda"
         self.flow_stream = torch.cuda.Stream(self.device) if multi else None
         self.loss_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if multi else None
+        # ... and the whole D step (netD forward / backward on 8 ... 64 px planes, its gradient packing and Adam) on one more: the
+        # generator's loss networks need nothing from it until the adversarial term.  One GPU only: with several ranks the D
+        # gradients' all-reduce sits between the captured segments.
+        self.d_stream = (torch.cuda.Stream(self.device)
+                         if multi and world_size == 1 and os.environ.get("FFWM_D_STREAM", "1") == "1" else None)
+        self._d_pending = False
         self.batched_losses = batched_losses
         # the ~25 L1 terms of backward_G as one launch per direction (losses.l1_terms, csrc/l1_loss.hip); needs the batched passes
         self.fused_l1 = (self.device.type == "cuda" and batched_losses) if fused_l1 is None else bool(fused_l1)
@@ -332,8 +338,9 @@ class FFWMTrainer(object):
         m = b["mask_F"]
         fake = self.netD(self.img_GF128.detach() * m)
         real = self.netD(b["img_F"] * m)
-        self.loss_D = (self.lsgan(fake, False) + self.lsgan(real, True)) * 0.5
-        self.loss_D.backward()
+        loss_D = (self.lsgan(fake, False) + self.lsgan(real, True)) * 0.5
+        loss_D.backward()
+        self.loss_D = loss_D.detach()
 
     def _backward_G_fused_l1(self, b):
         """backward_G with every `w * F.l1_loss(x * m, y * m)` term (pixel, perceptual, part crops, illumination, identity:
@@ -414,6 +421,7 @@ class FFWMTrainer(object):
                 t[1].record_stream(cur)
         terms += side_terms
         v = l1_terms(terms, 5)
+        self._join_D()
         loss_adv = self.lsgan(self.netD(self.img_GF128 * mask_F), True) * 0.1
         self.loss_G = v.sum() + loss_adv
         self.losses = {"G": self.loss_G, "l1": v[L1], "iden": v[IDEN], "illu": v[ILLU], "adv": loss_adv, "prc": v[PRC], "fc": v[FC]}
@@ -453,6 +461,7 @@ class FFWMTrainer(object):
             loss_iden = self.identity_many((self.fake128, gf128), img_F, (0.5, 1.0))
         else:
             loss_iden = self.identity(self.fake128, img_F) * 0.5 + self.identity(gf128, img_F) * 1
+        self._join_D()
         loss_adv = self.lsgan(self.netD(self.img_GF128 * mask_F), True) * 0.1
         self.loss_G = loss_iden + loss_l1 + loss_prc + loss_illu + loss_fc + loss_adv
         self.losses = {"G": self.loss_G, "l1": loss_l1, "iden": loss_iden, "illu": loss_illu, "adv": loss_adv,
@@ -465,15 +474,53 @@ class FFWMTrainer(object):
         self.forward(b)
         for p in self.netD.parameters():
             p.requires_grad = True
+        if self.d_stream is not None and self.world_size == 1:
+            # fork: the D step (forward, backward, gradient packing, Adam) beside the generator's loss passes; _join_D() in
+            # front of the adversarial term (the first reader of the updated netD) is the join
+            self.d_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.d_stream):
+                self.red_D.zero_grad()
+                self.backward_D(b)
+                self.red_D.finish()
+                self.opt_D.step()
+            self._d_pending = True
+            return
         self.red_D.zero_grad()
         self.backward_D(b)
 
+    def _reduce_D(self):
+        if not self._d_pending:
+            self.red_D.finish()
+
+    def _drop_autograd_graph(self):
+        """Detach what the step keeps for logging / visuals.  A live graph keeps every parameter's AccumulateGrad node alive, and a
+        node remembers the stream it was created on: the next step (or the capture after the warm-up steps, which runs on another
+        stream) would accumulate -- and pack the gradient buckets -- on that stale stream, serialising the side streams' backward."""
+        self.losses = {k: v.detach() for k, v in self.losses.items()}
+        self.loss_G = self.loss_G.detach()
+        for name in ("fake32", "fake64", "fake128", "img_GF128", "img_S_warp", "img_S_rec"):
+            setattr(self, name, getattr(self, name).detach())
+        self.flows_B = [f.detach() for f in self.flows_B]
+        self.parts = [(a.detach(), b.detach()) for a, b in self.parts]
+        for net in (self.netG, self.netD):
+            for m in net.modules():                  # spectral norm leaves the normalised weight (a graph output) on the module
+                w = m.__dict__.get("weight")
+                if torch.is_tensor(w) and w.grad_fn is not None:
+                    m.weight = w.detach()
+
+    def _join_D(self):
+        if self._d_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.d_stream)
+            self._d_pending = False
+
     def _seg_stepD_and_G(self, b):
-        self.opt_D.step()
+        if not self._d_pending:
+            self.opt_D.step()
         for p in self.netD.parameters():
             p.requires_grad = False
         self.red_G.zero_grad()
         self.backward_G(b)
+        self._drop_autograd_graph()
 
     def _seg_stepG(self):
         self.opt_G.step()
@@ -484,7 +531,7 @@ class FFWMTrainer(object):
         if self._graphs is not None:
             return self._step_graphed(b, batch_increment)
         self._seg_forward_and_D(b)
-        self.red_D.finish()
+        self._reduce_D()
         self._seg_stepD_and_G(b)
         self.red_G.finish()
         self._seg_stepG()
@@ -519,7 +566,7 @@ class FFWMTrainer(object):
         with torch.cuda.stream(side):
             for _ in range(warmup):          # MIOpen solver selection, allocator warm-up, Adam state
                 self._seg_forward_and_D(sb)
-                self.red_D.finish()
+                self._reduce_D()
                 self._seg_stepD_and_G(sb)
                 self.red_G.finish()
                 self._seg_stepG()
@@ -536,7 +583,7 @@ class FFWMTrainer(object):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._seg_forward_and_D(sb)
-                self.red_D.finish()              # one GPU: packs the D gradients into the flat array (a captured multi-tensor copy)
+                self._reduce_D()                 # one GPU: packs the D gradients into the flat array (a captured multi-tensor copy)
                 self._seg_stepD_and_G(sb)
                 self.red_G.finish()
                 self._seg_stepG()
