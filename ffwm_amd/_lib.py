@@ -56,7 +56,7 @@ _SIGNATURES = {
     "ffwm_guided_filter_forward": [_p, _p, _p, _p, _i64, _i64, _i64, _i, ctypes.c_double, _i, _p],
     "ffwm_affine_regularization": [_p, _p, _p, _p, _i64, _i64, _i64, _i, ctypes.c_double, _i, _p],
     "ffwm_correlation_colmax": [_p, _p, _p, _i64, _i64, _i64, _i, _p],
-    "ffwm_guided_filter_backward": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
+    "ffwm_guided_filter_backward": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
     "ffwm_l1_multi": [_p, _i, _p, _p, _i, _i, _p],          # (array of ffwm_l1_problem, n, out, grad_out, n_slots, dtype, stream)
     "ffwm_prof_enable": [_i],
     "ffwm_prof_collect": [],

@@ -345,9 +345,10 @@ def guided_filter_backward(x, y, saved, grad_output, r):
     gx = torch.empty_like(x)
     if gx.numel() == 0:
         return gx
+    ws = x.new_empty((2, B, C, H, W))
     with _on_device(x) as stream:
         _lib.check(_lib.load().ffwm_guided_filter_backward(
-            _ptr(x), _ptr(y), _ptr(saved), _ptr(grad_output), _ptr(gx), B * C, H, W, int(r), _dtype_code(x), stream),
+            _ptr(x), _ptr(y), _ptr(saved), _ptr(grad_output), _ptr(gx), _ptr(ws), B * C, H, W, int(r), _dtype_code(x), stream),
             "ffwm_guided_filter_backward")
     return gx
 

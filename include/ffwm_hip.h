@@ -211,15 +211,17 @@ int ffwm_spectral_norm_backward(const ffwm_sn_grad_layer* layers, int n_layers, 
  * differences, :164-193), per [H, W] plane; x, y, out are [planes = B*C, H, W] contiguous with
  * c_x == c_y (the only way FFWM calls it: models/ffwm_model.py:57-59,81,104-105).  H, W <= 128,
  * H > 2r+1, W > 2r+1.  `saved` [5, planes, H, W] receives mean_x, mean_y, A, var_x+eps, mean_A for the
- * backward.  One launch (the PyTorch module issues ~100). */
+ * backward.  Four launches (column pass / row pass + pointwise stage, twice), each over planes x W/32 x quantities or
+ * planes x H/4 workgroups; the PyTorch module issues ~100. */
 int ffwm_guided_filter_forward(const void* x, const void* y, void* output, void* saved,
                                int64_t planes, int64_t H, int64_t W, int r, double eps, int dtype,
                                void* stream);
 
-/* grad_x (OVERWRITTEN) of the above; y is data (the ground-truth image) and gets no gradient. */
+/* grad_x (OVERWRITTEN) of the above; y is data (the ground-truth image) and gets no gradient.
+ * `workspace`: [2, planes, H, W] elements of the tensors' dtype, contents irrelevant on entry and exit. */
 int ffwm_guided_filter_backward(const void* x, const void* y, const void* saved,
-                                const void* grad_output, void* grad_x, int64_t planes, int64_t H,
-                                int64_t W, int r, int dtype, void* stream);
+                                const void* grad_output, void* grad_x, void* workspace,
+                                int64_t planes, int64_t H, int64_t W, int r, int dtype, void* stream);
 
 /* ---- fused affine regularisation (FlowNet pre-training) -----------------------------------------
  * AffineRegularizationLoss.__call__ of models/losses.py:200-219 for one flow scale in ONE launch:
