@@ -842,7 +842,7 @@ rs_bwd2_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
 template <int HALF, int RPT>
 __global__ void __launch_bounds__(kBlock)
 rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi,
-                    int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+                    int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate) {
     constexpr int NW = kBlock / kWave;
     constexpr int NT = 2 * HALF;
     constexpr int TH = NW * RPT;
@@ -885,7 +885,13 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
         const size_t poff = static_cast<size_t>(y) * W + x;
         const float dx = fb[poff], dy = fb[plane + poff], sgm = fb[2 * plane + poff];
         RsTaps<float, HALF> t;
-        make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+        if (ablate & 8) {                  // bench-only: no Gaussian weights
+#pragma unroll
+            for (int f = 0; f < 2 * HALF; ++f) { t.wx[f] = dx; t.wy[f] = dy; }
+            t.sum = sgm;
+        } else {
+            make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+        }
         const float flx = floor_t(static_cast<float>(x) + dx), fly = floor_t(static_cast<float>(y) + dy);
         const float lim = static_cast<float>(1 << 20);
         const bool ok = (flx > -lim) && (flx < lim) && (fly > -lim) && (fly < lim);
@@ -935,7 +941,8 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 #pragma unroll
         for (int r = 0; r < RPT; ++r) lbase[r] = (v0[r] - vmin) * kRsBoxW + (u0[r] - umin);
         for (int c = c0; c < c1; c += 4) {
-            for (int i = threadIdx.x; i < NCELL * 2; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
+            if (!(ablate & 4))
+                for (int i = threadIdx.x; i < NCELL * 2; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
             __syncthreads();
             const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
             const rsrc_t rg0 = make_rsrc(g0, obytes);
@@ -947,6 +954,7 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
                 const float gx = buf_ld<float>(rg0, poffb[r]), gy = buf_ld<float>(rg1, poffb[r]);
                 const float gz = buf_ld<float>(rg2, poffb[r]), gw = buf_ld<float>(rg3, poffb[r]);
                 if (!live[r]) continue;
+                if (ablate & 1) { if (gx + gy + gz + gw == 12345.f) box[0] = 1; continue; }
                 double* nb = box + lbase[r];
 #pragma unroll
                 for (int pr = 0; pr < NT; ++pr)
@@ -971,6 +979,210 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float v = static_cast<float>(box[q * NCELL + i]);
+                    if (q < nch && v != 0.f && !(ablate & 2)) atomic_add(dst + static_cast<size_t>(q) * iplane, v);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // fallback: per-tap global atomics through clamped offsets
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        if (!live[r]) continue;
+        const float fxv = static_cast<float>(x) + fb[static_cast<size_t>(ys[r]) * W + x];
+        const float fyv = static_cast<float>(ys[r]) + fb[plane + static_cast<size_t>(ys[r]) * W + x];
+        const float flx = floor_t(fxv), fly = floor_t(fyv);
+        unsigned col[NT], row[NT];
+#pragma unroll
+        for (int f = 0; f < HALF; ++f) {
+            col[HALF - 1 - f] = static_cast<unsigned>(clamp_index(flx - static_cast<float>(f), Wi));
+            col[HALF + f] = static_cast<unsigned>(clamp_index(flx + static_cast<float>(f + 1), Wi));
+            row[HALF - 1 - f] = static_cast<unsigned>(clamp_index(fly - static_cast<float>(f), Hi)) * static_cast<unsigned>(Wi);
+            row[HALF + f] = static_cast<unsigned>(clamp_index(fly + static_cast<float>(f + 1), Hi)) * static_cast<unsigned>(Wi);
+        }
+        for (int c = c0; c < c1; ++c) {
+            const float g = gp[static_cast<size_t>(c - c0) * plane + poffb[r] / 4u];
+            float* d = dp + static_cast<size_t>(c - c0) * iplane;
+#pragma unroll
+            for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+                for (int pc = 0; pc < NT; ++pc) atomic_add(d + row[pr] + col[pc], wn[r][pr * NT + pc] * g);
+        }
+    }
+}
+
+// rs_bwd1_taplane_kernel (d_input1, ks = 4): the same LDS box accumulator, other work assignment.  The tile kernel above gives a
+// lane one PIXEL and adds one tap of 64 pixels per ds_add_f64: under a random flow the 64 target cells fall on random banks
+// (measured at cfg-1: 18 of 34 us are the LDS atomics, 5x their conflict-free time).  Here a wave-instruction adds the 16 taps x 4
+// channels of ONE pixel (lane = 16 ch + 4 pr + pc): 64 distinct cells, and with a box pitch of 88 (= 24 mod 32) and a channel
+// plane stride = 4 (mod 32) the 64 doubles cover every one of the 32 eight-byte bank pairs exactly twice -- the minimum for
+// 512 bytes -- for ANY flow.  The pixel's 16 normalised weights and 4 channel gradients are computed / loaded by its owner lane
+// as before, handed over through a small wave-private staging area in LDS (conflict-free pitch 65), and the box origin of the
+// pixel comes from the owner's register by v_readlane.
+template <int RPT>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi,
+                       int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+    constexpr int HALF = 2;
+    constexpr int NW = kBlock / kWave;
+    constexpr int NT = 2 * HALF;
+    constexpr int NTAP = NT * NT;
+    constexpr int TH = NW * RPT;
+    constexpr int BOXH = TH + 12;
+    constexpr int BP = 88;                                    // box pitch
+    constexpr int NCELL = BOXH * BP;
+    constexpr int PS = NCELL + ((4 - NCELL % 32) + 32) % 32;  // channel plane stride = 4 (mod 32)
+    constexpr int SP = kWave + 1;                             // staging pitch
+    static_assert(kWave == 4 * NTAP && BP % 32 == 24 && PS % 32 == 4, "bank mapping of the tap-lane scatter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* box = reinterpret_cast<double*>(smem_raw);                           // [4][PS]
+    float* wst = reinterpret_cast<float*>(box + 4 * PS);                         // [NW][NTAP][SP]
+    float* gst = wst + NW * NTAP * SP;                                           // [NW][4][SP]
+    __shared__ int red[4][NW];
+    __shared__ int flag;
+
+    unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = tid % tiles_x;
+    tid /= tiles_x;
+    const int ty = tid % tiles_y;
+    tid /= tiles_y;
+    const int slab = tid % cslabs;
+    const int b = tid / cslabs;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int x_raw = tx * kTileX + lane;
+    const bool inx = x_raw < W;
+    const int x = inx ? x_raw : W - 1;
+    if (threadIdx.x == 0) flag = 0;
+
+    float wn[RPT][NTAP];                    // SAFE_DIV(w, sum) (:196-199), [row position][col position]
+    int u0[RPT], v0[RPT], ys[RPT];
+    bool live[RPT];
+    bool regular = true;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fb = in2 + static_cast<size_t>(b) * 3 * plane;
+    int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int yraw = ty * TH + wave + r * NW;
+        live[r] = inx && yraw < H;
+        const int y = yraw < H ? yraw : H - 1;
+        ys[r] = y;
+        const size_t poff = static_cast<size_t>(y) * W + x;
+        const float dx = fb[poff], dy = fb[plane + poff], sgm = fb[2 * plane + poff];
+        RsTaps<float, HALF> t;
+        make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+        const float flx = floor_t(static_cast<float>(x) + dx), fly = floor_t(static_cast<float>(y) + dy);
+        const float lim = static_cast<float>(1 << 20);
+        const bool ok = (flx > -lim) && (flx < lim) && (fly > -lim) && (fly < lim);
+        regular = regular && ok;
+        u0[r] = ok ? static_cast<int>(flx) - (HALF - 1) : 0;
+        v0[r] = ok ? static_cast<int>(fly) - (HALF - 1) : 0;
+        umin = min(umin, u0[r]); umax = max(umax, u0[r] + NT - 1);
+        vmin = min(vmin, v0[r]); vmax = max(vmax, v0[r] + NT - 1);
+        float wxp[NT], wyp[NT];
+#pragma unroll
+        for (int f = 0; f < HALF; ++f) {
+            wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
+            wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
+        }
+#pragma unroll
+        for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+            for (int pc = 0; pc < NT; ++pc)
+                wn[r][pr * NT + pc] = static_cast<float>(safe_div<float>(wyp[pr] * wxp[pc], t.sum));
+    }
+    umin = wave_min(umin); umax = wave_max(umax); vmin = wave_min(vmin); vmax = wave_max(vmax);
+    if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
+    __syncthreads();
+    if (!regular) flag = 1;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        umin = min(umin, red[0][k]); umax = max(umax, red[1][k]);
+        vmin = min(vmin, red[2][k]); vmax = max(vmax, red[3][k]);
+    }
+    __syncthreads();
+    const int bw = umax - umin + 1, bh = vmax - vmin + 1;
+    const bool use_lds = (flag == 0) && bw <= BP && bh <= BOXH;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned obytes = static_cast<unsigned>(plane * sizeof(float));
+    const float* gp = gout + (static_cast<size_t>(b) * C + c0) * plane;
+    float* dp = gin1 + (static_cast<size_t>(b) * C + c0) * iplane;
+    unsigned poffb[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        poffb[r] = live[r] ? (static_cast<unsigned>(ys[r]) * W + static_cast<unsigned>(x)) * 4u : 0xFFFFFFF0u;     // dead lanes read g = 0
+
+    if (use_lds) {
+        int lbase[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) lbase[r] = (v0[r] - vmin) * BP + (u0[r] - umin);
+        const int tap = lane & (NTAP - 1), chl = lane / NTAP;
+        double* mycell = box + (tap / NT) * BP + (tap % NT) + chl * PS;
+        float* wS = wst + wave * NTAP * SP;
+        float* gS = gst + wave * 4 * SP;
+        const float* wR = wS + tap * SP;
+        const float* gR = gS + chl * SP;
+        for (int c = c0; c < c1; c += 4) {
+            for (int i = threadIdx.x; i < 2 * PS; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
+            __syncthreads();
+            const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
+            const rsrc_t rg0 = make_rsrc(g0, obytes);
+            const rsrc_t rg1 = make_rsrc(g0 + plane, c + 1 < c1 ? obytes : 0u);
+            const rsrc_t rg2 = make_rsrc(g0 + 2 * plane, c + 2 < c1 ? obytes : 0u);
+            const rsrc_t rg3 = make_rsrc(g0 + 3 * plane, c + 3 < c1 ? obytes : 0u);
+            float gv[RPT][4];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                gv[r][0] = buf_ld<float>(rg0, poffb[r]); gv[r][1] = buf_ld<float>(rg1, poffb[r]);
+                gv[r][2] = buf_ld<float>(rg2, poffb[r]); gv[r][3] = buf_ld<float>(rg3, poffb[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                // the owner lanes hand their pixel's weights and gradients to the wave (a dead pixel hands g = 0)
+#pragma unroll
+                for (int k = 0; k < NTAP; ++k) wS[k * SP + lane] = wn[r][k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gS[q * SP + lane] = gv[r][q];
+                __builtin_amdgcn_wave_barrier();
+                const int lb = lbase[r];
+                // batches of 8 pixels, the next batch's weights and gradients read before this batch's atomics are issued (the
+                // staging area and the box are one LDS array to the compiler: it keeps program order, and a rolled loop waited
+                // for a full LDS round trip per pixel)
+                constexpr int NB = 8;
+                float wa[NB], ga[NB], wb[NB], gb[NB];
+                auto fetch = [&](int px0, float (&wv)[NB], float (&gq)[NB]) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) { wv[k] = wR[px0 + k]; gq[k] = gR[px0 + k]; }
+                };
+                auto emit = [&](int px0, const float (&wv)[NB], const float (&gq)[NB]) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) lds_add(mycell + __builtin_amdgcn_readlane(lb, px0 + k), wv[k] * gq[k]);
+                };
+                fetch(0, wa, ga);
+#pragma unroll
+                for (int px0 = 0; px0 < kWave; px0 += 2 * NB) {
+                    fetch(px0 + NB, wb, gb);
+                    emit(px0, wa, ga);
+                    if (px0 + 2 * NB < kWave) fetch(px0 + 2 * NB, wa, ga);
+                    emit(px0 + NB, wb, gb);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __syncthreads();
+            // fold the box onto the clamped image: one global atomic per non-zero cell and channel
+            const int nch = c1 - c < 4 ? c1 - c : 4;
+            for (int i = threadIdx.x; i < bh * BP; i += kBlock) {
+                const int r = i / BP, cc = i - r * BP;
+                if (cc >= bw) continue;
+                const int gy = min(max(vmin + r, 0), Hi - 1), gx = min(max(umin + cc, 0), Wi - 1);
+                float* dst = dp + static_cast<size_t>(c - c0) * iplane + static_cast<size_t>(gy) * Wi + gx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = static_cast<float>(box[q * PS + i]);
                     if (q < nch && v != 0.f) atomic_add(dst + static_cast<size_t>(q) * iplane, v);
                 }
             }
@@ -1265,6 +1477,30 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             };
             // d_input1: planes that fit LDS whole keep the plane kernel below (measured, cfg-1: 36 vs 47 us; [8,64,128,128]: 218 vs
             // 235 us); larger planes take the tile kernel ([8,64,512,512]: 3.1 ms vs 57 ms with per-tap global atomics)
+            if (gin1 && half == 2 && (options().rs_bwd1_variant == 0 || options().rs_bwd1_variant == 5)) {
+                // ks = 4: one pixel's 16 taps x 4 channels per LDS atomic instruction -- bank-conflict-free for any flow
+                const int rpt = options().rs_bwd1_variant == 5 ? 4 : 2;
+                const int tiles_y = static_cast<int>((H + 4 * rpt - 1) / (4 * rpt));
+                int cs, cslabs;
+                slabs(B * tiles_x * tiles_y, cs, cslabs);
+                const unsigned grid = static_cast<unsigned>(B * tiles_x * tiles_y * cslabs);
+                const int ncell = (4 * rpt + 12) * 88;
+                const int ps = ncell + ((4 - ncell % 32) + 32) % 32;
+                const size_t lds = static_cast<size_t>(4) * ps * sizeof(double) + static_cast<size_t>(4) * (16 + 4) * 65 * sizeof(float);
+                const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
+                LaunchScope ls("resample2d_bwd_input1_taplane", st, bytes);
+                if (rpt == 4) {
+                    allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<4>));
+                    hipLaunchKernelGGL((rs_bwd1_taplane_kernel<4>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, (int)Hi,
+                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap);
+                } else {
+                    allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<2>));
+                    hipLaunchKernelGGL((rs_bwd1_taplane_kernel<2>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, (int)Hi,
+                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap);
+                }
+                if (int rc = check_launch("ffwm_resample2d_backward(input1, tap-lane)")) return rc;
+                gin1 = nullptr;
+            }
             if (gin1 && (plane_lds > 131072 || options().rs_bwd1_variant == 2)) {
                 const int rpt = H >= 32 ? 4 : 1;
                 const int tiles_y = static_cast<int>((H + 4 * rpt - 1) / (4 * rpt));
@@ -1278,7 +1514,7 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
     do {                                                                                                      \
         allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_tile_kernel<HH, RR>));                          \
         hipLaunchKernelGGL((rs_bwd1_tile_kernel<HH, RR>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, \
-                           (int)Hi, (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap);     \
+                           (int)Hi, (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate); \
     } while (0)
                 if (rpt == 4) { if (half == 1) FFWM_RS_B1T(1, 4); else if (half == 2) FFWM_RS_B1T(2, 4); else FFWM_RS_B1T(3, 4); }
                 else { if (half == 1) FFWM_RS_B1T(1, 1); else if (half == 2) FFWM_RS_B1T(2, 1); else FFWM_RS_B1T(3, 1); }
