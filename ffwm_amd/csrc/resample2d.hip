@@ -1020,12 +1020,12 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 // 512 bytes -- for ANY flow.  The pixel's 16 normalised weights and 4 channel gradients are computed / loaded by its owner lane
 // as before, handed over through a small wave-private staging area in LDS (conflict-free pitch 65), and the box origin of the
 // pixel comes from the owner's register by v_readlane.
-template <int RPT>
-__global__ void __launch_bounds__(kBlock)
+template <int RPT, int NW>
+__global__ void __launch_bounds__(NW * kWave)
 rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi,
-                       int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap) {
+                       int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate) {
     constexpr int HALF = 2;
-    constexpr int NW = kBlock / kWave;
+    constexpr int NTHR = NW * kWave;
     constexpr int NT = 2 * HALF;
     constexpr int NTAP = NT * NT;
     constexpr int TH = NW * RPT;
@@ -1127,7 +1127,7 @@ rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ 
         const float* wR = wS + tap * SP;
         const float* gR = gS + chl * SP;
         for (int c = c0; c < c1; c += 4) {
-            for (int i = threadIdx.x; i < 2 * PS; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
+            for (int i = threadIdx.x; i < 2 * PS; i += NTHR) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
             __syncthreads();
             const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
             const rsrc_t rg0 = make_rsrc(g0, obytes);
@@ -1146,7 +1146,7 @@ rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ 
 #pragma unroll
                 for (int k = 0; k < NTAP; ++k) wS[k * SP + lane] = wn[r][k];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gS[q * SP + lane] = gv[r][q];
+                for (int q = 0; q < 4; ++q) gS[q * SP + lane] = (ablate & 16) ? 1.f : gv[r][q];
                 __builtin_amdgcn_wave_barrier();
                 const int lb = lbase[r];
                 // batches of 8 pixels, the next batch's weights and gradients read before this batch's atomics are issued (the
@@ -1160,7 +1160,10 @@ rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ 
                 };
                 auto emit = [&](int px0, const float (&wv)[NB], const float (&gq)[NB]) {
 #pragma unroll
-                    for (int k = 0; k < NB; ++k) lds_add(mycell + __builtin_amdgcn_readlane(lb, px0 + k), wv[k] * gq[k]);
+                    for (int k = 0; k < NB; ++k) {
+                        if (ablate & 1) { if (wv[k] * gq[k] == 12345.f) box[0] = 1; continue; }     // bench-only: no LDS atomics
+                        lds_add(mycell + __builtin_amdgcn_readlane(lb, px0 + k), wv[k] * gq[k]);
+                    }
                 };
                 fetch(0, wa, ga);
 #pragma unroll
@@ -1175,7 +1178,7 @@ rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ 
             __syncthreads();
             // fold the box onto the clamped image: one global atomic per non-zero cell and channel
             const int nch = c1 - c < 4 ? c1 - c : 4;
-            for (int i = threadIdx.x; i < bh * BP; i += kBlock) {
+            for (int i = threadIdx.x; i < bh * BP; i += NTHR) {
                 const int r = i / BP, cc = i - r * BP;
                 if (cc >= bw) continue;
                 const int gy = min(max(vmin + r, 0), Hi - 1), gx = min(max(umin + cc, 0), Wi - 1);
@@ -1183,7 +1186,7 @@ rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float v = static_cast<float>(box[q * PS + i]);
-                    if (q < nch && v != 0.f) atomic_add(dst + static_cast<size_t>(q) * iplane, v);
+                    if (q < nch && v != 0.f && !(ablate & 2)) atomic_add(dst + static_cast<size_t>(q) * iplane, v);
                 }
             }
             __syncthreads();
@@ -1479,24 +1482,27 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             // 235 us); larger planes take the tile kernel ([8,64,512,512]: 3.1 ms vs 57 ms with per-tap global atomics)
             if (gin1 && half == 2 && (options().rs_bwd1_variant == 0 || options().rs_bwd1_variant == 5)) {
                 // ks = 4: one pixel's 16 taps x 4 channels per LDS atomic instruction -- bank-conflict-free for any flow
-                const int rpt = options().rs_bwd1_variant == 5 ? 4 : 2;
-                const int tiles_y = static_cast<int>((H + 4 * rpt - 1) / (4 * rpt));
+                // default: 4 waves x 2 rows = 64 x 8 pixel tiles, two blocks per CU (56 KB box + 22 KB staging each); variant 5: 8 waves x 2 rows
+                // (one block per CU, a quarter fewer fold atomics: measured 1.61 against 1.53 ms at [8,64,512,512])
+                const int nw = options().rs_bwd1_variant == 5 ? 8 : 4, rpt = 2;
+                const int th = nw * rpt;
+                const int tiles_y = static_cast<int>((H + th - 1) / th);
                 int cs, cslabs;
                 slabs(B * tiles_x * tiles_y, cs, cslabs);
                 const unsigned grid = static_cast<unsigned>(B * tiles_x * tiles_y * cslabs);
-                const int ncell = (4 * rpt + 12) * 88;
+                const int ncell = (th + 12) * 88;
                 const int ps = ncell + ((4 - ncell % 32) + 32) % 32;
-                const size_t lds = static_cast<size_t>(4) * ps * sizeof(double) + static_cast<size_t>(4) * (16 + 4) * 65 * sizeof(float);
+                const size_t lds = static_cast<size_t>(4) * ps * sizeof(double) + static_cast<size_t>(nw) * (16 + 4) * 65 * sizeof(float);
                 const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
                 LaunchScope ls("resample2d_bwd_input1_taplane", st, bytes);
-                if (rpt == 4) {
-                    allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<4>));
-                    hipLaunchKernelGGL((rs_bwd1_taplane_kernel<4>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, (int)Hi,
-                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap);
+                if (nw == 8) {
+                    allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<2, 8>));
+                    hipLaunchKernelGGL((rs_bwd1_taplane_kernel<2, 8>), dim3(grid), dim3(8 * kWave), lds, st, in2, gout, gin1, (int)C, (int)Hi,
+                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
                 } else {
-                    allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<2>));
-                    hipLaunchKernelGGL((rs_bwd1_taplane_kernel<2>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, (int)Hi,
-                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap);
+                    allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<2, 4>));
+                    hipLaunchKernelGGL((rs_bwd1_taplane_kernel<2, 4>), dim3(grid), dim3(4 * kWave), lds, st, in2, gout, gin1, (int)C, (int)Hi,
+                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
                 }
                 if (int rc = check_launch("ffwm_resample2d_backward(input1, tap-lane)")) return rc;
                 gin1 = nullptr;

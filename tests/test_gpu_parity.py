@@ -509,7 +509,7 @@ def test_resample2d_backward_other_scatter_paths(oracle, case, variant):
     """d_input1 / d_input2 through every path: per-tap global atomics (scatter_variant 1), the pixel-major d_input2 kernel
     with the LDS-resident plane kernel (scatter_variant 2: what fp64 / dilated calls take), and the LDS-tile d_input1
     kernel (rs_bwd1_variant 2: the default for planes larger than 128 x 128 unless ks = 4) forced on small planes; ks = 4 takes the
-    tap-lane kernel by default: variant 1 = the plane kernel it replaced, 5 = its 16-row tiles."""
+    tap-lane kernel by default: variant 1 = the plane kernel it replaced, 5 = its 8-wave blocks."""
     from ffwm_amd import _lib, ops
     in1, in2, go, ks, dil = _rs_inputs(case, torch.float32, varying_sigma=True)
     g1_ref, g2_ref = oracle.resample2d_backward(in1, in2, go, ks, dil)

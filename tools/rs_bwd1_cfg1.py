@@ -30,23 +30,24 @@ for shape in ((1, 64, 128, 128), (8, 64, 512, 512)):
     lib.ffwm_set_option(b"rs_bwd1_variant", 0)
     lib.ffwm_set_option(b"channel_slab", 0)
 
-# ablations of the tile kernel at cfg-1 (bench-only option `ablate`: 1 = no LDS atomics, 2 = no global atomics in the fold, 4 = no zeroing,
-# 8 = no Gaussian weights)
-B, C, H, W = 1, 64, 128, 128
-in1 = torch.rand(B, C, H, W, generator=g).to(dev)
-in2 = torch.cat((torch.rand(B, 2, H, W, generator=g) * 6 - 3, torch.full((B, 1, H, W), 2.0)), 1).to(dev)
-go = torch.rand(B, C, H, W, generator=g).to(dev)
-g1 = torch.zeros_like(in1)
-lib.ffwm_set_option(b"rs_bwd1_variant", 2)
-for ab in (0, 1, 2, 3, 4, 7, 8, 15):
-    lib.ffwm_set_option(b"ablate", ab)
-    for _ in range(2):
-        ops.resample2d_backward(in1, in2, go, 4, 1, g1, None)
-    torch.cuda.synchronize()
-    _lib.prof_reset(); _lib.prof_enable(True)
-    for _ in range(5):
-        ops.resample2d_backward(in1, in2, go, 4, 1, g1, None)
-    torch.cuda.synchronize(); _lib.prof_enable(False)
-    print("ablate", ab, {k: round(v["avg_ms"] * 1e3, 1) for k, v in _lib.prof_collect().items()})
-lib.ffwm_set_option(b"ablate", 0)
-lib.ffwm_set_option(b"rs_bwd1_variant", 0)
+# ablations (bench-only option `ablate`: 1 = no LDS atomics, 2 = no global atomics in the fold, 16 = gradients not used (g = 1))
+for shape in ((1, 64, 128, 128), (8, 64, 512, 512)):
+    B, C, H, W = shape
+    in1 = torch.rand(*shape, generator=g).to(dev)
+    in2 = torch.cat((torch.rand(B, 2, H, W, generator=g) * 6 - 3, torch.full((B, 1, H, W), 2.0)), 1).to(dev)
+    go = torch.rand(*shape, generator=g).to(dev)
+    g1 = torch.zeros_like(in1)
+    for variant in (5, 2):
+        lib.ffwm_set_option(b"rs_bwd1_variant", variant)
+        for ab in (0, 1, 2, 3, 16):
+            lib.ffwm_set_option(b"ablate", ab)
+            for _ in range(2):
+                ops.resample2d_backward(in1, in2, go, 4, 1, g1, None)
+            torch.cuda.synchronize()
+            _lib.prof_reset(); _lib.prof_enable(True)
+            for _ in range(5):
+                ops.resample2d_backward(in1, in2, go, 4, 1, g1, None)
+            torch.cuda.synchronize(); _lib.prof_enable(False)
+            print(shape, "variant", variant, "ablate", ab, {k: round(v["avg_ms"] * 1e3, 1) for k, v in _lib.prof_collect().items()})
+    lib.ffwm_set_option(b"ablate", 0)
+    lib.ffwm_set_option(b"rs_bwd1_variant", 0)
