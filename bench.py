@@ -229,7 +229,13 @@ def standalone_kernels(reps=10):
     go = torch.rand(8, 64, 512, 512, generator=g).to(dev)
     g1, g2 = torch.zeros_like(in1), torch.empty_like(in2)
     run("HBM-resident resample2d ks=4 [8,64,512,512] backward, flow~U[-3,3)", lambda: ops.resample2d_backward(in1, in2, go, 4, 1, g1, g2), 3)
-    del in1, in2, o, go, g1, g2
+    # ... and with a SMOOTH displacement of the same amplitude (what a flow net produces; the random flow is BASELINE configs[0]'s)
+    lin = torch.linspace(-1, 1, 512)
+    yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+    sm = torch.stack((3 * torch.sin(3.1 * yy + 0.3) * torch.cos(2.3 * xx), 3 * torch.cos(2.7 * xx - 0.2) * torch.sin(1.9 * yy),
+                      torch.full((512, 512), 2.0)), 0).unsqueeze(0).repeat(8, 1, 1, 1).contiguous().to(dev)
+    run("HBM-resident resample2d ks=4 [8,64,512,512] backward, smooth flow, amplitude 3 px", lambda: ops.resample2d_backward(in1, sm, go, 4, 1, g1, g2), 3)
+    del in1, in2, o, go, g1, g2, sm
     # netG's warp + flip + cat at an HBM-resident shape (the HBM claim is taken from shapes beyond the caches)
     feat = torch.rand(32, 64, 256, 256, generator=g).to(dev)
     nflow = smooth_flow(32, 256).to(dev)

@@ -29,8 +29,9 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "conv_winograd_dgrad": "winograd_conv_raw_kernel<0>",
     "conv_winograd_fwd": "winograd_conv_raw_kernel<0>",
     "conv_winograd_weights": "winograd_weights_kernel",
-    "guided_filter_bwd": "gf_backward_kernel<float>",
-    "guided_filter_fwd": "gf_forward_kernel<float>",
+    # four launches per scope: the traffic of a scope is the SUM over its kernels
+    "guided_filter_bwd": ("gf_cols_kernel<float, 2>", "gf_rows_kernel<float, 2>", "gf_cols_kernel<float, 3>", "gf_rows_kernel<float, 3>"),
+    "guided_filter_fwd": ("gf_cols_kernel<float, 0>", "gf_rows_kernel<float, 0>", "gf_cols_kernel<float, 1>", "gf_rows_kernel<float, 1>"),
     "mfm_bwd": "mfm_bwd4_kernel",
     "mfm_fwd": "mfm_fwd4_kernel",
     "local_attn_reshape_bwd": "lar_bwd_kernel<float, 3, false>",
@@ -60,6 +61,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "flownet_flow_up": "flow_up_kernel",
     "flownet_flow_up_bwd": "flow_up_bwd_kernel",
     "resample2d_bwd_input1_tile": "rs_bwd1_tile_kernel<2,",
+    "resample2d_bwd_input1_taplane": "rs_bwd1_taplane_kernel<2,",
     "warp_flipcat_fwd@256": "warp_fwd_lds_kernel<true>",
     "warp_flipcat_bwd_feat_tile@256": "warp_bwd_feat_tile_kernel<true, 2>",
     "warp_flipcat_bwd_feat_far@256": "warp_bwd_feat_far_kernel<true>",
@@ -94,12 +96,27 @@ def main():
     }
     dropped = []
     for scope, frag in sorted(SCOPES.items()):
-        rows = [v for k, v in raw.items() if ("::" + frag) in k]
-        if not rows:
-            continue
-        n = sum(v["dispatches"] for v in rows)
-        fetch = sum(v.get("FETCH_SIZE", 0.0) * v["dispatches"] for v in rows) / n
-        write = sum(v.get("WRITE_SIZE", 0.0) * v["dispatches"] for v in rows) / n
+        if isinstance(frag, tuple):              # a scope of several launches: sum of the kernels' per-dispatch averages
+            parts = []
+            for f in frag:
+                rs = [v for k, v in raw.items() if ("::" + f) in k]
+                if rs:
+                    m = sum(v["dispatches"] for v in rs)
+                    parts.append((m, sum(v.get("FETCH_SIZE", 0.0) * v["dispatches"] for v in rs) / m,
+                                  sum(v.get("WRITE_SIZE", 0.0) * v["dispatches"] for v in rs) / m))
+            if len(parts) != len(frag):
+                continue
+            n = min(p[0] for p in parts)
+            fetch, write = sum(p[1] for p in parts), sum(p[2] for p in parts)
+            rows = []
+            frag = " + ".join(frag)
+        else:
+            rows = [v for k, v in raw.items() if ("::" + frag) in k]
+            if not rows:
+                continue
+            n = sum(v["dispatches"] for v in rows)
+            fetch = sum(v.get("FETCH_SIZE", 0.0) * v["dispatches"] for v in rows) / n
+            write = sum(v.get("WRITE_SIZE", 0.0) * v["dispatches"] for v in rows) / n
         if fetch <= 0 or write <= 0:
             dropped.append(scope)
             continue
@@ -132,7 +149,8 @@ def main():
               ("train_step_per_step.txt", "_train_step_per_step.txt"), ("train_step_eager_per_step.txt", "_train_step_eager_per_step.txt"),
               ("bwd_layers.txt", "_bwd_layers.txt"), ("warp_step_sweep.txt", "_warp_step_sweep.txt"), ("ab_results.txt", "_ab_switches.txt"),
               ("rs_bwd1.txt", "_resample2d_bwd_input1_variants.txt"), ("host_probe.txt", "_host_issue_vs_drain.txt"),
-              ("two_stream_check.txt", "_multi_stream_check.txt"), ("bench_eager.json", "_bench_eager.json")]
+              ("two_stream_check.txt", "_multi_stream_check.txt"), ("bench_eager.json", "_bench_eager.json"),
+              ("gf_trace.txt", "_guided_filter_kernels.txt"), ("ref_vs_hip.json", "_ref_vs_hip.json")]
     for a, b in copies:
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p) > 0:
