@@ -371,6 +371,8 @@ def run_warp_attention(dev, bs, steps, warmup, world, seed=1):
     torch.manual_seed(0)
     mod = nets.WarpAttention(sn=True).to(dev).train()
     fuse_spectral_norm(mod)
+    from ffwm_amd.residual import fuse_residual
+    fuse_residual(mod)                      # the gate `skip * att_i(skip)` with its sigmoid residual tail as one kernel, as in the trainer
     g = torch.Generator().manual_seed(seed)
     feats = [torch.rand(bs, c, s, s, generator=g).to(dev).requires_grad_(True) for c, s in mod.LEVELS]
     flows = [smooth_flow(bs, s).to(dev).requires_grad_(True) for _, s in mod.LEVELS]

@@ -26,6 +26,10 @@ _SIGNATURES = {
     "ffwm_bn_lrelu_backward": [_p] * 10 + [_i64] * 3 + [ctypes.c_double] + [_i, _p],
     "ffwm_mfm_forward": [_p, _p, _p] + [_i64] * 3 + [_i, _p],
     "ffwm_mfm_backward": [_p, _p, _p, _p] + [_i64] * 3 + [_i, _p],
+    "ffwm_add_act_forward": [_p, _p, _p, _i64, _i, ctypes.c_double, _i, _p],
+    "ffwm_add_act_backward": [_p, _p, _p, _i64, _i, ctypes.c_double, _i, _p],
+    "ffwm_sigmoid_gate_forward": [_p, _p, _p, _p, _p, _i64, _i, _p],
+    "ffwm_sigmoid_gate_backward": [_p, _p, _p, _p, _p, _i64, _i, _p],
     "ffwm_bias_relu_forward": [_p, _p, _p] + [_i64] * 3 + [_i, _p],
     "ffwm_bias_act_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, ctypes.c_double, _i, _p],
     "ffwm_flow_head_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],

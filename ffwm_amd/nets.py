@@ -142,6 +142,14 @@ class ResidualBlock(nn.Module):
         return self.activ(self.blocks(x) + self.input(x))
 
 
+class FusedResidualBlock(ResidualBlock):
+    """The same block with add + activation as one kernel (ffwm_amd/residual.py re-classes instances in place)."""
+
+    def forward(self, x):
+        from .residual import add_act
+        return add_act(self.blocks(x), self.input(x), self.activ)
+
+
 def _conv_block(inc, outc, ks, s, p, activ="lrelu", res=0, bn=True, sn=True):
     layers = [_sn(nn.Conv2d(inc, outc, ks, s, p), sn)]
     if bn:
@@ -190,6 +198,7 @@ class FFWM(nn.Module):
         self.warpNet = WarpNet()
         self._fused = warp_flipcat if warp_flipcat is not None else WarpFlipCat()
         self._multi = warp_flipcat is None           # the HIP path: all levels' warps in one multi-problem launch
+        self.fuse_gate = False                       # residual.fuse_residual: `skip * att_i(skip)` with its sigmoid tail as one kernel
 
     def _skip(self, feat, flow):
         if self.isflip:
@@ -215,8 +224,12 @@ class FFWM(nn.Module):
         for i in range(self.layers):
             dec = getattr(self, "d%d" % i)(fdec)
             skip = skips[i]
-            att = getattr(self, "att%d" % i)(skip)
-            skip = skip * att
+            if self.fuse_gate:
+                from .residual import gated
+                skip, att = gated(getattr(self, "att%d" % i), skip)
+            else:
+                att = getattr(self, "att%d" % i)(skip)
+                skip = skip * att
             parts = [skip, dec]
             if recons:   # TP-GAN style: feed the lower-resolution reconstruction to the next level
                 parts.append(F.interpolate(recons[-1], scale_factor=2, mode="bilinear"))
@@ -242,12 +255,16 @@ class WarpAttention(nn.Module):
                                                      ResidualBlock(2 * c, 2 * c, activ="sigmoid", sn=sn)))
         self._fused = warp_flipcat if warp_flipcat is not None else WarpFlipCat()
         self._multi = warp_flipcat is None
+        self.fuse_gate = False                       # residual.fuse_residual
 
     def forward(self, feats, flows):
         if self._multi and feats[0].is_cuda:
             skips = warp_many(list(feats), list(flows), True)
         else:
             skips = [self._fused(feat, flow) for feat, flow in zip(feats, flows)]
+        if self.fuse_gate:
+            from .residual import gated
+            return [gated(getattr(self, "att%d" % i), skip)[0] for i, skip in enumerate(skips)]
         return [skip * getattr(self, "att%d" % i)(skip) for i, skip in enumerate(skips)]
 
 

@@ -536,6 +536,61 @@ def _bias_ok(x, bias, n):
         raise ValueError("bias must be a contiguous float32 GPU vector of %d elements" % n)
 
 
+# ---------------------------------------------------------------- residual-block tails / warp-attention gate
+_ACT_CODES = {"lrelu": 1, "sigmoid": 3}
+
+
+def _same_f32(name, *ts):
+    t0 = ts[0]
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == t0.shape and t.device == t0.device):
+            raise NotImplementedError("%s: contiguous float32 GPU tensors of one shape only" % name)
+
+
+def add_act_forward(a, b, act, negative_slope=0.2):
+    """act(a + b): the tail of ResidualBlock.forward (base_networks.py:207-233) as one pass; act in {"lrelu", "sigmoid"}."""
+    _same_f32("add_act_forward", a, b)
+    y = torch.empty_like(a)
+    if y.numel():
+        with _on_device(a) as stream:
+            _lib.check(_lib.load().ffwm_add_act_forward(_ptr(a), _ptr(b), _ptr(y), a.numel(), _ACT_CODES[act], float(negative_slope),
+                                                        _lib.F32, stream), "ffwm_add_act_forward")
+    return y
+
+
+def add_act_backward(y, grad_y, act, negative_slope=0.2):
+    """grad_y * act'(a + b) from y = act(a + b): the gradient of a and of b."""
+    _same_f32("add_act_backward", y, grad_y)
+    dz = torch.empty_like(y)
+    if dz.numel():
+        with _on_device(y) as stream:
+            _lib.check(_lib.load().ffwm_add_act_backward(_ptr(y), _ptr(grad_y), _ptr(dz), y.numel(), _ACT_CODES[act],
+                                                         float(negative_slope), _lib.F32, stream), "ffwm_add_act_backward")
+    return dz
+
+
+def sigmoid_gate_forward(a, b, x):
+    """-> (y, att): att = sigmoid(a + b), y = x * att (FFWM.forward's `skip * att_i(skip)`, base_networks.py:330-333)."""
+    _same_f32("sigmoid_gate_forward", a, b, x)
+    att, y = torch.empty_like(a), torch.empty_like(a)
+    if y.numel():
+        with _on_device(a) as stream:
+            _lib.check(_lib.load().ffwm_sigmoid_gate_forward(_ptr(a), _ptr(b), _ptr(x), _ptr(att), _ptr(y), a.numel(), _lib.F32, stream),
+                       "ffwm_sigmoid_gate_forward")
+    return y, att
+
+
+def sigmoid_gate_backward(x, att, grad_y):
+    """-> (grad_z, grad_x): grad_z = the gradient of a and of b."""
+    _same_f32("sigmoid_gate_backward", x, att, grad_y)
+    dz, dx = torch.empty_like(x), torch.empty_like(x)
+    if dz.numel():
+        with _on_device(x) as stream:
+            _lib.check(_lib.load().ffwm_sigmoid_gate_backward(_ptr(x), _ptr(att), _ptr(grad_y), _ptr(dz), _ptr(dx), x.numel(), _lib.F32,
+                                                              stream), "ffwm_sigmoid_gate_backward")
+    return dz, dx
+
+
 def mfm_forward(x, bias=None):
     """max(x[:, :C] + bias[:C], x[:, C:] + bias[C:]) of a contiguous float32 [B, 2C, ...] tensor."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):

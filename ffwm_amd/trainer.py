@@ -143,6 +143,12 @@ class FFWMTrainer(object):
             # BatchNorm2d + LeakyReLU pairs of the conv blocks as one kernel per direction (norm.py, csrc/bn_lrelu.hip)
             from .norm import fuse_bn_lrelu
             self.fused_bn_layers = sum(fuse_bn_lrelu(net) for net in (self.flowNetF, self.flowNetB, self.netG, self.netD))
+        self.fused_residual_blocks = 0
+        if fused_bn and self.device.type == "cuda" and os.environ.get("FFWM_FUSED_RESIDUAL", "1") == "1":
+            # add + activation behind every residual block and the warp-attention gate `skip * att_i(skip)` as one kernel per
+            # direction (residual.py, csrc/residual.hip)
+            from .residual import fuse_residual
+            self.fused_residual_blocks = sum(fuse_residual(net) for net in (self.netG, self.netD))
         if fused_spectral_norm is None:
             fused_spectral_norm = self.device.type == "cuda"
         if fused_spectral_norm:

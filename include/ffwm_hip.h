@@ -308,6 +308,22 @@ int ffwm_mfm_forward(const void* x, const void* bias, void* y, int64_t B, int64_
 int ffwm_mfm_backward(const void* x, const void* bias, const void* grad_y, void* grad_x, int64_t B, int64_t C, int64_t HW,
                       int dtype, void* stream);
 
+/* ---- residual-block tails and the warp-attention gate of netG (models/base_networks.py:207-233, 326-333) ----------------
+ * ResidualBlock.forward = activ(blocks(x) + input(x)) and FFWM.forward's `skip = skip * att_i(skip)` (att_i ends in a sigmoid
+ * ResidualBlock) as one pass each instead of 2-3 element-wise launches.  Contiguous float32, n elements, 16-byte aligned.
+ *   ffwm_add_act_forward:       y = act(a + b), act 1 = LeakyReLU(negative_slope > 0), 3 = sigmoid (y may alias a or b)
+ *   ffwm_add_act_backward:      grad_z = grad_y * act'(a + b), formed from y alone (grad_z may alias grad_y); it is the gradient of
+ *                               a AND of b
+ *   ffwm_sigmoid_gate_forward:  att = sigmoid(a + b), y = x * att
+ *   ffwm_sigmoid_gate_backward: grad_z = grad_y * x * att * (1 - att) (gradient of a and of b), grad_x = grad_y * att
+ * ATen's operation order throughout (results equal the PyTorch composition's bit for bit up to expf). */
+int ffwm_add_act_forward(const void* a, const void* b, void* y, int64_t n, int act, double negative_slope, int dtype, void* stream);
+int ffwm_add_act_backward(const void* y, const void* grad_y, void* grad_z, int64_t n, int act, double negative_slope, int dtype,
+                          void* stream);
+int ffwm_sigmoid_gate_forward(const void* a, const void* b, const void* x, void* att, void* y, int64_t n, int dtype, void* stream);
+int ffwm_sigmoid_gate_backward(const void* x, const void* att, const void* grad_y, void* grad_z, void* grad_x, int64_t n, int dtype,
+                               void* stream);
+
 /* y[B,C,HW] = relu(h[B,C,HW] + bias[C]) -- the bias add and ReLU behind the frozen VGG19 convs (models/losses.py:398-519)
  * as one pass; y may alias h. */
 int ffwm_bias_relu_forward(const void* h, const void* bias, void* y, int64_t B, int64_t C, int64_t HW, int dtype, void* stream);

@@ -183,6 +183,8 @@ def _route_all(net, monkeypatch):
     n_w = conv.route_conv_wgrad(net)
     n_wino = conv.route_conv_winograd(net)
     n_fwd = conv.route_conv_fwd(net)
+    from ffwm_amd.residual import fuse_residual
+    assert fuse_residual(net) >= 13 and net.fuse_gate        # add + activation of the residual blocks, the warp-attention gate
     return n_w, n_wino, n_fwd
 
 

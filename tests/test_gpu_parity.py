@@ -896,6 +896,54 @@ def test_fused_spectral_norm_matches_torch_hooks(dtype):
         assert (p.grad - q.grad).abs().max().item() <= tol * (1 + p.grad.abs().max().item()), n
 
 
+# ------------------------------------------------------------------------- residual-block tails / warp-attention gate
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (1, 64, 32, 32), (3, 3, 1, 1)])
+@pytest.mark.parametrize("act", ["lrelu", "sigmoid"])
+def test_add_act_equals_the_pytorch_composition(shape, act):
+    """ResidualBlock.forward's tail (base_networks.py:207-233): act(a + b) and its backward as one kernel each -- the SAME values as
+    ATen's add + leaky_relu / sigmoid and their backward (bit for bit for LeakyReLU; sigmoid up to expf's last bit)."""
+    from ffwm_amd.residual import add_act
+    import torch.nn as nn
+    g = _gen(11)
+    a = torch.randn(*shape, generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn(*shape, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn(*shape, generator=g).to(DEV)
+    mod = nn.LeakyReLU(0.2) if act == "lrelu" else nn.Sigmoid()
+    y = add_act(a, b, mod)
+    assert type(y.grad_fn).__name__ == "_AddActBackward"
+    ga, gb = torch.autograd.grad(y, (a, b), go)
+    yr = mod(a + b)
+    gar, gbr = torch.autograd.grad(yr, (a, b), go)
+    tol = 0.0 if act == "lrelu" else 2e-7
+    assert (y - yr).abs().max().item() <= tol
+    assert (ga - gar).abs().max().item() <= tol * 4 and (gb - gbr).abs().max().item() <= tol * 4
+
+
+def test_sigmoid_gate_equals_the_pytorch_composition():
+    """FFWM.forward's `skip = skip * att_i(skip)` (base_networks.py:330-333) with att_i's sigmoid residual tail: one kernel per
+    direction, values of the PyTorch composition; att is returned (the reference returns it for visualisation)."""
+    import torch.nn as nn
+    from ffwm_amd import nets
+    from ffwm_amd.residual import fuse_residual, gated
+    torch.manual_seed(0)
+    att = nn.Sequential(nets._conv_block(6, 6, 3, 1, 1, sn=True), nets.ResidualBlock(6, 6, activ="sigmoid", sn=True)).to(DEV).eval()
+    x = torch.randn(2, 6, 9, 11, device=DEV).requires_grad_(True)
+    go = torch.randn(2, 6, 9, 11, device=DEV)
+    y, a = gated(att, x)
+    assert type(y.grad_fn).__name__ == "_SigmoidGateBackward" and not a.requires_grad
+    params = [p for p in att.parameters() if p.requires_grad]
+    gs = torch.autograd.grad(y, [x] + params, go)
+    ar = att(x)
+    yr = x * ar
+    gr = torch.autograd.grad(yr, [x] + params, go)
+    assert (y - yr).abs().max().item() <= 1e-6 and (a - ar).abs().max().item() <= 2e-7
+    for u, v in zip(gs, gr):
+        assert (u - v).abs().max().item() <= 1e-5 * (1 + v.abs().max().item())
+    # the re-classed net takes the same path
+    net = nets.WarpAttention(sn=True).to(DEV).eval()
+    assert fuse_residual(net) == 3 and net.fuse_gate
+
+
 # ------------------------------------------------------------------------- guided filter
 GF_CASES = [
     # (B, C, H, W, r, seed)
