@@ -17,6 +17,9 @@ void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 // Kernels that ask for more than 64 KiB of dynamic LDS need their limit raised once (160 KiB per CU on gfx950).
 void allow_large_lds(const void* kernel);
+// A 256-byte device scratch that belongs to (device, stream): counters a launch sequence hands from one kernel to the next without
+// a host round trip.  NULL when it cannot be had (allocation failure, or first use on a stream that is being captured).
+void* stream_scratch(hipStream_t st);
 constexpr int kMaxLdsBytes = 160 * 1024;
 
 struct Options {
@@ -30,7 +33,7 @@ struct Options {
     int be_bwd_halo = 0;      // block_extractor owned-tile backward: halo in pixels (<= 4 -> 4 (default), else 8)
     int be_bwd_rows = 0;      // ... region height: 32 (default) or 64 rows
     int rs_fwd_variant = 0;   // resample2d forward: 0 = auto, 1 = direct gathers, LDS-staged tiles 64 x 16 / 4 / 8: 2 / 3 / 4 (two buffers), 6 / 7 / 5 (one)
-    int rs_bwd1_variant = 0;  // resample2d d_input1: 0 = auto (ks 4: tap-lane kernel; else plane kernel when a plane fits LDS, else tile kernel), 1 = round-2 auto (plane / tile), 2 = tile kernel, 5 = tap-lane kernel with 8-wave blocks (16-row tiles)
+    int rs_bwd1_variant = 0;  // resample2d d_input1: 0 = auto (ks 4: tap-lane kernel, on calls of >= 2^18 pixels the tile kernel instead when a pre-pass finds the flow smooth; else plane kernel when a plane fits LDS, else tile kernel), 1 = round-2 auto (plane / tile), 2 = tile kernel, 5 = tap-lane kernel with 8-wave blocks (16-row tiles)
     int conv_tile_variant = 0; // conv_fwd.hip workgroup tile: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128
     int conv_wino_raw = 1;     // conv_winograd.hip: stage the input window through LDS when a workgroup covers whole tile rows
     int conv_thin_tail = 1;    // conv_winograd.hip: 1-4 output channels past a multiple of 64 on the thin direct kernel

@@ -839,10 +839,39 @@ rs_bwd2_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
     }
 }
 
+// Which d_input1 kernel serves a call?  The tile kernel (a lane per pixel) is conflict-free when the 64 pixels of a wave's row
+// share their integer displacement to within a cell -- any flow a network produces: 0.97 ms at [8,64,512,512] -- and pays 5 x for
+// its LDS atomics under a random flow (1.73 ms); the tap-lane kernel below costs the same for every flow (1.53 ms).  This pre-pass
+// counts the IRREGULAR 64-pixel row segments of the flow into a device counter; both kernels are launched and the one the
+// count does not select returns at once (no host round trip).
+__global__ void __launch_bounds__(kBlock)
+rs_flow_irregular_kernel(const float* __restrict__ in2, int* __restrict__ count, int H, int W, int segs_x, int64_t nseg) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t seg = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
+    if (seg >= nseg) return;
+    const int sx = static_cast<int>(seg % segs_x);
+    const int64_t row = seg / segs_x;                      // b * H + y
+    const int y = static_cast<int>(row % H);
+    const int64_t b = row / H;
+    const int xr = sx * kWave + lane;
+    const int x = xr < W ? xr : W - 1;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* f = in2 + static_cast<size_t>(b) * 3 * plane + static_cast<size_t>(y) * W + x;
+    const float fx = floor_t(static_cast<float>(x) + f[0]) - static_cast<float>(x);
+    const float fy = floor_t(static_cast<float>(y) + f[plane]) - static_cast<float>(y);
+    const float lim = static_cast<float>(1 << 20);
+    const bool ok = (fx > -lim) && (fx < lim) && (fy > -lim) && (fy < lim);
+    const int du = ok ? static_cast<int>(fx) : (lane & 1 ? 4096 : -4096), dv = ok ? static_cast<int>(fy) : 0;
+    const bool irregular = (wave_max(du) - wave_min(du) > 1) || (wave_max(dv) - wave_min(dv) > 1);
+    if (lane == 0 && irregular) atomicAdd(count, 1);
+}
+
 template <int HALF, int RPT>
 __global__ void __launch_bounds__(kBlock)
 rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi,
-                    int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate) {
+                    int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate,
+                    const int* __restrict__ sel = nullptr, int sel_limit = 0, int sel_want = 0) {
+    if (sel && ((sel[0] < sel_limit) ? 1 : 0) != sel_want) return;      // the other kernel of the pair serves this call (rs_flow_irregular_kernel)
     constexpr int NW = kBlock / kWave;
     constexpr int NT = 2 * HALF;
     constexpr int TH = NW * RPT;
@@ -1023,7 +1052,9 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 template <int RPT, int NW>
 __global__ void __launch_bounds__(NW * kWave)
 rs_bwd1_taplane_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi,
-                       int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate) {
+                       int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate,
+                       const int* __restrict__ sel = nullptr, int sel_limit = 0, int sel_want = 0) {
+    if (sel && ((sel[0] < sel_limit) ? 1 : 0) != sel_want) return;      // the other kernel of the pair serves this call
     constexpr int HALF = 2;
     constexpr int NTHR = NW * kWave;
     constexpr int NT = 2 * HALF;
@@ -1480,11 +1511,33 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             };
             // d_input1: planes that fit LDS whole keep the plane kernel below (measured, cfg-1: 36 vs 47 us; [8,64,128,128]: 218 vs
             // 235 us); larger planes take the tile kernel ([8,64,512,512]: 3.1 ms vs 57 ms with per-tap global atomics)
-            if (gin1 && half == 2 && (options().rs_bwd1_variant == 0 || options().rs_bwd1_variant == 5)) {
-                // ks = 4: one pixel's 16 taps x 4 channels per LDS atomic instruction -- bank-conflict-free for any flow
+            // d_input1, ks = 4.  Small calls: the tap-lane kernel (flow-independent).  Large calls (>= 2^18 pixels): the tile kernel when
+            // the flow is smooth, the tap-lane kernel when it is not -- rs_flow_irregular_kernel counts, both are launched, one returns.
+            const int variant = options().rs_bwd1_variant;
+            int* sel = nullptr;
+            int sel_limit = 0;
+            bool adaptive = gin1 && half == 2 && variant == 0 && B * H * W >= (1 << 18) && H >= 32;
+            if (adaptive) {
+                sel = static_cast<int*>(stream_scratch(st));
+                adaptive = sel != nullptr;
+            }
+            if (adaptive) {
+                const int segs_x = static_cast<int>((W + kWave - 1) / kWave);
+                const int64_t nseg = B * H * segs_x;
+                sel_limit = static_cast<int>(nseg / 4 > 0 ? nseg / 4 : 1);          // "smooth": fewer than a quarter of the row segments irregular
+                if (hipMemsetAsync(sel, 0, sizeof(int), st) != hipSuccess) return FFWM_ERR_LAUNCH;
+                const int per = kBlock / kWave;
+                hipLaunchKernelGGL(rs_flow_irregular_kernel, dim3(static_cast<unsigned>((nseg + per - 1) / per)), dim3(kBlock), 0, st, in2, sel,
+                                   (int)H, (int)W, segs_x, nseg);
+                if (int rc = check_launch("ffwm_resample2d_backward(flow regularity)")) return rc;
+            }
+            const bool run_taplane = gin1 && half == 2 && (variant == 0 || variant == 5);
+            const bool run_tile = gin1 && (adaptive || (!run_taplane && (plane_lds > 131072 || variant == 2)));
+            if (run_taplane) {
+                // one pixel's 16 taps x 4 channels per LDS atomic instruction -- bank-conflict-free for any flow
                 // default: 4 waves x 2 rows = 64 x 8 pixel tiles, two blocks per CU (56 KB box + 22 KB staging each); variant 5: 8 waves x 2 rows
                 // (one block per CU, a quarter fewer fold atomics: measured 1.61 against 1.53 ms at [8,64,512,512])
-                const int nw = options().rs_bwd1_variant == 5 ? 8 : 4, rpt = 2;
+                const int nw = variant == 5 ? 8 : 4, rpt = 2;
                 const int th = nw * rpt;
                 const int tiles_y = static_cast<int>((H + th - 1) / th);
                 int cs, cslabs;
@@ -1498,16 +1551,15 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                 if (nw == 8) {
                     allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<2, 8>));
                     hipLaunchKernelGGL((rs_bwd1_taplane_kernel<2, 8>), dim3(grid), dim3(8 * kWave), lds, st, in2, gout, gin1, (int)C, (int)Hi,
-                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
+                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate, sel, sel_limit, 0);
                 } else {
                     allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<2, 4>));
                     hipLaunchKernelGGL((rs_bwd1_taplane_kernel<2, 4>), dim3(grid), dim3(4 * kWave), lds, st, in2, gout, gin1, (int)C, (int)Hi,
-                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
+                                       (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate, sel, sel_limit, 0);
                 }
                 if (int rc = check_launch("ffwm_resample2d_backward(input1, tap-lane)")) return rc;
-                gin1 = nullptr;
             }
-            if (gin1 && (plane_lds > 131072 || options().rs_bwd1_variant == 2)) {
+            if (run_tile) {
                 const int rpt = H >= 32 ? 4 : 1;
                 const int tiles_y = static_cast<int>((H + 4 * rpt - 1) / (4 * rpt));
                 int cs, cslabs;
@@ -1520,14 +1572,15 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
     do {                                                                                                      \
         allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_tile_kernel<HH, RR>));                          \
         hipLaunchKernelGGL((rs_bwd1_tile_kernel<HH, RR>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, \
-                           (int)Hi, (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate); \
+                           (int)Hi, (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate, \
+                           adaptive ? sel : nullptr, sel_limit, 1); \
     } while (0)
                 if (rpt == 4) { if (half == 1) FFWM_RS_B1T(1, 4); else if (half == 2) FFWM_RS_B1T(2, 4); else FFWM_RS_B1T(3, 4); }
                 else { if (half == 1) FFWM_RS_B1T(1, 1); else if (half == 2) FFWM_RS_B1T(2, 1); else FFWM_RS_B1T(3, 1); }
 #undef FFWM_RS_B1T
                 if (int rc = check_launch("ffwm_resample2d_backward(input1, tile)")) return rc;
-                gin1 = nullptr;
             }
+            if (run_taplane || run_tile) gin1 = nullptr;
             if (gin2) {
                 const int tiles_y = static_cast<int>((H + 3) / 4);
                 int cs, cslabs;

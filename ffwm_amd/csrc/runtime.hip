@@ -58,6 +58,23 @@ Options& options() {
     return o;
 }
 
+void* stream_scratch(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, void*> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pool.find({dev, st});
+    if (it != pool.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;          // no allocation inside a capture
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    pool[{dev, st}] = p;
+    return p;
+}
+
 // Channel slab per block: large enough to amortise the per-pixel set-up, small enough that the
 // grid has many blocks per CU on all 256 CUs.
 Geometry plan(int64_t B, int64_t C, int64_t H, int64_t W, int cs_default) {

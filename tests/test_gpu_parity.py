@@ -524,6 +524,30 @@ def test_resample2d_backward_other_scatter_paths(oracle, case, variant):
     _close(g2, g2_ref, BWD_TOL[torch.float32] * 10, relative=True)
 
 
+@pytest.mark.parametrize("flow_kind", ["smooth", "random"])
+def test_resample2d_backward_large_call_picks_a_kernel_by_flow_regularity(oracle, flow_kind):
+    """ks = 4 calls of >= 2^18 pixels: a pre-pass counts the irregular 64-pixel row segments of the flow and the tile kernel (smooth flow)
+    or the tap-lane kernel (random flow) serves the call, the other one returning at once (resample2d.hip,
+    rs_flow_irregular_kernel) -- both against the oracle, and twice in a row (the counter is per stream and re-zeroed)."""
+    from ffwm_amd import ops
+    g = _gen(21)
+    B, C, H, W = 1, 4, 512, 512
+    in1 = torch.rand(B, C, H, W, generator=g)
+    if flow_kind == "smooth":
+        lin = torch.linspace(-1, 1, H)
+        yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+        fl = torch.stack((3 * torch.sin(3.1 * yy + 0.3) * torch.cos(2.3 * xx), 3 * torch.cos(2.7 * xx - 0.2) * torch.sin(1.9 * yy)), 0)[None]
+    else:
+        fl = torch.rand(B, 2, H, W, generator=g) * 6 - 3
+    in2 = torch.cat((fl, torch.full((B, 1, H, W), 1.5)), 1).contiguous()
+    go = torch.rand(B, C, H, W, generator=g)
+    g1_ref, _ = oracle.resample2d_backward(in1, in2, go, 4, 1)
+    for _ in range(2):
+        g1 = torch.zeros_like(in1, device=DEV)
+        ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), 4, 1, g1, None)
+        _close(g1, g1_ref, BWD_TOL[torch.float32], relative=True)
+
+
 def test_resample2d_backward_accumulates_into_grad_input1_and_overwrites_grad_input2(oracle):
     """The boundary's contract (external_function.py:137-138, resample2d_kernel.cu:98-330): grad_input1 is accumulated
     into (atomics), grad_input2 is written -- also when the channel slabs of the tile kernel add partial results."""
