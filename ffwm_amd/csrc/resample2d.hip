@@ -14,6 +14,8 @@
 // (sum_ch gO * in1[tap]) and combine them through LDS; the quotient-rule terms are applied once at
 // the end.  ks in {2, 4, 6} (HALF = 1..3) is templated; any other even ks falls back to a literal
 // per-element kernel.
+#include <memory>
+
 #include "common.hpp"
 
 namespace ffwm {
@@ -846,24 +848,34 @@ rs_bwd2_lds_kernel(const float* __restrict__ in1, const float* __restrict__ in2,
 // count does not select returns at once (no host round trip).
 __global__ void __launch_bounds__(kBlock)
 rs_flow_irregular_kernel(const float* __restrict__ in2, int* __restrict__ count, int H, int W, int segs_x, int64_t nseg) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t seg = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + threadIdx.x / kWave;
-    if (seg >= nseg) return;
-    const int sx = static_cast<int>(seg % segs_x);
-    const int64_t row = seg / segs_x;                      // b * H + y
-    const int y = static_cast<int>(row % H);
-    const int64_t b = row / H;
-    const int xr = sx * kWave + lane;
-    const int x = xr < W ? xr : W - 1;
+    __shared__ int part[kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const size_t plane = static_cast<size_t>(H) * W;
-    const float* f = in2 + static_cast<size_t>(b) * 3 * plane + static_cast<size_t>(y) * W + x;
-    const float fx = floor_t(static_cast<float>(x) + f[0]) - static_cast<float>(x);
-    const float fy = floor_t(static_cast<float>(y) + f[plane]) - static_cast<float>(y);
-    const float lim = static_cast<float>(1 << 20);
-    const bool ok = (fx > -lim) && (fx < lim) && (fy > -lim) && (fy < lim);
-    const int du = ok ? static_cast<int>(fx) : (lane & 1 ? 4096 : -4096), dv = ok ? static_cast<int>(fy) : 0;
-    const bool irregular = (wave_max(du) - wave_min(du) > 1) || (wave_max(dv) - wave_min(dv) > 1);
-    if (lane == 0 && irregular) atomicAdd(count, 1);
+    int mine = 0;                                            // grid-stride over the segments: ONE atomic per block at the end
+    for (int64_t seg = static_cast<int64_t>(blockIdx.x) * (kBlock / kWave) + wave; seg < nseg;
+         seg += static_cast<int64_t>(gridDim.x) * (kBlock / kWave)) {
+        const int sx = static_cast<int>(seg % segs_x);
+        const int64_t row = seg / segs_x;                      // b * H + y
+        const int y = static_cast<int>(row % H);
+        const int64_t b = row / H;
+        const int xr = sx * kWave + lane;
+        const int x = xr < W ? xr : W - 1;
+        const float* f = in2 + static_cast<size_t>(b) * 3 * plane + static_cast<size_t>(y) * W + x;
+        const float fx = floor_t(static_cast<float>(x) + f[0]) - static_cast<float>(x);
+        const float fy = floor_t(static_cast<float>(y) + f[plane]) - static_cast<float>(y);
+        const float lim = static_cast<float>(1 << 20);
+        const bool ok = (fx > -lim) && (fx < lim) && (fy > -lim) && (fy < lim);
+        const int du = ok ? static_cast<int>(fx) : (lane & 1 ? 4096 : -4096), dv = ok ? static_cast<int>(fy) : 0;
+        if ((wave_max(du) - wave_min(du) > 1) || (wave_max(dv) - wave_min(dv) > 1)) ++mine;
+    }
+    if (lane == 0) part[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < kBlock / kWave; ++k) sum += part[k];
+        if (sum) atomicAdd(count, sum);
+    }
 }
 
 template <int HALF, int RPT>
@@ -1521,13 +1533,19 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                 sel = static_cast<int*>(stream_scratch(st));
                 adaptive = sel != nullptr;
             }
+            // one profiling scope over the whole sequence of an adaptive call (pre-pass + the kernel that works + the one that returns)
+            std::unique_ptr<LaunchScope> auto_scope;
+            const double bytes1 = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
             if (adaptive) {
+                auto_scope.reset(new LaunchScope("resample2d_bwd_input1_auto", st, bytes1));
                 const int segs_x = static_cast<int>((W + kWave - 1) / kWave);
                 const int64_t nseg = B * H * segs_x;
                 sel_limit = static_cast<int>(nseg / 4 > 0 ? nseg / 4 : 1);          // "smooth": fewer than a quarter of the row segments irregular
                 if (hipMemsetAsync(sel, 0, sizeof(int), st) != hipSuccess) return FFWM_ERR_LAUNCH;
                 const int per = kBlock / kWave;
-                hipLaunchKernelGGL(rs_flow_irregular_kernel, dim3(static_cast<unsigned>((nseg + per - 1) / per)), dim3(kBlock), 0, st, in2, sel,
+                int64_t pre_blocks = (nseg + per - 1) / per;
+                if (pre_blocks > 1024) pre_blocks = 1024;
+                hipLaunchKernelGGL(rs_flow_irregular_kernel, dim3(static_cast<unsigned>(pre_blocks)), dim3(kBlock), 0, st, in2, sel,
                                    (int)H, (int)W, segs_x, nseg);
                 if (int rc = check_launch("ffwm_resample2d_backward(flow regularity)")) return rc;
             }
@@ -1546,8 +1564,8 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                 const int ncell = (th + 12) * 88;
                 const int ps = ncell + ((4 - ncell % 32) + 32) % 32;
                 const size_t lds = static_cast<size_t>(4) * ps * sizeof(double) + static_cast<size_t>(nw) * (16 + 4) * 65 * sizeof(float);
-                const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
-                LaunchScope ls("resample2d_bwd_input1_taplane", st, bytes);
+                std::unique_ptr<LaunchScope> ls;
+                if (!adaptive) ls.reset(new LaunchScope("resample2d_bwd_input1_taplane", st, bytes1));
                 if (nw == 8) {
                     allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_taplane_kernel<2, 8>));
                     hipLaunchKernelGGL((rs_bwd1_taplane_kernel<2, 8>), dim3(grid), dim3(8 * kWave), lds, st, in2, gout, gin1, (int)C, (int)Hi,
@@ -1566,8 +1584,8 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                 slabs(B * tiles_x * tiles_y, cs, cslabs);
                 const unsigned grid = static_cast<unsigned>(B * tiles_x * tiles_y * cslabs);
                 const size_t lds = static_cast<size_t>(4 * rpt + 12) * kRsBoxW * 4 * sizeof(double);
-                const double bytes = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
-                LaunchScope ls("resample2d_bwd_input1_tile", st, bytes);
+                std::unique_ptr<LaunchScope> ls;
+                if (!adaptive) ls.reset(new LaunchScope("resample2d_bwd_input1_tile", st, bytes1));
 #define FFWM_RS_B1T(HH, RR)                                                                                   \
     do {                                                                                                      \
         allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_tile_kernel<HH, RR>));                          \
@@ -1580,6 +1598,7 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
 #undef FFWM_RS_B1T
                 if (int rc = check_launch("ffwm_resample2d_backward(input1, tile)")) return rc;
             }
+            auto_scope.reset();
             if (run_taplane || run_tile) gin1 = nullptr;
             if (gin2) {
                 const int tiles_y = static_cast<int>((H + 3) / 4);

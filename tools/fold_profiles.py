@@ -61,6 +61,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "flownet_flow_up": "flow_up_kernel",
     "flownet_flow_up_bwd": "flow_up_bwd_kernel",
     "resample2d_bwd_input1_tile": "rs_bwd1_tile_kernel<2,",
+    # (large ks-4 calls launch BOTH d_input1 kernels and one returns at once: these two per-dispatch averages include such dispatches)
     "resample2d_bwd_input1_taplane": "rs_bwd1_taplane_kernel<2,",
     "warp_flipcat_fwd@256": "warp_fwd_lds_kernel<true>",
     "warp_flipcat_bwd_feat_tile@256": "warp_bwd_feat_tile_kernel<true, 2>",
