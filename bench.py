@@ -38,15 +38,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The captured train step runs its independent branches on five HIP streams (trainer.py).  With the HIP runtime's default of four
-# hardware queues per device the graph's branches land on queues the GPU's scheduler time-slices: the same step then takes
-# 45.3-45.9 ms, or 42.4-42.8 ms in the one process out of five where the assignment happens to fall well; three queues give
-# 43.3-43.6 ms every time (profiles/r03_hw_queues.txt; 5 or more: 70-97 ms).  Must be set before the HIP runtime starts.
-# One process only: the three-graph capture of the data-parallel step crashed inside the runtime with three queues when two ranks
-# shared the test box's GPU (tests/test_gpu_dp.py), so several ranks keep the runtime's default.
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
-
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -518,8 +509,8 @@ def main():
                                   "parallelism": "dp%d" % world,
                                   "launch": ("hipGraph replay" + (" (three graphs, the two gradient all-reduces between them)" if world > 1 else "")
                                              + (", flowNetB and the loss networks' side passes on their own HIP streams" if t.flow_stream is not None else "")
-                                             + (", the D step on another" if getattr(t, "d_stream", None) is not None else "")
-                                             + ("; GPU_MAX_HW_QUEUES=%s" % os.environ.get("GPU_MAX_HW_QUEUES", "default")))
+                                             + (", the D step beside them" if getattr(t, "d_stream", None) is not None else "")
+                                             + (" (%d side streams)" % len({id(x) for x in [t.flow_stream, getattr(t, "d_stream", None)] + list(t.loss_streams or []) if x is not None}) if t.flow_stream is not None else ""))
                                   if graphed else "eager (hook-launched all-reduces overlap backward)" if world > 1 else "eager",
                                   "miopen": "immediate mode%s" % (" + in-tree find-db (ffwm_amd/miopen_db)" if miopen_db else ", heuristic solver choice"),
                                   "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))

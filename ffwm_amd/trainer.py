@@ -169,21 +169,27 @@ class FFWMTrainer(object):
         # foreach implementation (1275 extra launches per step, measured)
         kw = {"fused": True, "capturable": cap} if self.device.type == "cuda" else {}
         self.world_size = world_size
-        # flowNetB on a second stream (FFWM_FLOW_STREAMS=1): the two flow nets read the same image and share nothing else, and most of
-        # their kernels (2 x 2 ... 16 x 16 planes) fill a fraction of the chip -- under hipGraph replay, where the step is bound by
-        # kernel time alone, the two nets' forward and backward kernels overlap
-        # ... and the loss networks' independent passes (VGG19 on the 64 / 32 px scales, LightCNN) on two more.  Default: on for a
-        # trainer built for capture (FFWM_STREAMS=0 / 1 overrides); in eager mode the host issues the launches one by one and
-        # nothing overlaps (measured: no change).
+        # Independent branches of the step on side streams (default: on for a trainer built for capture, FFWM_STREAMS=0 / 1 overrides;
+        # in eager mode the host issues the launches one by one and nothing overlaps).  Under hipGraph replay the step is bound by
+        # kernel time alone, and most kernels of these branches (2 x 2 ... 64 x 64 planes) fill a fraction of the chip:
+        #   * flowNetB beside flowNetF (forward and, because autograd replays a node on its forward's stream, backward);
+        #   * the loss networks' passes: VGG19 on the 64 / 32 px scales and LightCNN beside the 128 px VGG19 pass;
+        #   * the whole D step (netD forward / backward on 8 ... 64 px planes, its gradient packing and Adam): the generator's loss
+        #     networks need nothing from it until the adversarial term.  One GPU only: with several ranks the D gradients'
+        #     all-reduce sits between the captured segments.
+        # TWO side streams carry all of it (flowNetB, later VGG19 64 / 32 px on the first; the D step, then LightCNN on the second):
+        # the HIP runtime maps streams and a graph's branches onto 4 hardware queues, and with five streams (one per branch, the
+        # first version) the same binary ran at 45.2-45.9 ms or at 42.4-42.8 ms per step depending on the process -- queues
+        # beyond the fourth are time-sliced.  Three streams: 42.5 ms every time (profiles/r03_hw_queues.txt).
+        # FFWM_STREAM_LAYOUT=5 restores one stream per branch for an A/B.
         multi = os.environ.get("FFWM_STREAMS", os.environ.get("FFWM_FLOW_STREAMS", "1" if capturable else "0")) == "1"
         multi = multi and self.device.type == "cuda"
-        self.flow_stream = torch.cuda.Stream(self.device) if multi else None
+        five = os.environ.get("FFWM_STREAM_LAYOUT", "3") == "5"
         self.loss_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if multi else None
-        # ... and the whole D step (netD forward / backward on 8 ... 64 px planes, its gradient packing and Adam) on one more: the
-        # generator's loss networks need nothing from it until the adversarial term.  One GPU only: with several ranks the D
-        # gradients' all-reduce sits between the captured segments.
-        self.d_stream = (torch.cuda.Stream(self.device)
-                         if multi and world_size == 1 and os.environ.get("FFWM_D_STREAM", "1") == "1" else None)
+        self.flow_stream = (torch.cuda.Stream(self.device) if five else self.loss_streams[0]) if multi else None
+        self.d_stream = None
+        if multi and world_size == 1 and os.environ.get("FFWM_D_STREAM", "1") == "1":
+            self.d_stream = torch.cuda.Stream(self.device) if five else self.loss_streams[1]
         self._d_pending = False
         self.batched_losses = batched_losses
         # the ~25 L1 terms of backward_G as one launch per direction (losses.l1_terms, csrc/l1_loss.hip); needs the batched passes
