@@ -435,7 +435,7 @@ def main():
     args = parse()
     world, rank, local = init_dist(args)
     if args.graph == "auto":
-        args.graph = "on" if args.workload == "train" else "off"
+        args.graph = "on" if args.workload in ("train", "flowtrain") else "off"
     dev = torch.device("cuda", local)
     # MIOpen ships no gfx950 kernel database in this image: every conv kernel is JIT-compiled on a
     # fresh box.  Exhaustive find mode multiplies that start-up cost by the number of candidate
@@ -566,15 +566,31 @@ def main():
         # reference that runs the custom ops; README.md:105,116 trains it with batch 6
         from ffwm_amd import trainer
         bs = args.batch or 6
-        ft = trainer.FlowNetTrainer(dev, world_size=world, seed=0, bucket_bytes=args.bucket_mb << 20)
+        graphed = args.graph != "off"
+        ft = trainer.FlowNetTrainer(dev, world_size=world, seed=0, bucket_bytes=args.bucket_mb << 20, capturable=graphed)
         batch = trainer.synthetic_batch(bs, dev, seed=1 + rank)
+        if graphed:
+            ok = 1
+            try:
+                ft.capture(batch)
+            except Exception as e:       # e.g. a capture beside a live process group: every rank falls back to the eager step
+                ok = 0
+                sys.stderr.write("flowtrain: capture failed (%r), eager step\n" % (e,))
+            if world > 1:
+                flag = torch.tensor([ok], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                graphed = False
+                ft = trainer.FlowNetTrainer(dev, world_size=world, seed=0, bucket_bytes=args.bucket_mb << 20)
         dt, rows = timed(lambda: ft.step(batch), args.steps, args.warmup, world)
         imgs = bs * world * args.steps
         result.update({"metric": "FlowNet pre-training img/s (128x128)", "value": round(imgs / dt, 2), "unit": "img/s",
                        "ms_per_step": round(dt / args.steps * 1e3, 3),
                        "config": {"workload": "FlowNetModel train step (correctness + affine regularisation + landmark "
                                               "losses, Adam), synthetic 128x128", "batch_per_gpu": bs,
-                                  "parallelism": "dp%d" % world, "weights": "seeded random init"},
+                                  "parallelism": "dp%d" % world, "weights": "seeded random init",
+                                  "launch": "hipGraph replay" if graphed else "eager", "routed_layers": ft.routed_layers},
                        "losses": {k: round(v, 5) for k, v in ft.loss_values().items()}})
     elif args.workload == "warpatt":
         bs = args.batch or 8

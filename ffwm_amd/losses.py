@@ -204,11 +204,20 @@ class PerceptualCorrectness(nn.Module):
             input_sample = self.resample(source_vgg.contiguous(), flow.contiguous()).reshape(b, c, -1)
         correction_sample = F.cosine_similarity(input_sample, target_all)          # [b, N2]
         loss_map = torch.exp(-correction_sample / (correction_max + self.eps))
-        e1 = torch.exp(torch.tensor(-1.0, dtype=loss_map.dtype, device=loss_map.device))
+        e1 = _exp_minus_one(loss_map.dtype)      # exp(-1) rounded in the map's dtype, as a host constant (no H2D copy: capturable)
         if norm_mask is None:
             return torch.mean(loss_map) - e1
         norm_mask = F.interpolate(norm_mask, size=(h, w)).reshape(-1, h * w)
         return (torch.sum(norm_mask * loss_map) - e1) / (torch.sum(norm_mask) + self.eps)
+
+
+_E1 = {}
+
+
+def _exp_minus_one(dtype):
+    if dtype not in _E1:
+        _E1[dtype] = float(torch.exp(torch.tensor(-1.0, dtype=dtype)))
+    return _E1[dtype]
 
 
 # ================================================================================= fused L1 terms (csrc/l1_loss.hip)

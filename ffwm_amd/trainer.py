@@ -701,7 +701,8 @@ class FlowNetTrainer(object):
     the VGG features and of the image go through the HIP warp kernels and the regulariser is the fused
     affine-regularisation kernel.  VGG19 is seeded random (no pretrained weights offline), frozen."""
 
-    def __init__(self, device, world_size=1, seed=0, ngf=64, warp=None, fused_regularization=None, bucket_bytes=64 << 20):
+    def __init__(self, device, world_size=1, seed=0, ngf=64, warp=None, fused_regularization=None, bucket_bytes=64 << 20,
+                 routed=None, capturable=False):
         from .losses import MultiAffineRegularizationLoss, MultiScaleLDLoss, PerceptualCorrectness
         self.device = torch.device(device)
         torch.manual_seed(seed)
@@ -723,17 +724,31 @@ class FlowNetTrainer(object):
         self.Regularization = MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3}, fused=fused_regularization)
         self.Correctness = PerceptualCorrectness(self.vgg, self.warp)
         self.criterionLD = MultiScaleLDLoss()
+        # the same routes FFWMTrainer gives its flow nets (round 3): Winograd forward / data gradient, conv_fwd.hip for the stride-2 /
+        # transposed / small-plane layers, direct kernels for the two-channel layers, tiled weight gradients, fused BatchNorm + LeakyReLU
+        if routed is None:
+            routed = self.device.type == "cuda" and warp is None
+        self.routed_layers = 0
+        if routed:
+            from .conv import route_conv_bwd, route_conv_fwd, route_conv_winograd, route_flow_heads
+            from .norm import fuse_bn_lrelu
+            self.routed_layers = (route_conv_winograd(self.flowNet) + route_conv_fwd(self.flowNet) + route_flow_heads(self.flowNet)
+                                  + route_conv_bwd(self.flowNet) + fuse_bn_lrelu(self.flowNet))
+        self.world_size = world_size
+        cap = bool(capturable) and self.device.type == "cuda"
         params = [p for n, p in self.flowNet.named_parameters() if not n.startswith("inter_conv_occ")]
-        self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes, gather=True)
+        # (a captured step packs the gradients inside the graph on one GPU; several ranks accumulate into the bucket views, as FFWMTrainer)
+        self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes, gather=(not cap) or world_size == 1)
         if self.device.type == "cuda":
             from .optim import FlatAdam
-            self.optimizer = FlatAdam(params, self.reducer, lr=0.0004, betas=(0.5, 0.999))
+            self.optimizer = FlatAdam(params, self.reducer, lr=0.0004, betas=(0.5, 0.999), capturable=cap)
         else:
             self.optimizer = torch.optim.Adam(params, lr=0.0004, betas=(0.5, 0.999))
         self.losses = {}
+        self._graphs = None
+        self._static = None
 
-    def step(self, b):
-        """optimize_parameters (flownet_model.py:74-78)."""
+    def _seg_backward(self, b):
         gate = torch.cat((b["gate"], b["gate"]), 2)
         flow, flow64, flow32 = self.flowNet(b["img_S"])
         self.fake_F = self.warp(b["img_S"], flow)
@@ -744,9 +759,75 @@ class FlowNetTrainer(object):
         loss = loss_cor + loss_lm + loss_reg
         self.reducer.zero_grad()
         loss.backward()
+        self.losses = {"loss": loss.detach(), "cor": loss_cor.detach(), "reg": loss_reg.detach(), "lm": loss_lm.detach()}
+        self.fake_F = self.fake_F.detach()
+
+    def capture(self, b, warmup=3):
+        """The step as hipGraphs, like FFWMTrainer.capture: ONE graph on one GPU, two around the gradient all-reduce with several
+        ranks.  The eager step issues ~1400 launches of a few microseconds and is host-bound (GPU busy ~50 %)."""
+        assert self.device.type == "cuda" and self._graphs is None
+        if not getattr(self.optimizer, "param_groups", [{}])[0].get("capturable", False):
+            raise RuntimeError("capture() needs FlowNetTrainer(..., capturable=True)")
+        self._static = {k: v.clone() for k, v in b.items()}
+        sb = self._static
+        self.reducer.set_overlap(False)
+        if self.world_size > 1:
+            self.reducer.set_gather(False)
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._seg_backward(sb)
+                self.reducer.finish()
+                self.optimizer.step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        from .norm import BatchNormLeakyReLU2d, HostCountBatchNorm2d
+        fused = [m for m in self.flowNet.modules() if isinstance(m, (BatchNormLeakyReLU2d, HostCountBatchNorm2d))]
+        before = [m._pending_batches for m in fused]
+        if self.world_size == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._seg_backward(sb)
+                self.reducer.finish()
+                self.optimizer.step()
+            graphs = [g]
+        else:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._seg_backward(sb)
+            self.reducer.finish()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self.optimizer.step()
+            graphs = [g1, g2]
+        self._bn_calls_per_replay = [(m, m._pending_batches - n0) for m, n0 in zip(fused, before) if m._pending_batches != n0]
+        for m, n in self._bn_calls_per_replay:
+            m._pending_batches -= n          # the capture pass itself executed nothing
+        self._graphs = graphs
+        return self
+
+    def release_graphs(self):
+        self._graphs = None
+        self._static = None
+        self.reducer.set_overlap(True)
+        self.reducer.set_gather(True)
+
+    def step(self, b):
+        """optimize_parameters (flownet_model.py:74-78)."""
+        if self._graphs is not None:
+            for k, v in self._static.items():
+                if b[k] is not v:
+                    v.copy_(b[k], non_blocking=True)
+            self._graphs[0].replay()
+            if len(self._graphs) > 1:
+                self.reducer.finish()
+                self._graphs[1].replay()
+            for m, n in self._bn_calls_per_replay:
+                m._pending_batches += n
+            return self.losses
+        self._seg_backward(b)
         self.reducer.finish()
         self.optimizer.step()
-        self.losses = {"loss": loss, "cor": loss_cor, "reg": loss_reg, "lm": loss_lm}
         return self.losses
 
     def loss_values(self):

@@ -1125,6 +1125,43 @@ def test_flownet_pretraining_step_on_gpu_fused_vs_composed_regulariser():
         assert abs(vals[0][k] - vals[1][k]) <= 2e-3 * (1 + abs(vals[1][k])), (k, vals[0][k], vals[1][k])
 
 
+def test_flownet_pretraining_step_routed_and_captured_matches_the_plain_step():
+    """FlowNetTrainer (flownet_model.py:57-78) three ways from identical seeds: plain (vendor convolutions, PyTorch BatchNorm), routed
+    (the hand-written conv / BatchNorm / flow-head kernels, the default on the GPU) and routed + replayed from a captured hipGraph:
+    same losses after five steps (to the fp32 noise of different reduction orders), same BatchNorm batch counters.
+    (The plain trainer runs FIRST: an unrouted net interleaved with replays of a captured one made the replays read freed memory --
+    the vendor library's per-handle buffers are re-allocated under the captured kernels; one process, one trainer, is the product's use.)"""
+    from ffwm_amd import trainer
+    torch.backends.cudnn.benchmark = False
+    batch = trainer.synthetic_batch(2, DEV, seed=6)
+    plain = trainer.FlowNetTrainer(DEV, seed=0, ngf=16, routed=False)
+    assert plain.routed_layers == 0
+    for _ in range(5):
+        plain.step(batch)
+    torch.cuda.synchronize()
+    vp = plain.loss_values()
+    del plain
+    routed = trainer.FlowNetTrainer(DEV, seed=0, ngf=16)
+    graphed = trainer.FlowNetTrainer(DEV, seed=0, ngf=16, capturable=True)
+    assert routed.routed_layers > 20
+    for _ in range(2):                 # capture() runs 2 eager warm-up steps; the capture itself executes nothing
+        routed.step(batch)
+    graphed.capture(batch, warmup=2)
+    for _ in range(3):
+        routed.step(batch)
+        graphed.step(batch)
+    torch.cuda.synchronize()
+    vr, vg = routed.loss_values(), graphed.loss_values()
+    for k in vp:
+        assert abs(vr[k] - vp[k]) <= 5e-3 * (1 + abs(vp[k])), (k, vr[k], vp[k])
+        assert abs(vg[k] - vr[k]) <= 2e-3 * (1 + abs(vr[k])), (k, vg[k], vr[k])
+    sd_r, sd_g = routed.flowNet.state_dict(), graphed.flowNet.state_dict()
+    for k in sd_r:
+        if k.endswith("num_batches_tracked"):
+            want = 0 if k.startswith("inter_conv_occ") else 5          # (FlowNet never runs its occlusion branch)
+            assert int(sd_r[k]) == int(sd_g[k]) == want, (k, int(sd_r[k]), int(sd_g[k]))
+
+
 # ------------------------------------------------------------------------- correlation column maximum (MFMA)
 @pytest.mark.parametrize("shape", [(2, 1024, 64), (1, 4096, 128), (2, 1024, 256), (1, 1000, 64), (3, 160, 64)])
 def test_correlation_colmax_matches_bmm_max(shape):
