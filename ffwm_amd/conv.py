@@ -151,8 +151,9 @@ _WINOGRAD = _os.environ.get("FFWM_WINOGRAD", "1") != "0"
 WINOGRAD_MIN_TILES = int(_os.environ.get("FFWM_WINOGRAD_MIN_TILES", 2048))
 # (strips of 64 tiles) x (tiles of 64 output channels) a call must offer the 256 persistent workgroups: measured per shape of
 # the train step (tools/wino_layers.py), below ~160 pairs the vendor's kernel is as fast or faster in isolation (128 -> 128 @32²: 52 vs
-# 30 us); inside the captured multi-stream step 100 measures 0.3 ms per step better than 160 (42.33 vs 42.60 ms, three runs each; 64: 42.38)
-WINOGRAD_MIN_PAIRS = int(_os.environ.get("FFWM_WINOGRAD_MIN_PAIRS", 100))
+# 30 us); inside the captured multi-stream step 100 pairs measure 0.2-0.3 ms per step better (42.33 vs 42.60 ms) by moving 49 more
+# small launches from the vendor's kernel to this one at 0.2-0.3 of its peak -- within the noise of the step, so the threshold stays
+WINOGRAD_MIN_PAIRS = int(_os.environ.get("FFWM_WINOGRAD_MIN_PAIRS", 160))
 
 
 def _winograd_dir_ok(x, c_red, k_out):

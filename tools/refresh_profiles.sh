@@ -81,5 +81,5 @@ timeout 900 python $R/tools/two_stream_check.py 2>&1 | grep -v Warn | tail -13 >
 bash $R/tools/gf_trace.sh > $OUT/gf_trace.txt 2>&1
 (cd $R && timeout 900 python tools/ref_vs_hip.py > $OUT/ref_vs_hip.log 2>&1; cp gpurun_out/ref_vs_hip.json $OUT/ref_vs_hip.json)
 rm -f $R/gpurun_out/ab/results.txt
-bash $R/tools/ab_graph.sh "default=X=1" "one_stream=FFWM_STREAMS=0" "five_streams_one_per_branch=FFWM_STREAM_LAYOUT=5" "d_step_on_the_main_stream=FFWM_D_STREAM=0" "fused_residual_off=FFWM_FUSED_RESIDUAL=0" "tiled_wgrad_off=FFWM_TILED_WGRAD=0" "convT_dgrad_off=FFWM_CONVT_DGRAD=0" "conv_dgrad_all_own=FFWM_CONV_DGRAD=1" "bn_fused_from_0=FFWM_BN_MIN_NUMEL=0" "winograd_pairs_160=FFWM_WINOGRAD_MIN_PAIRS=160" > /dev/null 2>&1
+bash $R/tools/ab_graph.sh "default=X=1" "one_stream=FFWM_STREAMS=0" "five_streams_one_per_branch=FFWM_STREAM_LAYOUT=5" "d_step_on_the_main_stream=FFWM_D_STREAM=0" "fused_residual_off=FFWM_FUSED_RESIDUAL=0" "tiled_wgrad_off=FFWM_TILED_WGRAD=0" "convT_dgrad_off=FFWM_CONVT_DGRAD=0" "conv_dgrad_all_own=FFWM_CONV_DGRAD=1" "bn_fused_from_0=FFWM_BN_MIN_NUMEL=0" "winograd_pairs_100=FFWM_WINOGRAD_MIN_PAIRS=100" > /dev/null 2>&1
 cp $R/gpurun_out/ab/results.txt $OUT/ab_results.txt
