@@ -142,7 +142,7 @@ def main():
               ("flownet_kernel_stats.csv", "_flownet_lean_kernel_stats.csv"), ("flownet_module_kernel_stats.csv", "_flownet_module_kernel_stats.csv"),
               ("flowtrain_kernel_stats.csv", "_flowtrain_kernel_stats.csv"), ("ops_kernel_stats.csv", "_ops_kernel_stats.csv"),
               ("ffwm_kernels_whole_run.csv", "_ffwm_kernels_rocprofv3.csv"), ("bench_default.json", "_bench_default.json"),
-              ("warpatt_bench.json", "_bench_warpatt.json"), ("flownet_bench.json", "_bench_flownet.json"),
+              ("warpatt_bench.json", "_bench_warpatt.json"), ("warp_kernel_stats.csv", "_warp_kernel_stats.csv"), ("warp_bench.json", "_bench_warp.json"), ("flownet_bench.json", "_bench_flownet.json"),
               ("flowtrain_bench.json", "_bench_flowtrain.json"), ("ops_bench.json", "_bench_ops.json"),
               ("winograd_sq_192.txt", "_winograd_sq_counters_192.txt"), ("winograd_sq_256.txt", "_winograd_sq_counters_256.txt"),
               ("winograd_mem_192.txt", "_winograd_mem_counters_192.txt"), ("winograd_mem_256.txt", "_winograd_mem_counters_256.txt"),

@@ -27,6 +27,7 @@ rm -rf /tmp/kt_eager && mkdir -p /tmp/kt_eager
 timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_eager -- python $R/bench.py --graph off --steps 6 --warmup 3 --no-cpu-baseline --no-kernels --no-extras > $OUT/train_eager_bench.log 2>&1
 python $R/tools/step_trace.py $(find /tmp/kt_eager -name "*kernel_trace.csv" | head -1) --steps 3 --top 60 > $OUT/train_step_eager_per_step.txt 2>&1
 trace warpatt 30 --workload warpatt --steps 20 --warmup 5
+trace warp 10 --workload warp --steps 40 --warmup 10
 trace flownet 15 --workload flownet --steps 40 --warmup 10
 trace flownet_module 20 --workload flownet --flownet-path module --steps 40 --warmup 10
 trace flowtrain 60 --workload flowtrain --steps 10 --warmup 3
