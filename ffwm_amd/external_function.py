@@ -312,7 +312,7 @@ class WarpFlipCat(nn.Module):
 
 class GuidedFilterFunction(Function):
     """apply(x[B,C,H,W], y[B,C,H,W], r, eps) -> GuidedFilter(r, eps)(x, y) of the reference
-    (models/external_function.py:239-277), one launch forward and one backward.  y is data (FFWM filters
+    (models/external_function.py:239-277), four launches forward and four backward (separable column / row passes over the whole chip).  y is data (FFWM filters
     the generated image against the ground truth, models/ffwm_model.py:81): it gets no gradient."""
 
     @staticmethod
