@@ -225,6 +225,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "channel_slab")) slot = &o.channel_slab;
     else if (!strcmp(key, "xcd_remap")) slot = &o.xcd_remap;
     else if (!strcmp(key, "ablate")) slot = &o.ablate;
+    else if (!strcmp(key, "warp_multi_order")) slot = &o.warp_multi_order;
     else if (!strcmp(key, "rows_per_thread")) slot = &o.rows_per_thread;
     else if (!strcmp(key, "scatter_variant")) slot = &o.scatter_variant;
     else if (!strcmp(key, "be_bwd_halo")) slot = &o.be_bwd_halo;

@@ -15,6 +15,9 @@
 //     is the mirrored contiguous run;
 //   * backward: d(flow) accumulates in registers over the channel slab (2 atomics per pixel per
 //     slab); d(feat) is the 4-corner scatter.
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 
 namespace ffwm {
@@ -894,6 +897,18 @@ inline void fill_problem(WarpProblem& q, const ffwm_warp_problem& pr, int cs_def
     q.nblk = g.grid;
 }
 
+// Largest problem first: the workgroups of a launch are dispatched in index order, so the big level's tiles start at once and the
+// small levels fill the tail (longest-processing-time order; option warp_multi_order = 1 keeps the caller's order).
+inline std::vector<int> multi_order(const ffwm_warp_problem* probs, int n) {
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    if (options().warp_multi_order == 0)
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+            return probs[a].B * probs[a].C * probs[a].H * probs[a].W > probs[b].B * probs[b].C * probs[b].H * probs[b].W;
+        });
+    return idx;
+}
+
 template <typename T>
 int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_t st) {
     WarpTable tab;
@@ -911,8 +926,9 @@ int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
         tab.n = 0; blocks = 0; bytes = 0;
         return check_launch("ffwm_warp_multi_forward");
     };
-    for (int i = 0; i < n; ++i) {
-        const ffwm_warp_problem& pr = probs[i];
+    const std::vector<int> order = multi_order(probs, n);
+    for (int oi = 0; oi < n; ++oi) {
+        const ffwm_warp_problem& pr = probs[order[oi]];
         if (fwd_wants_lds(pr.B, pr.C, pr.H, pr.W, sizeof(T))) {      // HBM-resident output: the tile kernel, by itself
             if (int rc = launch_fwd<T>((const T*)pr.feat, (const T*)pr.flow, (T*)pr.output, pr.B, pr.C, pr.Hi, pr.Wi, pr.H, pr.W, flip, st)) return rc;
             continue;
@@ -954,8 +970,9 @@ int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
         tab.n = 0; blocks = 0; bytes = 0;
         return check_launch("ffwm_warp_multi_backward(flow)");
     };
-    for (int i = 0; i < n; ++i) {
-        const ffwm_warp_problem& pr = probs[i];
+    const std::vector<int> order = multi_order(probs, n);
+    for (int oi = 0; oi < n; ++oi) {
+        const ffwm_warp_problem& pr = probs[order[oi]];
         if (!pr.grad_flow) continue;
         WarpProblem& q = tab.p[tab.n];
         q.feat = pr.feat; q.flow = pr.flow; q.out = pr.grad_flow; q.gout = pr.grad_output;

@@ -51,3 +51,7 @@ for nt in (0, 1):
     lib.ffwm_set_option(b"warp_nt", nt)
     run("nt stores %d" % nt, False); run("nt stores %d" % nt, True)
 lib.ffwm_set_option(b"warp_nt", 0)
+for order in (1, 0, 1, 0):
+    lib.ffwm_set_option(b"warp_multi_order", order)
+    run("order %s" % ("caller's" if order else "largest first"), False); run("order %s" % ("caller's" if order else "largest first"), True)
+lib.ffwm_set_option(b"warp_multi_order", 0)
