@@ -7,6 +7,7 @@ streams are reproducible across machines; the golden file stores an input checks
 import torch
 
 SAMPLE_STRIDE = 101         # big tensors are stored as flat[::101] plus float64 sum / abs-sum
+CHUNK = 512                 # ... and the float64 sum of every run of 512 consecutive elements: every element is covered
 
 
 def _gen(seed):
@@ -111,7 +112,17 @@ def pack(t):
         d["full"] = t.clone()
     else:
         d["sample"] = t.flatten()[::SAMPLE_STRIDE].clone()
+        d["chunk_sums"] = chunk_sums(t)
     return d
+
+
+def chunk_sums(t):
+    """float64 sums of consecutive runs of CHUNK elements of the flattened tensor (the last run zero-padded)"""
+    f = t.detach().cpu().flatten().double()
+    pad = (-f.numel()) % CHUNK
+    if pad:
+        f = torch.cat((f, torch.zeros(pad, dtype=torch.float64)))
+    return f.view(-1, CHUNK).sum(1)
 
 
 def compare(got, packed, tol, relative=True):
@@ -129,4 +140,10 @@ def compare(got, packed, tol, relative=True):
     dsum = abs(float(got.double().sum()) - packed["sum"]) / n
     # 1e-12: the two float64 sums were taken on different machines (GPU reduction order vs CPU)
     assert dsum <= (tol + 1e-12) * scale, "mean drift %.3e > %.3e" % (dsum, tol * scale)
+    if "chunk_sums" in packed:
+        # every element takes part: a run of CHUNK elements may drift by CHUNK * tol at most; independent rounding adds up to
+        # ~sqrt(CHUNK) * tol, so 4 sqrt(CHUNK) tol separates a wrong region from noise
+        cd = (chunk_sums(got) - packed["chunk_sums"]).abs().max().item()
+        bound = 4.0 * (CHUNK ** 0.5) * (tol + 1e-12) * scale
+        assert cd <= bound, "a run of %d elements differs by %.3e in sum > %.3e" % (CHUNK, cd, bound)
     return diff
