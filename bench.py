@@ -299,8 +299,10 @@ def cpu_train_baseline(titers):
         dt = time.perf_counter() - t0
         out[key] = {"value": round(bs * steps / dt, 4), "unit": "img/s", "cores": n, "kind": "port",
                     "host_cores_usable": usable,
-                    "sample": "%d full FFWM train step(s), batch %d, after 1 warm-up step, %d torch/OpenMP threads, %.1f s"
-                              % (steps, bs, n, dt)}
+                    "sample": "%d full FFWM train step(s), batch %d, after 1 warm-up step, %d torch/OpenMP threads, %.1f s%s"
+                              % (steps, bs, n, dt, " (of %d usable cores: measured on this box 16 / 32 / 64 / 128 threads = 1.86 / 1.60 / 0.96 / "
+                                 "0.43 img/s -- PyTorch's CPU convolutions at batch 8 stop scaling, then collapse)" % usable
+                                 if key == "cpu_baseline" and usable > n else "")}
     return out
 
 
