@@ -119,6 +119,59 @@ def _worker8(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _worker_graph(rank, world, port, ret):
+    """What `bench.py --gpus N` runs for N > 1: the step replayed from THREE captured graphs with the two gradient all-reduces between
+    them (gloo here: two ranks share the box's GPU).  Per-rank data; after the replays the weights must be in lock-step across the
+    ranks, the losses finite, and equal (to fp32 reduction noise) to an eager data-parallel trainer fed the same batches."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ffwm_amd import trainer
+        torch.backends.cudnn.benchmark = False
+        dev = torch.device("cuda", 0)
+        tg = trainer.FFWMTrainer(dev, world_size=world, seed=30 + rank, ngf=16, bucket_bytes=4 << 20, capturable=True)
+        te = trainer.FFWMTrainer(dev, world_size=world, seed=30 + rank, ngf=16, bucket_bytes=4 << 20)
+        batch = trainer.synthetic_batch(2, dev, seed=700 + rank)
+
+        def flat(t):
+            return torch.cat([p.detach().flatten().float() for m in (t.flowNetF, t.flowNetB, t.netG, t.netD) for p in m.parameters()])
+
+        def spread(v):
+            got = [torch.zeros_like(v) for _ in range(world)]
+            dist.all_gather(got, v)
+            return max((g - got[0]).abs().max().item() for g in got)
+        for _ in range(2):                         # capture() runs 2 eager warm-up steps
+            te.step(batch)
+        tg.capture(batch, warmup=2)
+        assert len(tg._graphs) == 3
+        for _ in range(3):
+            te.step(batch)
+            tg.step(batch)
+        torch.cuda.synchronize()
+        vg, ve = tg.loss_values(), te.loss_values()
+        assert all(torch.isfinite(torch.tensor(v)) for v in vg.values()), vg
+        assert spread(flat(tg)) <= 1e-6, "captured data-parallel step: weights diverged across the ranks"
+        for k in ("G", "D", "l1", "illu"):
+            assert abs(vg[k] - ve[k]) <= 5e-3 * (1 + abs(ve[k])), (k, vg[k], ve[k])
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "FAIL: %s\n%s" % (e, traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_captured_three_graph_step_two_ranks_on_one_gpu():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_graph, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
 def test_dp_train_step_eight_ranks_dry_run_on_one_gpu():
     world = 8
     mgr = mp.Manager()
