@@ -130,6 +130,13 @@ class BucketedGradReducer(object):
         if src:
             torch._foreach_copy_(dst, src)
 
+    def pack_all(self):
+        """gather mode: pack every bucket now (a captured step calls it at the end of a backward segment, so that the copies are
+        part of the graph and finish() -- outside the graphs -- only has the all-reduces left)."""
+        if self.gather:
+            for b in self.buckets:
+                self._pack(b)
+
     def _launch(self, b, where="hook"):
         b["launched"] = True
         # (bucket index, who launched it): what the dry-run tests assert the overlap on -- a bucket reduced from an autograd

@@ -201,7 +201,7 @@ class FFWMTrainer(object):
         # (round 3: on ONE GPU the captured step packs too -- inside a capture the fresh gradients come from the graph's private pool,
         # their addresses are as static as the views'; with several ranks the packing runs between the graphs, in Python, where the
         # replayed gradients are not visible as new tensors: those keep the in-place accumulation)
-        gather = (not cap) or world_size == 1
+        gather = True          # (several ranks under capture: the buckets are packed at the end of each captured backward segment)
         self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
                                          bucket_bytes=bucket_bytes, gather=gather)
         self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes, gather=gather)
@@ -568,11 +568,6 @@ class FFWMTrainer(object):
         sb = self._static
         self.red_D.set_overlap(False)
         self.red_G.set_overlap(False)
-        if self.world_size > 1:
-            # three graphs with the all-reduces between them: the packing of fresh gradients would run in Python between the replays,
-            # where a replayed gradient is not a new tensor -- accumulate in place into the bucket views instead
-            self.red_D.set_gather(False)
-            self.red_G.set_gather(False)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -602,11 +597,15 @@ class FFWMTrainer(object):
             graphs = [g]
         else:
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # three graphs with the all-reduces between them; the fresh gradients are packed into the flat buckets INSIDE the graph that
+            # produced them (a replayed gradient is not a new tensor to Python), finish() outside only reduces
             with torch.cuda.graph(g1):
                 self._seg_forward_and_D(sb)
+                self.red_D.pack_all()
             self.red_D.finish()
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self._seg_stepD_and_G(sb)
+                self.red_G.pack_all()
             self.red_G.finish()
             with torch.cuda.graph(g3, pool=g1.pool()):
                 self._seg_stepG()
@@ -737,8 +736,8 @@ class FlowNetTrainer(object):
         self.world_size = world_size
         cap = bool(capturable) and self.device.type == "cuda"
         params = [p for n, p in self.flowNet.named_parameters() if not n.startswith("inter_conv_occ")]
-        # (a captured step packs the gradients inside the graph on one GPU; several ranks accumulate into the bucket views, as FFWMTrainer)
-        self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes, gather=(not cap) or world_size == 1)
+        # (a captured step packs the gradients inside the graph that produced them, as FFWMTrainer)
+        self.reducer = BucketedGradReducer(params, bucket_bytes=bucket_bytes, gather=True)
         if self.device.type == "cuda":
             from .optim import FlatAdam
             self.optimizer = FlatAdam(params, self.reducer, lr=0.0004, betas=(0.5, 0.999), capturable=cap)
@@ -771,8 +770,6 @@ class FlowNetTrainer(object):
         self._static = {k: v.clone() for k, v in b.items()}
         sb = self._static
         self.reducer.set_overlap(False)
-        if self.world_size > 1:
-            self.reducer.set_gather(False)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -796,6 +793,7 @@ class FlowNetTrainer(object):
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 self._seg_backward(sb)
+                self.reducer.pack_all()
             self.reducer.finish()
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self.optimizer.step()
