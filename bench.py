@@ -87,7 +87,8 @@ def emit_lines(result):
     for k in FINAL_KEYS:
         v = result.get(k)
         if k == "config" and isinstance(v, dict):
-            v = {kk: _short(vv, 160) for kk, vv in v.items() if kk in ("workload", "batch_per_gpu", "global_batch", "parallelism", "launch")}
+            v = {kk: _short(vv, 160) for kk, vv in v.items()
+                 if kk in ("workload", "batch_per_gpu", "global_batch", "parallelism", "launch") or isinstance(vv, (int, float, bool))}
         elif k == "roofline":
             v = _slim_roofline(v)
         elif k == "cpu_baseline" and isinstance(v, dict):
@@ -534,30 +535,56 @@ def main():
             del tc
         else:
             step_flops = flops.count_step(nets_all, lambda: t.step(batch, batch_increment=0))       # one untimed eager step
+        capture_mode, d_side = None, False
         if graphed:
-            # several ranks: three graphs with the two gradient all-reduces issued between them (RCCL stays outside the captures).
-            # Should the capture fail beside a live process group (it cannot be tried on the one-GPU development box), every rank
-            # falls back to the eager step with hook-launched, overlapped all-reduces -- the ranks agree on it first.
-            ok = True
-            try:
-                t.capture(batch, warmup=max(2, args.warmup))
-            except Exception as e:
-                if world == 1:
-                    raise
-                ok = False
-                print("rank %d: hipGraph capture failed (%r): falling back to the eager step" % (rank, e), file=sys.stderr)
-            if world > 1:
-                flag = torch.tensor([1.0 if ok else 0.0], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if float(flag.item()) < 0.5:
-                    graphed = False
-                    args.graph = "off"
-                    del t
-                    torch.cuda.synchronize()
+            # several ranks: the capture modes of FFWMTrainer.capture, best first -- "ingraph" (RCCL captured into ONE graph; chosen by
+            # a probe graph every rank must replay correctly), then "segments" (five graphs, a finished network's all-reduce overlaps
+            # the next backward segment).  Should a capture fail beside the live process group (RCCL cannot be tried on the one-GPU
+            # development box), the ranks agree on it and try the next mode on a fresh trainer; the last resort is the eager step with
+            # hook-launched, overlapped all-reduces.
+            forced = os.environ.get("FFWM_DP_CAPTURE")
+            modes = [None] if world == 1 else ([forced] if forced else ["auto", "segments"])
+            tried, captured = [], False
+            for m in modes:
+                mode = m
+                if m == "auto":
+                    mode = "ingraph" if trainer.probe_collective_capture(dev) else "segments"
+                if mode in tried:
+                    continue
+                tried.append(mode)
+                if t is None:
                     t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers, bucket_bytes=args.bucket_mb << 20,
-                                            capturable=False, mfma_wgrad=args.mfma_wgrad == "on")
+                                            capturable=True, mfma_wgrad=args.mfma_wgrad == "on")
                     flow_fit = t.pretrain_flow_identity(batch) if args.flow_init == "fit-identity" else None
-                    nets_all = [t.flowNetF, t.flowNetB, t.netG, t.netD, t.lightCNN, t.vgg]
+                ok = True
+                try:
+                    t.capture(batch, warmup=max(2, args.warmup), mode=mode)
+                    if world > 1:                       # one replay must run before the mode counts as working
+                        t.step(batch, batch_increment=0)
+                        torch.cuda.synchronize()
+                except Exception as e:
+                    if world == 1:
+                        raise
+                    ok = False
+                    print("rank %d: hipGraph capture (mode %s) failed (%r)" % (rank, mode, e), file=sys.stderr)
+                if world > 1:
+                    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    ok = float(flag.item()) > 0.5
+                if ok:
+                    captured = True
+                    capture_mode, d_side = t.capture_mode, bool(t._d_side and t.d_stream is not None)
+                    break
+                del t
+                t = None
+                torch.cuda.synchronize()
+            if not captured:
+                graphed = False
+                args.graph = "off"
+                t = trainer.FFWMTrainer(dev, world_size=world, seed=0, titers=args.titers, bucket_bytes=args.bucket_mb << 20,
+                                        capturable=False, mfma_wgrad=args.mfma_wgrad == "on")
+                flow_fit = t.pretrain_flow_identity(batch) if args.flow_init == "fit-identity" else None
+            nets_all = [t.flowNetF, t.flowNetB, t.netG, t.netD, t.lightCNN, t.vgg]
         dt, rows = timed(lambda: t.step(batch, batch_increment=0), args.steps, args.warmup, world)
         if graphed:
             # HIP events cannot bracket kernels inside a replayed graph: time the hand-written kernels
@@ -572,11 +599,16 @@ def main():
                                               "all losses, 3x Adam), synthetic MultiPIE-shaped 128x128",
                                   "batch_per_gpu": bs, "global_batch": bs * world,
                                   "parallelism": "dp%d" % world,
-                                  "launch": ("hipGraph replay" + (" (three graphs, the two gradient all-reduces between them)" if world > 1 else "")
+                                  "launch": ("hipGraph replay"
+                                             + ({"ingraph": " (ONE graph, the bucket all-reduces captured inside it on RCCL's stream, overlapping backward)",
+                                                 "segments": " (five graphs: backward_G cut at network boundaries, each finished network's all-reduce "
+                                                             "overlaps the next segment)",
+                                                 "serial": " (three graphs, the two gradient all-reduces between them)"}.get(capture_mode, ""))
                                              + (", flowNetB and the loss networks' side passes on their own HIP streams" if t.flow_stream is not None else "")
-                                             + (", the D step beside them" if getattr(t, "d_stream", None) is not None else "")
-                                             + (" (%d side streams)" % len({id(x) for x in [t.flow_stream, getattr(t, "d_stream", None)] + list(t.loss_streams or []) if x is not None}) if t.flow_stream is not None else ""))
+                                             + (", the D step beside them" if d_side else "")
+                                             + (" (%d side streams)" % len({id(x) for x in [t.flow_stream, t.d_stream if d_side else None] + list(t.loss_streams or []) if x is not None}) if t.flow_stream is not None else ""))
                                   if graphed else "eager (hook-launched all-reduces overlap backward)" if world > 1 else "eager",
+                                  "dp_capture_mode": capture_mode if graphed and world > 1 else None,
                                   "miopen": "immediate mode%s" % (" + in-tree find-db (ffwm_amd/miopen_db)" if miopen_db else ", heuristic solver choice"),
                                   "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))
                                   if args.mfma_wgrad == "on" else "vendor library",

@@ -16,6 +16,14 @@ The reference has no working multi-GPU path; this is new.  Design fo
     array by ONE multi-tensor copy when its last gradient arrives (world > 1) or in ``finish()`` (world 1) --
     instead of one ``grad += new`` launch per parameter (~600 tiny kernels per train step).  ``gather=False`` keeps
     the views installed as ``param.grad`` all the time (static addresses: what a captured hipGraph needs).
+  * ``groups``: parameter lists that must not share a bucket (the trainer passes one per network).  A network's backward
+    runs on ONE stream (autograd replays a node on its forward's stream), so a bucket never mixes gradients produced on
+    different streams; should it happen anyway, the packing stream waits for every stream a gradient of the bucket arrived on.
+    Per-network buckets are also what a segmented (captured) backward hands to ``launch_group`` segment by segment.
+  * under a hipGraph capture the hooks still run (capture executes the Python once): with RCCL the hook-launched
+    all-reduces are captured INTO the graph on RCCL's own stream, forked from and joined to the step's streams by the
+    events torch.distributed records -- one graph then holds backward and its overlapped collectives (trainer.capture,
+    mode "ingraph").
 Works with any ``torch.distributed`` backend: ``nccl`` (= RCCL) on GPUs, ``gloo`` in the CPU tests.
 """
 import torch
@@ -27,11 +35,22 @@ def _pad4(n):
 
 
 class BucketedGradReducer(object):
-    def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True, gather=False):
+    def __init__(self, params, process_group=None, bucket_bytes=64 << 20, average=True, gather=False, groups=None,
+                 force_collectives=False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # force_collectives: issue the all-reduces even in a one-rank group (a one-rank RCCL all-reduce runs through the same
+        # launch / capture machinery: the one-GPU box's test of capturing the collectives into the step's graph)
+        self.active = self.world > 1 or (bool(force_collectives) and dist.is_available() and dist.is_initialized())
         self.average = average
-        params = [p for p in params if p.requires_grad]
+        if groups is not None:
+            groups_in = [[p for p in g if p.requires_grad] for g in groups]
+            params = [p for g in groups_in for p in g]
+            gid = {p: i for i, g in enumerate(groups_in) for p in g}
+        else:
+            params = [p for p in params if p.requires_grad]
+            gid = {p: 0 for p in params}
+        self._gid = gid
         # autograd produces gradients roughly in reverse registration order: fill buckets that way
         # so the first bucket completes early in backward
         ordered = list(reversed(params))
@@ -41,7 +60,8 @@ class BucketedGradReducer(object):
         groups, cur, cur_bytes = [], [], 0
         for p in ordered:
             nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device):
+            if cur and (cur_bytes + nbytes > bucket_bytes or cur[0].dtype != p.dtype or cur[0].device != p.device
+                        or gid[cur[0]] != gid[p]):
                 groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
@@ -65,7 +85,7 @@ class BucketedGradReducer(object):
         self.launch_log = []       # (bucket index, "hook" | "finish") of the current step, in launch order
         self.set_gather(gather)
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -83,7 +103,8 @@ class BucketedGradReducer(object):
             self._view[p] = view
             self.offset[p] = (base + off, base + off + n)
             off += _pad4(n)
-        b = {"flat": flat, "params": plist, "pending": len(plist), "launched": False, "handle": None, "index": len(self.buckets)}
+        b = {"flat": flat, "params": plist, "pending": len(plist), "launched": False, "handle": None, "index": len(self.buckets),
+             "group": self._gid[plist[0]], "streams": []}
         for p in plist:
             self._bucket_of[p] = b
         self.buckets.append(b)
@@ -102,9 +123,18 @@ class BucketedGradReducer(object):
             b["launched"] = False
             b["packed"] = False
             b["handle"] = None
+            b["streams"] = []
             if self.gather:
                 for p in b["params"]:
                     p.grad = None             # autograd will install its own tensor: no accumulation kernel
+
+    def begin_replay(self):
+        """A replayed (captured) step runs no Python: zero_grad() inside the graph does not reset the host-side launch state.
+        Call before the replays of a step whose all-reduces are issued from the host (between the graphs)."""
+        self.launch_log = []
+        for b in self.buckets:
+            b["launched"] = False
+            b["handle"] = None
 
     def set_gather(self, on):
         """Switch between packing the gradients after backward (True) and accumulating in place into the views."""
@@ -120,6 +150,13 @@ class BucketedGradReducer(object):
         if b.get("packed"):
             return
         b["packed"] = True
+        if b["streams"] and b["flat"].is_cuda:
+            # gradients of this bucket arrived on more than one stream (does not happen with per-network groups): the stream
+            # that packs and reduces waits for the others' work issued so far -- all of the bucket's gradients are among it
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for st in b["streams"]:
+                if st != cur:
+                    cur.wait_stream(st)
         src, dst = [], []
         for p in b["params"]:
             g, view = p.grad, self._view[p]
@@ -130,12 +167,27 @@ class BucketedGradReducer(object):
         if src:
             torch._foreach_copy_(dst, src)
 
-    def pack_all(self):
-        """gather mode: pack every bucket now (a captured step calls it at the end of a backward segment, so that the copies are
-        part of the graph and finish() -- outside the graphs -- only has the all-reduces left)."""
+    def pack_all(self, group=None):
+        """gather mode: pack every bucket (of parameter group `group`) now (a captured step calls it at the end of a backward
+        segment, so that the copies are part of the graph and only the all-reduces are left outside the graphs)."""
         if self.gather:
             for b in self.buckets:
-                self._pack(b)
+                if group is None or b["group"] == group:
+                    self._pack(b)
+
+    def launch_group(self, group, where="segment"):
+        """Start the all-reduce of every bucket of parameter group `group` that has not gone out yet (asynchronous: the next
+        backward segment is issued while it runs); finish() waits.  -> number of buckets launched."""
+        n = 0
+        if not self.active:
+            return n
+        for b in self.buckets:
+            if b["group"] == group and not b["launched"]:
+                if self.gather:
+                    self._pack(b)
+                self._launch(b, where)
+                n += 1
+        return n
 
     def _launch(self, b, where="hook"):
         b["launched"] = True
@@ -154,6 +206,10 @@ class BucketedGradReducer(object):
         if not self.overlap:
             return
         b = self._bucket_of[p]
+        if b["flat"].is_cuda:
+            st = torch.cuda.current_stream(b["flat"].device)
+            if st not in b["streams"]:
+                b["streams"].append(st)
         if self.gather:
             b["pending"] -= 1
             if b["pending"] == 0 and not b["launched"]:
@@ -176,15 +232,19 @@ class BucketedGradReducer(object):
             for b in self.buckets:
                 if not b["launched"]:
                     self._pack(b)
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:
-            if not b["launched"] or not self.overlap:
+            if not b["launched"]:
                 self._launch(b, "finish")       # parameters without a gradient this step still take part
         for b in self.buckets:
             b["handle"].wait()
-            if self.average:
-                b["flat"].div_(self.world)
+        if self.average and self.world > 1:
+            if self.flat is not None:
+                self.flat.div_(self.world)      # one launch for every bucket (padding elements stay zero)
+            else:
+                for b in self.buckets:
+                    b["flat"].div_(self.world)
 
     def time_buckets(self, reps=3):
         """Stand-alone duration of every bucket's all-reduce (ms, max over `reps` excluded: the median), measured OUTSIDE a step with
@@ -192,7 +252,7 @@ class BucketedGradReducer(object):
         bandwidth and ring bus bandwidth 2 (n - 1) / n x bytes / time in GB/s).  The flat arrays are summed in place `reps` times:
         call it after the measurement, or zero_grad() afterwards."""
         out = []
-        if self.world == 1:
+        if not self.active:
             return out
         cuda = self.buckets[0]["flat"].is_cuda
         import time

@@ -76,12 +76,60 @@ def part_grids(lm_F, torch15_integer_division=False):
     return [build_part_grid(c, 32) for c in (el, er, nc, mc)]
 
 
+def probe_collective_capture(device, group=None):
+    """Can this process group's all-reduce be captured into a hipGraph and replayed?  One tiny graph (an asynchronous all-reduce
+    and its wait, the shape the reducers use) captured on a side stream, replayed on fresh data and checked; the ranks agree on the
+    answer (MIN over ranks), so all of them pick the same capture mode.  Only RCCL is tried: gloo's collectives run on the host."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend(group) != "nccl":
+        return False
+    import time
+    device = torch.device(device)
+    world = dist.get_world_size(group)
+    ok = True
+    x = torch.ones(4096, device=device)
+    try:
+        dist.all_reduce(x, group=group)               # communicator set-up outside the capture
+        torch.cuda.synchronize(device)
+        time.sleep(0.3)                               # (the watchdog retires the finished work)
+        x.fill_(1.0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode=os.environ.get("FFWM_CAPTURE_ERROR_MODE", "thread_local")):
+            h = dist.all_reduce(x, group=group, async_op=True)
+            h.wait()
+            x.mul_(0.5)
+        for _ in range(2):
+            x.fill_(1.0)
+            g.replay()
+            torch.cuda.synchronize(device)
+            ok = ok and abs(float(x[0]) - 0.5 * world) < 1e-6 and abs(float(x[-1]) - 0.5 * world) < 1e-6
+        del g
+    except Exception as e:                            # noqa: BLE001 -- any failure means "do not capture the collectives"
+        import sys
+        print("probe_collective_capture: %r" % (e,), file=sys.stderr)
+        ok = False
+    try:
+        flag = torch.tensor([1.0 if ok else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = float(flag.item()) > 0.5
+    except Exception:                                 # noqa: BLE001
+        ok = False
+    return ok
+
+
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
                  warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True,
-                 mfma_wgrad=None, flat_adam=None, fused_bn=None, mfma_fwd=None, fused_l1=None):
+                 mfma_wgrad=None, flat_adam=None, fused_bn=None, mfma_fwd=None, fused_l1=None, segmented_backward=False,
+                 force_collectives=False):
         self.device = torch.device(device)
         self.titers = titers
+        # data parallelism is live when there are several ranks (force_collectives: also in a one-rank process group -- the
+        # one-GPU box's way to run RCCL calls through the capture path)
+        self.dp_active = world_size > 1 or bool(force_collectives)
+        # backward_G in three segments cut where a network's gradients are complete (flowNetB | netG | flowNetF): the all-reduce of a
+        # finished network overlaps the next segment even when every segment is a replayed hipGraph (capture mode "segments")
+        self.segmented = bool(segmented_backward)
         torch.manual_seed(seed)
         self.warp = warp if warp is not None else WarpNet()
         if warp is None and self.device.type == "cuda":
@@ -188,8 +236,11 @@ class FFWMTrainer(object):
         self.loss_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if multi else None
         self.flow_stream = (torch.cuda.Stream(self.device) if five else self.loss_streams[0]) if multi else None
         self.d_stream = None
-        if multi and world_size == 1 and os.environ.get("FFWM_D_STREAM", "1") == "1":
+        if multi and os.environ.get("FFWM_D_STREAM", "1") == "1":
             self.d_stream = torch.cuda.Stream(self.device) if five else self.loss_streams[1]
+        # the D step on its side stream: always on one GPU; with several ranks only when the collectives are captured into the
+        # step's graph (capture mode "ingraph": the D gradients' all-reduce is then a node of the side branch)
+        self._d_side = not self.dp_active
         self._d_pending = False
         self.batched_losses = batched_losses
         # the ~25 L1 terms of backward_G as one launch per direction (losses.l1_terms, csrc/l1_loss.hip); needs the batched passes
@@ -202,9 +253,13 @@ class FFWMTrainer(object):
         # their addresses are as static as the views'; with several ranks the packing runs between the graphs, in Python, where the
         # replayed gradients are not visible as new tensors: those keep the in-place accumulation)
         gather = True          # (several ranks under capture: the buckets are packed at the end of each captured backward segment)
-        self.red_G = BucketedGradReducer(itertools.chain(flow_params, self.netG.parameters()),
-                                         bucket_bytes=bucket_bytes, gather=gather)
-        self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes, gather=gather)
+        # one bucket group per network: a network's backward runs on one stream, and a segmented backward completes them one by one
+        self._params_F = [p for n, p in self.flowNetF.named_parameters() if not n.startswith("inter_conv_occ")]
+        self._params_B = [p for n, p in self.flowNetB.named_parameters() if not n.startswith("inter_conv_occ")]
+        self.red_G = BucketedGradReducer(None, groups=[self._params_F, self._params_B, list(self.netG.parameters())],
+                                         bucket_bytes=bucket_bytes, gather=gather, force_collectives=force_collectives)
+        self.red_D = BucketedGradReducer(self.netD.parameters(), bucket_bytes=bucket_bytes, gather=gather,
+                                         force_collectives=force_collectives)
         if flat_adam is None:
             flat_adam = self.device.type == "cuda"
         self.flat_adam = bool(flat_adam)
@@ -339,8 +394,16 @@ class FFWMTrainer(object):
         else:
             flow_F128, flow_F64, flow_F32 = self.flowNetF(img_S)
             self.flows_B = self.flowNetB(img_S)
+        if self.segmented:
+            # a segment boundary must be a CUT of the autograd graph: FlowNet feeds its coarse flows into the finer ones and netG its
+            # coarse reconstructions into the next level, so the tensors themselves are not one (a coarse output is an ancestor of a
+            # fine one).  Aliases (views: no kernel) consumed only on the far side of the boundary are.
+            flow_F128, flow_F64, flow_F32 = (f.view_as(f) for f in (flow_F128, flow_F64, flow_F32))
+        self.flows_F = [flow_F128, flow_F64, flow_F32]
         self.img_S_warp, self.img_S_rec = self.warp_many([img_S, img_F], [flow_F128, self.flows_B[0]])
         self.fake32, self.fake64, self.fake128 = self.netG(img_S, flow=[flow_F32, flow_F64, flow_F128])
+        if self.segmented:
+            self.fake32, self.fake64, self.fake128 = (f.view_as(f) for f in (self.fake32, self.fake64, self.fake128))
         self.img_GF128 = self.gf[128](self.fake128, img_F)
         grids = part_grids(b["lm_F"])            # eye-l, eye-r, nose, mouth
         crops = self.warp_many([self.img_GF128, img_F] * len(grids), [g for g in grids for _ in (0, 1)])   # 8 crops: one launch
@@ -437,7 +500,7 @@ class FFWMTrainer(object):
         loss_adv = self.lsgan(self.netD(self.img_GF128 * mask_F), True) * 0.1
         self.loss_G = v.sum() + loss_adv
         self.losses = {"G": self.loss_G, "l1": v[L1], "iden": v[IDEN], "illu": v[ILLU], "adv": loss_adv, "prc": v[PRC], "fc": v[FC]}
-        self.loss_G.backward()
+        self._backward_from_loss_G()
 
     def backward_G(self, b):
         if self.fused_l1 and self.parts[0][0].shape[2:] == (32, 32):
@@ -478,7 +541,46 @@ class FFWMTrainer(object):
         self.loss_G = loss_iden + loss_l1 + loss_prc + loss_illu + loss_fc + loss_adv
         self.losses = {"G": self.loss_G, "l1": loss_l1, "iden": loss_iden, "illu": loss_illu, "adv": loss_adv,
                        "prc": loss_prc, "fc": loss_fc}
-        self.loss_G.backward()
+        self._backward_from_loss_G()
+
+    # ------------------------------------------------------------------ backward of the generator loss, whole or in segments
+    G_F, G_B, G_NET = 0, 1, 2          # bucket groups of red_G (dp.BucketedGradReducer groups=)
+
+    def _backward_from_loss_G(self):
+        """loss_G.backward() -- or, segmented, its first part: the loss networks back to the generated images and, beside it (its own
+        stream), flowNetB: d(loss)/d(flows_B) comes straight from the illumination warp, so flowNetB's gradients are the first complete."""
+        if not self.segmented:
+            self.loss_G.backward()
+            return
+        fakes = [self.fake128, self.fake64, self.fake32]
+        torch.autograd.backward([self.loss_G], inputs=fakes + self._params_B, retain_graph=True)
+
+    def _bwd_netG(self):
+        """second segment: netG, from the gradients of the three generated scales down to its weights and the flow fields."""
+        fakes = [self.fake128, self.fake64, self.fake32]
+        grads = [f.grad for f in fakes]
+        for f in fakes:
+            f.grad = None
+        torch.autograd.backward(fakes, grads, inputs=[p for p in self.netG.parameters() if p.requires_grad] + self.flows_F,
+                                retain_graph=True)
+
+    def _bwd_flowF(self):
+        """third segment: flowNetF from the gradients of its three flow fields."""
+        grads = [f.grad for f in self.flows_F]
+        for f in self.flows_F:
+            f.grad = None
+        torch.autograd.backward(self.flows_F, grads, inputs=self._params_F)
+
+    def _finish_backward_G(self):
+        """the segments after the first, eagerly: every finished network's buckets go out (asynchronous) before the next segment is
+        issued.  (An unsegmented step has nothing left to do here.)"""
+        if not self.segmented:
+            return
+        self.red_G.launch_group(self.G_B)
+        self._bwd_netG()
+        self.red_G.launch_group(self.G_NET)
+        self._bwd_flowF()
+        self.red_G.launch_group(self.G_F)
 
     # optimize_parameters (ffwm_model.py:151-160) in three segments, cut where data parallelism has its
     # exchange steps (gradient all-reduce of the D set, then of the G set)
@@ -486,7 +588,7 @@ class FFWMTrainer(object):
         self.forward(b)
         for p in self.netD.parameters():
             p.requires_grad = True
-        if self.d_stream is not None and self.world_size == 1:
+        if self.d_stream is not None and self._d_side:
             # fork: the D step (forward, backward, gradient packing, Adam) beside the generator's loss passes; _join_D() in
             # front of the adversarial term (the first reader of the updated netD) is the join
             self.d_stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -513,6 +615,7 @@ class FFWMTrainer(object):
         for name in ("fake32", "fake64", "fake128", "img_GF128", "img_S_warp", "img_S_rec"):
             setattr(self, name, getattr(self, name).detach())
         self.flows_B = [f.detach() for f in self.flows_B]
+        self.flows_F = [f.detach() for f in self.flows_F]
         self.parts = [(a.detach(), b.detach()) for a, b in self.parts]
         for net in (self.netG, self.netD):
             for m in net.modules():                  # spectral norm leaves the normalised weight (a graph output) on the module
@@ -532,7 +635,8 @@ class FFWMTrainer(object):
             p.requires_grad = False
         self.red_G.zero_grad()
         self.backward_G(b)
-        self._drop_autograd_graph()
+        if not self.segmented:
+            self._drop_autograd_graph()
 
     def _seg_stepG(self):
         self.opt_G.step()
@@ -545,6 +649,9 @@ class FFWMTrainer(object):
         self._seg_forward_and_D(b)
         self._reduce_D()
         self._seg_stepD_and_G(b)
+        if self.segmented:
+            self._finish_backward_G()
+            self._drop_autograd_graph()
         self.red_G.finish()
         self._seg_stepG()
         self.titers += batch_increment if batch_increment is not None else b["img_S"].size(0)
@@ -552,22 +659,41 @@ class FFWMTrainer(object):
         return self.losses
 
     # ------------------------------------------------------------------ hipGraph replay
-    def capture(self, b, warmup=3):
+    def capture(self, b, warmup=3, mode=None):
         """Capture the train step into hipGraphs (HIP graphs through torch.cuda.CUDAGraph): the eager
-        step issues ~4600 small launches and is launch-bound (SURVEY 7 'hard parts'); a replay submits
-        them as pre-built graphs.  Single GPU: ONE graph for the whole step.  Data parallel: three
-        graphs with the two gradient all-reduces issued between them (RCCL stays outside the capture;
-        the buckets are reduced in one shot instead of overlapping with backward).
+        step issues ~2700 small launches and is launch-bound (SURVEY 7 'hard parts'); a replay submits
+        them as pre-built graphs.  Single GPU: ONE graph for the whole step.  Data parallel, `mode`
+        (default: FFWM_DP_CAPTURE, else "ingraph" when the backend is RCCL and a probe graph with one
+        all-reduce replays correctly on every rank, else "segments"):
+          "ingraph"   ONE graph, as on one GPU, with the collectives inside it: capture runs the Python once, so the reducers'
+                      autograd hooks fire and launch each bucket's all-reduce the moment its last gradient is written; RCCL's
+                      stream is forked from / joined to the step's streams by the events torch.distributed records, and the
+                      replayed graph overlaps every all-reduce with the rest of backward.  The D step keeps its side stream
+                      (its all-reduce joins before the adversarial term).
+          "segments"  backward_G cut where a network's gradients are complete (loss networks + flowNetB | netG | flowNetF), one graph
+                      per segment; the finished network's buckets are reduced asynchronously while the next segment replays.
+                      Works with any backend (gloo in the tests); only flowNetF's buckets are left exposed.
+          "serial"    round 3's three graphs with the two all-reduces between them, nothing overlapped (kept as a fallback).
         The batch is copied into static device buffers before every replay; the `titers` branch
         (< 20000 / >= 20000) is frozen at capture time -- re-capture when it flips."""
         assert self.device.type == "cuda" and self._graphs is None
         if not all(g.get("capturable", False) for o in (self.opt_F, self.opt_G, self.opt_D)
                    for g in getattr(o, "param_groups", [{}])):
             raise RuntimeError("capture() needs FFWMTrainer(..., capturable=True)")
+        if self.dp_active:
+            mode = mode or os.environ.get("FFWM_DP_CAPTURE") or ("ingraph" if probe_collective_capture(self.device) else "segments")
+            if mode not in ("ingraph", "segments", "serial"):
+                raise ValueError("capture mode %r" % (mode,))
+        else:
+            mode = "single"
+        self.capture_mode = mode
+        self.segmented = mode == "segments"
+        self._d_side = mode in ("single", "ingraph")
         self._static = {k: v.clone() for k, v in b.items()}
         sb = self._static
-        self.red_D.set_overlap(False)
-        self.red_G.set_overlap(False)
+        hooks_on = mode == "ingraph"
+        self.red_D.set_overlap(hooks_on)
+        self.red_G.set_overlap(hooks_on)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -575,6 +701,9 @@ class FFWMTrainer(object):
                 self._seg_forward_and_D(sb)
                 self._reduce_D()
                 self._seg_stepD_and_G(sb)
+                if self.segmented:
+                    self._finish_backward_G()
+                    self._drop_autograd_graph()
                 self.red_G.finish()
                 self._seg_stepG()
         torch.cuda.current_stream(self.device).wait_stream(side)
@@ -586,16 +715,24 @@ class FFWMTrainer(object):
                  if isinstance(m, (BatchNormLeakyReLU2d, HostCountBatchNorm2d))]
         before = [m._pending_batches for m in fused]
         graphs = []
-        if self.world_size == 1:
+        if mode in ("single", "ingraph"):
+            kw = {}
+            if mode == "ingraph":
+                # the process group's watchdog thread polls the events of collectives in flight: let everything issued so far retire
+                # before the capture starts, and do not let another thread's event query invalidate it
+                import time
+                time.sleep(0.3)
+                kw["capture_error_mode"] = os.environ.get("FFWM_CAPTURE_ERROR_MODE", "thread_local")
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **kw):
                 self._seg_forward_and_D(sb)
                 self._reduce_D()                 # one GPU: packs the D gradients into the flat array (a captured multi-tensor copy)
                 self._seg_stepD_and_G(sb)
-                self.red_G.finish()
+                self.red_G.finish()              # "ingraph": joins RCCL's stream back (the hooks launched the buckets during backward)
                 self._seg_stepG()
             graphs = [g]
-        else:
+            self._captured_launch_log = (list(self.red_D.launch_log), list(self.red_G.launch_log))
+        elif mode == "serial":
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             # three graphs with the all-reduces between them; the fresh gradients are packed into the flat buckets INSIDE the graph that
             # produced them (a replayed gradient is not a new tensor to Python), finish() outside only reduces
@@ -610,6 +747,30 @@ class FFWMTrainer(object):
             with torch.cuda.graph(g3, pool=g1.pool()):
                 self._seg_stepG()
             graphs = [g1, g2, g3]
+        else:
+            gs = [torch.cuda.CUDAGraph() for _ in range(5)]
+            with torch.cuda.graph(gs[0]):
+                self._seg_forward_and_D(sb)
+                self.red_D.pack_all()
+            self.red_D.finish()
+            pool = gs[0].pool()
+            with torch.cuda.graph(gs[1], pool=pool):       # D's Adam, the loss passes, backward down to the generated images + flowNetB
+                self._seg_stepD_and_G(sb)
+                self.red_G.pack_all(self.G_B)
+            self.red_G.launch_group(self.G_B)
+            with torch.cuda.graph(gs[2], pool=pool):
+                self._bwd_netG()
+                self.red_G.pack_all(self.G_NET)
+            self.red_G.launch_group(self.G_NET)
+            with torch.cuda.graph(gs[3], pool=pool):
+                self._bwd_flowF()
+                self._drop_autograd_graph()
+                self.red_G.pack_all(self.G_F)
+            self.red_G.launch_group(self.G_F)
+            self.red_G.finish()
+            with torch.cuda.graph(gs[4], pool=pool):
+                self._seg_stepG()
+            graphs = gs
         self.losses["D"] = self.loss_D
         self._bn_calls_per_replay = [(m, m._pending_batches - n0) for m, n0 in zip(fused, before) if m._pending_batches != n0]
         for m, n in self._bn_calls_per_replay:
@@ -624,14 +785,30 @@ class FFWMTrainer(object):
         for k, v in self._static.items():
             if b[k] is not v:
                 v.copy_(b[k], non_blocking=True)
-        if len(self._graphs) == 1:
-            self._graphs[0].replay()
-        else:
-            self._graphs[0].replay()
+        gs = self._graphs
+        if len(gs) == 1:
+            gs[0].replay()
+        elif len(gs) == 3:
+            self.red_D.begin_replay()
+            self.red_G.begin_replay()
+            gs[0].replay()
             self.red_D.finish()
-            self._graphs[1].replay()
+            gs[1].replay()
             self.red_G.finish()
-            self._graphs[2].replay()
+            gs[2].replay()
+        else:
+            self.red_D.begin_replay()
+            self.red_G.begin_replay()
+            gs[0].replay()
+            self.red_D.finish()
+            gs[1].replay()
+            self.red_G.launch_group(self.G_B)        # flowNetB's buckets travel while netG's backward replays
+            gs[2].replay()
+            self.red_G.launch_group(self.G_NET)      # netG's while flowNetF's backward replays
+            gs[3].replay()
+            self.red_G.launch_group(self.G_F)
+            self.red_G.finish()
+            gs[4].replay()
         for m, n in self._bn_calls_per_replay:
             m._pending_batches += n
         self.titers += batch_increment if batch_increment is not None else b["img_S"].size(0)
@@ -640,6 +817,8 @@ class FFWMTrainer(object):
     def release_graphs(self):
         self._graphs = None
         self._static = None
+        self.segmented = False
+        self._d_side = not self.dp_active
         self.red_D.set_overlap(True)
         self.red_G.set_overlap(True)
         self.red_D.set_gather(True)
@@ -816,6 +995,7 @@ class FlowNetTrainer(object):
             for k, v in self._static.items():
                 if b[k] is not v:
                     v.copy_(b[k], non_blocking=True)
+            self.reducer.begin_replay()
             self._graphs[0].replay()
             if len(self._graphs) > 1:
                 self.reducer.finish()

@@ -197,3 +197,61 @@ def test_bucketed_reducer_world8_gloo_launch_order_overlap_and_lockstep():
     ret = mgr.dict()
     mp.spawn(_worker8, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
+# ------------------------------------------------------------------------------------------------ segmented backward_G (capture mode "segments")
+def _worker_segments(rank, world, port, ret):
+    """FFWMTrainer(segmented_backward=True) on CPU, two gloo ranks: backward_G runs as three autograd segments cut at ALIASES of the
+    generated images / flow fields (a coarse output feeds the next level, so the tensors themselves are no cut); every finished
+    network's buckets go out before the next segment is issued.  The result must be the unsegmented data-parallel step's, bit for
+    bit, and the ranks stay in lock-step."""
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import torch_refs
+        from ffwm_amd import trainer
+        torch.set_num_threads(4)
+        out = []
+        for seg in (False, True):
+            t = trainer.FFWMTrainer("cpu", world_size=world, seed=3, warp=torch_refs.warp, warp_flipcat=torch_refs.warp_flipcat, ngf=8,
+                                    bucket_bytes=1 << 20, segmented_backward=seg)
+            groups = [b["group"] for b in t.red_G.buckets]
+            assert set(groups) == {0, 1, 2} and groups == sorted(groups, reverse=True), groups      # a bucket never spans two networks
+            batch = trainer.synthetic_batch(2, "cpu", seed=50 + rank)                                # per-rank data
+            if seg:
+                t.red_G.set_overlap(False)       # the regime of a replayed graph: no hook runs, the segments hand the buckets over
+            t.step(batch)
+            log = list(t.red_G.launch_log)
+            assert sorted(i for i, _ in log) == list(range(len(groups))), log
+            if seg:
+                # launch order = completion order of the segments: flowNetB's buckets, netG's, flowNetF's; none left to finish()
+                assert [groups[i] for i, _ in log] == sorted((groups[i] for i, _ in log), key=lambda g: {1: 0, 2: 1, 0: 2}[g]), log
+                assert all(w == "segment" for _, w in log), log
+                last_seg = [i for i, _ in log if groups[i] == 0]
+                assert len(log) - len(last_seg) >= 2            # in flight before the last backward segment is issued
+            t.step(batch)
+            w = torch.cat([p.detach().flatten() for m in (t.flowNetF, t.flowNetB, t.netG, t.netD) for p in m.parameters()])
+            out.append((w, t.red_G.flat.clone(), t.loss_values()))
+            got = [torch.zeros_like(w) for _ in range(world)]
+            dist.all_gather(got, w)
+            assert torch.equal(got[0], got[1]), "weights differ across the ranks (segmented=%s)" % seg
+        assert torch.equal(out[0][1], out[1][1]), "segmented backward changed the reduced gradients: %g" % (out[0][1] - out[1][1]).abs().max()
+        assert torch.equal(out[0][0], out[1][0])
+        assert out[0][2] == out[1][2]
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "FAIL: %s\n%s" % (e, traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_segmented_backward_G_two_ranks_gloo_equals_the_unsegmented_step():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_segments, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
