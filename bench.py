@@ -537,18 +537,18 @@ def main():
             step_flops = flops.count_step(nets_all, lambda: t.step(batch, batch_increment=0))       # one untimed eager step
         capture_mode, d_side = None, False
         if graphed:
-            # several ranks: the capture modes of FFWMTrainer.capture, best first -- "ingraph" (RCCL captured into ONE graph; chosen by
-            # a probe graph every rank must replay correctly), then "segments" (five graphs, a finished network's all-reduce overlaps
-            # the next backward segment).  Should a capture fail beside the live process group (RCCL cannot be tried on the one-GPU
-            # development box), the ranks agree on it and try the next mode on a fresh trainer; the last resort is the eager step with
-            # hook-launched, overlapped all-reduces.
+            # several ranks: the capture modes of FFWMTrainer.capture, best first -- "ingraph" (RCCL captured into ONE graph, every
+            # bucket's all-reduce overlapping backward; chosen by a probe graph every rank must replay correctly), then "serial" (three
+            # graphs, the all-reduces between them).  Should a capture or its first replay fail beside the live process group (several
+            # RCCL ranks cannot be tried on the one-GPU development box), the ranks agree on it and try the next mode on a fresh
+            # trainer; the last resort is the eager step with hook-launched, overlapped all-reduces.
             forced = os.environ.get("FFWM_DP_CAPTURE")
-            modes = [None] if world == 1 else ([forced] if forced else ["auto", "segments"])
+            modes = [None] if world == 1 else ([forced] if forced else ["auto", "serial"])
             tried, captured = [], False
             for m in modes:
                 mode = m
                 if m == "auto":
-                    mode = "ingraph" if trainer.probe_collective_capture(dev) else "segments"
+                    mode = "ingraph" if trainer.probe_collective_capture(dev) else "serial"
                 if mode in tried:
                     continue
                 tried.append(mode)
@@ -602,7 +602,7 @@ def main():
                                   "launch": ("hipGraph replay"
                                              + ({"ingraph": " (ONE graph, the bucket all-reduces captured inside it on RCCL's stream, overlapping backward)",
                                                  "segments": " (five graphs: backward_G cut at network boundaries, each finished network's all-reduce "
-                                                             "overlaps the next segment)",
+                                                             "overlaps the next segment; experimental)",
                                                  "serial": " (three graphs, the two gradient all-reduces between them)"}.get(capture_mode, ""))
                                              + (", flowNetB and the loss networks' side passes on their own HIP streams" if t.flow_stream is not None else "")
                                              + (", the D step beside them" if d_side else "")

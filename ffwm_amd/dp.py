@@ -226,6 +226,15 @@ class BucketedGradReducer(object):
         if b["pending"] == 0 and not b["launched"]:
             self._launch(b)
 
+    def wait_launched(self, host=False):
+        """Wait for the all-reduces in flight (no averaging: finish() does that once).  host=True also blocks the host until the
+        device has caught up -- nothing of a collective may still be running on some backend thread when a capture begins."""
+        for b in self.buckets:
+            if b["launched"] and b["handle"] is not None:
+                b["handle"].wait()
+        if host and self.buckets and self.buckets[0]["flat"].is_cuda:
+            torch.cuda.synchronize(self.buckets[0]["flat"].device)
+
     def finish(self):
         """Block (stream-wise) until every bucket is reduced; call before optimizer.step()."""
         if self.gather:

@@ -595,8 +595,14 @@ class FFWMTrainer(object):
             with torch.cuda.stream(self.d_stream):
                 self.red_D.zero_grad()
                 self.backward_D(b)
-                self.red_D.finish()
-                self.opt_D.step()
+                if self._d_side == "reduce_on_main":
+                    # several ranks, collectives captured into the graph: only netD's forward / backward run on the side branch; the
+                    # all-reduce of its gradients and its Adam are issued on the step's stream at the join (RCCL's stream forked from a
+                    # side branch AND joined into it crashed hipStreamEndCapture on ROCm 7.0 -- profiles/r04_dp_capture_modes.txt)
+                    self.red_D.pack_all()
+                else:
+                    self.red_D.finish()
+                    self.opt_D.step()
             self._d_pending = True
             return
         self.red_D.zero_grad()
@@ -627,6 +633,9 @@ class FFWMTrainer(object):
         if self._d_pending:
             torch.cuda.current_stream(self.device).wait_stream(self.d_stream)
             self._d_pending = False
+            if self._d_side == "reduce_on_main":
+                self.red_D.finish()
+                self.opt_D.step()
 
     def _seg_stepD_and_G(self, b):
         if not self._d_pending:
@@ -664,16 +673,20 @@ class FFWMTrainer(object):
         step issues ~2700 small launches and is launch-bound (SURVEY 7 'hard parts'); a replay submits
         them as pre-built graphs.  Single GPU: ONE graph for the whole step.  Data parallel, `mode`
         (default: FFWM_DP_CAPTURE, else "ingraph" when the backend is RCCL and a probe graph with one
-        all-reduce replays correctly on every rank, else "segments"):
-          "ingraph"   ONE graph, as on one GPU, with the collectives inside it: capture runs the Python once, so the reducers'
+        all-reduce replays correctly on every rank, else "serial"):
+          "ingraph"   ONE graph, as on one GPU, with the collectives inside it: capture runs the Python once, so red_G's
                       autograd hooks fire and launch each bucket's all-reduce the moment its last gradient is written; RCCL's
                       stream is forked from / joined to the step's streams by the events torch.distributed records, and the
-                      replayed graph overlaps every all-reduce with the rest of backward.  The D step keeps its side stream
-                      (its all-reduce joins before the adversarial term).
-          "segments"  backward_G cut where a network's gradients are complete (loss networks + flowNetB | netG | flowNetF), one graph
-                      per segment; the finished network's buckets are reduced asynchronously while the next segment replays.
-                      Works with any backend (gloo in the tests); only flowNetF's buckets are left exposed.
-          "serial"    round 3's three graphs with the two all-reduces between them, nothing overlapped (kept as a fallback).
+                      replayed graph overlaps every all-reduce with the rest of backward.  netD's forward / backward keep their side
+                      branch; its (4.5 MB) all-reduce and Adam are issued on the step's stream at the join in front of the
+                      adversarial term.  Verified on the one-GPU box with a one-rank RCCL group (tests/test_gpu_dp.py).
+          "serial"    round 3's three graphs with the two all-reduces between them, nothing overlapped: the fallback.
+          "segments"  EXPERIMENTAL, never chosen automatically: backward_G cut where a network's gradients are complete (loss networks +
+                      flowNetB | netG | flowNetF), one graph per segment, the finished network's buckets reduced asynchronously while
+                      the next segment replays.  The segmented backward itself is exact (tests/test_dp_gloo.py: bit-equal to the
+                      unsegmented step, eager), but the five-graph REPLAY produced non-finite weight gradients on the MI355X box in a
+                      timing-dependent way (side streams on: three netG layers every time; side streams off: one of four two-rank runs
+                      -- profiles/r04_dp_capture_modes.txt); cause not found, so it stays opt-in.
         The batch is copied into static device buffers before every replay; the `titers` branch
         (< 20000 / >= 20000) is frozen at capture time -- re-capture when it flips."""
         assert self.device.type == "cuda" and self._graphs is None
@@ -681,18 +694,26 @@ class FFWMTrainer(object):
                    for g in getattr(o, "param_groups", [{}])):
             raise RuntimeError("capture() needs FFWMTrainer(..., capturable=True)")
         if self.dp_active:
-            mode = mode or os.environ.get("FFWM_DP_CAPTURE") or ("ingraph" if probe_collective_capture(self.device) else "segments")
+            mode = mode or os.environ.get("FFWM_DP_CAPTURE") or ("ingraph" if probe_collective_capture(self.device) else "serial")
             if mode not in ("ingraph", "segments", "serial"):
                 raise ValueError("capture mode %r" % (mode,))
         else:
             mode = "single"
         self.capture_mode = mode
         self.segmented = mode == "segments"
-        self._d_side = mode in ("single", "ingraph")
+        # FFWM_INGRAPH_DSIDE: "main" (the D step's all-reduce and Adam at the join, on the step's stream; default), "side" (all of the D
+        # step on the side branch), "0" (no side branch for D)
+        dside = os.environ.get("FFWM_INGRAPH_DSIDE", "main")
+        self._d_side = True if mode == "single" else ({"main": "reduce_on_main", "side": True}.get(dside, False) if mode == "ingraph" else False)
+        if mode == "segments":
+            # measured (profiles/r04_dp_capture_modes.txt): with side streams inside the five-graph step the replayed weight gradients of
+            # three netG layers came out non-finite; without them the step equals the eager one.  This mode is the fallback: one stream.
+            self._streams_saved = (self.flow_stream, self.loss_streams)
+            self.flow_stream, self.loss_streams = None, None
         self._static = {k: v.clone() for k, v in b.items()}
         sb = self._static
-        hooks_on = mode == "ingraph"
-        self.red_D.set_overlap(hooks_on)
+        hooks_on = mode == "ingraph" and os.environ.get("FFWM_INGRAPH_HOOKS", "1") == "1"     # (0: all-reduces at the end of backward, still in-graph)
+        self.red_D.set_overlap(hooks_on and self._d_side != "reduce_on_main")
         self.red_G.set_overlap(hooks_on)
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -740,34 +761,42 @@ class FFWMTrainer(object):
                 self._seg_forward_and_D(sb)
                 self.red_D.pack_all()
             self.red_D.finish()
+            torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self._seg_stepD_and_G(sb)
                 self.red_G.pack_all()
             self.red_G.finish()
+            torch.cuda.synchronize(self.device)
             with torch.cuda.graph(g3, pool=g1.pool()):
                 self._seg_stepG()
             graphs = [g1, g2, g3]
         else:
             gs = [torch.cuda.CUDAGraph() for _ in range(5)]
+            # (between the captures the collectives run for real, on whatever the buffers hold -- every rank issues the same sequence --
+            # and are WAITED for: a backend thread still copying / synchronising while the next capture is open would invalidate it)
             with torch.cuda.graph(gs[0]):
                 self._seg_forward_and_D(sb)
                 self.red_D.pack_all()
             self.red_D.finish()
+            torch.cuda.synchronize(self.device)
             pool = gs[0].pool()
             with torch.cuda.graph(gs[1], pool=pool):       # D's Adam, the loss passes, backward down to the generated images + flowNetB
                 self._seg_stepD_and_G(sb)
                 self.red_G.pack_all(self.G_B)
             self.red_G.launch_group(self.G_B)
+            self.red_G.wait_launched(host=True)
             with torch.cuda.graph(gs[2], pool=pool):
                 self._bwd_netG()
                 self.red_G.pack_all(self.G_NET)
             self.red_G.launch_group(self.G_NET)
+            self.red_G.wait_launched(host=True)
             with torch.cuda.graph(gs[3], pool=pool):
                 self._bwd_flowF()
                 self._drop_autograd_graph()
                 self.red_G.pack_all(self.G_F)
             self.red_G.launch_group(self.G_F)
             self.red_G.finish()
+            torch.cuda.synchronize(self.device)
             with torch.cuda.graph(gs[4], pool=pool):
                 self._seg_stepG()
             graphs = gs
@@ -819,6 +848,9 @@ class FFWMTrainer(object):
         self._static = None
         self.segmented = False
         self._d_side = not self.dp_active
+        if getattr(self, "_streams_saved", None) is not None:
+            self.flow_stream, self.loss_streams = self._streams_saved
+            self._streams_saved = None
         self.red_D.set_overlap(True)
         self.red_G.set_overlap(True)
         self.red_D.set_gather(True)
