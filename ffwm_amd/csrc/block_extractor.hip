@@ -1152,12 +1152,15 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
 // FUSED (block attention backward): gout is the gradient of the attention output, [B, C, Hf, Wf], and the
 // k x k grad_output window of a pixel is (g / k^2) * w_ij with the attention weights w [B, k^2, Hf, Wf]
 // (what avg_pool2d's and the product's backward hand to the extractor) -- formed in registers, never stored.
-template <int K, int RH, int H, bool FUSED = false>
+template <int K, int RH, int H, bool FUSED = false, bool ABL = false>
 __global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 && H <= 4 ? 4 : 2))
 be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
                    float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
-                   int ntx, int nty, int cslabs, int cs, int remap, const float* __restrict__ attn = nullptr) {
+                   int ntx, int nty, int cslabs, int cs, int remap, const float* __restrict__ attn = nullptr, int ablate_arg = 0) {
     using T = float;
+    // bench-only ablation (tools/be_bwd_ablate.py; profiles/r04_be_bwd_ablation.txt): 1 = no LDS atomics, 2 = no flush atomics,
+    // 4 = no d(flow) arithmetic.  A compile-time zero in the product instantiations.
+    const int ablate = ABL ? ablate_arg : 0;
     constexpr int RW = kTileRW, NW = kBlock / kWave, PPT = RH / NW;
     constexpr int TW = RW, TH = RH;                       // the block's flow pixels: no overlap with its neighbours
     constexpr int AP = RW + 2 * H, AH = RH + 2 * H;       // accumulator / source box = tile grown by H
@@ -1348,6 +1351,7 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                             T v = 0;
                             if (r2 < K) v = tx[r2][c2] * yt[r2];
                             if (r2 > 0) v = (r2 < K) ? fma_t<T>(tx[r2 - 1][c2], wyb[r2 - 1], v) : tx[r2 - 1][c2] * wyb[r2 - 1];
+                            if (ablate & 1) { if (v == 12345.f) A[0] = 1; continue; }            // bench-only: no LDS atomics
                             __hip_atomic_fetch_add(ap + r2 * AP + c2, static_cast<double>(v), __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
@@ -1355,7 +1359,7 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                     // d(flow) (:163-164), only where this wave's row belongs to the tile (wave-uniform) and for
                     // the lanes that own their pixel: products regrouped into source differences, summed along
                     // the rows (gx) / columns (gy) of the window first
-                    if (row_owned) {
+                    if (row_owned && !(ablate & 4)) {
                         const T* nb = S + (owned ? sv * AP + su : 0);
                         T sp[K + 1], sc[K + 1];
 #pragma unroll
@@ -1472,7 +1476,9 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                     if (idx < NA) {
                         const T v = static_cast<T>(A[idx]);
                         A[idx] = 0;
-                        if (v != 0 && off[q] != 0xFFFFFFFFu) atomic_add(gplane + off[q], v);
+                        // (measured, round 4: a plain read-modify-write for the 56 x 24 cells no other block can reach is SLOWER than the
+                        // return-less atomic -- 679 vs 597 us: the atomic is one write transaction resolved at L2, the RMW a round trip)
+                        if (v != 0 && off[q] != 0xFFFFFFFFu && !(ablate & 2)) atomic_add(gplane + off[q], v);
                         if (more) S[idx] = st[q];
                     }
                 }
@@ -1793,11 +1799,15 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
     hipLaunchKernelGGL((KERNEL<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,              \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
                        (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap)
+#define FFWM_BE_TILE2(KK, RR, HH)                                                                             \
+    hipLaunchKernelGGL((be_bwd_tile2_kernel<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src, \
+                       (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
+                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, 0)
 #define FFWM_BE_TILE_K(KK)                                                                                    \
     case KK:                                                                                                  \
         if (shared_cells) {                                                                                   \
-            if (h == 8) FFWM_BE_TILE(be_bwd_tile2_kernel, KK, 32, 8);                                         \
-            else FFWM_BE_TILE(be_bwd_tile2_kernel, KK, 32, 4);                                                \
+            if (h == 8) FFWM_BE_TILE2(KK, 32, 8);                                                             \
+            else FFWM_BE_TILE2(KK, 32, 4);                                                                    \
         } else {                                                                                              \
             if (h == 8) FFWM_BE_TILE(be_bwd_tile_kernel, KK, 32, 8);                                          \
             else FFWM_BE_TILE(be_bwd_tile_kernel, KK, 32, 4);                                                 \
@@ -1805,10 +1815,15 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
         break;
                 if (RH == 64) {
                     FFWM_BE_TILE(be_bwd_tile_kernel, 3, 64, 4);
+                } else if (shared_cells && k == 3 && h == 4 && options().ablate != 0) {
+                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, false, true>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,
+                                       (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs, (int)Ws, (int)Hf,
+                                       (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate);
                 } else {
                     switch (k) { FFWM_BE_TILE_K(1) FFWM_BE_TILE_K(2) FFWM_BE_TILE_K(3) FFWM_BE_TILE_K(4) }
                 }
 #undef FFWM_BE_TILE_K
+#undef FFWM_BE_TILE2
 #undef FFWM_BE_TILE
             }
             return check_launch("ffwm_block_extractor_backward(tile)");
