@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libffwm_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

@@ -527,8 +527,9 @@ class _FlowHead(Function):
         B, C, H, W = x.shape
         gz = torch.empty_like(y)
         gx = torch.empty_like(x)
-        _lib.check(_lib.load().ffwm_flow_head_backward(y.data_ptr(), go.data_ptr(), weight.data_ptr(), gz.data_ptr(), gx.data_ptr(), B, C, H, W,
-                                                       _lib.F32, torch.cuda.current_stream(x.device).cuda_stream), "ffwm_flow_head_backward")
+        with ops._on_device(x) as stream:          # the tensors' device, not the thread's current one
+            _lib.check(_lib.load().ffwm_flow_head_backward(y.data_ptr(), go.data_ptr(), weight.data_ptr(), gz.data_ptr(), gx.data_ptr(), B, C, H, W,
+                                                           _lib.F32, stream), "ffwm_flow_head_backward")
         gw = gb = None
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -574,8 +575,9 @@ class _FlowUp(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            _lib.check(_lib.load().ffwm_flow_up_backward(go.data_ptr(), weight.data_ptr(), gx.data_ptr(), B, H, W, go.stride(0), _lib.F32,
-                                                         torch.cuda.current_stream(x.device).cuda_stream), "ffwm_flow_up_backward")
+            with ops._on_device(x) as stream:
+                _lib.check(_lib.load().ffwm_flow_up_backward(go.data_ptr(), weight.data_ptr(), gx.data_ptr(), B, H, W, go.stride(0), _lib.F32,
+                                                             stream), "ffwm_flow_up_backward")
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw, gb = conv_transpose_weight_grad(x, go.contiguous(), weight, need_b)

@@ -49,9 +49,11 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
 }
 
 // The step counter on the DEVICE (a step that sits inside a captured hipGraph: a replay runs no host code, so the bias corrections
-// cannot come from a host integer).  state[0] = steps taken so far, state[1] = lr / bc1, state[2] = sqrt(bc2) of the current step.
+// cannot come from a host integer).  state[0] = steps taken so far, state[1] = lr / bc1, state[2] = sqrt(bc2) of the current step,
+// state[3] = learning-rate override (> 0: replaces the kernel argument).
 __global__ void adam_advance_kernel(double* __restrict__ state, double lr, double beta1, double beta2) {
     const double step = state[0] + 1.0;
+    if (state[3] > 0.0) lr = state[3];          // the host's current learning rate (a schedule under hipGraph replay)
     state[0] = step;
     state[1] = lr / (1.0 - pow(beta1, step));
     state[2] = sqrt(1.0 - pow(beta2, step));
@@ -85,8 +87,8 @@ adam_flat_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* 
 
 using namespace ffwm;
 
-// The same step with the step counter in device memory: state = 3 doubles (steps taken so far -- start it at 0 --, then two
-// scratch values).  Two launches (a one-thread advance of the counter, the streaming pass); safe to capture in a hipGraph.
+// The same step with the step counter in device memory: state = 4 doubles (steps taken so far -- start it at 0 --, two
+// scratch values, the learning-rate override).  Two launches (a one-thread advance of the counter, the streaming pass); safe to capture in a hipGraph.
 extern "C" int ffwm_adam_step_device(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr,
                                      double beta1, double beta2, double eps, void* state, int dtype, void* stream) {
     const char* fn = "ffwm_adam_step_device";

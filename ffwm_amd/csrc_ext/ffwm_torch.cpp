@@ -41,11 +41,23 @@ Tensor opt(const c10::optional<Tensor>& t, const Tensor& like) { return t.has_va
 
 // One zero-filled scratch per (device, C, stream), filled once: the kernels hand it back zero-filled (include/ffwm_hip.h) and the
 // calls that share it are ordered on their stream.  (Round 2 filled a fresh one per call: 60 fill launches per train step.)
+std::mutex& scratch_mu() { static std::mutex mu; return mu; }
+std::map<std::tuple<int, int64_t, void*>, Tensor>& scratch_cache() {
+    static std::map<std::tuple<int, int64_t, void*>, Tensor> cache;
+    return cache;
+}
+// A buffer first made inside a hipGraph capture lives in that graph's private pool and its zero-fill is a node of that graph only:
+// capture() drops every cached buffer before it starts (norm.reset_scratch), so each capture makes -- and fills, on every replay --
+// its own.
+void bn_scratch_reset() {
+    std::lock_guard<std::mutex> lock(scratch_mu());
+    scratch_cache().clear();
+}
 Tensor bn_scratch(const Tensor& x) {
     const int64_t C = x.size(1);
     if (!(C < 512 && x.numel() / C >= 32768)) return Tensor();
-    static std::mutex mu;
-    static std::map<std::tuple<int, int64_t, void*>, Tensor> cache;
+    std::mutex& mu = scratch_mu();
+    auto& cache = scratch_cache();
     std::lock_guard<std::mutex> lock(mu);
     auto key = std::make_tuple(static_cast<int>(x.device().index()), C, stream_of(x));
     auto it = cache.find(key);
@@ -149,6 +161,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                          const c10::optional<Tensor>& rv, double eps, double momentum, double slope) {
         return BnLrelu::apply(x, opt(w, x), opt(b, x), opt(rm, x), opt(rv, x), eps, momentum, slope);
     });
+    m.def("bn_scratch_reset", &bn_scratch_reset);
     m.def("bias_relu", [](const Tensor& h, const Tensor& bias) { return BiasRelu::apply(h, bias); });
     m.def("mfm", [](const Tensor& x, const c10::optional<Tensor>& bias) { return Mfm::apply(x, opt(bias, x)); });
 }

@@ -8,7 +8,6 @@ the two ops are the gfx950 kernels behind ``ffwm_amd.external_function``.  ``fus
 same loss and its gradient with ONE kernel per scale (csrc/affine_reg.hip) instead of
 6 launches forward + ~10 backward per coordinate grid.
 """
-import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -33,6 +32,19 @@ class _FusedAffineReg(Function):
         return (grad * grad_output if grad is not None else None), None, None
 
 
+def affine_residual_kernels(kz):
+    """The kz^2 filters [kz^2, 1, kz, kz] (float64) whose responses, dotted with a window of the sampling grid, give the squared
+    distance of that window from the nearest affine map (what losses.py:192-199 builds).  With the design matrix D of the window's
+    kz^2 cells -- one row (y, x, 1) per cell, y-major -- the least-squares affine fit of a window g is P g, P = D (D^T D)^-1 D^T,
+    and the residual is R g with R = I - P.  R is a symmetric projector, so the reference's K^T K (K = P - I) is R itself up to
+    rounding; it is formed as R^T R here to follow the reference's arithmetic to the last bits the fixtures pin."""
+    ys, xs = torch.meshgrid(torch.arange(kz, dtype=torch.float64), torch.arange(kz, dtype=torch.float64), indexing="ij")
+    design = torch.stack((ys.reshape(-1), xs.reshape(-1), torch.ones(kz * kz, dtype=torch.float64)), 1)          # [kz^2, 3]
+    fit = design @ torch.linalg.solve(design.T @ design, design.T)                                                # P
+    resid = fit - torch.eye(kz * kz, dtype=torch.float64)                                                         # -R
+    return (resid.T @ resid).reshape(kz * kz, 1, kz, kz)
+
+
 class AffineRegularizationLoss(nn.Module):
     """Penalises the deviation of every kz x kz window of the sampling grid from an affine map
     (losses.py:181-223).  kernel = K^T K with K = A (A^T A)^-1 A^T - I, A = [row, col, 1]."""
@@ -43,14 +55,7 @@ class AffineRegularizationLoss(nn.Module):
         self.fused = fused        # True: the whole loss (and its gradient) as one HIP kernel per scale
         self.extractor = BlockExtractor(kernel_size=kz)
         self.reshape = LocalAttnReshape()
-        temp = np.arange(kz)
-        A = np.ones([kz * kz, 3])
-        A[:, 0] = temp.repeat(kz)
-        A[:, 1] = temp.repeat(kz).reshape((kz, kz)).transpose().reshape(kz ** 2)
-        AH = A.transpose()
-        k = np.dot(A, np.dot(np.linalg.inv(np.dot(AH, A)), AH)) - np.identity(kz ** 2)
-        kernel = np.dot(k.transpose(), k)
-        self.kernel = torch.from_numpy(kernel).unsqueeze(1).view(kz ** 2, kz, kz).unsqueeze(1)
+        self.kernel = affine_residual_kernels(kz)
         self._cache = {}
 
     def _weights(self, like):
@@ -123,13 +128,12 @@ class LandmarkLoss(nn.Module):
     (losses.py:61-74).  flow [B,2,s,s]; lm_S / lm_F integer pixel coordinates [B,L,2]; gate [B,L,2]."""
 
     def forward(self, flow, lm_S, lm_F, gate):
-        b, _, s, _ = flow.size()
-        flow_view = flow.transpose(1, 2).transpose(2, 3).reshape(b, -1, 2)
-        index = lm_F[:, :, 0:1] + lm_F[:, :, 1:2] * s
-        index = torch.cat((index, index), 2)
-        flow_points = torch.gather(flow_view, 1, index)
-        gt_points = lm_S.float() / (s / 2.0) - 1
-        return F.mse_loss(flow_points * gate, gt_points * gate)
+        side = flow.size(-1)
+        # the flow vectors at the frontal landmarks: pixel (x, y) of the row-major plane is element y * side + x
+        cell = (lm_F[..., 1] * side + lm_F[..., 0]).unsqueeze(1).expand(-1, 2, -1)             # [B, 2, L]
+        picked = flow.flatten(2).gather(2, cell).transpose(1, 2)                                # [B, L, 2] = (flow_x, flow_y) per landmark
+        wanted = lm_S.to(flow.dtype) * (2.0 / side) - 1                                         # profile landmarks on the [-1, 1] grid
+        return F.mse_loss(picked * gate, wanted * gate)
 
 
 class MultiScaleLDLoss(nn.Module):
@@ -235,14 +239,23 @@ class _L1Terms(torch.autograd.Function):
             row = x.numel() // max(x.shape[0], 1)
             terms.append((x, y.contiguous(), None if m is None else m.contiguous(),
                           [(x0, y0, rows, w / float(max(rows * row, 1)), slot) for (x0, y0, rows, w, slot) in segments]))
-        ctx.terms = terms
+        # saved through autograd (not parked on ctx): an in-place change of x, y or a mask between forward and backward is then caught by
+        # the version check instead of silently producing the gradient of other data
+        flat, layout = [], []
+        for (x, y, m, segs) in terms:
+            layout.append((len(flat), m is not None, segs))
+            flat += [x, y] + ([m] if m is not None else [])
+        ctx.save_for_backward(*flat)
+        ctx.layout = layout
         return ops.l1_multi_forward(terms, n_slots)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
         from . import ops
-        grads = ops.l1_multi_backward(ctx.terms, grad_out, ctx.needs_input_grad[2:])
+        saved = ctx.saved_tensors
+        terms = [(saved[i], saved[i + 1], saved[i + 2] if has_m else None, segs) for (i, has_m, segs) in ctx.layout]
+        grads = ops.l1_multi_backward(terms, grad_out, ctx.needs_input_grad[2:])
         return (None, None) + tuple(grads)
 
 

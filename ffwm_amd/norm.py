@@ -50,6 +50,16 @@ def _scratch(x):
     return None
 
 
+def reset_scratch():
+    """Drop every cached scratch buffer (here and in the C++ binding).  trainer.capture() calls it before a capture starts: a buffer
+    first made inside a capture lives in that graph's private pool and its zero-fill is a node of that graph alone -- a later capture
+    (capture -> release_graphs -> capture) that found it in the cache would replay on memory nobody filled."""
+    _SCRATCH.clear()
+    ext = _ext.get()
+    if ext is not None and hasattr(ext, "bn_scratch_reset"):
+        ext.bn_scratch_reset()
+
+
 class _BnLreluFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, slope):

@@ -684,7 +684,14 @@ def l1_multi_backward(terms, grad_out, need):
     grads = []
     for i in sel:
         x, segments = terms[i][0], terms[i][3]
-        covered = sum(r for (_, _, r, _, _) in segments) == x.shape[0] and len({s0 for (s0, _, _, _, _) in segments}) == len(segments)
+        # the kernel WRITES a segment's rows (it does not accumulate): segments of one tensor must not overlap; rows none of them covers
+        # get no gradient, so unless the segments tile the tensor exactly it starts from zeros
+        spans = sorted((s0, s0 + r) for (s0, _, r, _, _) in segments)
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            if b0 < a1:
+                raise ValueError("l1_multi: term %d: segments [%d, %d) and [%d, %d) overlap (a row would keep only one gradient)"
+                                 % (i, a0, a1, b0, b1))
+        covered = bool(spans) and spans[0][0] == 0 and spans[-1][1] == x.shape[0] and all(a1 == b0 for (_, a1), (b0, _) in zip(spans, spans[1:]))
         grads.append(torch.empty_like(x) if covered else torch.zeros_like(x))
     arr, n = _l1_table([terms[i] for i in sel], grads)
     go = grad_out.contiguous()

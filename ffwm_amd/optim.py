@@ -43,10 +43,26 @@ class FlatAdam(object):
         self.steps = 0
         # capturable: the step counter lives on the device (ffwm_adam_step_device), so that step() can sit inside a captured hipGraph
         self.capturable = bool(capturable)
-        self.state = torch.zeros(3, device=dev, dtype=torch.float64) if self.capturable else None
-        self.param_groups = [{"capturable": self.capturable, "lr": self.lr}]
+        # state[0] step counter, state[1..2] scratch, state[3] the current learning rate (csrc/adam.hip: it overrides the kernel argument
+        # a captured graph has baked in)
+        self.state = torch.zeros(4, device=dev, dtype=torch.float64) if self.capturable else None
+        # torch.optim's interface for schedulers (base_model.update_learning_rate: StepLR / lambda rules write param_groups[i]['lr'])
+        self.param_groups = [{"capturable": self.capturable, "lr": self.lr, "params": params}]
+        self._lr_on_device = None
+
+    def sync_lr(self):
+        """Take the learning rate a scheduler wrote into param_groups[0]['lr'] (or self.lr).  Eager: used by the next step() directly.
+        Capturable: written to the device state, so it also reaches the REPLAYS of a captured step -- call it (or step()) from the host
+        after the scheduler ran; a replay itself runs no Python."""
+        lr = float(self.param_groups[0]["lr"])
+        self.lr = lr
+        if self.capturable and lr != self._lr_on_device and not torch.cuda.is_current_stream_capturing():
+            self.state[3:4].fill_(lr)
+            self._lr_on_device = lr
+        return lr
 
     def step(self):
+        self.sync_lr()
         self.steps += 1
         g = self.reducer.flat[self.lo:self.hi]
         dev = self.params.device.index

@@ -285,6 +285,7 @@ class FFWMTrainer(object):
         (all lanes on one cache line, all scatter-adds on four cells) that real training never sees.
         This fits both nets to the identity grid for a few Adam steps (own throw-away optimizer;
         the step's optimizers and their state are untouched) so the timed step runs on realistic flows."""
+        self._no_eager_while_captured("pretrain_flow_identity")
         def grid(s):
             lin = (torch.arange(s, dtype=torch.float32, device=self.device) + 0.5) / s * 2 - 1
             yy, xx = torch.meshgrid(lin, lin, indexing="ij")
@@ -731,7 +732,8 @@ class FFWMTrainer(object):
         torch.cuda.synchronize(self.device)
         # the fused BatchNorm + LeakyReLU modules count their batches on the host (norm.py): a replay runs no Python, so the
         # calls of ONE captured step are recorded here and added per replay (num_batches_tracked stays what nn.BatchNorm2d's is)
-        from .norm import BatchNormLeakyReLU2d, HostCountBatchNorm2d
+        from .norm import BatchNormLeakyReLU2d, HostCountBatchNorm2d, reset_scratch
+        reset_scratch()                      # the capture makes (and fills, on every replay) its own BatchNorm scratch buffers
         fused = [m for net in (self.flowNetF, self.flowNetB, self.netG, self.netD) for m in net.modules()
                  if isinstance(m, (BatchNormLeakyReLU2d, HostCountBatchNorm2d))]
         before = [m._pending_batches for m in fused]
@@ -814,6 +816,9 @@ class FFWMTrainer(object):
         for k, v in self._static.items():
             if b[k] is not v:
                 v.copy_(b[k], non_blocking=True)
+        for opt in (self.opt_F, self.opt_G, self.opt_D):          # a learning-rate schedule reaches the replay through the device state
+            if hasattr(opt, "sync_lr"):
+                opt.sync_lr()
         gs = self._graphs
         if len(gs) == 1:
             gs[0].replay()
@@ -882,10 +887,20 @@ class FFWMTrainer(object):
                 del sd._metadata
             getattr(self, name).load_state_dict(sd)
 
+    def _no_eager_while_captured(self, what):
+        """Vendor convolutions issued eagerly between replays of a captured step made the replays read freed memory (measured in
+        round 3; not root-caused: MIOpen's workspaces of the eager calls and the graph's private pool meet
+        somewhere).  Until that is understood the eager entry points refuse to run beside live graphs instead of silently corrupting
+        the training run: release_graphs() first (and capture() again afterwards)."""
+        if self._graphs is not None:
+            raise RuntimeError("%s: the step is captured in hipGraphs; eager network passes beside the live graphs are not safe "
+                               "-- call release_graphs() first, capture() again afterwards" % what)
+
     @torch.no_grad()
     def test_forward(self, b):
         """FFWMModel.test_forward (models/ffwm_model.py:183-189): flowNetF -> warped profile, netG -> frontal view and
         attention map, guided-filtered output.  Returns (fake_F128, img_GF128, img_S_warp, att)."""
+        self._no_eager_while_captured("test_forward")
         flow_F128, flow_F64, flow_F32 = self.flowNetF(b["img_S"])
         img_S_warp = self.warp(b["img_S"], flow_F128)
         _, _, fake_F128, att = self.netG(b["img_S"], flow=[flow_F32, flow_F64, flow_F128], return_att=True)
@@ -896,6 +911,7 @@ class FFWMTrainer(object):
     @torch.no_grad()
     def identity_feature(self, fake_F128):
         """FFWMModel.test (ffwm_model.py:191-202, crop=False): the LightCNN feature used for rank-1 matching."""
+        self._no_eager_while_captured("identity_feature")
         _, fea, _ = self.lightCNN(torch.mean(fake_F128, dim=(1,), keepdim=True))
         return fea
 
@@ -990,7 +1006,8 @@ class FlowNetTrainer(object):
                 self.optimizer.step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        from .norm import BatchNormLeakyReLU2d, HostCountBatchNorm2d
+        from .norm import BatchNormLeakyReLU2d, HostCountBatchNorm2d, reset_scratch
+        reset_scratch()
         fused = [m for m in self.flowNet.modules() if isinstance(m, (BatchNormLeakyReLU2d, HostCountBatchNorm2d))]
         before = [m._pending_batches for m in fused]
         if self.world_size == 1:
@@ -1027,6 +1044,8 @@ class FlowNetTrainer(object):
             for k, v in self._static.items():
                 if b[k] is not v:
                     v.copy_(b[k], non_blocking=True)
+            if hasattr(self.optimizer, "sync_lr"):
+                self.optimizer.sync_lr()
             self.reducer.begin_replay()
             self._graphs[0].replay()
             if len(self._graphs) > 1:

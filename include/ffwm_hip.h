@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FFWM_ABI_VERSION 2
+#define FFWM_ABI_VERSION 3
 
 typedef enum {
     FFWM_OK = 0,
@@ -405,7 +405,9 @@ int ffwm_adam_step(void* params, const void* grads, void* exp_avg, void* exp_avg
                    double beta1, double beta2, double eps, int64_t step, int dtype, void* stream);
 
 /* The same step with the step counter in DEVICE memory (a step inside a captured hipGraph: a replay runs no host code).  state:
- * three doubles, state[0] = steps taken so far (start it at 0), the other two are scratch.  Two launches. */
+ * FOUR doubles (ABI 3; three before): state[0] = steps taken so far (start it at 0), state[1] and state[2] are scratch,
+ * state[3] = learning-rate override -- when > 0 it replaces `lr`, so that a learning-rate schedule reaches a captured step
+ * (`lr` is baked into the graph as a kernel argument; the host writes state[3] between replays).  Two launches. */
 int ffwm_adam_step_device(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr, double beta1,
                           double beta2, double eps, void* state, int dtype, void* stream);
 

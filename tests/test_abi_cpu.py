@@ -38,7 +38,7 @@ def test_binding_table_matches_header():
 
 def test_abi_version(hiplib):
     from ffwm_amd import _lib
-    assert hiplib.ffwm_abi_version() == _lib.ABI_VERSION == 2          # round 3: + ffwm_conv2d_wgrad_tiled, ffwm_l1_multi
+    assert hiplib.ffwm_abi_version() == _lib.ABI_VERSION == 3          # round 4: ffwm_adam_step_device takes a FOUR-double state (learning-rate override)
 
 
 def test_argument_errors_are_reported_before_launch(hiplib):

@@ -150,3 +150,18 @@ def test_flownet_pretraining_losses_match_reference(gold):
     pmask = (fill.image(2, 1, 32, 32, "pc_mask") > 0.4).float()
     assert abs(float(pc.calculate_loss(pflow, "relu1_1", pmask, True)) - float(gold["correctness"]["masked"])) <= 1e-5
     assert abs(float(pc.calculate_loss(pflow, "relu1_1", None, True)) - float(gold["correctness"]["unmasked"])) <= 1e-5
+
+
+def test_affine_residual_kernels_match_the_reference_fixture():
+    """losses.affine_residual_kernels (the projector onto the complement of the affine maps of a kz x kz window, built with
+    torch.linalg in float64) against the K^T K kernels the imported reference class built (fixture affine_reg/kz*/kernel)."""
+    from ffwm_amd.losses import AffineRegularizationLoss, affine_residual_kernels
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules.pt"))["affine_reg"]
+    for kz in (3, 5, 7):
+        ref = gold["kz%d" % kz]["kernel"]
+        mine = affine_residual_kernels(kz)
+        assert mine.shape == ref.shape and mine.dtype == ref.dtype == torch.float64
+        assert (mine - ref).abs().max().item() <= 1e-14
+        flat = mine.reshape(kz * kz, kz * kz)
+        assert (flat - flat.T).abs().max().item() <= 1e-14 and (flat @ flat - flat).abs().max().item() <= 1e-13     # a symmetric projector
+        assert torch.equal(AffineRegularizationLoss(kz).kernel, mine)
