@@ -152,6 +152,7 @@ struct WarpProblem {
     const void* gout;    // backward: grad_output
     int C, Hi, Wi, H, W;
     int tiles_x, tiles_y, cslabs, cs;
+    int lds;             // 1: LDS-staged 64 x 16 tiles (warp_fwd_lds_body / warp_bwd_flow_lds_body), 0: direct gathers on 64 x 4 tiles
     unsigned begin;      // first workgroup of this problem (a multiple of 8: workgroup b runs on XCD b % 8)
     unsigned nblk;       // its real workgroups; the ids up to the next multiple of 8 exit at once
 };
@@ -174,21 +175,6 @@ __device__ __forceinline__ TileCoord decode_tile_local(unsigned t, int tiles_x, 
     return tc;
 }
 
-template <typename T, bool FLIP>
-__global__ void __launch_bounds__(kBlock)
-warp_fwd_multi_kernel(const WarpTable tab) {
-    int i = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxWarpProblems; ++k)
-        if (k < tab.n && blockIdx.x >= tab.p[k].begin) i = k;
-    const WarpProblem& q = tab.p[i];
-    // every XCD gets a contiguous range of the problem's tiles (neighbouring tiles share source rows: one L2 fetches them)
-    const unsigned t = xcd_remap(blockIdx.x - q.begin, (q.nblk + 7u) & ~7u, 1);
-    if (t >= q.nblk) return;
-    warp_fwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<T*>(q.out), q.C, q.Hi, q.Wi,
-                           q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs, tab.nt);
-}
-
 // ------------------------------------------------------------------------------ forward, LDS-staged
 // The direct kernel above issues 4 dword gathers + 1-2 dword stores per pixel and channel: with 4 bytes per
 // lane every memory instruction costs a full address-processing slot, so it is instruction-rate-bound
@@ -201,22 +187,20 @@ warp_fwd_multi_kernel(const WarpTable tab) {
 // (flow zooming out by more than ~2x, or random) falls back to direct gathers -- a block-uniform choice.
 constexpr int kWlTileX = 64, kWlTileY = 16, kWlPix = 4, kWlRows = 32, kWlCols = 128;
 
+struct WlShared {
+    float tile[2][kWlRows * kWlCols];       // two staged boxes (the copy of channel c+1 overlaps the arithmetic of channel c)
+    int red[4][kBlock / kWave];
+};
+
 template <bool FLIP>
-__global__ void __launch_bounds__(kBlock)
-warp_fwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ flow, float* __restrict__ out, int C,
-                    int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int nt) {
+__device__ __forceinline__ void warp_fwd_lds_body(const float* __restrict__ feat, const float* __restrict__ flow, float* __restrict__ out,
+                                                  int C, int Hi, int Wi, int H, int W, int tx, int ty, int slab, int b, int cs, int nt,
+                                                  WlShared& sh) {
     using T = float;
     constexpr int NW = kBlock / kWave;
     constexpr unsigned E = sizeof(T);
-    __shared__ __attribute__((aligned(16))) T tile[2][kWlRows * kWlCols];
-    __shared__ int red[4][NW];
-    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y;
-    t /= tiles_y;
-    const int slab = t % cslabs;
-    const int b = t / cslabs;
+    T (&tile)[2][kWlRows * kWlCols] = sh.tile;
+    int (&red)[4][NW] = sh.red;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int y = ty * kWlTileY + (threadIdx.x >> 4);
     const int xb = tx * kWlTileX + (threadIdx.x & 15) * kWlPix;
@@ -395,6 +379,238 @@ warp_fwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ fl
     }
 }
 
+template <bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_fwd_lds_kernel(const float* __restrict__ feat, const float* __restrict__ flow, float* __restrict__ out, int C,
+                    int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int nt) {
+    __shared__ __attribute__((aligned(16))) WlShared sh;
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    t /= tiles_y;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    warp_fwd_lds_body<FLIP>(feat, flow, out, C, Hi, Wi, H, W, tx, ty, slab, b, cs, nt, sh);
+}
+
+// ------------------------------------------------------------------------------ d(flow), LDS-staged
+// The same tile decomposition for the gradient of the flow field: a block owns 64 x 16 output pixels (4 consecutive pixels per
+// lane) and a slab of channels; per channel it stages the zero-padded source box through LDS with 16-byte loads (the next
+// channel's copy in flight during the arithmetic), reads grad_output as one dwordx4 (direct half) + one mirrored dwordx4 (flipped
+// half of the fused flip + cat) per lane, takes the four corners from LDS and accumulates d(ix), d(iy) in registers over the
+// slab: 2 atomics per pixel and slab at the end.  Per pixel and channel: 0.5 + 1 vector memory instructions instead of the
+// direct kernel's 2 + 4 dword ones.  Same arithmetic, same order over the channels of a slab as warp_bwd_body.
+template <bool FLIP>
+__device__ __forceinline__ void warp_bwd_flow_lds_body(const float* __restrict__ feat, const float* __restrict__ flow,
+                                                       const float* __restrict__ gout, float* __restrict__ gflow, int C, int Hi, int Wi,
+                                                       int H, int W, int tx, int ty, int slab, int b, int cs, WlShared& sh) {
+    using T = float;
+    constexpr int NW = kBlock / kWave;
+    constexpr unsigned E = sizeof(T);
+    T (&tile)[2][kWlRows * kWlCols] = sh.tile;
+    int (&red)[4][NW] = sh.red;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int y = ty * kWlTileY + (threadIdx.x >> 4);
+    const int xb = tx * kWlTileX + (threadIdx.x & 15) * kWlPix;
+    const bool yin = y < H;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * plane, static_cast<unsigned>(2 * plane * E));
+
+    int x0[kWlPix], y0[kWlPix];
+    T dxw[kWlPix][2], dyw[kWlPix][2];
+    bool live[kWlPix], pin[kWlPix];
+    int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < kWlPix; ++k) {
+        const int x = xb + k;
+        pin[k] = yin && x < W;
+        const unsigned fo = pin[k] ? (static_cast<unsigned>(y) * W + x) * E : kOob;
+        const T gx = buf_ld<T>(rfl, fo), gy = buf_ld<T>(rfl, pin[k] ? fo + static_cast<unsigned>(plane * E) : kOob);
+        Corners<T> cn;
+        make_corners<T>(cn, gx, gy, Hi, Wi);
+        const bool any = pin[k] && (cn.valid[0] || cn.valid[1] || cn.valid[2] || cn.valid[3]);
+        live[k] = any;
+        const T ix = ((gx + 1) * static_cast<T>(Wi) - 1) / 2, iy = ((gy + 1) * static_cast<T>(Hi) - 1) / 2;
+        x0[k] = any ? static_cast<int>(floor_t(ix)) : 0;
+        y0[k] = any ? static_cast<int>(floor_t(iy)) : 0;
+        // a pixel without a valid corner contributes nothing (every sample it would read is padding)
+        dxw[k][0] = any ? cn.dxw[0] : static_cast<T>(0);
+        dxw[k][1] = any ? cn.dxw[1] : static_cast<T>(0);
+        dyw[k][0] = any ? cn.dyw[0] : static_cast<T>(0);
+        dyw[k][1] = any ? cn.dyw[1] : static_cast<T>(0);
+        if (any) {
+            umin = min(umin, x0[k]); umax = max(umax, x0[k] + 1);
+            vmin = min(vmin, y0[k]); vmax = max(vmax, y0[k] + 1);
+        }
+    }
+    umin = wave_min(umin); umax = wave_max(umax); vmin = wave_min(vmin); vmax = wave_max(vmax);
+    if (lane == 0) { red[0][wave] = umin; red[1][wave] = umax; red[2][wave] = vmin; red[3][wave] = vmax; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        umin = min(umin, red[0][k]); umax = max(umax, red[1][k]);
+        vmin = min(vmin, red[2][k]); vmax = max(vmax, red[3][k]);
+    }
+    const bool empty = umin > umax;
+    const int bx0 = empty ? 0 : (umin & ~3), by0 = empty ? 0 : vmin;
+    const int bw = empty ? 0 : umax - bx0 + 1, bh = empty ? 0 : vmax - by0 + 1;
+    const bool use_lds = bw <= kWlCols && bh <= kWlRows;
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const int Co = FLIP ? 2 * C : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned ibytes = static_cast<unsigned>(iplane * E);
+    const unsigned obytes = static_cast<unsigned>(plane * E);
+    const T* fp = feat + (static_cast<size_t>(b) * C + c0) * iplane;
+    const T* op = gout + (static_cast<size_t>(b) * Co + c0) * plane;
+    const size_t flip_planes = static_cast<size_t>(C) * plane;
+    const bool full = yin && xb + kWlPix <= W;
+    const unsigned o_direct = full ? (static_cast<unsigned>(y) * W + xb) * E : kOob;
+    const unsigned o_flip = full ? (static_cast<unsigned>(y) * W + (W - kWlPix - xb)) * E : kOob;
+
+    // grad_output of the lane's 4 pixels: direct half + mirrored flipped half
+    auto load_g = [&](const T* plane_g, T (&g)[kWlPix]) {
+        if (full || !yin) {        // (rows outside the image: kOob offsets read 0)
+            const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(plane_g, obytes), o_direct, 0, 0);
+            g[0] = __uint_as_float(d.x); g[1] = __uint_as_float(d.y); g[2] = __uint_as_float(d.z); g[3] = __uint_as_float(d.w);
+            if (FLIP) {
+                const u32x4 m = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(plane_g + flip_planes, obytes), o_flip, 0, 0);
+                g[0] += __uint_as_float(m.w); g[1] += __uint_as_float(m.z); g[2] += __uint_as_float(m.y); g[3] += __uint_as_float(m.x);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kWlPix; ++k) {
+                const unsigned od = pin[k] ? (static_cast<unsigned>(y) * W + xb + k) * E : kOob;
+                g[k] = buf_ld<T>(make_rsrc(plane_g, obytes), od);
+                if (FLIP) g[k] += buf_ld<T>(make_rsrc(plane_g + flip_planes, obytes),
+                                            pin[k] ? (static_cast<unsigned>(y) * W + (W - 1 - xb - k)) * E : kOob);
+            }
+        }
+    };
+    T gix[kWlPix], giy[kWlPix];
+#pragma unroll
+    for (int k = 0; k < kWlPix; ++k) gix[k] = giy[k] = 0;
+    auto one = [&](int k, const T g, const T s0, const T s1, const T s2, const T s3) {
+        // ATen grid_sampler_2d_backward, the operation order of warp_bwd_body
+        gix[k] -= s0 * dyw[k][0] * g;
+        giy[k] -= s0 * dxw[k][0] * g;
+        gix[k] += s1 * dyw[k][0] * g;
+        giy[k] -= s1 * dxw[k][1] * g;
+        gix[k] -= s2 * dyw[k][1] * g;
+        giy[k] += s2 * dxw[k][0] * g;
+        gix[k] += s3 * dyw[k][1] * g;
+        giy[k] += s3 * dxw[k][1] * g;
+    };
+
+    if (use_lds) {
+        constexpr int NCH = kWlRows * kWlCols / 4 / kBlock;
+        unsigned goff[NCH];
+        unsigned keep[NCH];
+        const int col4 = (threadIdx.x & 31) * 4;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int r = (threadIdx.x >> 5) + 8 * i;
+            const int gy = by0 + r, gx = bx0 + col4;
+            const bool rowok = r < bh && col4 < bw && gy >= 0 && gy < Hi && gx >= 0;
+            unsigned m = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m |= (rowok && gx + e < Wi) ? (1u << e) : 0u;
+            keep[i] = m;
+            goff[i] = m ? (static_cast<unsigned>(gy) * Wi + gx) * E : kOob;
+        }
+        u32x4 stage[NCH];
+        auto fetch = [&](const T* pl) {
+            const rsrc_t rs = make_rsrc(pl, ibytes);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], 0, 0);
+        };
+        auto commit = [&](T* buf) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                u32x4 v = stage[i];
+                v.x = (keep[i] & 1u) ? v.x : 0u;
+                v.y = (keep[i] & 2u) ? v.y : 0u;
+                v.z = (keep[i] & 4u) ? v.z : 0u;
+                v.w = (keep[i] & 8u) ? v.w : 0u;
+                *reinterpret_cast<u32x4*>(buf + ((threadIdx.x >> 5) + 8 * i) * kWlCols + col4) = v;
+            }
+        };
+        int lbase[kWlPix];
+#pragma unroll
+        for (int k = 0; k < kWlPix; ++k) lbase[k] = live[k] ? (y0[k] - by0) * kWlCols + (x0[k] - bx0) : 0;
+        fetch(fp);
+        T gn[kWlPix];
+        load_g(op, gn);                        // grad_output of a channel is requested one channel ahead, like the source box
+        commit(tile[0]);
+        __syncthreads();
+        int p = 0;
+        for (int c = c0; c < c1; ++c, op += plane, p ^= 1) {
+            const bool more = c + 1 < c1;
+            T g[kWlPix];
+#pragma unroll
+            for (int k = 0; k < kWlPix; ++k) g[k] = gn[k];
+            if (more) {
+                fetch(fp + static_cast<size_t>(c + 1 - c0) * iplane);
+                load_g(op + plane, gn);
+            }
+#pragma unroll
+            for (int k = 0; k < kWlPix; ++k) {
+                const T* nb = tile[p] + lbase[k];
+                one(k, g[k], nb[0], nb[1], nb[kWlCols], nb[kWlCols + 1]);
+            }
+            if (more) commit(tile[p ^ 1]);
+            __syncthreads();
+        }
+    } else {
+        // fallback (box too large for LDS): direct gathers with hardware zero padding
+        unsigned off[kWlPix][4];
+#pragma unroll
+        for (int k = 0; k < kWlPix; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cx = x0[k] + (q & 1), cy = y0[k] + (q >> 1);
+                const bool ok = live[k] && cx >= 0 && cx < Wi && cy >= 0 && cy < Hi;
+                off[k][q] = ok ? (static_cast<unsigned>(cy) * Wi + cx) * E : kOob;
+            }
+        }
+        for (int c = c0; c < c1; ++c, fp += iplane, op += plane) {
+            const rsrc_t rf = make_rsrc(fp, ibytes);
+            T g[kWlPix];
+            load_g(op, g);
+#pragma unroll
+            for (int k = 0; k < kWlPix; ++k)
+                one(k, g[k], buf_ld<T>(rf, off[k][0]), buf_ld<T>(rf, off[k][1]), buf_ld<T>(rf, off[k][2]), buf_ld<T>(rf, off[k][3]));
+        }
+    }
+    T* gf = gflow + static_cast<size_t>(b) * 2 * plane;
+#pragma unroll
+    for (int k = 0; k < kWlPix; ++k) {
+        if (pin[k]) {
+            const size_t fo = static_cast<size_t>(y) * W + xb + k;
+            atomic_add(gf + fo, (static_cast<T>(Wi) / 2) * gix[k]);
+            atomic_add(gf + fo + plane, (static_cast<T>(Hi) / 2) * giy[k]);
+        }
+    }
+}
+
+template <bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_bwd_flow_lds_kernel(const float* __restrict__ feat, const float* __restrict__ flow, const float* __restrict__ gout,
+                         float* __restrict__ gflow, int C, int Hi, int Wi, int H, int W, int tiles_x, int tiles_y, int cslabs, int cs,
+                         int remap) {
+    __shared__ __attribute__((aligned(16))) WlShared sh;
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    t /= tiles_y;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    warp_bwd_flow_lds_body<FLIP>(feat, flow, gout, gflow, C, Hi, Wi, H, W, tx, ty, slab, b, cs, sh);
+}
+
 template <typename T, bool FLIP>
 __device__ __forceinline__ void warp_bwd_body(const T* __restrict__ feat, const T* __restrict__ flow, const T* __restrict__ gout,
                                               T* __restrict__ gfeat, T* __restrict__ gflow, int C, int Hi, int Wi, int H, int W,
@@ -480,7 +696,38 @@ warp_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ flow, const T*
     warp_bwd_body<T, FLIP>(feat, flow, gout, gfeat, gflow, C, Hi, Wi, H, W, decode_tile(tiles_x, tiles_y, cslabs, remap), cs);
 }
 
-// d(flow) of several warps in one launch (the pixel-major kernel with grad_feat == NULL)
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(kBlock)
+warp_fwd_multi_kernel(const WarpTable tab) {
+    __shared__ __attribute__((aligned(16))) WlShared sh;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxWarpProblems; ++k)
+        if (k < tab.n && blockIdx.x >= tab.p[k].begin) i = k;
+    const WarpProblem& q = tab.p[i];
+    // every XCD gets a contiguous range of the problem's tiles (neighbouring tiles share source rows: one L2 fetches them)
+    const unsigned t = xcd_remap(blockIdx.x - q.begin, (q.nblk + 7u) & ~7u, 1);
+    if (t >= q.nblk) return;
+    if constexpr (sizeof(T) == 4) {
+        if (q.lds) {           // (block-uniform: a problem is served by one kind of tile)
+            unsigned u = t;
+            const int tx = u % q.tiles_x;
+            u /= q.tiles_x;
+            const int ty = u % q.tiles_y;
+            u /= q.tiles_y;
+            warp_fwd_lds_body<FLIP>(static_cast<const float*>(q.feat), static_cast<const float*>(q.flow), static_cast<float*>(q.out), q.C,
+                                    q.Hi, q.Wi, q.H, q.W, tx, ty, static_cast<int>(u % q.cslabs), static_cast<int>(u / q.cslabs), q.cs, tab.nt, sh);
+            return;
+        }
+    }
+    warp_fwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<T*>(q.out), q.C, q.Hi, q.Wi,
+                           q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs, tab.nt);
+}
+
+// d(flow) of several warps in one launch (the pixel-major kernel with grad_feat == NULL).  The LDS-staged body is NOT used here:
+// measured on the step's three levels (profiles/r04_warp_multi_lds_sweep.txt) it loses -- 66 vs 25 us on [8,64,128,128]: with so few
+// tiles a block keeps 4-8 channels, and the 2 atomics per pixel and slab of 16 slabs meet on the same addresses -- and its 33 KB of
+// static LDS alone cost the direct body a third of its waves (45 vs 37 us).  It wins from ~2^24 pixel-channels up (single launches).
 template <typename T, bool FLIP>
 __global__ void __launch_bounds__(kBlock)
 warp_bwd_flow_multi_kernel(const WarpTable tab) {
@@ -868,6 +1115,29 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
             gfeat = nullptr;
         }
     }
+    if constexpr (sizeof(T) == 4) {
+        // d(flow) alone on LDS-staged tiles (warp_bwd_flow_lds_body) for the same tensors the forward takes there; warp_multi_lds = 1: never
+        const int variant = options().warp_fwd_variant;
+        if (!gfeat && gflow && options().warp_multi_lds != 1 &&
+            (variant == 2 || (variant == 0 && H >= 64 && W >= 64 && B * C * H * W >= (1LL << 24)))) {
+            const int txs = static_cast<int>((W + kWlTileX - 1) / kWlTileX), tys = static_cast<int>((H + kWlTileY - 1) / kWlTileY);
+            // measured at [32,64,256,256] (tools/warp_bwd_flow_variants.py): slab 8 / 16 / 32 / 64 -> 492 / 375 / 330 / 310 us (direct: 423)
+            int cs = options().channel_slab > 0 ? options().channel_slab : 64;
+            if (cs > C) cs = static_cast<int>(C);
+            while (cs > 8 && B * txs * tys * ((C + cs - 1) / cs) < 2048) cs = (cs + 1) / 2;
+            const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            const unsigned grid = static_cast<unsigned>(B * txs * tys * cslabs);
+            LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_flow" : "warp_bwd_flow", H), st,
+                           sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
+            if (flip)
+                hipLaunchKernelGGL((warp_bwd_flow_lds_kernel<true>), dim3(grid), dim3(kBlock), 0, st, (const float*)feat, (const float*)flow,
+                                   (const float*)gout, (float*)gflow, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, txs, tys, cslabs, cs, remap);
+            else
+                hipLaunchKernelGGL((warp_bwd_flow_lds_kernel<false>), dim3(grid), dim3(kBlock), 0, st, (const float*)feat, (const float*)flow,
+                                   (const float*)gout, (float*)gflow, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, txs, tys, cslabs, cs, remap);
+            return check_launch("ffwm_warp_backward(flow, lds)");
+        }
+    }
     const Geometry g = plan(B, C, H, W, 32);
     LaunchScope ls(scope_at(gfeat ? (flip ? "warp_flipcat_bwd" : "warp_bwd") : (flip ? "warp_flipcat_bwd_flow" : "warp_bwd_flow"), H), st,
                    gfeat ? bytes : sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
@@ -888,12 +1158,32 @@ inline bool fwd_wants_lds(int64_t B, int64_t C, int64_t H, int64_t W, size_t esz
     return esz == 4 && (variant == 2 || (variant == 0 && H >= 64 && W >= 64 && B * C * H * W >= (1LL << 24)));
 }
 
-inline void fill_problem(WarpProblem& q, const ffwm_warp_problem& pr, int cs_default, unsigned begin) {
-    const Geometry g = plan(pr.B, pr.C, pr.H, pr.W, cs_default);
+// A problem of a multi FORWARD launch on LDS-staged tiles?  warp_multi_lds: 0 = auto (float, planes of >= 32 x 32 output pixels with
+// >= 32 channels: netG's three levels -- 31 vs 42 us warm, 49 vs 69 us cold for the launch, profiles/r04_warp_multi_lds_sweep.txt;
+// the 3-channel image warps stay on direct gathers), 1 = never, 2 = always (float).
+inline bool multi_wants_lds(const ffwm_warp_problem& pr, size_t esz) {
+    const int v = options().warp_multi_lds;
+    if (esz != 4 || v == 1) return false;
+    return v == 2 || (pr.H >= 32 && pr.W >= 32 && pr.C >= 32);
+}
+
+inline void fill_problem(WarpProblem& q, const ffwm_warp_problem& pr, int cs_default, unsigned begin, bool lds) {
     q.C = static_cast<int>(pr.C); q.Hi = static_cast<int>(pr.Hi); q.Wi = static_cast<int>(pr.Wi);
     q.H = static_cast<int>(pr.H); q.W = static_cast<int>(pr.W);
-    q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.cslabs = g.cslabs; q.cs = g.cs;
     q.begin = begin;
+    q.lds = lds ? 1 : 0;
+    if (lds) {
+        const int txs = static_cast<int>((pr.W + kWlTileX - 1) / kWlTileX), tys = static_cast<int>((pr.H + kWlTileY - 1) / kWlTileY);
+        int cs = options().channel_slab > 0 ? options().channel_slab : 16;
+        if (cs > pr.C) cs = static_cast<int>(pr.C);
+        while (cs > 4 && pr.B * txs * tys * ((pr.C + cs - 1) / cs) < 1024) cs = (cs + 1) / 2;     // >= 4 tiles per CU for the problem
+        q.tiles_x = txs; q.tiles_y = tys; q.cs = cs;
+        q.cslabs = static_cast<int>((pr.C + cs - 1) / cs);
+        q.nblk = static_cast<unsigned>(pr.B * txs * tys * q.cslabs);
+        return;
+    }
+    const Geometry g = plan(pr.B, pr.C, pr.H, pr.W, cs_default);
+    q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.cslabs = g.cslabs; q.cs = g.cs;
     q.nblk = g.grid;
 }
 
@@ -935,8 +1225,8 @@ int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
         }
         WarpProblem& q = tab.p[tab.n];
         q.feat = pr.feat; q.flow = pr.flow; q.out = pr.output; q.gout = nullptr;
-        fill_problem(q, pr, 16, blocks);
-        blocks += (plan(pr.B, pr.C, pr.H, pr.W, 16).grid + 7u) & ~7u;
+        fill_problem(q, pr, 16, blocks, multi_wants_lds(pr, sizeof(T)));
+        blocks += (q.nblk + 7u) & ~7u;
         bytes += sizeof(T) * static_cast<double>(pr.B) * (static_cast<double>(pr.C) * pr.Hi * pr.Wi + 2.0 * pr.H * pr.W + (flip ? 2.0 : 1.0) * pr.C * pr.H * pr.W);
         if (++tab.n == kMaxWarpProblems)
             if (int rc = flush()) return rc;
@@ -976,8 +1266,8 @@ int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
         if (!pr.grad_flow) continue;
         WarpProblem& q = tab.p[tab.n];
         q.feat = pr.feat; q.flow = pr.flow; q.out = pr.grad_flow; q.gout = pr.grad_output;
-        fill_problem(q, pr, 32, blocks);
-        blocks += (plan(pr.B, pr.C, pr.H, pr.W, 32).grid + 7u) & ~7u;
+        fill_problem(q, pr, 32, blocks, false);
+        blocks += (q.nblk + 7u) & ~7u;
         bytes += sizeof(T) * static_cast<double>(pr.B) * (static_cast<double>(pr.C) * pr.Hi * pr.Wi + 4.0 * pr.H * pr.W + (flip ? 2.0 : 1.0) * pr.C * pr.H * pr.W);
         if (++tab.n == kMaxWarpProblems)
             if (int rc = flush()) return rc;

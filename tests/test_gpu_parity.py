@@ -872,7 +872,6 @@ def test_captured_trainer_refuses_eager_passes_and_can_be_recaptured(monkeypatch
         with pytest.raises(RuntimeError, match="release_graphs"):
             call()
     tg.release_graphs()
-    assert not norm._SCRATCH or all(not k for k in ())          # (the cache may hold the first capture's buffers until the next capture)
     for net in (tg.netG, tg.flowNetF):
         net.eval()
     out = tg.test_forward(batch)                                  # eager vendor convolutions: fine without live graphs
@@ -1364,7 +1363,7 @@ def test_flat_adam_follows_a_learning_rate_schedule_eagerly_and_under_replay():
             opt.param_groups[0]["lr"] = opt_ref.param_groups[0]["lr"]      # what a scheduler bound to FlatAdam would write
             for p, q in zip(net.parameters(), ref.parameters()):
                 _close(p.detach(), q.detach().cpu(), 2e-6, relative=True)
-        assert opt_ref.param_groups[0]["lr"] < 4e-6                         # the schedule did decay (twice)
+        assert opt_ref.param_groups[0]["lr"] < 5e-6                         # the schedule did decay (twice: 4e-4 -> 4e-6)
 
 
 # ------------------------------------------------------------------------- fused BatchNorm2d + LeakyReLU
