@@ -14,7 +14,7 @@ driver parses -- with the contract's keys (emit_lines):
   roofline          : the SURVEY 8 a1-a6 kernel (warp / resample2d / block_extractor / local_attn_reshape family) that
                       moves the most algorithmic bytes inside the timed region: algorithmic bytes per launch / average
                       launch duration (HIP events on its launch stream, ffwm_prof_*) vs the 8 TB/s HBM peak;
-                      traffic = PMC-measured HBM bytes per launch (profiles/r03_pmc_traffic.json, rocprofv3 FETCH_SIZE /
+                      traffic = PMC-measured HBM bytes per launch (profiles/r04_pmc_traffic.json, rocprofv3 FETCH_SIZE /
                       WRITE_SIZE passes of this same command) or null when no valid measurement is committed
   roofline_mfma     : the hand-written MFMA kernel with the largest share of the step (the Winograd convolution, forward + data
                       gradient scopes together); roofline_mfma_2nd: the next one (the 3x3 weight gradient)
@@ -46,9 +46,8 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP32_PEAK = 157.3e12       # FLOP/s, fp32 vector/MFMA
 REF_TRAIN_FLOP_PER_IMG = 444e9   # the REFERENCE's step, ~222 GMAC per image (quoted for comparison only)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-if not os.path.exists(PMC_FILE):
-    PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_traffic.json" % r) for r in (4, 3, 2)) if os.path.exists(p)),
+                os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"))            # the newest committed counter passes
 # launch scopes of the SURVEY 8 a1-a6 operators (ffwm_prof_* names)
 HOT_PATH_PREFIXES = ("warp", "resample2d", "block_extractor", "local_attn_reshape", "block_attention")
 

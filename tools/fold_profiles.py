@@ -1,4 +1,4 @@
-"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r03_*.
+"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r04_*.
 
     python tools/fold_profiles.py [gpurun_out/refresh]
 
@@ -46,6 +46,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "spectral_norm_fwd_wtu": "sn_phase1_kernel<float>",
     "spectral_norm_fwd_wv": "sn_phase2_kernel<float>",
     "warp_flipcat_fwd_multi": "warp_fwd_multi_kernel<float, true>",
+    "warp_flipcat_bwd_flow@256": "warp_bwd_flow_lds_kernel<true>",
     "warp_fwd_multi": "warp_fwd_multi_kernel<float, false>",
     "warp_flipcat_bwd_flow_multi": "warp_bwd_flow_multi_kernel<float, true>",
     "warp_bwd_flow_multi": "warp_bwd_flow_multi_kernel<float, false>",
@@ -72,7 +73,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "block_attention_bwd_weights": "be_fwd_lds_kernel<float, 3, 4, 2>",
 }
 FETCH_CORRECTION = 2.0
-ROUND = "r03"
+ROUND = "r04"
 
 
 def main():
@@ -151,7 +152,9 @@ def main():
               ("bwd_layers.txt", "_bwd_layers.txt"), ("warp_step_sweep.txt", "_warp_step_sweep.txt"), ("ab_results.txt", "_ab_switches.txt"),
               ("rs_bwd1.txt", "_resample2d_bwd_input1_variants.txt"), ("host_probe.txt", "_host_issue_vs_drain.txt"),
               ("two_stream_check.txt", "_multi_stream_check.txt"), ("bench_eager.json", "_bench_eager.json"),
-              ("gf_trace.txt", "_guided_filter_kernels.txt"), ("ref_vs_hip.json", "_ref_vs_hip.json")]
+              ("gf_trace.txt", "_guided_filter_kernels.txt"), ("ref_vs_hip.json", "_ref_vs_hip.json"),
+              ("warp_multi_lds_sweep.txt", "_warp_multi_lds_sweep_refresh.txt"), ("warp_bwd_flow_variants.txt", "_warp_bwd_flow_variants.txt"),
+              ("be_bwd_ablate.txt", "_be_bwd_ablate_refresh.txt"), ("dp_capture_probe.txt", "_dp_capture_probe.txt")]
     for a, b in copies:
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p) > 0:

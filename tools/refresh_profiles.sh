@@ -6,7 +6,7 @@
 #      that also instruments MIOpen's kernels aborts with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT): FETCH_SIZE, WRITE_SIZE
 #      and two SQ sets in SEPARATE runs (counters + --kernel-trace only)
 #   4. the default `python bench.py` line
-# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/r03_*.
+# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/r04_*.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh
@@ -84,3 +84,9 @@ bash $R/tools/gf_trace.sh > $OUT/gf_trace.txt 2>&1
 rm -f $R/gpurun_out/ab/results.txt
 bash $R/tools/ab_graph.sh "default=X=1" "one_stream=FFWM_STREAMS=0" "five_streams_one_per_branch=FFWM_STREAM_LAYOUT=5" "d_step_on_the_main_stream=FFWM_D_STREAM=0" "fused_residual_off=FFWM_FUSED_RESIDUAL=0" "tiled_wgrad_off=FFWM_TILED_WGRAD=0" "convT_dgrad_off=FFWM_CONVT_DGRAD=0" "conv_dgrad_all_own=FFWM_CONV_DGRAD=1" "bn_fused_from_0=FFWM_BN_MIN_NUMEL=0" "winograd_pairs_100=FFWM_WINOGRAD_MIN_PAIRS=100" > /dev/null 2>&1
 cp $R/gpurun_out/ab/results.txt $OUT/ab_results.txt
+# round 4: the multi-problem warp launches on direct gathers vs LDS-staged tiles, d(flow) variants per level, block_extractor backward
+# with parts switched off, the data-parallel capture modes on the one-GPU box (one-rank RCCL group, forced collectives)
+timeout 600 python $R/tools/warp_multi_lds_sweep.py 2>&1 | grep -v "Warn\|amdgpu" > $OUT/warp_multi_lds_sweep.txt
+timeout 600 python $R/tools/warp_bwd_flow_variants.py 2>&1 | grep "^(" > $OUT/warp_bwd_flow_variants.txt
+timeout 600 python $R/tools/be_bwd_ablate.py 2>&1 | grep "^ablate" > $OUT/be_bwd_ablate.txt
+(for m in "nccl probe" "nccl ingraph" "gloo serial"; do echo "=== $m"; timeout 300 python $R/tools/dp_capture_probe.py $m 4 2>&1 | grep -v "amdgpu.ids\|^\[W\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -6 | cut -c1-300; done) > $OUT/dp_capture_probe.txt 2>&1
