@@ -757,12 +757,9 @@ constexpr int kPlaneLdsBytes = kMaxLdsBytes;
 constexpr int kPlaneUnroll = 4;
 
 template <typename T, bool FLIP, int CG>
-__global__ void __launch_bounds__(kPlaneThreads)
-warp_bwd_feat_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gfeat,
-                           int C, int Hi, int Wi, int H, int W, int groups, int nsplit) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* acc = reinterpret_cast<double*>(smem_raw);
-    unsigned t = blockIdx.x;
+__device__ __forceinline__ void warp_bwd_feat_plane_body(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gfeat,
+                                                         int C, int Hi, int Wi, int H, int W, int groups, int nsplit, unsigned t,
+                                                         double* acc) {
     const int split = t % nsplit;
     t /= nsplit;
     const int grp = t % groups;
@@ -824,6 +821,43 @@ warp_bwd_feat_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gou
             if (v != 0) atomic_add(dst + i, v);
         }
     }
+}
+
+template <typename T, bool FLIP, int CG>
+__global__ void __launch_bounds__(kPlaneThreads)
+warp_bwd_feat_plane_kernel(const T* __restrict__ flow, const T* __restrict__ gout, T* __restrict__ gfeat,
+                           int C, int Hi, int Wi, int H, int W, int groups, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    warp_bwd_feat_plane_body<T, FLIP, CG>(flow, gout, gfeat, C, Hi, Wi, H, W, groups, nsplit, blockIdx.x,
+                                          reinterpret_cast<double*>(smem_raw));
+}
+
+// d(feat) of several warps in ONE launch: the step's image warps (three illumination warps, the part crops) each need the plane
+// kernel for a 3-channel tensor -- five to seven launches of ~10 us per step, one per problem.  Problems that share the channels
+// per block (CG) share a launch; the dynamic LDS is the largest plane group's.
+struct PlaneProblem {
+    const void* flow;
+    const void* gout;
+    void* gfeat;
+    int C, Hi, Wi, H, W, groups, nsplit;
+    unsigned begin;
+};
+struct PlaneTable {
+    int n;
+    PlaneProblem p[kMaxWarpProblems];
+};
+
+template <typename T, bool FLIP, int CG>
+__global__ void __launch_bounds__(kPlaneThreads)
+warp_bwd_feat_plane_multi_kernel(const PlaneTable tab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxWarpProblems; ++k)
+        if (k < tab.n && blockIdx.x >= tab.p[k].begin) i = k;
+    const PlaneProblem& q = tab.p[i];
+    warp_bwd_feat_plane_body<T, FLIP, CG>(static_cast<const T*>(q.flow), static_cast<const T*>(q.gout), static_cast<T*>(q.gfeat), q.C, q.Hi,
+                                          q.Wi, q.H, q.W, q.groups, q.nsplit, blockIdx.x - q.begin, reinterpret_cast<double*>(smem_raw));
 }
 
 // d(feat) for planes BEYOND LDS (Hi * Wi > 20480 cells) when the warp keeps the resolution (Hi == H, Wi == W) and the
@@ -1237,10 +1271,68 @@ int launch_fwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
 template <typename T>
 int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_t st) {
     // (the d(flow) table below does not use the store policy)
-    // d(feat): one plane launch per problem (the LDS footprint is per plane size; scope names carry the level)
+    // d(feat): problems whose planes fit LDS and that share the channels-per-block of their plane plan go out together (one launch per
+    // CG value: the step's seven image-warp problems are two launches); everything else one launch per problem (scope names carry the level)
+    std::vector<bool> done(n, false);
+    if (options().scatter_variant != 1 && options().warp_multi_planes != 1) {
+        for (int cg = 1; cg <= 8; cg *= 2) {
+            PlaneTable tab;
+            tab.n = 0;
+            unsigned blocks = 0;
+            size_t lds = 0;
+            double bytes = 0;
+            std::vector<int> members;
+            auto flush = [&]() -> int {
+                if (tab.n < 2) {                 // a lone problem keeps its own launch (and its per-level scope name)
+                    tab.n = 0; blocks = 0; lds = 0; bytes = 0; members.clear();
+                    return FFWM_OK;
+                }
+                {
+                    LaunchScope ls(flip ? "warp_flipcat_bwd_feat_multi" : "warp_bwd_feat_multi", st, bytes);
+#define FFWM_PLANE_MULTI(FL, CGV)                                                                                  \
+    do {                                                                                                           \
+        auto kfn = warp_bwd_feat_plane_multi_kernel<T, FL, CGV>;                                                   \
+        allow_large_lds(reinterpret_cast<const void*>(kfn));                                                       \
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(kPlaneThreads), lds, st, tab);                                  \
+    } while (0)
+                    if (flip) {
+                        switch (cg) { case 8: FFWM_PLANE_MULTI(true, 8); break; case 4: FFWM_PLANE_MULTI(true, 4); break;
+                                      case 2: FFWM_PLANE_MULTI(true, 2); break; default: FFWM_PLANE_MULTI(true, 1); break; }
+                    } else {
+                        switch (cg) { case 8: FFWM_PLANE_MULTI(false, 8); break; case 4: FFWM_PLANE_MULTI(false, 4); break;
+                                      case 2: FFWM_PLANE_MULTI(false, 2); break; default: FFWM_PLANE_MULTI(false, 1); break; }
+                    }
+#undef FFWM_PLANE_MULTI
+                }
+                for (int m : members) done[m] = true;
+                tab.n = 0; blocks = 0; lds = 0; bytes = 0; members.clear();
+                return check_launch("ffwm_warp_multi_backward(feat, planes)");
+            };
+            for (int i = 0; i < n; ++i) {
+                const ffwm_warp_problem& pr = probs[i];
+                if (!pr.grad_feat || done[i]) continue;
+                const PlanePlan pp = plan_planes(pr.B, pr.C, pr.Hi * pr.Wi, pr.H * pr.W, sizeof(T) == 8 ? 2 : 8);
+                // (only the few-channel image warps: netG's 64 / 128-channel levels gain nothing from sharing a launch -- measured 63 us
+                //  for the 128 + 64 px levels together against 51 + 13 us apart)
+                if (!pp.ok || pp.cg != cg || pr.C > 8) continue;
+                PlaneProblem& q = tab.p[tab.n];
+                q.flow = pr.flow; q.gout = pr.grad_output; q.gfeat = pr.grad_feat;
+                q.C = static_cast<int>(pr.C); q.Hi = static_cast<int>(pr.Hi); q.Wi = static_cast<int>(pr.Wi);
+                q.H = static_cast<int>(pr.H); q.W = static_cast<int>(pr.W);
+                q.groups = pp.groups; q.nsplit = pp.nsplit; q.begin = blocks;
+                blocks += static_cast<unsigned>(pr.B * pp.groups * pp.nsplit);
+                if (pp.lds > lds) lds = pp.lds;
+                bytes += sizeof(T) * static_cast<double>(pr.B) * (2.0 * pr.C * pr.Hi * pr.Wi + 2.0 * pr.H * pr.W + (flip ? 2.0 : 1.0) * pr.C * pr.H * pr.W);
+                members.push_back(i);
+                if (++tab.n == kMaxWarpProblems)
+                    if (int rc = flush()) return rc;
+            }
+            if (int rc = flush()) return rc;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const ffwm_warp_problem& pr = probs[i];
-        if (!pr.grad_feat) continue;
+        if (!pr.grad_feat || done[i]) continue;
         if (int rc = launch_bwd<T>((const T*)pr.feat, (const T*)pr.flow, (const T*)pr.grad_output, (T*)pr.grad_feat, nullptr, pr.B, pr.C,
                                    pr.Hi, pr.Wi, pr.H, pr.W, flip, st)) return rc;
     }

@@ -1543,6 +1543,39 @@ def test_warp_many_matches_the_oracle_per_problem(oracle, flipcat):
             assert dl[i].grad is None
 
 
+def test_image_warp_feature_gradients_share_one_plane_launch(oracle):
+    """The train step's image warps (three illumination warps of the generated scales, the part crops of the 128 px output:
+    3-channel tensors) each need the LDS plane kernel for d(feat); problems with the same channels-per-block go out as ONE
+    multi-problem launch (`warp_bwd_feat_multi`) instead of one launch each.  Same gradients as the per-problem launches
+    (bit for bit where a problem's pixels are not split over blocks, else to the float atomics' order) and as the oracle."""
+    from ffwm_amd import _lib, ops
+    lib = _lib.load()
+    g = _gen(77)
+    shapes = [(2, 3, 128, 128, 128, 128), (2, 3, 64, 64, 64, 64), (2, 3, 32, 32, 32, 32), (2, 3, 128, 128, 32, 32), (2, 3, 128, 128, 32, 32)]
+    feats = [torch.rand(B, C, Hi, Wi, generator=g) for B, C, Hi, Wi, H, W in shapes]
+    flows = [torch.rand(B, 2, H, W, generator=g) * 2.2 - 1.1 for B, C, Hi, Wi, H, W in shapes]
+    gos = [torch.rand(B, C, H, W, generator=g) for B, C, Hi, Wi, H, W in shapes]
+    df, dl, dg = [f.to(DEV) for f in feats], [f.to(DEV) for f in flows], [f.to(DEV) for f in gos]
+    res = {}
+    for mode in (1, 0):
+        lib.ffwm_set_option(b"warp_multi_planes", mode)
+        gf = [torch.zeros_like(f) for f in df]
+        gl = [torch.zeros_like(f) for f in dl]
+        _lib.prof_reset(); _lib.prof_enable(True)
+        ops.warp_multi_backward(df, dl, dg, False, gf, gl)
+        torch.cuda.synchronize(); _lib.prof_enable(False)
+        res[mode] = (gf, gl, {k: v["launches"] for k, v in _lib.prof_collect().items()})
+    lib.ffwm_set_option(b"warp_multi_planes", 0)
+    single, multi = res[1][2], res[0][2]
+    assert sum(n for k, n in single.items() if k.startswith("warp_bwd_feat")) == len(shapes), single
+    assert multi.get("warp_bwd_feat_multi", 0) >= 1 and sum(n for k, n in multi.items() if k.startswith("warp_bwd_feat")) <= 2, multi
+    for i in range(len(shapes)):
+        gf_ref, gl_ref = oracle.warp_backward(feats[i], flows[i], gos[i], False)
+        _close(res[0][0][i], gf_ref, BWD_TOL[torch.float32], relative=True)
+        _close(res[0][0][i], res[1][0][i].cpu(), 2e-6, relative=True)
+        _close(res[0][1][i], gl_ref, BWD_TOL[torch.float32] * 10, relative=True)
+
+
 def test_ffwm_generator_levels_in_one_launch_match_the_per_level_path():
     """nets.FFWM with the multi-problem warp (default on the GPU) against the same network warping level by level:
     same outputs; and the autograd wiring of the multi-output Function (one backward for all levels) against three
