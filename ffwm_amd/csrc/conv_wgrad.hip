@@ -352,6 +352,10 @@ int launch_wgrad(const char* name, const float* S, const float* A, float* dW, in
 }
 
 }  // namespace
+
+// conv_wgrad_wino.hip
+int launch_wgrad_wino(const float* X, const float* G, float* dW, float* dbias, int64_t B, int64_t C, int64_t K, int64_t H, int64_t W,
+                      int64_t k_begin, int64_t k_end, int64_t c_begin, int64_t c_end, hipStream_t st);
 }  // namespace ffwm
 
 using namespace ffwm;
@@ -383,10 +387,18 @@ extern "C" int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_outp
     const int64_t km = k_end - thin(k_begin, k_end), cm = c_end - thin(c_begin, c_end);
     // full tiles: A = grad_output rows [k_begin, km), S = input channels [c_begin, cm)
     float* db = (float*)grad_bias;
-    const bool main_has_bias = db && km > k_begin && cm > c_begin;      // the full-tile launch sums its A rows on the way
-    if (int rc = launch_wgrad<false>("conv3x3_wgrad", X, G, dW, B, C, K, H, W, k_begin, km, c_begin, cm, C * 9, 9, 0, st,
-                                     main_has_bias ? db : nullptr))
-        return rc;
+    bool main_has_bias = db && km > k_begin && cm > c_begin;            // the full-tile launch sums its A rows on the way
+    // conv_wgrad_wino: 1 = the full tiles on the Winograd-domain kernel (conv_wgrad_wino.hip; it sums its dY rows on the way like
+    // the direct kernel); a shape it does not serve comes back > 0 and takes the direct kernel
+    int wino = 1;
+    if (options().conv_wgrad_wino != 0 && km > k_begin && cm > c_begin) {
+        wino = launch_wgrad_wino(X, G, dW, main_has_bias ? db : nullptr, B, C, K, H, W, k_begin, km, c_begin, cm, st);
+        if (wino < 0) return wino;
+    }
+    if (wino != FFWM_OK)
+        if (int rc = launch_wgrad<false>("conv3x3_wgrad", X, G, dW, B, C, K, H, W, k_begin, km, c_begin, cm, C * 9, 9, 0, st,
+                                         main_has_bias ? db : nullptr))
+            return rc;
     if (db) {
         const int64_t r0 = main_has_bias ? km : k_begin;                 // rows nobody summed yet
         if (r0 < k_end) {

@@ -233,6 +233,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "warp_nt")) slot = &o.warp_nt;
     else if (!strcmp(key, "warp_multi_lds")) slot = &o.warp_multi_lds;
     else if (!strcmp(key, "warp_multi_planes")) slot = &o.warp_multi_planes;
+    else if (!strcmp(key, "conv_wgrad_wino")) slot = &o.conv_wgrad_wino;
     else if (!strcmp(key, "be_bwd_rows")) slot = &o.be_bwd_rows;
     else if (!strcmp(key, "rs_fwd_variant")) slot = &o.rs_fwd_variant;
     else if (!strcmp(key, "rs_bwd1_variant")) slot = &o.rs_bwd1_variant;
