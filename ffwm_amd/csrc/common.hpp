@@ -38,7 +38,7 @@ struct Options {
     int conv_wino_raw = 1;     // conv_winograd.hip: stage the input window through LDS when a workgroup covers whole tile rows
     int conv_thin_tail = 1;    // conv_winograd.hip: 1-4 output channels past a multiple of 64 on the thin direct kernel
     int warp_nt = 0;          // warp forward (direct / multi-problem kernels): 1 = streaming (nt) stores, 2 = nt feature loads too
-    int conv_wgrad_wino = 0;   // conv_wgrad.hip: 1 = the full 64-channel tiles on the Winograd-domain weight-gradient kernel (conv_wgrad_wino.hip)
+    int conv_wgrad_wino = 0;   // conv_wgrad.hip, the full 64-channel tiles on the Winograd-domain kernel (conv_wgrad_wino.hip): 0 = auto (>= 16 chunks per CU), 1 = whenever served, 2 = never
     int warp_multi_planes = 0; // multi-problem warp backward: 0 = d(feat) plane problems of one CG share a launch, 1 = one launch per problem
     int warp_multi_lds = 0;   // multi-problem warp launches: 0 = auto (LDS-staged tiles for float planes >= 64 x 64, C >= 32), 1 = direct gathers, 2 = LDS tiles
     int warp_multi_order = 0; // multi-problem warp launches: 0 = largest problem first, 1 = the caller's order

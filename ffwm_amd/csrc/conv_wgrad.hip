@@ -388,10 +388,11 @@ extern "C" int ffwm_conv3x3_wgrad_block(const void* input, const void* grad_outp
     // full tiles: A = grad_output rows [k_begin, km), S = input channels [c_begin, cm)
     float* db = (float*)grad_bias;
     bool main_has_bias = db && km > k_begin && cm > c_begin;            // the full-tile launch sums its A rows on the way
-    // conv_wgrad_wino: 1 = the full tiles on the Winograd-domain kernel (conv_wgrad_wino.hip; it sums its dY rows on the way like
-    // the direct kernel); a shape it does not serve comes back > 0 and takes the direct kernel
+    // the full tiles on the Winograd-domain kernel (conv_wgrad_wino.hip; it sums its dY rows on the way like the direct kernel) when it
+    // serves the shape and -- conv_wgrad_wino 0 = auto -- every CU gets >= 16 chunks of it (1 = whenever served, 2 = never); a shape
+    // it leaves comes back > 0 and takes the direct kernel
     int wino = 1;
-    if (options().conv_wgrad_wino != 0 && km > k_begin && cm > c_begin) {
+    if (options().conv_wgrad_wino != 2 && km > k_begin && cm > c_begin) {
         wino = launch_wgrad_wino(X, G, dW, main_has_bias ? db : nullptr, B, C, K, H, W, k_begin, km, c_begin, cm, st);
         if (wino < 0) return wino;
     }

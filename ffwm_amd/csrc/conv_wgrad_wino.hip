@@ -44,7 +44,7 @@ struct WwGeo {
     int KT, CT;                      // 64-channel tiles of the two ranges
     int TH, TWC;                     // tile rows, chunks (8 tiles) per tile row
     int chunks;                      // B * TH * TWC
-    int nsplit;
+    int nsplit, remap;
     unsigned x_bytes, g_bytes;
 };
 
@@ -57,7 +57,9 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
     const int l31 = lane & 31, half = lane >> 5;
     const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
 
-    unsigned t = blockIdx.x;
+    // the (k, c) tiles of one pixel slice are consecutive logical ids: with xcd_remap they run on ONE XCD and share its L2
+    // (workgroup b runs on XCD b % 8: unremapped, the nine tiles of a slice of a 192 x 192 weight fetch it through eight L2s)
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, g.remap);
     const int kt = t % g.KT; t /= g.KT;
     const int ct = t % g.CT; t /= g.CT;
     const int split = static_cast<int>(t);
@@ -196,9 +198,9 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
         // now: buffer 0 = chunk n0, R[1] = chunk n0 + 1 and R[0] = chunk n0 + 2 in flight.  Step n commits R[(n + 1) & 1] (chunk
         // n + 1) into the other buffer and refills that set with chunk n + 3: a load has 1.5-2 steps to land
         const int n = ch_end - ch_begin;
-        for (int i = 0; i < n; i += 2) {
+        for (int i = 0; i < n; i += 2) {          // (an odd count ends with a step on a buffer of zeros: no branch around it)
             step(std::integral_constant<int, 0>());
-            if (i + 1 < n) step(std::integral_constant<int, 1>());
+            step(std::integral_constant<int, 1>());
         }
     }
     if (dbias && ct == 0) {
@@ -277,18 +279,22 @@ int launch_wgrad_wino(const float* X, const float* G, float* dW, float* dbias, i
     if (chunks >= (1LL << 30)) return 1;
     g.chunks = static_cast<int>(chunks);
     const int64_t tiles = static_cast<int64_t>(g.KT) * g.CT;
+    // measured (tools/wgrad_wino_check.py, profiles/r04_wgrad_winograd.txt): 1.3-1.6 x the direct kernel from 64 x 64 planes at batch 8
+    // up; [2,64,64,64] -> 64 (256 chunks, one tile: 16 workgroups) loses, 64 vs 50 us
+    if (options().conv_wgrad_wino == 0 && chunks * tiles < 4096) return 1;
     int64_t nsplit = tiles >= 256 ? 1 : 256 / tiles;               // one workgroup per CU (147 KB of LDS)
     if (nsplit > chunks / 16) nsplit = chunks / 16;
     if (nsplit < 1) return 1;                                       // fewer than 16 chunks in all: the direct kernel
     g.nsplit = static_cast<int>(nsplit);
+    g.remap = options().xcd_remap;
     g.x_bytes = static_cast<unsigned>(B * C * H * W * 4);
     g.g_bytes = static_cast<unsigned>(B * K * H * W * 4);
     const size_t lds = 64 * 576 * sizeof(float);                    // >= the 128 KB of operand buffers
     allow_large_lds(reinterpret_cast<const void*>(conv3x3_wgrad_wino_kernel));
     const double kk = static_cast<double>(k_end - k_begin), cc = static_cast<double>(c_end - c_begin);
-    // flops = the direct sum's (what the call replaces); the MFMAs execute 16 / 36 of them
+    // flops = the multiplications the MFMAs execute, as for the forward kernel's scope (the direct sum this call replaces has 2.25 x as many)
     LaunchScope ls("conv3x3_wgrad_winograd", st, 4.0 * (static_cast<double>(B) * H * W * (kk + cc) + 9.0 * kk * cc),
-                   2.0 * 9.0 * static_cast<double>(B) * H * W * kk * cc);
+                   2.0 * 16.0 * (static_cast<double>(B) * H * W / 4.0) * kk * cc);
     hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, dim3(static_cast<unsigned>(tiles * nsplit)), dim3(kWwThreads), lds, st, X, G, dW, dbias, g);
     return check_launch("ffwm_conv3x3_wgrad(winograd)");
 }

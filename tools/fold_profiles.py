@@ -23,6 +23,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "block_extractor_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 0>",
     "conv3x3_thin_tail": "conv3x3_thin_kernel<3>",
     "conv3x3_wgrad": "conv3x3_wgrad_kernel<false>",
+    "conv3x3_wgrad_winograd": "conv3x3_wgrad_wino_kernel",
     "conv3x3_wgrad_packed": "conv3x3_wgrad_kernel<true>",
     "conv_fwd_mfma": "conv_fwd_kernel<0,",
     "conv_fwd_mfma_transposed": "conv_fwd_kernel<1,",

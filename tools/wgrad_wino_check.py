@@ -17,8 +17,9 @@ for (B, C, K, H, W) in shapes:
     if B * C * K * H * W <= 8 * 195 * 195 * 64 * 64:
         ref = torch.ops.aten.convolution_backward(go.double(), x.double(), torch.zeros(K, C, 3, 3, device=dev, dtype=torch.float64), [K], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, True])
     out = {}
-    for mode in (0, 1):
-        lib.ffwm_set_option(b"conv_wgrad_wino", mode)
+    for mode in (0, 1, 2):
+        lib.ffwm_set_option(b"conv_wgrad_wino", 2 if mode == 0 else 1)
+        lib.ffwm_set_option(b"xcd_remap", 0 if mode == 2 else 1)
         for _ in range(2):
             gw = torch.zeros(K, C, 3, 3, device=dev); gb = torch.zeros(K, device=dev)
             ops.conv3x3_wgrad(x, go, gw, gb)
@@ -30,7 +31,8 @@ for (B, C, K, H, W) in shapes:
         out[mode] = (gw, gb, {k: round(v["avg_ms"] * 1e3, 1) for k, v in _lib.prof_collect().items()})
     lib.ffwm_set_option(b"conv_wgrad_wino", 0)
     scale = out[0][0].abs().max().item()
-    msg = "(%d,%d->%d,%d,%d) direct %s | wino %s | wino-vs-direct %.2e" % (B, C, K, H, W, out[0][2], out[1][2], (out[1][0] - out[0][0]).abs().max().item() / scale)
+    lib.ffwm_set_option(b"xcd_remap", 1)
+    msg = "(%d,%d->%d,%d,%d) direct %s | wino %s | wino, no xcd remap %s | wino-vs-direct %.2e" % (B, C, K, H, W, out[0][2], out[1][2], out[2][2].get("conv3x3_wgrad_winograd"), (out[1][0] - out[0][0]).abs().max().item() / scale)
     if ref is not None:
         msg += " | vs fp64: direct %.2e wino %.2e bias %.2e" % ((out[0][0].double() - ref[1]).abs().max().item() / scale, (out[1][0].double() - ref[1]).abs().max().item() / scale,
                                                                   (out[1][1].double() - ref[2]).abs().max().item() / ref[2].abs().max().item())
