@@ -611,3 +611,26 @@ def route_flow_heads(net):
             m.__class__ = FlowUpConvTranspose2d
             n += 1
     return n
+
+
+# ================================================================================= every route of a training network, in the trainer's order
+def route_training_kernels(net, convs=True, wgrad=True):
+    """Apply to `net` what FFWMTrainer applies to netG / netD (trainer.py:160-205), in the same order, and return the counts: the
+    3x3 weight gradients (conv_wgrad.hip / conv_wgrad_wino.hip), Winograd forward + data gradient (conv_winograd.hip), the direct
+    MFMA kernel for stride-2 / transposed / small-plane layers (conv_fwd.hip), the tiled weight gradient for what is left
+    (conv_bwd.hip), BatchNorm + LeakyReLU pairs, residual tails / the warp-attention gate, batched spectral norm.  For a module that
+    is trained outside the trainer (bench.py's warp + attention sub-path); convs=False keeps the vendor's convolutions (A/B)."""
+    from .norm import fuse_bn_lrelu
+    from .residual import fuse_residual
+    from .spectral_norm import fuse_spectral_norm
+    n = {}
+    if convs:
+        if wgrad:
+            n["mfma_wgrad"] = route_conv_wgrad(net)
+        n["winograd"] = route_conv_winograd(net)
+        n["mfma_fwd"] = route_conv_fwd(net)
+        n["own_bwd"] = route_conv_bwd(net)
+    n["bn_lrelu"] = fuse_bn_lrelu(net)
+    n["residual"] = fuse_residual(net)
+    fuse_spectral_norm(net)
+    return n

@@ -325,3 +325,61 @@ def test_spectral_norm_product_never_keeps_a_stale_winograd_transform(monkeypatc
             assert (y - ref).abs().max().item() <= 1e-4 * (1 + ref.abs().max().item()), it
             layer.weight_orig.mul_(1.5).add_(0.01 * torch.randn_like(layer.weight_orig))      # a training update in between
     assert "_winograd_frozen" not in layer.__dict__ or not layer.__dict__["_winograd_frozen"]
+
+
+def test_warp_attention_module_on_the_routed_kernels_matches_the_unrouted_module():
+    """bench.py's warp + attention sub-path (base_networks.py:323-333 for all three levels, batch 8) runs its att convs on the
+    trainer's kernels (conv.route_training_kernels): Winograd forward / data gradient, MFMA weight gradients, fused
+    BatchNorm + LeakyReLU, the fused gate.  Same weights, same inputs, train mode.  The backward of conv -> BatchNorm(train) ->
+    sigmoid gates amplifies fp32 rounding whatever kernels run, so the yardstick is the SAME module in float64: the routed module's
+    distance to it may be at most 3 x the distance of the fp32 module on PyTorch-ROCm's convolutions (+ 1e-5 of the scale), for the
+    outputs, the input / flow gradients and every parameter gradient -- and the hand-written kernels really ran."""
+    import copy
+    from ffwm_amd import nets
+    from ffwm_amd.conv import route_training_kernels
+    from ffwm_amd.external_function import WarpFlipCat
+    from ffwm_amd.spectral_norm import fuse_spectral_norm
+    torch.manual_seed(3)
+    ref = nets.WarpAttention(sn=True).to(DEV).train()
+    own = copy.deepcopy(ref)
+    r64 = nets.WarpAttention(sn=True, warp_flipcat=WarpFlipCat()).to(DEV).train()
+    r64.load_state_dict(ref.state_dict())
+    r64 = r64.double()
+    fuse_spectral_norm(ref)
+    counts = route_training_kernels(own)
+    assert counts["winograd"] >= 9 and counts["residual"] == 3 and own.fuse_gate, counts
+    g = torch.Generator().manual_seed(5)
+    bs = 8
+    feats = [torch.rand(bs, c, s, s, generator=g).to(DEV) for c, s in ref.LEVELS]
+    flows = []
+    for _, s in ref.LEVELS:
+        lin = (torch.arange(s, dtype=torch.float32) + 0.5) / s * 2 - 1
+        yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+        fl = torch.stack((xx + 0.05 * torch.sin(3 * yy), yy + 0.05 * torch.cos(2 * xx)), 0)
+        flows.append(fl.unsqueeze(0).repeat(bs, 1, 1, 1).contiguous().to(DEV))
+    gos = [torch.rand(bs, 2 * c, s, s, generator=g).to(DEV) for c, s in ref.LEVELS]
+
+    def run(mod, dt=torch.float32):
+        fs = [f.detach().to(dt).clone().requires_grad_(True) for f in feats]
+        ws = [f.detach().to(dt).clone().requires_grad_(True) for f in flows]
+        outs = mod(fs, ws)
+        torch.autograd.backward(outs, [go.to(dt) for go in gos])
+        res = {"out%d" % i: o.detach() for i, o in enumerate(outs)}
+        res.update({"dfeat%d" % i: f.grad for i, f in enumerate(fs)})
+        res.update({"dflow%d" % i: f.grad for i, f in enumerate(ws)})
+        res.update({n: p.grad for n, p in mod.named_parameters() if p.grad is not None})
+        return res
+    r_own, launches = _launch_counts(lambda: run(own))
+    assert launches.get("conv_winograd_fwd", 0) >= 6 and launches.get("conv_winograd_dgrad", 0) >= 6, launches
+    assert sum(v for k, v in launches.items() if k.startswith("conv3x3_wgrad")) >= 3, launches
+    r_ref = run(ref)
+    r_64 = run(r64, torch.float64)
+    dist = lambda a, b: (a.double() - b).abs().max().item() / (1e-30 + b.abs().max().item())
+    n = 0
+    for name, want in r_64.items():
+        if name not in r_own or name not in r_ref:
+            continue
+        e_own, e_ref = dist(r_own[name], want), dist(r_ref[name], want)
+        assert e_own <= 3 * e_ref + 1e-5, (name, e_own, e_ref)
+        n += 1
+    assert n >= 9 + 18, n
