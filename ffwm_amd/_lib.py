@@ -67,12 +67,13 @@ _SIGNATURES = {
     "ffwm_prof_get": [_i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),
                       ctypes.POINTER(ctypes.c_double)],
     "ffwm_prof_get_flops": [_i, ctypes.POINTER(ctypes.c_double)],
+    "ffwm_prof_get_bound": [_i, ctypes.POINTER(ctypes.c_double)],
     "ffwm_prof_reset": [],
     "ffwm_set_option": [ctypes.c_char_p, _i],
     "ffwm_abi_version": [],
 }
 
-EXPORTS = sorted(list(_SIGNATURES) + ["ffwm_last_error", "ffwm_conv3x3_winograd_workspace_bytes"])
+EXPORTS = sorted(list(_SIGNATURES) + ["ffwm_last_error", "ffwm_conv3x3_winograd_workspace_bytes", "ffwm_conv3x3_winograd_splits"])
 
 
 class FFWMError(RuntimeError):
@@ -95,6 +96,8 @@ def load():
         fn.restype = _i
     lib.ffwm_conv3x3_winograd_workspace_bytes.argtypes = [_i64, _i64]
     lib.ffwm_conv3x3_winograd_workspace_bytes.restype = _i64
+    lib.ffwm_conv3x3_winograd_splits.argtypes = [_i64, _i64, _i64, _i64, _i64, _i]
+    lib.ffwm_conv3x3_winograd_splits.restype = _i
     lib.ffwm_last_error.argtypes = []
     lib.ffwm_last_error.restype = ctypes.c_char_p
     got = lib.ffwm_abi_version()
@@ -130,7 +133,8 @@ def prof_reset():
 
 
 def prof_collect():
-    """-> {kernel_name: {"launches": n, "total_ms": ms, "avg_ms": ms, "bytes_per_launch": b, "flops_per_launch": f}}"""
+    """-> {kernel_name: {"launches": n, "total_ms": ms, "avg_ms": ms, "bytes_per_launch": b, "flops_per_launch": f,
+    "roofline_ms": the time the binding roofline of every launch allows, summed}}"""
     lib = load()
     n = lib.ffwm_prof_collect()
     rows = {}
@@ -143,10 +147,12 @@ def prof_collect():
                                 ctypes.byref(nbytes)), "ffwm_prof_get")
         flops = ctypes.c_double()
         check(lib.ffwm_prof_get_flops(i, ctypes.byref(flops)), "ffwm_prof_get_flops")
+        bound = ctypes.c_double()
+        check(lib.ffwm_prof_get_bound(i, ctypes.byref(bound)), "ffwm_prof_get_bound")
         k = max(launches.value, 1)
         rows[name.value.decode()] = {"launches": launches.value, "total_ms": ms.value,
                                      "avg_ms": ms.value / k, "bytes_per_launch": nbytes.value / k,
-                                     "flops_per_launch": flops.value / k}
+                                     "flops_per_launch": flops.value / k, "roofline_ms": bound.value}
     return rows
 
 

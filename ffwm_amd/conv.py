@@ -156,14 +156,20 @@ WINOGRAD_MIN_TILES = int(_os.environ.get("FFWM_WINOGRAD_MIN_TILES", 2048))
 WINOGRAD_MIN_PAIRS = int(_os.environ.get("FFWM_WINOGRAD_MIN_PAIRS", 160))
 
 
-def _winograd_dir_ok(x, c_red, k_out):
+def _winograd_dir_ok(x, c_red, k_out, act=0):
     tiles = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2)
-    return (min(c_red, k_out) >= 32 and tiles >= WINOGRAD_MIN_TILES and ((tiles + 63) // 64) * ((k_out + 63) // 64) >= WINOGRAD_MIN_PAIRS
-            and x.shape[0] * max(c_red, k_out) * x.shape[2] * x.shape[3] < (1 << 29))
+    if not (min(c_red, k_out) >= 32 and tiles >= WINOGRAD_MIN_TILES and x.shape[0] * max(c_red, k_out) * x.shape[2] * x.shape[3] < (1 << 29)):
+        return False
+    pairs = ((tiles + 63) // 64) * ((k_out + 63) // 64)
+    if pairs < WINOGRAD_MIN_PAIRS and act == 0:
+        # few pairs: the library cuts the reduction over 2 / 4 workgroups (256 -> 256 at 32 x 32, batch 8: 128 pairs x 2)
+        pairs *= ops.conv3x3_winograd_splits(x.shape[0], c_red, x.shape[2], x.shape[3], k_out, act)
+    return pairs >= WINOGRAD_MIN_PAIRS
 
 
-def winograd_dirs(x, weight):
-    """(forward, data gradient): which directions of Conv2d(C, K, 3, 1, 1) on this input run on the Winograd kernel."""
+def winograd_dirs(x, weight, act=0):
+    """(forward, data gradient): which directions of Conv2d(C, K, 3, 1, 1) on this input run on the Winograd kernel.  act: the
+    activation fused into the FORWARD call (the data gradient never has one)."""
     if not (_WINOGRAD and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4
             and not torch.is_autocast_enabled()):          # (under autocast the fp32 kernels stand aside: the vendor path casts)
         return False, False
@@ -172,11 +178,11 @@ def winograd_dirs(x, weight):
         # an image head (netG's 195 -> 3 output layer): the forward is the thin direct kernel of conv_winograd.hip alone (a lane
         # owns 4 pixels x K channels), measured 50 us against the vendor's 137 at 128 x 128, batch 8; its data gradient stays
         return x.shape[3] % 4 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= 65536 and x.numel() < (1 << 29), False
-    return _winograd_dir_ok(x, C, K), _winograd_dir_ok(x, K, C)
+    return _winograd_dir_ok(x, C, K, act), _winograd_dir_ok(x, K, C)
 
 
-def winograd_ok(x, weight):
-    return winograd_dirs(x, weight)[0]
+def winograd_ok(x, weight, act=0):
+    return winograd_dirs(x, weight, act)[0]
 
 
 class _WinogradConv3x3(Function):
@@ -255,7 +261,7 @@ def winograd_bias_relu(x, layer):
     """relu(layer(x)) for a FROZEN nn.Conv2d(C, K, 3, 1, 1) with a bias; the caller has checked winograd_ok(x, layer.weight)."""
     cache = frozen_cache(layer, layer.weight)
     if torch.is_grad_enabled() and x.requires_grad:
-        return _WinogradConvBiasReLU.apply(x, layer.weight, layer.bias, cache, winograd_dirs(x, layer.weight)[1])
+        return _WinogradConvBiasReLU.apply(x, layer.weight, layer.bias, cache, winograd_dirs(x, layer.weight, 1)[1])
     return ops.conv3x3_winograd(x.contiguous(), layer.weight, layer.bias, act=1, slope=0.0, frozen=cache)
 
 

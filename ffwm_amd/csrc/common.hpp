@@ -36,6 +36,7 @@ struct Options {
     int rs_bwd1_variant = 0;  // resample2d d_input1: 0 = auto (ks 4: tap-lane kernel, on calls of >= 2^18 pixels the tile kernel instead when a pre-pass finds the flow smooth; else plane kernel when a plane fits LDS, else tile kernel), 1 = round-2 auto (plane / tile), 2 = tile kernel, 5 = tap-lane kernel with 8-wave blocks (16-row tiles)
     int conv_tile_variant = 0; // conv_fwd.hip workgroup tile: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128
     int conv_wino_raw = 1;     // conv_winograd.hip: stage the input window through LDS when a workgroup covers whole tile rows
+    int conv_wino_split = 1;   // conv_winograd.hip: cut the reduction of a call with few (strip, k tile) pairs over 2 / 4 workgroups (atomics into a zeroed output)
     int conv_thin_tail = 1;    // conv_winograd.hip: 1-4 output channels past a multiple of 64 on the thin direct kernel
     int warp_nt = 0;          // warp forward (direct / multi-problem kernels): 1 = streaming (nt) stores, 2 = nt feature loads too
     int conv_wgrad_wino = 0;   // conv_wgrad.hip, the full 64-channel tiles on the Winograd-domain kernel (conv_wgrad_wino.hip): 0 = auto (>= 16 chunks per CU), 1 = whenever served, 2 = never

@@ -48,6 +48,8 @@ struct WinoGeo {
     float slope;
     unsigned x_bytes, u_bytes;
     int R, ROWS;             // raw-staged variant: tile rows per workgroup (64 / TW) and input rows it stages (2 R + 2)
+    int CS, CHS;             // raw-staged variant: the reduction cut into CS splits of CHS chunks each (CS == 1: CHS == CH); a workgroup
+                             // unit is then (strip, k tile, split) and the splits' partial outputs meet by atomics in a zero-filled output
 
 };
 
@@ -328,13 +330,14 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
 
     // this workgroup's pairs: [pair_begin, pair_begin + pair_cnt) of the tt-major list (the k tiles of a strip are consecutive:
     // the same CU re-reads the strip's input from L2); each XCD gets a contiguous range of the list
-    const int npairs = g.TT * g.KT;
+    const int CS = g.CS;
+    const int npairs = g.TT * g.KT * CS;
     const int L = static_cast<int>(xcd_remap(blockIdx.x, gridDim.x, remap));
     const int per = npairs / static_cast<int>(gridDim.x), extra = npairs - per * static_cast<int>(gridDim.x);
     const int pair_begin = L * per + min(L, extra), pair_cnt = per + (L < extra ? 1 : 0);
     const int pair_end = pair_begin + pair_cnt;
     if (pair_cnt == 0) return;
-    const int CHp = (g.CH + 1) & ~1;         // chunks per pair, even: an odd count ends with a chunk of zeros (channels >= C read 0)
+    const int CHp = (g.CHS + 1) & ~1;        // chunks per pair, even: an odd count ends with a chunk of zeros (channels >= C read 0)
 
     // ---- W stage role: quads q = tid, tid + 512 of the [8 channels][ROWS][W / 4] window
     const int W4 = g.W >> 2, nquads = 8 * g.ROWS * W4;
@@ -355,24 +358,28 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     // a load cursor: the (pair, chunk) a stream of loads has reached, and what depends on the pair
     struct Cursor {
         int pair, ch;
-        unsigned qoff[2];            // byte offset of the quad in channel 0, or kOobOff
-        unsigned u_base;             // byte offset of this thread's first U quad of chunk 0, or kOobOff past the last pair
+        int ch0;                     // first chunk of the pair's split of the reduction
+        unsigned qoff[2];            // byte offset of the quad in the first channel of chunk ch0, or kOobOff
+        unsigned u_base;             // byte offset of this thread's first U quad of chunk ch0, or kOobOff past the last pair
     };
     auto seat = [&](Cursor& c) {
         if (c.pair >= pair_end) {
             c.qoff[0] = c.qoff[1] = kOobOff;
             c.u_base = kOobOff;
+            c.ch0 = 0;
             return;
         }
-        const int tt = c.pair / g.KT, kt = c.pair - tt * g.KT;
+        const int pk = c.pair / CS;
+        c.ch0 = (c.pair - pk * CS) * g.CHS;
+        const int tt = pk / g.KT, kt = pk - tt * g.KT;
         const int b = tt / strips_per_img, ty0 = (tt - b * strips_per_img) * g.R;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int iy = 2 * ty0 - 1 + qrow[i];
             const bool ok = qc[i] < 8 && iy >= 0 && iy < g.H;
-            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + qc[i]) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol[i])) * 4u : kOobOff;
+            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + 8 * c.ch0 + qc[i]) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol[i])) * 4u : kOobOff;
         }
-        c.u_base = (static_cast<unsigned>(kt) * g.CH) * (kWinoChunk * 4u) + threadIdx.x * 16u;
+        c.u_base = (static_cast<unsigned>(kt) * g.CH + c.ch0) * (kWinoChunk * 4u) + threadIdx.x * 16u;
     };
     auto advance = [&](Cursor& c) {
         if (++c.ch == CHp) {
@@ -403,7 +410,7 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         if (!(ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const bool cin = cr.ch * 8 + qc[i] < g.C;
+                const bool cin = (cr.ch0 + cr.ch) * 8 + qc[i] < g.C;
                 q[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (cin & (cr.qoff[i] != kOobOff)) ? cr.qoff[i] + static_cast<unsigned>(cr.ch) * (32u * HW) : kOobOff, 0, 0);
             }
         }
@@ -521,7 +528,8 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
             step(std::integral_constant<int, 0>());
             step(std::integral_constant<int, 1>());
         }
-        const int tt = pair / g.KT, kt = pair - tt * g.KT;
+        const int pk = pair / CS, csplit = pair - pk * CS;
+        const int tt = pk / g.KT, kt = pk - tt * g.KT;
         if (ph == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -546,7 +554,7 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
                 if (k >= g.K) continue;
                 const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 0
                 const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 1
-                const float bv = bias ? bias[k] : 0.f;
+                const float bv = (bias && csplit == 0) ? bias[k] : 0.f;
                 float y[4] = {za0 + zb0, za1 + zb1, zb0, zb1};   // y0 = z0 + z1 (+ z2), y1 = z1 (- z2 - z3)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -555,6 +563,13 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
                     y[v] = t;
                 }
                 float* o = ob + static_cast<size_t>(k) * HW;         // W and H are even here: whole 2 x 2 tiles, 8-byte aligned pairs
+                if (CS > 1) {
+                    // a split of the reduction: the output transform is linear, the splits' shares meet in the zero-filled output
+                    // (the host only splits a call without an activation; the bias rides with split 0)
+                    atomic_add(o, y[0]); atomic_add(o + 1, y[1]);
+                    atomic_add(o + g.W, y[2]); atomic_add(o + g.W + 1, y[3]);
+                    continue;
+                }
                 *reinterpret_cast<float2*>(o) = make_float2(y[0], y[1]);
                 *reinterpret_cast<float2*>(o + g.W) = make_float2(y[2], y[3]);
             }
@@ -676,6 +691,40 @@ conv3x3_thin_kernel(const float* __restrict__ x, const float* __restrict__ wt, c
 
 using namespace ffwm;
 
+// Splits of the reduction for a raw-staged call that offers the persistent workgroups fewer (strip, k tile) pairs than half the
+// CUs (256 -> 256 at 32 x 32, batch 8: 128 pairs; 512 -> 512 at 16 x 16: 64): the largest of 4 / 2 that keeps one round of
+// workgroups, whole even chunk counts per split and >= 16 chunks (128 channels) each -- measured (tools/wino_split_check.py,
+// profiles/r04_winograd_split.txt): with shorter splits the prologue / epilogue of a workgroup, the zero-fill and the atomics
+// cost more than the idle CUs (64 -> 64 at 64 x 64: 35 -> 50 us), with 16 chunks 256 -> 256 at 32 x 32 goes 106 -> 92 us and
+// 512 -> 512 at 16 x 16 199 -> 99 us.  Only without a fused activation (the epilogue of a split cannot apply one); 1 = no split.
+static int winograd_splits(int pairs, int CH, int act, int cus) {
+    if (act != 0 || !options().conv_wino_split || pairs <= 0) return 1;
+    for (int cs = 4; cs >= 2; cs -= 2) {
+        if (pairs * cs > cus) continue;
+        if (CH % cs != 0) continue;
+        const int chs = CH / cs;
+        if (chs < 16 || (chs & 1)) continue;
+        return cs;
+    }
+    return 1;
+}
+
+extern "C" int ffwm_conv3x3_winograd_splits(int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int act) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return 1;
+    const bool rawshape = options().conv_wino_raw && (W == 16 || W == 32 || W == 64 || W == 128) && H % 2 == 0;
+    if (!rawshape) return 1;
+    const int TH = static_cast<int>((H + 1) / 2), TW = static_cast<int>((W + 1) / 2);
+    if (!(TW <= 64 && 64 % TW == 0 && TH % (64 / TW) == 0)) return 1;
+    const int tail = static_cast<int>(K % 64);
+    const bool thin = (K > 64 || K <= 4) && tail >= 1 && tail <= 4 && W % 4 == 0 && options().conv_thin_tail;
+    const int64_t Kw = thin ? K - tail : K;
+    const int64_t pairs = ((B * TH * TW + kWinoTiles - 1) / kWinoTiles) * ((Kw + 63) / 64);
+    if (pairs <= 0 || pairs > 4096) return 1;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return winograd_splits(static_cast<int>(pairs), static_cast<int>((C + 7) / 8), act, cus);
+}
+
 extern "C" int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C) {
     if (K <= 0 || C <= 0) return 0;
     return ((K + 63) / 64) * ((C + 7) / 8) * static_cast<int64_t>(kWinoChunk) * 4;
@@ -727,13 +776,27 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
         // flops = the multiplications the MFMAs actually perform (16 per tile, channel pair), not the 36 of the direct sum
         const double flops = 2.0 * 16.0 * static_cast<double>(T) * g.K * C;
         const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(B) * g.K * H * W) + static_cast<double>(ub);
-        LaunchScope ls(data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd", st, bytes, flops);
         const unsigned nblk = static_cast<unsigned>(g.TT) * static_cast<unsigned>(g.KT);
         // whole tile rows of one image per workgroup -> the raw-staged variant
         const bool rawv = options().conv_wino_raw && (W == 16 || W == 32 || W == 64 || W == 128) && H % 2 == 0 && g.TW <= 64 && 64 % g.TW == 0 &&
                           g.TH % (64 / g.TW) == 0 && (2 * (64 / g.TW) + 2) * g.W * 8 <= kWinoRawFloats;
         g.R = rawv ? 64 / g.TW : 0;
         g.ROWS = 2 * g.R + 2;
+        g.CS = 1;
+        g.CHS = g.CH;
+        if (rawv) {
+            static const int cus0 = [] {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                return n;
+            }();
+            g.CS = winograd_splits(static_cast<int>(nblk), g.CH, act, cus0);
+            g.CHS = g.CH / g.CS;
+        }
+        // (a split call -- zero-fill + atomics, few pairs -- is a launch configuration of its own: its own profiling scope)
+        LaunchScope ls(g.CS > 1 ? (data_gradient ? "conv_winograd_dgrad_split" : "conv_winograd_fwd_split")
+                                : (data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd"), st, bytes, flops);
+        if (g.CS > 1 && hipMemsetAsync(output, 0, static_cast<size_t>(B) * K * H * W * 4, st) != hipSuccess) return FFWM_ERR_LAUNCH;
         if (rawv) {
             auto kern = winograd_conv_raw_kernel<0>;
             switch (options().ablate) {
@@ -749,7 +812,8 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 return n;
             }();
-            const unsigned pgrid = nblk < static_cast<unsigned>(cus) ? nblk : static_cast<unsigned>(cus);     // persistent: one workgroup per CU
+            const unsigned units = nblk * static_cast<unsigned>(g.CS);
+            const unsigned pgrid = units < static_cast<unsigned>(cus) ? units : static_cast<unsigned>(cus);     // persistent: one workgroup per CU
             hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kWinoThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st, static_cast<const float*>(input), U,
                                static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
             const int rc = check_launch(fn);

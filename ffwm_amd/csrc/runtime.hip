@@ -101,6 +101,7 @@ struct Pending {
 struct Row {
     int64_t launches = 0;
     double ms = 0, bytes = 0, flops = 0;
+    double bound_ms = 0;      // sum over launches of max(bytes / HBM peak, flops / fp32 MFMA peak): the time the binding roofline allows
 };
 std::mutex g_mu;
 bool g_prof = false;
@@ -166,6 +167,8 @@ int ffwm_prof_collect(void) {
             r.ms += ms;
             r.bytes += p.bytes;
             r.flops += p.flops;
+            const double tb = p.bytes / 8.0e12, tf = p.flops / 157.3e12;
+            r.bound_ms += (tb > tf ? tb : tf) * 1e3;
         }
         g_pool.push_back(p.start);
         g_pool.push_back(p.stop);
@@ -200,6 +203,16 @@ int ffwm_prof_get_flops(int row, double* algorithmic_flops) {
         return FFWM_ERR_ARG;
     }
     if (algorithmic_flops) *algorithmic_flops = g_snapshot[row].second.flops;
+    return FFWM_OK;
+}
+
+int ffwm_prof_get_bound(int row, double* roofline_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (row < 0 || row >= static_cast<int>(g_snapshot.size())) {
+        set_error("ffwm_prof_get_bound: row %d out of range", row);
+        return FFWM_ERR_ARG;
+    }
+    if (roofline_ms) *roofline_ms = g_snapshot[row].second.bound_ms;
     return FFWM_OK;
 }
 
@@ -240,6 +253,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "conv_tile_variant")) slot = &o.conv_tile_variant;
     else if (!strcmp(key, "conv_thin_tail")) slot = &o.conv_thin_tail;
     else if (!strcmp(key, "conv_wino_raw")) slot = &o.conv_wino_raw;
+    else if (!strcmp(key, "conv_wino_split")) slot = &o.conv_wino_split;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;

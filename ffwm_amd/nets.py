@@ -220,6 +220,10 @@ class FFWM(nn.Module):
             enc.append(getattr(self, "e%d" % i)(enc[-1]))
         fdec = enc[-1]
         recons, att = [], None
+        if callable(flow):
+            # the encoder does not need the flows: a caller that computes them on another HIP stream passes a function that joins
+            # that stream and returns them (trainer.FFWMTrainer.forward: flowNetF beside the encoder)
+            flow = flow()
         skips = self._skips(enc, flow)
         for i in range(self.layers):
             dec = getattr(self, "d%d" % i)(fdec)
@@ -431,7 +435,7 @@ class VGG19(nn.Module):
                 while i < len(mods):
                     m = mods[i]
                     if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and m.bias is not None:
-                        if not m.weight.requires_grad and _conv.winograd_ok(x, m.weight):
+                        if not m.weight.requires_grad and _conv.winograd_ok(x, m.weight, 1):
                             # large planes: conv + bias + ReLU as ONE launch of the Winograd MFMA kernel (csrc/conv_winograd.hip)
                             x = _conv.winograd_bias_relu(x, m)
                             i += 2

@@ -519,6 +519,11 @@ def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0
     return out
 
 
+def conv3x3_winograd_splits(B, C, H, W, K, act=0):
+    """In how many pieces conv3x3_winograd will cut the reduction of this call (1, 2 or 4): ffwm_conv3x3_winograd_splits."""
+    return int(_lib.load().ffwm_conv3x3_winograd_splits(int(B), int(C), int(H), int(W), int(K), int(act)))
+
+
 # ---------------------------------------------------------------- LightCNN max-feature-map
 def _mfm_dims(x):
     if x.dim() < 2 or x.shape[1] % 2:

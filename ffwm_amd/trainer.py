@@ -117,6 +117,32 @@ def probe_collective_capture(device, group=None):
     return ok
 
 
+class _FlowGate(torch.autograd.Function):
+    """Identity on a flow net's outputs whose BACKWARD orders two streams: the gate of flowNetF (record=True) records an event on its
+    stream when its backward runs -- autograd reaches it when d(flows_F) is complete, i.e. after netG's backward --, the gate of
+    flowNetB (record=False) makes its stream wait for that event before flowNetB's backward starts.  The autograd engine pops ready
+    nodes by descending sequence number: flowNetB's gate is the older node, so the host records the event before it issues the wait
+    (hipGraph capture needs that order); if the event is missing (flows_F without gradient) the wait is skipped."""
+
+    @staticmethod
+    def forward(ctx, box, record, *flows):
+        ctx.box, ctx.record = box, record
+        return tuple(f.view_as(f) for f in flows)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if grads and any(g is not None for g in grads):
+            dev = next(g for g in grads if g is not None).device
+            cur = torch.cuda.current_stream(dev)
+            if ctx.record:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                ctx.box["ev"] = ev
+            elif ctx.box.get("ev") is not None:
+                cur.wait_event(ctx.box["ev"])
+        return (None, None) + tuple(grads)
+
+
 class FFWMTrainer(object):
     def __init__(self, device, world_size=1, seed=0, titers=0, bucket_bytes=64 << 20, warp=None,
                  warp_flipcat=None, ngf=64, capturable=False, fused_spectral_norm=None, batched_losses=True,
@@ -238,6 +264,26 @@ class FFWMTrainer(object):
         self.d_stream = None
         if multi and os.environ.get("FFWM_D_STREAM", "1") == "1":
             self.d_stream = torch.cuda.Stream(self.device) if five else self.loss_streams[1]
+        # flowNetF on the SECOND side stream (idle until the D step forks, and idle again once LightCNN's backward is through), beside
+        # netG's encoder: e0-e3 need no flow, so the step's stream runs them while both flow nets -- ~3 ms of 2 x 2 ... 64 x 64 plane
+        # kernels each -- run beside it, and in the backward flowNetF's pass (the tail of the step: it waits for d(flow) from the
+        # warps) runs beside the encoder's.  No new stream: the four hardware queues stay enough (see above).  One GPU only for now:
+        # with several ranks the reducers' hooks would launch flowNetF's buckets from that stream.
+        # (measured, round 4: 41.3 ms against 41.0-41.1 with flowNetF on the step's stream -- netG's encoder is Winograd kernels that
+        # own every CU's LDS and registers while they run, a side stream's kernels wait for them instead of running beside them; what
+        # overlaps on this chip is small kernels with OTHER small kernels.  Opt-in: FFWM_FLOWF_STREAM=1.)
+        self._event_joins = multi and not five and os.environ.get("FFWM_EVENT_JOINS", "1") == "1"
+        self._prefetch_targets = os.environ.get("FFWM_TARGET_PREFETCH", "1") == "1"
+        # Opt-in experiment (FFWM_PAIR_FLOW_BWD=1): the flow nets' BACKWARD passes side by side.  flowNetB's gradient is complete long
+        # before flowNetF's (it comes straight from the illumination warp), so its backward runs on its side stream in the middle of
+        # netG's backward and flowNetF's alone at the tail of the step; a gate (_FlowGate) can hold flowNetB's backward until flowNetF's
+        # starts.  Measured neutral (40.47 / 40.63 ms with the gate, 40.48 without, profiles/r04_stream_experiments.txt): flowNetB's
+        # backward already finds room between netG's kernels.
+        self._pair_flow_backward = os.environ.get("FFWM_PAIR_FLOW_BWD", "0") == "1"
+        self._tgt = {}
+        self.flowf_stream = None
+        if multi and not five and not self.dp_active and os.environ.get("FFWM_FLOWF_STREAM", "0") == "1":
+            self.flowf_stream = self.loss_streams[1]
         # the D step on its side stream: always on one GPU; with several ranks only when the collectives are captured into the
         # step's graph (capture mode "ingraph": the D gradients' all-reduce is then a node of the side branch)
         self._d_side = not self.dp_active
@@ -383,6 +429,59 @@ class FFWMTrainer(object):
     # ------------------------------------------------------------------ one optimisation step
     def forward(self, b):
         img_S, img_F = b["img_S"], b["img_F"]
+        self._tgt = {}
+        if self.flow_stream is not None and self._event_joins and not self.segmented and not self.dp_active:
+            # One GPU, one graph: the side branches are joined by EVENTS, not whole-stream waits, so that more work can follow on a side
+            # stream behind the point the step's stream waits for (the ground-truth passes below), and the two flow nets' BACKWARD
+            # passes are paired at the tail of the step (the gates).
+            cur = torch.cuda.current_stream(self.device)
+            box = {}
+            self.flow_stream.wait_stream(cur)                  # fork: img_S and last step's weights are ready
+            with torch.cuda.stream(self.flow_stream):
+                flows_B = self.flowNetB(img_S)
+                if self._pair_flow_backward:
+                    flows_B = _FlowGate.apply(box, False, *flows_B)
+                self.flows_B = list(flows_B)
+            ev_B = torch.cuda.Event()
+            ev_B.record(self.flow_stream)
+            fstream = self.flowf_stream                        # (opt-in: flowNetF on the second side stream beside netG's encoder)
+            ev_F = None
+            if fstream is not None:
+                fstream.wait_stream(cur)
+            with (torch.cuda.stream(fstream) if fstream is not None else contextlib.nullcontext()):
+                flows_F = self.flowNetF(img_S)
+                if self._pair_flow_backward:
+                    flows_F = _FlowGate.apply(box, True, *flows_F)
+            if fstream is not None:
+                ev_F = torch.cuda.Event()
+                ev_F.record(fstream)
+            if self._prefetch_targets and self.fused_l1:
+                # the loss networks' passes over the GROUND TRUTH (no_grad, inputs only) behind flowNetB / on the second side stream,
+                # beside netG's forward, instead of on the step's stream in the middle of the loss section
+                mask_F = b["mask_F"]
+                with torch.cuda.stream(self.flow_stream), torch.no_grad():
+                    self._tgt["vgg128"] = self.vgg(img_F * mask_F)
+                    self._tgt["vgg64"] = self.vgg(F.interpolate(img_F, (64, 64), mode="bilinear") * F.interpolate(mask_F, (64, 64), mode="nearest"))
+                self.loss_streams[1].wait_stream(cur)
+                with torch.cuda.stream(self.loss_streams[1]), torch.no_grad():
+                    self._tgt["light"] = self.lightCNN(img_F.mean(1, keepdim=True))
+
+            def flows_ready():
+                # called by netG once its encoder is issued: join the flow nets, warp the images, hand the flows over
+                if ev_F is not None:
+                    cur.wait_event(ev_F)
+                cur.wait_event(ev_B)
+                for f in list(self.flows_B) + (list(flows_F) if ev_F is not None else []):
+                    f.record_stream(cur)                       # allocated on a side stream, consumed on this one
+                self.flows_F = list(flows_F)
+                self.img_S_warp, self.img_S_rec = self.warp_many([img_S, img_F], [flows_F[0], self.flows_B[0]])
+                return [flows_F[2], flows_F[1], flows_F[0]]
+            self.fake32, self.fake64, self.fake128 = self.netG(img_S, flow=flows_ready)
+            self.img_GF128 = self.gf[128](self.fake128, img_F)
+            grids = part_grids(b["lm_F"])            # eye-l, eye-r, nose, mouth
+            crops = self.warp_many([self.img_GF128, img_F] * len(grids), [g for g in grids for _ in (0, 1)])   # 8 crops: one launch
+            self.parts = [(crops[2 * i], crops[2 * i + 1]) for i in range(len(grids))]
+            return
         if self.flow_stream is not None:
             cur = torch.cuda.current_stream(self.device)
             self.flow_stream.wait_stream(cur)                  # fork: img_S and last step's weights are ready
@@ -450,14 +549,19 @@ class FFWMTrainer(object):
             self.loss_streams[i].wait_stream(cur)
             return torch.cuda.stream(self.loss_streams[i])
 
-        def vgg_pair(x, y, m):
+        pre = getattr(self, "_tgt", None) or {}            # ground-truth features computed at the start of the step (forward())
+
+        def vgg_pair(x, y, m, key):
             fx = self.vgg(x * m)
-            with torch.no_grad():
-                fy = self.vgg(y * m)
+            if key in pre:
+                fy = pre[key]
+            else:
+                with torch.no_grad():
+                    fy = self.vgg(y * m)
             return [(fx[k], fy[k], None, w, PRC) for k, w in zip(PRC_LAYERS, PRC_WEIGHTS)]
         # perceptual: the two large scales one VGG pass each, the 32 x 32 scale and the four part crops share one (5 B rows)
         with branch(0):
-            side_terms += vgg_pair(gf64, img_F64, mask64)
+            side_terms += vgg_pair(gf64, img_F64, mask64, "vgg64")
             (el, elt), (er, ert), (no, nog), (mo, mog) = self.parts
             fx = self.vgg(torch.cat((gf32 * mask32, el, er, mo, no), 0))
             with torch.no_grad():
@@ -476,12 +580,16 @@ class FFWMTrainer(object):
                 uniq.append(o)
                 wsum.append(w)
         with branch(1):
-            with torch.no_grad():
-                _, fc_g, pool_g = self.lightCNN(img_F.mean(1, keepdim=True))
+            if "light" in pre:
+                _, fc_g, pool_g = pre["light"]
+            else:
+                with torch.no_grad():
+                    _, fc_g, pool_g = self.lightCNN(img_F.mean(1, keepdim=True))
             _, fc_o, pool_o = self.lightCNN(torch.cat([u.mean(1, keepdim=True) for u in uniq], 0))
             side_terms.append((fc_o, fc_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
             side_terms.append((pool_o, pool_g, None, [(i * B, 0, B, w, IDEN) for i, w in enumerate(wsum)]))
-        terms += vgg_pair(gf128, img_F, mask_F)
+        t128 = vgg_pair(gf128, img_F, mask_F, "vgg128")
+        terms += t128
         # illumination (MSL1Loss): the three generated scales warped back with flowNetB (one multi-problem launch)
         warped = self.warp_many([self.fake128, self.fake64, self.fake32], list(self.flows_B))
         for w, flow, back in zip((1, 1, 1.5), self.flows_B, warped):
@@ -495,6 +603,9 @@ class FFWMTrainer(object):
             for t in side_terms:                           # allocated on a side stream, read by the fused L1 launch on this one
                 t[0].record_stream(cur)
                 t[1].record_stream(cur)
+            if "vgg128" in pre:
+                for t in t128:
+                    t[1].record_stream(cur)
         terms += side_terms
         v = l1_terms(terms, 5)
         self._join_D()
@@ -860,6 +971,19 @@ class FFWMTrainer(object):
         self.red_G.set_overlap(True)
         self.red_D.set_gather(True)
         self.red_G.set_gather(True)
+
+    def set_side_streams(self, on):
+        """Switch the side streams of the EAGER step off / back on (a captured step keeps the layout it was captured with).  With
+        them off every kernel of a step runs alone on the step's stream: what a per-kernel measurement with HIP events needs --
+        beside a side stream's kernels a launch shares the chip and its duration says nothing about the kernel (bench.py)."""
+        if self._graphs is not None:
+            raise RuntimeError("set_side_streams: release_graphs() first")
+        if not on and getattr(self, "_streams_parked", None) is None:
+            self._streams_parked = (self.flow_stream, self.loss_streams, self.d_stream, self.flowf_stream)
+            self.flow_stream = self.loss_streams = self.d_stream = self.flowf_stream = None
+        elif on and getattr(self, "_streams_parked", None) is not None:
+            self.flow_stream, self.loss_streams, self.d_stream, self.flowf_stream = self._streams_parked
+            self._streams_parked = None
 
     def loss_values(self):
         return {k: float(v.detach()) for k, v in self.losses.items()}

@@ -394,6 +394,11 @@ int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, void* grad_w
  * data_gradient + 2: the workspace still holds the transformed weights of an earlier call with the same weight values,
  * direction, K, C and (W % 4 == 0) -- frozen networks (VGG19, LightCNN: models/losses.py:398-519) skip the transform. */
 int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C);
+/* In how many pieces ffwm_conv3x3_winograd_forward will cut the reduction (input channels) of this call: 1, 2 or 4.  A call whose
+ * (64 tiles, 64 output channels) pairs fill less than half the CUs (256 -> 256 at 32 x 32, batch 8) is cut so that one round of
+ * persistent workgroups covers the chip; the pieces' partial outputs meet by atomics in the output, which the library zero-fills
+ * itself.  Only for act = 0.  The caller's routing policy (ffwm_amd/conv.py) uses it to price a call. */
+int ffwm_conv3x3_winograd_splits(int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int act);
 int ffwm_conv3x3_winograd_forward(const void* input, const void* weight, const void* bias, void* output, void* workspace,
                                   int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int data_gradient, int act,
                                   double slope, int dtype, void* stream);
@@ -422,6 +427,10 @@ int ffwm_prof_get(int row, char* name, int name_len, int64_t* launches, double* 
                   double* algorithmic_bytes);
 /* total algorithmic flops of row `row` (non-zero for the MFMA kernels: conv3x3_wgrad, correlation_colmax) */
 int ffwm_prof_get_flops(int row, double* algorithmic_flops);
+/* Sum over the row's launches of max(algorithmic bytes / 8 TB/s, algorithmic flops / 157.3 TFLOP/s), in ms: the time the BINDING
+ * roofline of each launch allows.  A scope that serves many shapes (a weight gradient from 128 x 128 planes down to 2 x 2) is
+ * MFMA-bound on some launches and weight-streaming on others; total_ms / this = how far the scope is from its own rooflines. */
+int ffwm_prof_get_bound(int row, double* roofline_ms);
 int ffwm_prof_reset(void);
 
 /* Tuning/ablation switches (bench and tests only): returns the previous value, or

@@ -1774,6 +1774,47 @@ def test_conv3x3_winograd_matches_aten(case, raw_staging):
     _lib.set_option("conv_wino_raw", 1)
 
 
+@pytest.mark.parametrize("case", [
+    # (B, C, H, W, K, expected splits of the forward without activation)
+    (8, 256, 32, 32, 256, 2),        # netG att0 / VGG19 conv3_x at batch 8: 128 pairs -> 2 x 16 chunks
+    (8, 512, 16, 16, 512, 4),        # VGG19 conv4_x: 64 pairs -> 4 x 16 chunks
+    (8, 128, 32, 32, 128, 1),        # 64 pairs but only 16 chunks: splits shorter than 16 chunks do not pay
+    (2, 256, 32, 32, 195, 2),        # a thin tail (195 = 192 + 3) beside a split body: 8 strips x 3 k tiles
+    (8, 384, 32, 32, 384, 1),        # 192 pairs: one round already, not split
+    (8, 200, 32, 32, 256, 1),        # 25 chunks: no even split
+])
+def test_conv3x3_winograd_split_reduction_matches_aten(case):
+    """Calls with few (64 tiles, 64 output channels) pairs: the reduction over the input channels is cut over 2 / 4 persistent
+    workgroups whose partial outputs meet by atomics in the zero-filled output (conv_winograd.hip, WinoGeo::CS).  Forward with and
+    without bias and the data gradient against ATen's float64 convolution, the same with the split switched off, and a call with a
+    fused activation (never split) still correct."""
+    from ffwm_amd import ops, _lib
+    B, C, H, W, K, want = case
+    assert ops.conv3x3_winograd_splits(B, C, H, W, K, 0) == want
+    assert ops.conv3x3_winograd_splits(B, C, H, W, K, 1) == 1
+    g = _gen(sum(case))
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(K, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    tol = 2e-5 * (1 + ref.abs().max().item())
+    go = torch.randn(B, K, H, W, generator=g)
+    dref = torch.nn.grad.conv2d_input((B, C, H, W), w.double(), go.double(), 1, 1)
+    for split in (1, 0):
+        _lib.set_option("conv_wino_split", split)
+        try:
+            out = torch.full((B, K, H, W), 7.0, device=DEV)            # the library zero-fills the output of a split call itself
+            assert ops.conv3x3_winograd(xd, wd, bd, out=out) is out
+            assert (out.cpu().double() - ref).abs().max().item() <= tol
+            assert (ops.conv3x3_winograd(xd, wd).cpu().double() - (ref - b.double().view(1, -1, 1, 1))).abs().max().item() <= tol
+            assert (ops.conv3x3_winograd(xd, wd, bd, act=1, slope=0.2).cpu().double() - F.leaky_relu(ref, 0.2)).abs().max().item() <= tol
+            dx = ops.conv3x3_winograd(go.to(DEV), wd, None, data_gradient=True)
+            assert (dx.cpu().double() - dref).abs().max().item() <= 2e-5 * (1 + dref.abs().max().item())
+        finally:
+            _lib.set_option("conv_wino_split", 1)
+
+
 @pytest.mark.parametrize("min_pairs", [1, 64])
 def test_winograd_routing_matches_aten_autograd(min_pairs, monkeypatch):
     """conv.route_conv_winograd: re-classed 3x3 / stride-1 Conv2d layers (forward + data gradient on csrc/conv_winograd.hip,
