@@ -24,6 +24,8 @@ _SIGNATURES = {
     "ffwm_block_extractor_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_bn_lrelu_forward": [_p] * 9 + [_i64] * 3 + [ctypes.c_double] * 3 + [_i, _p],
     "ffwm_bn_lrelu_backward": [_p] * 10 + [_i64] * 3 + [ctypes.c_double] + [_i, _p],
+    "ffwm_bn_res_act_forward": [_p] * 11 + [_i64] * 3 + [ctypes.c_double] * 3 + [_i, _i, _p],
+    "ffwm_bn_res_act_backward": [_p] * 11 + [_i64] * 3 + [ctypes.c_double] + [_i, _i, _p],
     "ffwm_mfm_forward": [_p, _p, _p] + [_i64] * 3 + [_i, _p],
     "ffwm_mfm_backward": [_p, _p, _p, _p] + [_i64] * 3 + [_i, _p],
     "ffwm_add_act_forward": [_p, _p, _p, _i64, _i, ctypes.c_double, _i, _p],

@@ -71,6 +71,11 @@ class MfmaWgradConv2d(nn.Conv2d):
 
 
 def _tiled_wgrad_layer_ok(m):
+    if m.kernel_size == (1, 1):
+        # the 1x1 shortcut of a residual block: through the vendor library its weight gradient is an NHWC implicit GEMM behind two
+        # layout transposes, a fill and a separate bias-gradient reduction (296 us at 195 -> 195, 128 x 128, batch 8); one launch here
+        return (_TILED_WGRAD and _TILED_WGRAD_1X1 and m.stride == (1, 1) and m.padding == (0, 0) and m.dilation == (1, 1) and m.groups == 1
+                and min(m.in_channels, m.out_channels) >= 32)
     return (_TILED_WGRAD and m.kernel_size in ((3, 3), (4, 4)) and m.stride in ((1, 1), (2, 2)) and m.padding[0] == m.padding[1]
             and m.padding[0] < m.kernel_size[0] and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros")
 
@@ -102,12 +107,15 @@ def route_conv_wgrad(net):
 #   * left with the vendor: image heads (<= 4 output channels) on large planes, where a 64-row MFMA tile is mostly empty.
 import os as _os1
 _TILED_WGRAD = _os1.environ.get("FFWM_TILED_WGRAD", "1") != "0"
+_TILED_WGRAD_1X1 = _os1.environ.get("FFWM_TILED_WGRAD_1X1", "1") != "0"
 
 
 def _tiled_wgrad_wins(rows, gathered, kernel):
     K, P = rows.shape[1], rows.shape[2] * rows.shape[3]
-    if not (_TILED_WGRAD and kernel in (3, 4) and ops.conv2d_wgrad_tiled_ok(rows) and gathered.numel() < (1 << 29)):
+    if not (_TILED_WGRAD and kernel in (1, 3, 4) and ops.conv2d_wgrad_tiled_ok(rows) and gathered.numel() < (1 << 29)):
         return False
+    if kernel == 1 and (min(K, gathered.shape[1]) < 32 or not _TILED_WGRAD_1X1):
+        return False             # thin 1x1 layers stay with the vendor's GEMM
     if K <= 4 and (P >= 16384 or (P >= 4096 and gathered.shape[1] >= 128)):
         return False
     return True

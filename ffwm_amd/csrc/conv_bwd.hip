@@ -383,8 +383,8 @@ extern "C" int ffwm_conv2d_wgrad(const void* rows, const void* gathered, void* g
     FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
     FFWM_REQUIRE(rows && gathered && grad_weight, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
     FFWM_REQUIRE(B > 0 && K > 0 && C > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0, FFWM_ERR_ARG, "%s: sizes must be positive", fn);
-    FFWM_REQUIRE((kernel == 3 || kernel == 4) && (stride == 1 || stride == 2) && pad >= 0 && pad < kernel, FFWM_ERR_ARG,
-                 "%s: 3x3 / 4x4 kernels with stride 1 / 2 only", fn);
+    FFWM_REQUIRE((kernel == 1 || kernel == 3 || kernel == 4) && (stride == 1 || stride == 2) && pad >= 0 && pad < kernel, FFWM_ERR_ARG,
+                 "%s: 1x1 / 3x3 / 4x4 kernels with stride 1 / 2 only", fn);
     FFWM_REQUIRE(Ho == (H + 2 * pad - kernel) / stride + 1 && Wo == (W + 2 * pad - kernel) / stride + 1, FFWM_ERR_ARG,
                  "%s: the row tensor's plane (%lld x %lld) is not the output plane of this convolution over %lld x %lld", fn,
                  (long long)Ho, (long long)Wo, (long long)H, (long long)W);
@@ -429,8 +429,8 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
     FFWM_REQUIRE(rows && gathered && grad_weight, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
     FFWM_REQUIRE(B > 0 && K > 0 && C > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0, FFWM_ERR_ARG, "%s: sizes must be positive", fn);
-    FFWM_REQUIRE((kernel == 3 || kernel == 4) && (stride == 1 || stride == 2) && pad >= 0 && pad < kernel, FFWM_ERR_ARG,
-                 "%s: 3x3 / 4x4 kernels with stride 1 / 2 only", fn);
+    FFWM_REQUIRE((kernel == 1 || kernel == 3 || kernel == 4) && (stride == 1 || stride == 2) && pad >= 0 && pad < kernel, FFWM_ERR_ARG,
+                 "%s: 1x1 / 3x3 / 4x4 kernels with stride 1 / 2 only", fn);
     FFWM_REQUIRE(Ho == (H + 2 * pad - kernel) / stride + 1 && Wo == (W + 2 * pad - kernel) / stride + 1, FFWM_ERR_ARG,
                  "%s: the row tensor's plane (%lld x %lld) is not the output plane of this convolution over %lld x %lld", fn,
                  (long long)Ho, (long long)Wo, (long long)H, (long long)W);
@@ -505,7 +505,8 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
         else FFWM_WG2(RR, 1, 1);                                                                                              \
     } while (0)
     if (kernel == 3) FFWM_WG2_K(3);
-    else FFWM_WG2_K(4);
+    else if (kernel == 4) FFWM_WG2_K(4);
+    else FFWM_WG2_K(1);          // 1x1 (the shortcut convolution of netG's residual blocks, base_networks.py:213): a plain [K x P] . [P x C] product
 #undef FFWM_WG2_K
 #undef FFWM_WG2
     return check_launch(fn);

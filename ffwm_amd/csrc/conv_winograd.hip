@@ -48,8 +48,6 @@ struct WinoGeo {
     float slope;
     unsigned x_bytes, u_bytes;
     int R, ROWS;             // raw-staged variant: tile rows per workgroup (64 / TW) and input rows it stages (2 R + 2)
-    int CS, CHS;             // raw-staged variant: the reduction cut into CS splits of CHS chunks each (CS == 1: CHS == CH); a workgroup
-                             // unit is then (strip, k tile, split) and the splits' partial outputs meet by atomics in a zero-filled output
 
 };
 
@@ -313,10 +311,15 @@ constexpr int kWinoRawFloats = 8 * 4 * 128;      // 8 channels x (2 R + 2) rows 
 // trips before the first MFMA, the epilogue, uneven dynamic distribution) next to 2.3 us per chunk: 45 % of a 64-channel
 // layer, 17 % of a 256-channel one.  Here the epilogue of a pair costs two barriers: the ph = 1 waves park their share of the
 // output transform in the operand buffers the last step just finished with.
-template <int ABL>
+// SPLIT: the variant for calls with few pairs (WinoGeo::CS > 1).  A template parameter on purpose: the kernel lives on exactly 256
+// registers, and the split's extra state (a chunk origin per load cursor) as run-time values pushed three more registers to
+// scratch in the hot loop of EVERY call (measured: 146 -> 165 us per launch over the train step's layers).
+template <int ABL, bool SPLIT = false>
 __global__ void __launch_bounds__(kWinoThreads)
 winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out,
-                         const WinoGeo g, int remap) {
+                         const WinoGeo g, int remap, int split_n, int split_chunks) {
+    // split_n / split_chunks (SPLIT only): the reduction cut into split_n pieces of split_chunks chunks each; a workgroup's unit is then
+    // (strip, k tile, piece) and the pieces' partial outputs meet by atomics in the zero-filled output
     extern __shared__ f32x4 smem[];          // operands as above (8192 f32x4), then raw[2][kWinoRawFloats]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -330,14 +333,14 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
 
     // this workgroup's pairs: [pair_begin, pair_begin + pair_cnt) of the tt-major list (the k tiles of a strip are consecutive:
     // the same CU re-reads the strip's input from L2); each XCD gets a contiguous range of the list
-    const int CS = g.CS;
+    const int CS = SPLIT ? split_n : 1;
     const int npairs = g.TT * g.KT * CS;
     const int L = static_cast<int>(xcd_remap(blockIdx.x, gridDim.x, remap));
     const int per = npairs / static_cast<int>(gridDim.x), extra = npairs - per * static_cast<int>(gridDim.x);
     const int pair_begin = L * per + min(L, extra), pair_cnt = per + (L < extra ? 1 : 0);
     const int pair_end = pair_begin + pair_cnt;
     if (pair_cnt == 0) return;
-    const int CHp = (g.CHS + 1) & ~1;        // chunks per pair, even: an odd count ends with a chunk of zeros (channels >= C read 0)
+    const int CHp = ((SPLIT ? split_chunks : g.CH) + 1) & ~1;        // chunks per pair, even: an odd count ends with a chunk of zeros (channels >= C read 0)
 
     // ---- W stage role: quads q = tid, tid + 512 of the [8 channels][ROWS][W / 4] window
     const int W4 = g.W >> 2, nquads = 8 * g.ROWS * W4;
@@ -358,28 +361,28 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     // a load cursor: the (pair, chunk) a stream of loads has reached, and what depends on the pair
     struct Cursor {
         int pair, ch;
-        int ch0;                     // first chunk of the pair's split of the reduction
-        unsigned qoff[2];            // byte offset of the quad in the first channel of chunk ch0, or kOobOff
-        unsigned u_base;             // byte offset of this thread's first U quad of chunk ch0, or kOobOff past the last pair
+        unsigned qoff[2];            // byte offset of the quad in the first channel of the pair's first chunk, or kOobOff
+        unsigned u_base;             // byte offset of this thread's first U quad of that chunk, or kOobOff past the last pair
     };
+    const int cs_shift = CS == 4 ? 2 : (CS == 2 ? 1 : 0);          // CS is 1, 2 or 4 (winograd_splits)
+    auto first_chunk = [&](int pair) { return SPLIT ? (pair & (CS - 1)) * split_chunks : 0; };     // of the pair's piece of the reduction
     auto seat = [&](Cursor& c) {
         if (c.pair >= pair_end) {
             c.qoff[0] = c.qoff[1] = kOobOff;
             c.u_base = kOobOff;
-            c.ch0 = 0;
             return;
         }
-        const int pk = c.pair / CS;
-        c.ch0 = (c.pair - pk * CS) * g.CHS;
+        const int pk = SPLIT ? c.pair >> cs_shift : c.pair;
+        const int ch0 = first_chunk(c.pair);
         const int tt = pk / g.KT, kt = pk - tt * g.KT;
         const int b = tt / strips_per_img, ty0 = (tt - b * strips_per_img) * g.R;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int iy = 2 * ty0 - 1 + qrow[i];
             const bool ok = qc[i] < 8 && iy >= 0 && iy < g.H;
-            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + 8 * c.ch0 + qc[i]) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol[i])) * 4u : kOobOff;
+            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + 8 * ch0 + qc[i]) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol[i])) * 4u : kOobOff;
         }
-        c.u_base = (static_cast<unsigned>(kt) * g.CH + c.ch0) * (kWinoChunk * 4u) + threadIdx.x * 16u;
+        c.u_base = (static_cast<unsigned>(kt) * g.CH + ch0) * (kWinoChunk * 4u) + threadIdx.x * 16u;
     };
     auto advance = [&](Cursor& c) {
         if (++c.ch == CHp) {
@@ -410,7 +413,7 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         if (!(ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const bool cin = (cr.ch0 + cr.ch) * 8 + qc[i] < g.C;
+                const bool cin = (first_chunk(cr.pair) + cr.ch) * 8 + qc[i] < g.C;
                 q[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (cin & (cr.qoff[i] != kOobOff)) ? cr.qoff[i] + static_cast<unsigned>(cr.ch) * (32u * HW) : kOobOff, 0, 0);
             }
         }
@@ -528,7 +531,7 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
             step(std::integral_constant<int, 0>());
             step(std::integral_constant<int, 1>());
         }
-        const int pk = pair / CS, csplit = pair - pk * CS;
+        const int pk = SPLIT ? pair >> cs_shift : pair, csplit = SPLIT ? pair & (CS - 1) : 0;
         const int tt = pk / g.KT, kt = pk - tt * g.KT;
         if (ph == 1) {
 #pragma unroll
@@ -563,7 +566,7 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
                     y[v] = t;
                 }
                 float* o = ob + static_cast<size_t>(k) * HW;         // W and H are even here: whole 2 x 2 tiles, 8-byte aligned pairs
-                if (CS > 1) {
+                if (SPLIT) {
                     // a split of the reduction: the output transform is linear, the splits' shares meet in the zero-filled output
                     // (the host only splits a call without an activation; the bias rides with split 0)
                     atomic_add(o, y[0]); atomic_add(o + 1, y[1]);
@@ -782,21 +785,19 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
                           g.TH % (64 / g.TW) == 0 && (2 * (64 / g.TW) + 2) * g.W * 8 <= kWinoRawFloats;
         g.R = rawv ? 64 / g.TW : 0;
         g.ROWS = 2 * g.R + 2;
-        g.CS = 1;
-        g.CHS = g.CH;
+        int split_n = 1;
         if (rawv) {
             static const int cus0 = [] {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 return n;
             }();
-            g.CS = winograd_splits(static_cast<int>(nblk), g.CH, act, cus0);
-            g.CHS = g.CH / g.CS;
+            split_n = winograd_splits(static_cast<int>(nblk), g.CH, act, cus0);
         }
         // (a split call -- zero-fill + atomics, few pairs -- is a launch configuration of its own: its own profiling scope)
-        LaunchScope ls(g.CS > 1 ? (data_gradient ? "conv_winograd_dgrad_split" : "conv_winograd_fwd_split")
+        LaunchScope ls(split_n > 1 ? (data_gradient ? "conv_winograd_dgrad_split" : "conv_winograd_fwd_split")
                                 : (data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd"), st, bytes, flops);
-        if (g.CS > 1 && hipMemsetAsync(output, 0, static_cast<size_t>(B) * K * H * W * 4, st) != hipSuccess) return FFWM_ERR_LAUNCH;
+        if (split_n > 1 && hipMemsetAsync(output, 0, static_cast<size_t>(B) * K * H * W * 4, st) != hipSuccess) return FFWM_ERR_LAUNCH;
         if (rawv) {
             auto kern = winograd_conv_raw_kernel<0>;
             switch (options().ablate) {
@@ -806,16 +807,17 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
                 case 7: kern = winograd_conv_raw_kernel<7>; break;
                 default: break;
             }
+            if (split_n > 1) kern = winograd_conv_raw_kernel<0, true>;
             allow_large_lds(reinterpret_cast<const void*>(kern));
             static const int cus = [] {
                 int dev = 0, n = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 return n;
             }();
-            const unsigned units = nblk * static_cast<unsigned>(g.CS);
+            const unsigned units = nblk * static_cast<unsigned>(split_n);
             const unsigned pgrid = units < static_cast<unsigned>(cus) ? units : static_cast<unsigned>(cus);     // persistent: one workgroup per CU
             hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kWinoThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st, static_cast<const float*>(input), U,
-                               static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
+                               static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap, split_n, g.CH / split_n);
             const int rc = check_launch(fn);
             if (rc || !thin) return rc;
         } else {

@@ -89,6 +89,79 @@ class _BnLreluFunction(Function):
         return dx, dw, db, None, None, None, None, None
 
 
+def _launch_act(fn_name, x, act, *args):
+    dev = x.device.index
+    cur = torch.cuda.current_device()
+    if cur != dev:
+        torch.cuda.set_device(dev)
+    try:
+        fn = getattr(_lib.load(), fn_name)
+        _lib.check(fn(*args, int(act), _lib.F32, torch.cuda.current_stream(dev).cuda_stream), fn_name)
+    finally:
+        if cur != dev:
+            torch.cuda.set_device(cur)
+
+
+class _BnResActFunction(Function):
+    """y = act(BatchNorm_train(x) + res + rbias[c]): the tail of a residual block (csrc/bn_lrelu.hip, RES variant)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, rbias, eps, momentum, slope, act):
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        save_invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        scratch = _scratch(x)
+        _launch_act("ffwm_bn_res_act_forward", x, act, _p(x), _p(weight), _p(bias), _p(running_mean), _p(running_var), _p(res), _p(rbias),
+                    _p(y), _p(save_mean), _p(save_invstd), _p(scratch), B, C, H * W, float(eps), float(momentum), float(slope))
+        ctx.save_for_backward(x, weight, save_mean, save_invstd, y)
+        ctx.slope, ctx.act = float(slope), int(act)
+        ctx.has_bias, ctx.has_rbias = bias is not None, rbias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_y):
+        x, weight, save_mean, save_invstd, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        go = grad_y.contiguous()
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dres = torch.empty_like(x) if need[5] else None
+        dw = torch.empty(C, device=x.device, dtype=torch.float32) if (need[1] and weight is not None) else None
+        want_db = (need[2] and ctx.has_bias) or (need[6] and ctx.has_rbias)
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if want_db else None
+        scratch = _scratch(x)
+        _launch_act("ffwm_bn_res_act_backward", x, ctx.act, _p(x), _p(y), _p(go), _p(weight), _p(save_mean), _p(save_invstd), _p(dx), _p(dres),
+                    _p(dw), _p(db), _p(scratch), B, C, H * W, ctx.slope)
+        return (dx, dw, db if (need[2] and ctx.has_bias) else None, None, None, dres, db if (need[6] and ctx.has_rbias) else None,
+                None, None, None, None)
+
+
+RES_ACTS = {"lrelu": 0, "sigmoid": 1}
+_BN_RES = os.environ.get("FFWM_BN_RES_ACT", "1") != "0"
+
+
+def bn_res_act_ok(bn, x, act_code):
+    """The fused tail serves: a training-mode BatchNorm2d with a fixed momentum on a contiguous float32 GPU tensor, LeakyReLU / sigmoid."""
+    return (_BN_RES and act_code is not None and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.momentum is not None and torch.is_tensor(x)
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() // x.shape[1] > 1 and not torch.is_autocast_enabled()
+            and (bn.weight is None or bn.weight.dtype == torch.float32))
+
+
+def bn_res_act(x, bn, res, rbias, act_code, slope):
+    """act(bn(x) + res + rbias) with bn in training mode: one kernel per direction; the batch counter is kept on the host like the
+    other fused BatchNorm modules do (norm._bn_host_counted)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if hasattr(bn, "flush_batch_counter"):
+            bn._pending_batches += 1
+        else:
+            bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BnResActFunction.apply(x.contiguous(), bn.weight, bn.bias, rm, rv, res.contiguous(), rbias, bn.eps, bn.momentum, slope, act_code)
+
+
 # Below this many elements a BatchNorm + LeakyReLU pair is launch-bound either way and the two native ops cost
 # less host time than one Python autograd Function; above it the saved read-modify-write passes win.
 MIN_FUSED_NUMEL = 1 << 20

@@ -300,6 +300,23 @@ int ffwm_bn_lrelu_backward(const void* x, const void* grad_out, const void* weig
                            void* grad_bias, void* scratch, int64_t B, int64_t C, int64_t HW, double negative_slope,
                            int dtype, void* stream);
 
+/* The tail of a residual block, activ(blocks(x) + input(x)) with blocks ending in a training-mode BatchNorm2d and input = a 1x1
+ * convolution (models/base_networks.py:207-233), as one kernel per direction: y = act(BatchNorm(x) + res + rbias[c]) where res is the
+ * shortcut convolution's output WITHOUT its bias and rbias that bias (NULL: none); act 0 = LeakyReLU(negative_slope), 1 = sigmoid.
+ * Statistics, running buffers, save_mean / save_invstd and scratch as in ffwm_bn_lrelu_forward.  Replaces, per block and direction,
+ * the library's BatchNorm kernel, the GEMM path's separate bias add and the add + activation pass. */
+int ffwm_bn_res_act_forward(const void* x, const void* weight, const void* bias, void* running_mean, void* running_var,
+                            const void* res, const void* rbias, void* y, void* save_mean, void* save_invstd, void* scratch,
+                            int64_t B, int64_t C, int64_t HW, double eps, double momentum, double negative_slope, int act,
+                            int dtype, void* stream);
+/* grad_res = grad_out * act'(.) (taken from the saved output y; also the gradient of `input(x)`), grad_x = BatchNorm backward of
+ * it, grad_weight / grad_bias = the BatchNorm's affine gradients (grad_bias is the gradient of rbias too).  grad_x, grad_res,
+ * grad_weight, grad_bias may be NULL. */
+int ffwm_bn_res_act_backward(const void* x, const void* y, const void* grad_out, const void* weight, const void* save_mean,
+                             const void* save_invstd, void* grad_x, void* grad_res, void* grad_weight, void* grad_bias,
+                             void* scratch, int64_t B, int64_t C, int64_t HW, double negative_slope, int act, int dtype,
+                             void* stream);
+
 /* LightCNN's max-feature-map activation (lightcnn/light_cnn.py `mfm.forward`: torch.split + torch.max):
  * y[B,C,HW] = max(x[B,0:C,HW] + bias[0:C], x[B,C:2C,HW] + bias[C:2C]); bias [2C] or NULL (the bias of the layer in front,
  * folded in: bit-identical to adding it first); backward grad_x[B,2C,HW] (overwritten) with ATen's tie rule for

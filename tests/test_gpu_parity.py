@@ -1009,6 +1009,73 @@ def test_sigmoid_gate_equals_the_pytorch_composition():
     assert fuse_residual(net) == 3 and net.fuse_gate
 
 
+@pytest.mark.parametrize("case", [
+    # (B, C, H, W, activation, spectral norm)
+    (8, 195, 64, 64, "lrelu", True),       # dres1 of netG: the split-channel statistics path (scratch)
+    (2, 64, 128, 128, "lrelu", True), (3, 70, 9, 11, "lrelu", False), (2, 130, 16, 16, "sigmoid", True), (4, 600, 4, 4, "lrelu", False),
+])
+def test_residual_block_fused_tail_matches_the_composition(case):
+    """nets.FusedResidualBlock in training mode: the last BatchNorm2d of `blocks`, the shortcut's bias, the add and the activation
+    as one kernel per direction (norm.bn_res_act, csrc/bn_lrelu.hip RES variant) against the same block evaluated as the PyTorch
+    composition activ(blocks(x) + input(x)) (base_networks.py:207-233): output, running statistics, batch counter, d(x) and every
+    parameter gradient; eval mode and no_grad take the unfused path and agree as well."""
+    import copy
+    import torch.nn as nn
+    from ffwm_amd import _lib, nets
+    from ffwm_amd.residual import fuse_residual
+    from ffwm_amd.spectral_norm import fuse_spectral_norm
+
+    def _launch_counts(fn):
+        torch.cuda.synchronize()
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        try:
+            out = fn()
+            torch.cuda.synchronize()
+        finally:
+            _lib.prof_enable(False)
+        return out, {k: v["launches"] for k, v in _lib.prof_collect().items()}
+    B, C, H, W, act, sn = case
+    torch.manual_seed(sum(case[:4]))
+    ref = nn.Sequential(nets.ResidualBlock(C, activ=act, sn=sn)).to(DEV).train()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    own = copy.deepcopy(ref)
+    assert fuse_residual(own) == 1
+    if sn:
+        fuse_spectral_norm(ref)
+        fuse_spectral_norm(own)
+    x = torch.randn(B, C, H, W, generator=_gen(5)).to(DEV)
+    go = torch.randn(B, C, H, W, generator=_gen(6)).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = ref(xa)
+    yb, launches = _launch_counts(lambda: own(xb))
+    assert launches.get("bn_res_act_fwd", 0) == 1, launches
+    assert (ya - yb).abs().max().item() <= 2e-5 * (1 + ya.abs().max().item())
+    ya.backward(go)
+    _, launches = _launch_counts(lambda: yb.backward(go))
+    assert launches.get("bn_res_act_bwd", 0) == 1, launches
+    assert (xa.grad - xb.grad).abs().max().item() <= 1e-4 * (1 + xa.grad.abs().max().item())
+    # (the bias of a convolution in front of a BatchNorm has a gradient of exactly zero: both sides hold the rounding noise of a sum
+    # over B * H * W values, hence the absolute term)
+    noise = 2e-6 * (B * H * W) ** 0.5 * go.abs().max().item()
+    for (n, p), (_, q) in zip(ref.named_parameters(), own.named_parameters()):
+        assert q.grad is not None and (p.grad - q.grad).abs().max().item() <= 1e-4 * (1 + p.grad.abs().max().item()) + noise, n
+    sa, sb = ref.state_dict(), own.state_dict()
+    for k in sa:
+        if "running" in k:
+            assert (sa[k] - sb[k]).abs().max().item() <= 1e-5 * (1 + sa[k].abs().max().item()), k
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]) == 1, k
+    ref.eval()
+    own.eval()
+    with torch.no_grad():
+        assert (ref(x) - own(x)).abs().max().item() <= 2e-5 * (1 + ref(x).abs().max().item())
+
+
 # ------------------------------------------------------------------------- guided filter
 GF_CASES = [
     # (B, C, H, W, r, seed)
@@ -1706,6 +1773,9 @@ def test_conv2d_wgrad_generic_matches_aten(case):
     (8, 1024, 2, 2, 1024, 3, 1, 1, False), (8, 18, 128, 128, 16, 3, 1, 1, False), (8, 16, 128, 128, 2, 3, 1, 1, False),
     (5, 130, 12, 20, 66, 3, 1, 1, False), (8, 64, 64, 64, 128, 3, 1, 1, False), (8, 2, 16, 16, 2, 4, 2, 1, True),
     (8, 256, 32, 32, 256, 3, 1, 1, False), (8, 128, 32, 32, 256, 4, 2, 1, False),
+    # 1x1 / stride 1 / pad 0: the shortcut convolutions of netG's residual blocks (base_networks.py:213)
+    (8, 195, 64, 64, 195, 1, 1, 0, False), (2, 128, 128, 128, 128, 1, 1, 0, False), (3, 70, 10, 12, 130, 1, 1, 0, False),
+    (8, 256, 16, 16, 256, 1, 1, 0, False),
 ])
 def test_conv2d_wgrad_tiled_matches_aten(case):
     """csrc/conv_bwd.hip, tiled variant, against ATen's float64 convolution_backward: Conv2d (with the fused bias gradient) and
