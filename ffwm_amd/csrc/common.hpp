@@ -39,6 +39,7 @@ struct Options {
     int conv_wino_split = 1;   // conv_winograd.hip: cut the reduction of a call with few (strip, k tile) pairs over 2 / 4 workgroups (atomics into a zeroed output)
     int conv_thin_tail = 1;    // conv_winograd.hip: 1-4 output channels past a multiple of 64 on the thin direct kernel
     int warp_nt = 0;          // warp forward (direct / multi-problem kernels): 1 = streaming (nt) stores, 2 = nt feature loads too
+    int warp_pair_loads = 1;  // warp d(flow), multi-problem launch, fp32: one 8-byte load per corner ROW instead of two dword gathers
     int conv_wgrad_wino = 0;   // conv_wgrad.hip, the full 64-channel tiles on the Winograd-domain kernel (conv_wgrad_wino.hip): 0 = auto (>= 16 chunks per CU), 1 = whenever served, 2 = never
     int warp_multi_planes = 0; // multi-problem warp backward: 0 = d(feat) plane problems of one CG share a launch, 1 = one launch per problem
     int warp_multi_lds = 0;   // multi-problem warp launches: 0 = auto (LDS-staged tiles for float planes >= 64 x 64, C >= 32), 1 = direct gathers, 2 = LDS tiles

@@ -244,6 +244,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "be_bwd_halo")) slot = &o.be_bwd_halo;
     else if (!strcmp(key, "warp_fwd_variant")) slot = &o.warp_fwd_variant;
     else if (!strcmp(key, "warp_nt")) slot = &o.warp_nt;
+    else if (!strcmp(key, "warp_pair_loads")) slot = &o.warp_pair_loads;
     else if (!strcmp(key, "warp_multi_lds")) slot = &o.warp_multi_lds;
     else if (!strcmp(key, "warp_multi_planes")) slot = &o.warp_multi_planes;
     else if (!strcmp(key, "conv_wgrad_wino")) slot = &o.conv_wgrad_wino;

@@ -614,7 +614,7 @@ warp_bwd_flow_lds_kernel(const float* __restrict__ feat, const float* __restrict
 template <typename T, bool FLIP>
 __device__ __forceinline__ void warp_bwd_body(const T* __restrict__ feat, const T* __restrict__ flow, const T* __restrict__ gout,
                                               T* __restrict__ gfeat, T* __restrict__ gflow, int C, int Hi, int Wi, int H, int W,
-                                              const TileCoord tc, int cs) {
+                                              const TileCoord tc, int cs, bool pair_loads = false) {
     const int x = tc.xf, y = tc.yf;
     if (x >= W || y >= H) return;
     const size_t plane = static_cast<size_t>(H) * W;
@@ -635,6 +635,7 @@ __device__ __forceinline__ void warp_bwd_body(const T* __restrict__ feat, const 
     const unsigned o_direct = static_cast<unsigned>(y * W + x) * static_cast<unsigned>(sizeof(T));
     const unsigned o_flip = static_cast<unsigned>(y * W + (W - 1 - x)) * static_cast<unsigned>(sizeof(T));
     const size_t flip_planes = static_cast<size_t>(C) * plane;
+    const bool options_pair_loads = pair_loads;
     T gix = 0, giy = 0;
 
     auto one = [&](const T g, const T s0, const T s1, const T s2, const T s3) {
@@ -649,6 +650,35 @@ __device__ __forceinline__ void warp_bwd_body(const T* __restrict__ feat, const 
         giy += s3 * cn.dxw[1] * g;
     };
     int c = c0;
+    if constexpr (sizeof(T) == 4) {
+        if (!gp && gflow && options_pair_loads) {
+            // d(flow) alone, fp32: the two corners of a row are neighbours in memory, so ONE 8-byte load per row replaces two dword
+            // gathers (4 instead of 6 vector memory instructions per pixel and channel) wherever, for every lane of the wave, a row
+            // is either inside the image with both corners or outside with both (a lane at the left / right border has half a
+            // row: its wave takes the dword path below)
+            const bool top_pair = cn.valid[0] && cn.valid[1], bot_pair = cn.valid[2] && cn.valid[3];
+            const bool whole = (top_pair || !(cn.valid[0] || cn.valid[1])) && (bot_pair || !(cn.valid[2] || cn.valid[3]));
+            if (__all(whole)) {
+                const unsigned ot = top_pair ? cn.off[0] : kOob, ob = bot_pair ? cn.off[2] : kOob;
+                constexpr int U = 4;
+                for (; c + U <= c1; c += U, fp += U * iplane, op += U * plane) {
+                    T g[U];
+                    u32x2 st[U], sb[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        g[u] = buf_ld<T>(make_rsrc(op + u * plane, obytes), o_direct);
+                        if (FLIP) g[u] += buf_ld<T>(make_rsrc(op + u * plane + flip_planes, obytes), o_flip);
+                        const rsrc_t rf = make_rsrc(fp + u * iplane, ibytes);
+                        st[u] = __builtin_amdgcn_raw_buffer_load_b64(rf, ot, 0, 0);
+                        sb[u] = __builtin_amdgcn_raw_buffer_load_b64(rf, ob, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        one(g[u], __uint_as_float(st[u].x), __uint_as_float(st[u].y), __uint_as_float(sb[u].x), __uint_as_float(sb[u].y));
+                }
+            }
+        }
+    }
     if (!gp && gflow) {
         // d(flow) alone (the plane / tile kernels took d(feat)): four channels per trip, their 24 loads in flight together
         constexpr int U = 4;
@@ -739,7 +769,7 @@ warp_bwd_flow_multi_kernel(const WarpTable tab) {
     const unsigned t = xcd_remap(blockIdx.x - q.begin, (q.nblk + 7u) & ~7u, 1);
     if (t >= q.nblk) return;
     warp_bwd_body<T, FLIP>(static_cast<const T*>(q.feat), static_cast<const T*>(q.flow), static_cast<const T*>(q.gout), nullptr,
-                           static_cast<T*>(q.out), q.C, q.Hi, q.Wi, q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs);
+                           static_cast<T*>(q.out), q.C, q.Hi, q.Wi, q.H, q.W, decode_tile_local(t, q.tiles_x, q.tiles_y, q.cslabs), q.cs, tab.nt != 0);
 }
 
 // d(feat) without contended global atomics: a block owns `cg` whole (b, c) planes of grad_feat in LDS.
@@ -1339,7 +1369,7 @@ int launch_bwd_multi(const ffwm_warp_problem* probs, int n, int flip, hipStream_
     // d(flow): every problem that wants it, one launch
     WarpTable tab;
     tab.n = 0;
-    tab.nt = 0;
+    tab.nt = options().warp_pair_loads;            // (the backward has no stores to stream: the field carries the pair-load switch)
     unsigned blocks = 0;
     double bytes = 0;
     auto flush = [&]() -> int {
