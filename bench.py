@@ -69,7 +69,8 @@ def _slim_roofline(r):
     if not isinstance(r, dict):
         return r
     keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_us", "launches", "alg_MB_per_launch",
-            "alg_GFLOP_per_launch", "frac_binding_roofline", "warp_kernels_GBps", "warp_kernels_frac_hbm_peak")
+            "alg_GFLOP_per_launch", "frac_binding_roofline", "warp_kernels_GBps", "warp_kernels_frac_hbm_peak", "copy_same_bytes_us",
+            "copy_same_bytes_frac_cold")
     return {k: r[k] for k in keep if k in r}
 
 
@@ -846,6 +847,34 @@ def main():
             result["roofline"] = roofline_row(max(hot, key=lambda r: r["alg_MB"] * r["launches"]), "hbm")
             result["roofline"].update(hot_rows_summary(inrun))
             result["roofline"].pop("kernels", None)
+            try:
+                # context for a launch of this SIZE: torch's copy_ moving the same number of bytes (half read, half written), timed the
+                # same way on warm caches and after a 1 GiB fill (the cache state an in-step launch finds) -- tools/stream_probe.py
+                nbytes = int(result["roofline"]["alg_MB_per_launch"] * 1e6)
+                src = torch.rand(nbytes // 8, device=dev)
+                dst = torch.empty_like(src)
+                big = torch.empty(256 << 20, device=dev)
+
+                def copy_us(cold, n=8):
+                    dst.copy_(src)
+                    torch.cuda.synchronize()
+                    tot = 0.0
+                    for _ in range(n):
+                        if cold:
+                            big.fill_(1.0)
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record()
+                        dst.copy_(src)
+                        b.record()
+                        torch.cuda.synchronize()
+                        tot += a.elapsed_time(b)
+                    return tot / n * 1e3
+                warm, cold = copy_us(False), copy_us(True)
+                result["roofline"]["copy_same_bytes_us"] = {"warm": round(warm, 1), "cold": round(cold, 1)}
+                result["roofline"]["copy_same_bytes_frac_cold"] = round(nbytes / (cold * 1e-6) / HBM_PEAK, 4)
+                del src, dst, big
+            except Exception as e:
+                result["roofline"]["copy_same_bytes_us"] = {"error": repr(e)}
         elif other_hbm:
             result["roofline"] = roofline_row(max(other_hbm, key=lambda r: r["alg_MB"] * r["launches"]), "hbm")
         else:
