@@ -430,10 +430,12 @@ class FFWMTrainer(object):
     def forward(self, b):
         img_S, img_F = b["img_S"], b["img_F"]
         self._tgt = {}
-        if self.flow_stream is not None and self._event_joins and not self.segmented and not self.dp_active:
-            # One GPU, one graph: the side branches are joined by EVENTS, not whole-stream waits, so that more work can follow on a side
-            # stream behind the point the step's stream waits for (the ground-truth passes below), and the two flow nets' BACKWARD
-            # passes are paired at the tail of the step (the gates).
+        if (self.flow_stream is not None and self._event_joins and not self.segmented
+                and (not self.dp_active or getattr(self, "capture_mode", None) == "ingraph")):
+            # ONE graph (one GPU, or several ranks with the collectives captured inside it -- the three-graph split must find every side
+            # stream joined where a graph ends): the side branches are joined by EVENTS, not whole-stream waits, so that more work can
+            # follow on a side stream behind the point the step's stream waits for (the ground-truth passes below), and the two flow
+            # nets' BACKWARD passes can be paired at the tail of the step (the gates, opt-in).
             cur = torch.cuda.current_stream(self.device)
             box = {}
             self.flow_stream.wait_stream(cur)                  # fork: img_S and last step's weights are ready
