@@ -64,6 +64,7 @@ _SIGNATURES = {
     "ffwm_correlation_colmax": [_p, _p, _p, _i64, _i64, _i64, _i, _p],
     "ffwm_guided_filter_backward": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
     "ffwm_l1_multi": [_p, _i, _p, _p, _i, _i, _p],          # (array of ffwm_l1_problem, n, out, grad_out, n_slots, dtype, stream)
+    "ffwm_conv3x3_winograd_weights_multi": [_p, _i, _i, _p],      # (array of ffwm_wino_weights, n, dtype, stream)
     "ffwm_prof_enable": [_i],
     "ffwm_prof_collect": [],
     "ffwm_prof_get": [_i, ctypes.c_char_p, _i, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double),

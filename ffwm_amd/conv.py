@@ -193,19 +193,41 @@ def winograd_ok(x, weight, act=0):
     return winograd_dirs(x, weight, act)[0]
 
 
+# Weight transforms prepared ahead of the calls.  A producer that knows every weight of a network at once (the batched spectral norm)
+# tags each product with its layer (`_ffwm_wino_owner`) and, from the second forward on, with the transforms the layer's calls used
+# last time (`_ffwm_wino`: {(data_gradient, W % 4 == 0): workspace}, all of a network's in one launch:
+# ops.conv3x3_winograd_weights_multi).  A call notes what it uses on the owner and takes its transform from the dict.
+_WINO_BATCH = _os.environ.get("FFWM_WINO_BATCH", "1") != "0"
+
+
+def _note_winograd_use(weight, x, dirs, need_dgrad):
+    owner = getattr(weight, "_ffwm_wino_owner", None)
+    if owner is None or not _WINO_BATCH:
+        return None
+    keys = owner.__dict__.setdefault("_wino_keys", set())
+    wm4 = x.shape[3] % 4 == 0
+    if dirs[0]:
+        keys.add((0, wm4))
+    if dirs[1] and need_dgrad:
+        keys.add((1, wm4))
+    return getattr(weight, "_ffwm_wino", None)
+
+
 class _WinogradConv3x3(Function):
     """Conv2d(C, K, 3, 1, 1): forward and d(input) on csrc/conv_winograd.hip, d(weight) on csrc/conv_wgrad.hip where that
     kernel serves the shape (wgrad_route_ok), else the vendor's."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, frozen=None, dirs=(True, True)):
+        pre = _note_winograd_use(weight, x, dirs, ctx.needs_input_grad[0])          # transforms prepared with the weights (spectral_norm.SpectralNormGroup), or None
         x, weight = x.contiguous(), weight.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.frozen = frozen
         ctx.own_dgrad = dirs[1]
+        ctx.wino_pre = pre
         if dirs[0]:
-            return ops.conv3x3_winograd(x, weight, bias, frozen=frozen)
+            return ops.conv3x3_winograd(x, weight, bias, frozen=frozen, pre=pre)
         return torch.ops.aten.convolution(x, weight, bias, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
 
     @staticmethod
@@ -216,7 +238,7 @@ class _WinogradConv3x3(Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         gx = gw = gb = None
         if need_x and ctx.own_dgrad:
-            gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True, frozen=ctx.frozen)
+            gx = ops.conv3x3_winograd(go, weight, None, data_gradient=True, frozen=ctx.frozen, pre=ctx.wino_pre)
         elif need_x:
             gx = torch.ops.aten.convolution_backward(go, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
         if need_w:
@@ -294,7 +316,8 @@ class WinogradConv2d(MfmaWgradConv2d):
             cache = frozen_cache(self, weight) if weight is self._parameters.get("weight") else None
             if grad:
                 return _WinogradConv3x3.apply(input, weight, bias, cache, dirs)
-            return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=cache)
+            return ops.conv3x3_winograd(input.contiguous(), weight.contiguous(), bias, frozen=cache,
+                                        pre=_note_winograd_use(weight, input, (True, False), False))
         if self.__dict__.get("_mfma_fwd_small") and fwd_route_ok(input, weight) and input.size(2) <= 32:
             return _MfmaConv2d.apply(input, weight, bias, 1, 1)          # small planes: the direct MFMA kernel (route_conv_fwd)
         return super()._conv_forward(input, weight, bias)

@@ -53,10 +53,9 @@ struct WinoGeo {
 
 // U[kt][ch][p][h][k64][c4] = (G w Gt)[p] of output channel kt * 64 + k64 and input channel ch * 8 + 4 h + c4; zero outside
 // K x C.  mode 0: w is [K][C][3][3]; mode 1 (data gradient): w is the layer's own [C][K][3][3], used transposed and flipped.
-__global__ void __launch_bounds__(kBlock)
-winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int Kw, int C, int CH, int KT, int mode, int tail) {
+__device__ __forceinline__ void winograd_weights_elem(const float* __restrict__ w, float* __restrict__ U, int K, int Kw, int C, int CH, int KT,
+                                                      int mode, int tail, int e) {
     const int Cp = CH * 8;
-    const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= KT * 64 * Cp) {
         // the thin tail's weights (output channels K .. K + tail): Wt[c][36] = (k, tap) -> w, rotated for the data gradient,
         // in the slot of the k tile the Winograd kernel no longer computes
@@ -101,6 +100,36 @@ winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int 
         dst[(i * 4 + 2) * 512] = u2;
         dst[(i * 4 + 3) * 512] = u3;
     }
+}
+
+__global__ void __launch_bounds__(kBlock)
+winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int Kw, int C, int CH, int KT, int mode, int tail) {
+    winograd_weights_elem(w, U, K, Kw, C, CH, KT, mode, tail, blockIdx.x * kBlock + threadIdx.x);
+}
+
+// The transforms of SEVERAL layers in one launch (ffwm_conv3x3_winograd_weights_multi): the weights of a spectrally normalised
+// network are all known once its batched normalisation has run, so the ~45 per-call transform launches of netG's forward and data
+// gradient (6 us each, every one in front of the convolution that needs it) become two or three launches at the start of the pass.
+constexpr int kWinoMaxMulti = 24;
+struct WinoWeightsItem {
+    const float* w;
+    float* U;
+    int K, Kw, C, CH, KT, mode, tail;
+    int begin;               // first workgroup of this item
+};
+struct WinoWeightsTable {
+    int n;
+    WinoWeightsItem it[kWinoMaxMulti];
+};
+
+__global__ void __launch_bounds__(kBlock)
+winograd_weights_multi_kernel(const WinoWeightsTable tab) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kWinoMaxMulti; ++k)
+        if (k < tab.n && static_cast<int>(blockIdx.x) >= tab.it[k].begin) i = k;
+    const WinoWeightsItem& q = tab.it[i];
+    winograd_weights_elem(q.w, q.U, q.K, q.Kw, q.C, q.CH, q.KT, q.mode, q.tail, (static_cast<int>(blockIdx.x) - q.begin) * kBlock + threadIdx.x);
 }
 
 constexpr int kWinoThreads = 512;        // 8 waves: two per SIMD, 128 accumulator + <= 128 other registers each
@@ -340,7 +369,12 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     const int pair_begin = L * per + min(L, extra), pair_cnt = per + (L < extra ? 1 : 0);
     const int pair_end = pair_begin + pair_cnt;
     if (pair_cnt == 0) return;
-    const int CHp = ((SPLIT ? split_chunks : g.CH) + 1) & ~1;        // chunks per pair, even: an odd count ends with a chunk of zeros (channels >= C read 0)
+    const int CHn = SPLIT ? split_chunks : g.CH;                     // chunks per pair
+    // ... rounded up to even: an odd count ends with a chunk of zeros -- input channels >= C read 0 through the range check, and the
+    // U loads of that chunk are sent out of range too: they would fetch the NEXT k tile's first chunk or, behind the last k tile,
+    // whatever lies in the workspace past the transformed weights -- and 0 x NaN from recycled memory is NaN (found in round 4 with a
+    // NaN-poisoned allocator: every 195-channel layer, 25 chunks)
+    const int CHp = (CHn + 1) & ~1;
 
     // ---- W stage role: quads q = tid, tid + 512 of the [8 channels][ROWS][W / 4] window
     const int W4 = g.W >> 2, nquads = 8 * g.ROWS * W4;
@@ -429,7 +463,7 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         if (!(ABL & 2)) {
 #pragma unroll
             for (int i = 2 * s; i < 2 * s + 2; ++i)
-                u[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, cu.u_base != kOobOff ? cu.u_base + static_cast<unsigned>(cu.ch) * (kWinoChunk * 4u) + i * 8192u : kOobOff, 0, 0);
+                u[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, (cu.u_base != kOobOff && cu.ch < CHn) ? cu.u_base + static_cast<unsigned>(cu.ch) * (kWinoChunk * 4u) + i * 8192u : kOobOff, 0, 0);
         }
         if (s == 1) advance(cu);
     };
@@ -731,6 +765,53 @@ extern "C" int ffwm_conv3x3_winograd_splits(int64_t B, int64_t C, int64_t H, int
 extern "C" int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C) {
     if (K <= 0 || C <= 0) return 0;
     return ((K + 63) / 64) * ((C + 7) / 8) * static_cast<int64_t>(kWinoChunk) * 4;
+}
+
+extern "C" int ffwm_conv3x3_winograd_weights_multi(const ffwm_wino_weights* items, int n, int dtype, void* stream) {
+    const char* fn = "ffwm_conv3x3_winograd_weights_multi";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(items || n == 0, FFWM_ERR_ARG, "%s: NULL item array", fn);
+    FFWM_REQUIRE(n >= 0 && n <= 4096, FFWM_ERR_ARG, "%s: 0 .. 4096 items", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WinoWeightsTable tab;
+    tab.n = 0;
+    int blocks = 0;
+    double bytes = 0;
+    auto flush = [&]() -> int {
+        if (tab.n == 0) return FFWM_OK;
+        {
+            LaunchScope ls("conv_winograd_weights_multi", st, bytes);
+            hipLaunchKernelGGL(winograd_weights_multi_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, st, tab);
+        }
+        tab.n = 0; blocks = 0; bytes = 0;
+        return check_launch(fn);
+    };
+    for (int i = 0; i < n; ++i) {
+        const ffwm_wino_weights& w = items[i];
+        FFWM_REQUIRE(w.weight && w.workspace && w.K > 0 && w.C > 0 && (w.data_gradient == 0 || w.data_gradient == 1), FFWM_ERR_ARG,
+                     "%s: item %d: NULL pointer, non-positive size or data_gradient not 0 / 1", fn, i);
+        FFWM_REQUIRE(ffwm_conv3x3_winograd_workspace_bytes(w.K, w.C) < (1LL << 31), FFWM_ERR_SIZE, "%s: item %d: workspace beyond 2 GiB", fn, i);
+        // the same split of the output channels as ffwm_conv3x3_winograd_forward makes for this (K, W % 4)
+        const int tail = static_cast<int>(w.K % 64);
+        const bool thin = (w.K > 64 || w.K <= 4) && tail >= 1 && tail <= 4 && w.width_multiple_of_4 && options().conv_thin_tail;
+        WinoWeightsItem& q = tab.it[tab.n];
+        q.w = static_cast<const float*>(w.weight);
+        q.U = static_cast<float*>(w.workspace);
+        q.K = static_cast<int>(thin ? w.K - tail : w.K);
+        q.Kw = static_cast<int>(w.K);
+        q.C = static_cast<int>(w.C);
+        q.CH = (q.C + 7) / 8;
+        q.KT = (q.K + 63) / 64;
+        q.mode = w.data_gradient;
+        q.tail = thin ? tail : 0;
+        q.begin = blocks;
+        const int64_t elems = static_cast<int64_t>(q.KT) * 64 * q.CH * 8 + (thin ? w.C * kThinStride : 0);
+        blocks += static_cast<int>((elems + kBlock - 1) / kBlock);
+        bytes += 4.0 * (9.0 * w.K * w.C + 16.0 * elems);
+        if (++tab.n == kWinoMaxMulti)
+            if (int rc = flush()) return rc;
+    }
+    return flush();
 }
 
 extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weight, const void* bias, void* output, void* workspace,

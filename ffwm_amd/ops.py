@@ -469,7 +469,7 @@ def conv2d_wgrad_tiled(rows, gathered, kernel, stride, pad, want_bias=False):
     return gw, gb
 
 
-def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0, out=None, frozen=None):
+def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0, out=None, frozen=None, pre=None):
     """Conv2d(C, K, 3, 1, 1) forward (weight [K, C, 3, 3]) or its data gradient (x = grad_output [B, K_layer, H, W], weight =
     the layer's own [K_layer, C_layer, 3, 3]; returns [B, C_layer, H, W]) by fp32 Winograd F(2x2, 3x3) on the MFMA units
     (csrc/conv_winograd.hip).  act = 1 applies LeakyReLU(slope) after the bias (slope 0 = ReLU).  frozen: a dict OWNED BY THE
@@ -496,7 +496,14 @@ def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0
     lib = _lib.load()
     mode = int(bool(data_gradient))
     ws = None
-    if frozen is not None and frozen is not False:
+    if pre is not None:
+        # transformed weights prepared beforehand for exactly this weight tensor, direction and width class (a dict the producer of
+        # the weights attached to them: conv3x3_winograd_weights_multi)
+        ws = pre.get((mode, W % 4 == 0))
+        if ws is not None:
+            mode |= 2
+            frozen = None
+    if ws is None and frozen is not None and frozen is not False:
         key = (mode, W % 4 == 0, weight._version, weight.data_ptr())
         ws = frozen.get(key)
         if ws is not None:
@@ -516,6 +523,33 @@ def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0
         # a transform that was just written into a layer's cache may be picked up by a call on ANOTHER stream (the trainer runs the
         # loss networks' passes on side streams): make it visible to every stream, once per frozen layer
         torch.cuda.current_stream(x.device).synchronize()
+    return out
+
+
+class _WinoWeightsItem(ctypes.Structure):
+    _fields_ = [("weight", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("K", ctypes.c_int64), ("C", ctypes.c_int64),
+                ("data_gradient", ctypes.c_int), ("width_multiple_of_4", ctypes.c_int)]
+
+
+def conv3x3_winograd_weights_multi(items):
+    """items: [(weight [Kl, Cl, 3, 3], data_gradient, width_multiple_of_4), ...] -> the transformed weights of every item (one
+    tensor each, what conv3x3_winograd(..., pre=...) takes), all from ONE launch per 24 items (ffwm_conv3x3_winograd_weights_multi)."""
+    if not items:
+        return []
+    lib = _lib.load()
+    w0 = items[0][0]
+    arr = (_WinoWeightsItem * len(items))()
+    out = []
+    for a, (w, dg, wm4) in zip(arr, items):
+        if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and w.device == w0.device):
+            raise ValueError("conv3x3_winograd_weights_multi: contiguous float32 [K, C, 3, 3] weights on one GPU")
+        K, C = (w.shape[1], w.shape[0]) if dg else (w.shape[0], w.shape[1])
+        ws = w.new_empty((lib.ffwm_conv3x3_winograd_workspace_bytes(K, C) // 4,))
+        a.weight, a.workspace, a.K, a.C, a.data_gradient, a.width_multiple_of_4 = w.data_ptr(), ws.data_ptr(), K, C, int(bool(dg)), int(bool(wm4))
+        out.append(ws)
+    with _on_device(w0) as stream:
+        _lib.check(lib.ffwm_conv3x3_winograd_weights_multi(ctypes.cast(arr, ctypes.c_void_p), len(items), _lib.F32, stream),
+                   "ffwm_conv3x3_winograd_weights_multi")
     return out
 
 

@@ -164,6 +164,29 @@ class SpectralNormGroup(object):
         outs = _SnGroupFunction.apply(self, training, *weights)
         for (m, name), w in zip(self.layers, outs):
             setattr(m, name, w)            # what the per-layer hook does: a plain attribute, not a Parameter
+        self._prepare_winograd(outs)
+
+    def _prepare_winograd(self, outs):
+        """Every weight of the network is known here: the Winograd transforms its 3x3 layers used in the last pass (forward, and the data
+        gradient when gradients are on) go out as ONE launch per 24 instead of one small launch in front of every convolution."""
+        from . import conv, ops
+        if not conv._WINO_BATCH or outs[0].dtype != torch.float32:
+            return
+        items, slots = [], []
+        grad = torch.is_grad_enabled()
+        for (m, name), w in zip(self.layers, outs):
+            if name != "weight" or not isinstance(m, conv.WinogradConv2d) or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+                continue
+            w._ffwm_wino_owner = m
+            w._ffwm_wino = {}
+            for key in sorted(m.__dict__.get("_wino_keys", ())):
+                if key[0] == 1 and not grad:
+                    continue
+                items.append((w, key[0], key[1]))
+                slots.append((w, key))
+        if items:
+            for (w, key), ws in zip(slots, ops.conv3x3_winograd_weights_multi(items)):
+                w._ffwm_wino[key] = ws
 
 
 def fuse_spectral_norm(net):

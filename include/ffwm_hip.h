@@ -416,6 +416,20 @@ int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C);
  * persistent workgroups covers the chip; the pieces' partial outputs meet by atomics in the output, which the library zero-fills
  * itself.  Only for act = 0.  The caller's routing policy (ffwm_amd/conv.py) uses it to price a call. */
 int ffwm_conv3x3_winograd_splits(int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int act);
+
+/* The weight transforms of several Winograd calls in ONE launch.  Item i fills `workspace` (ffwm_conv3x3_winograd_workspace_bytes(K, C)
+ * bytes) exactly as ffwm_conv3x3_winograd_forward(.., K, C, data_gradient, ..) would for an input whose width is (or is not) a
+ * multiple of 4; that call is then made with data_gradient + 2 (reuse).  K / C in the CALL's terms: for the data gradient K = the
+ * layer's input channels, C = its output channels, weight = the layer's own [C, K, 3, 3].  (ffwm_amd/spectral_norm.py: all layers of
+ * a spectrally normalised network right after its batched normalisation.) */
+typedef struct ffwm_wino_weights {
+    const void* weight;
+    void* workspace;
+    int64_t K, C;
+    int data_gradient;            /* 0 = forward, 1 = data gradient */
+    int width_multiple_of_4;      /* of the planes the transform will be used on (selects the thin-tail split of K) */
+} ffwm_wino_weights;
+int ffwm_conv3x3_winograd_weights_multi(const ffwm_wino_weights* items, int n, int dtype, void* stream);
 int ffwm_conv3x3_winograd_forward(const void* input, const void* weight, const void* bias, void* output, void* workspace,
                                   int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int data_gradient, int act,
                                   double slope, int dtype, void* stream);

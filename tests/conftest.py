@@ -17,3 +17,16 @@ def oracle():
     import oracle as _oracle
     _oracle.build()
     return _oracle
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_allocator(request):
+    """FFWM_TEST_POISON=1: before every GPU test the caching allocator's free blocks are filled with NaN, so a kernel that reads memory
+    nobody wrote (a workspace tail, a padded chunk, a scratch buffer) fails its comparison instead of passing on zeros that happened to
+    be there.  (Found this way in round 4: the Winograd kernel's padded chunk read past the transformed weights.)"""
+    if os.environ.get("FFWM_TEST_POISON") == "1" and request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            bufs = [torch.full((n,), float("nan"), device="cuda") for n in (1 << 26, 1 << 24, 1 << 22, 1 << 20, 1 << 18, 1 << 16, 1 << 14) for _ in range(4)]
+            del bufs
+    yield

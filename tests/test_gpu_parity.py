@@ -1887,6 +1887,30 @@ def test_conv3x3_winograd_split_reduction_matches_aten(case):
             _lib.set_option("conv_wino_split", 1)
 
 
+def test_conv3x3_winograd_ignores_what_lies_behind_the_transformed_weights():
+    """Round 4 bug: with an ODD number of 8-channel chunks (195 channels = 25) the persistent kernel pads the reduction with a chunk
+    of zero inputs, but it fetched that chunk's WEIGHTS from behind the transformed weights in the workspace -- recycled memory;
+    0 x NaN = NaN whenever the allocator handed back a block that held NaN / Inf.  The caching allocator is poisoned with NaN before
+    the calls; forward and data gradient must still match float64."""
+    from ffwm_amd import ops
+    g = _gen(77)
+    for (B, C, H, W, K) in ((2, 195, 64, 64, 195), (1, 200, 32, 32, 72), (2, 72, 32, 32, 200)):
+        x = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+        go = torch.randn(B, K, H, W, generator=g)
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+        dref = torch.nn.grad.conv2d_input((B, C, H, W), w.double(), go.double(), 1, 1)
+        xd, wd, god = x.to(DEV), w.to(DEV), go.to(DEV)
+        for _ in range(2):
+            poison = [torch.full((n,), float("nan"), device=DEV) for n in (1 << 24, 1 << 22, 1 << 21, 1 << 20, 1 << 19, 1 << 18) for _ in range(4)]
+            del poison
+            y = ops.conv3x3_winograd(xd, wd)
+            dx = ops.conv3x3_winograd(god, wd, None, data_gradient=True)
+            assert torch.isfinite(y).all() and torch.isfinite(dx).all()
+            assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
+            assert (dx.cpu().double() - dref).abs().max().item() <= 2e-5 * (1 + dref.abs().max().item())
+
+
 @pytest.mark.parametrize("min_pairs", [1, 64])
 def test_winograd_routing_matches_aten_autograd(min_pairs, monkeypatch):
     """conv.route_conv_winograd: re-classed 3x3 / stride-1 Conv2d layers (forward + data gradient on csrc/conv_winograd.hip,

@@ -1,0 +1,56 @@
+"""Robustness probe: the caching allocator is filled with NaN between train steps, so any kernel that reads memory it (or its producer)
+never wrote -- workspaces, padded tails, scratch -- turns the step non-finite.  Eager steps of the full FFWM trainer and of the FlowNet
+pre-training step; prints the first module whose output is not finite."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ffwm_amd import trainer
+
+dev = torch.device("cuda", 0)
+
+
+def poison():
+    bufs = [torch.full((n,), float("nan"), device=dev) for n in (1 << 27, 1 << 25, 1 << 23, 1 << 22, 1 << 21, 1 << 20, 1 << 19, 1 << 18, 1 << 16, 1 << 14, 1 << 12) for _ in range(5)]
+    del bufs
+
+
+def watch(nets):
+    bad = []
+
+    def hook(name):
+        def h(m, inp, out):
+            outs = out if isinstance(out, (tuple, list)) else (out,)
+            for o in outs:
+                if torch.is_tensor(o) and o.is_floating_point() and not torch.isfinite(o).all():
+                    bad.append((name, type(m).__name__, tuple(o.shape)))
+                    break
+        return h
+    for tag, net in nets:
+        for name, m in net.named_modules():
+            if not list(m.children()):
+                m.register_forward_hook(hook(tag + "." + name))
+    return bad
+
+
+bs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+t = trainer.FFWMTrainer(dev, seed=0)
+bad = watch([("flowNetF", t.flowNetF), ("flowNetB", t.flowNetB), ("netG", t.netG), ("netD", t.netD), ("vgg", t.vgg), ("lightCNN", t.lightCNN)])
+batch = trainer.synthetic_batch(bs, dev, seed=1)
+for i in range(4):
+    poison()
+    t.step(batch)
+    torch.cuda.synchronize()
+    vals = t.loss_values()
+    fin = all(torch.isfinite(torch.tensor(v)) for v in vals.values())
+    wfin = all(bool(torch.isfinite(p).all()) for net in (t.flowNetF, t.flowNetB, t.netG, t.netD) for p in net.parameters())
+    print("FFWM step %d (batch %d): losses finite %s, weights finite %s, first non-finite outputs: %s" % (i, bs, fin, wfin, bad[:3]), flush=True)
+    if not (fin and wfin):
+        break
+ft = trainer.FlowNetTrainer(dev, seed=0)
+bad2 = watch([("flowNet", ft.flowNet)])
+fb = trainer.synthetic_flow_batch(6, dev, seed=2) if hasattr(trainer, "synthetic_flow_batch") else None
+if fb is not None:
+    for i in range(3):
+        poison()
+        ft.step(fb)
+        torch.cuda.synchronize()
+        print("FlowNet step %d: %s first non-finite: %s" % (i, {k: round(v, 4) for k, v in ft.loss_values().items()}, bad2[:3]), flush=True)
