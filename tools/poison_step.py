@@ -47,10 +47,22 @@ for i in range(4):
         break
 ft = trainer.FlowNetTrainer(dev, seed=0)
 bad2 = watch([("flowNet", ft.flowNet)])
-fb = trainer.synthetic_flow_batch(6, dev, seed=2) if hasattr(trainer, "synthetic_flow_batch") else None
+fb = trainer.synthetic_batch(6, dev, seed=2)
 if fb is not None:
     for i in range(3):
         poison()
         ft.step(fb)
         torch.cuda.synchronize()
         print("FlowNet step %d: %s first non-finite: %s" % (i, {k: round(v, 4) for k, v in ft.loss_values().items()}, bad2[:3]), flush=True)
+
+# the titers >= 20000 branch (guided filter) and the evaluation forward
+t2 = trainer.FFWMTrainer(dev, seed=0, titers=20000)
+for i in range(2):
+    poison()
+    t2.step(batch)
+    torch.cuda.synchronize()
+    print("FFWM step %d, guided-filter branch: %s" % (i, {k: round(v, 4) for k, v in t2.loss_values().items()}), flush=True)
+poison()
+with torch.no_grad():
+    outs = t2.test_forward(batch)
+print("test_forward finite:", all(bool(torch.isfinite(o).all()) for o in (outs if isinstance(outs, (tuple, list)) else [outs]) if torch.is_tensor(o)))
