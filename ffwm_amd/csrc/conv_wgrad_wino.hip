@@ -35,7 +35,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWwThreads = 512;
-constexpr int kWwOperand = 16 * 2 * 64;             // f32x4 per operand buffer: [16 positions][2 halves][64 channels] x 4 tiles
+// f32x4 per operand buffer: [16 positions][2 tile halves][64 channels (+ 8 of padding)] x 4 tiles.  The padding shifts the second tile
+// half by 32 banks: a wave's ds_write_b32 covers (8 channels x 4 tiles) of BOTH halves, which sat on the same 32 banks at a half
+// stride of 256 floats -- a 2-way conflict on every one of the 32 writes per thread and chunk (SQ_LDS_BANK_CONFLICT = 33 % of the
+// LDS cycles, profiles/r04_wgrad_wino_counters.txt); 4 x 36 KiB = 144 KiB, what the epilogue's staging needs anyway.
+constexpr int kWwHalf = 72;                         // f32x4 per tile half of a position
+constexpr int kWwPos = 2 * kWwHalf;                 // f32x4 per position
+constexpr int kWwOperand = 16 * kWwPos;
 constexpr unsigned kWwOob = 0xFFFFFFF0u;
 
 struct WwGeo {
@@ -74,7 +80,7 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
     const bool k_ok = k0 + chn < g.k_end, c_ok = c0 + chn < g.c_end;
     const unsigned gk_base = static_cast<unsigned>(k0 + chn) * static_cast<unsigned>(HW);       // floats; + b * K * HW
     const unsigned xc_base = static_cast<unsigned>(c0 + chn) * static_cast<unsigned>(HW);
-    const int wr_off = (t8 >> 2) * 256 + chn * 4 + (t8 & 3);       // float index inside a position block of 512 floats
+    const int wr_off = (t8 >> 2) * (4 * kWwHalf) + chn * 4 + (t8 & 3);       // float index inside a position block of 4 * kWwPos floats
 
     // the load cursor: chunk index and its (image, tile row, chunk of the row), advanced without divisions
     int cur = ch_begin;
@@ -127,10 +133,10 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
             const float rp[4] = {a, a + c, a - c, -c}, rq[4] = {b, b + d, b - d, -d};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                A[(i * 4 + 0) * 512] = rp[i];
-                A[(i * 4 + 1) * 512] = rp[i] + rq[i];
-                A[(i * 4 + 2) * 512] = rp[i] - rq[i];
-                A[(i * 4 + 3) * 512] = -rq[i];
+                A[(i * 4 + 0) * (4 * kWwPos)] = rp[i];
+                A[(i * 4 + 1) * (4 * kWwPos)] = rp[i] + rq[i];
+                A[(i * 4 + 2) * (4 * kWwPos)] = rp[i] - rq[i];
+                A[(i * 4 + 3) * (4 * kWwPos)] = -rq[i];
             }
         }
         // V = Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
@@ -140,10 +146,10 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 r[j] = i == 0 ? R.xp[0 + j] - R.xp[8 + j] : i == 1 ? R.xp[4 + j] + R.xp[8 + j] : i == 2 ? R.xp[8 + j] - R.xp[4 + j] : R.xp[4 + j] - R.xp[12 + j];
-            Bv[(i * 4 + 0) * 512] = r[0] - r[2];
-            Bv[(i * 4 + 1) * 512] = r[1] + r[2];
-            Bv[(i * 4 + 2) * 512] = r[2] - r[1];
-            Bv[(i * 4 + 3) * 512] = r[1] - r[3];
+            Bv[(i * 4 + 0) * (4 * kWwPos)] = r[0] - r[2];
+            Bv[(i * 4 + 1) * (4 * kWwPos)] = r[1] + r[2];
+            Bv[(i * 4 + 2) * (4 * kWwPos)] = r[2] - r[1];
+            Bv[(i * 4 + 3) * (4 * kWwPos)] = r[1] - r[3];
         }
     };
 
@@ -159,16 +165,16 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
     Regs R[2];
     auto step = [&](auto parity) {
         constexpr int P = decltype(parity)::value, Q = 1 - P;
-        const f32x4* ap = smem + P * (2 * kWwOperand) + (ph * 8) * 128 + half * 64 + wm * 32 + l31;
-        const f32x4* bp = smem + P * (2 * kWwOperand) + kWwOperand + (ph * 8) * 128 + half * 64 + wn * 32 + l31;
+        const f32x4* ap = smem + P * (2 * kWwOperand) + (ph * 8) * kWwPos + half * kWwHalf + wm * 32 + l31;
+        const f32x4* bp = smem + P * (2 * kWwOperand) + kWwOperand + (ph * 8) * kWwPos + half * kWwHalf + wn * 32 + l31;
         f32x4 oa[2][2], ob[2][2];
-        oa[0][0] = ap[0]; ob[0][0] = bp[0]; oa[0][1] = ap[128]; ob[0][1] = bp[128];
+        oa[0][0] = ap[0]; ob[0][0] = bp[0]; oa[0][1] = ap[kWwPos]; ob[0][1] = bp[kWwPos];
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int c2 = grp & 1, n2 = c2 ^ 1;
             if (grp < 3) {
-                oa[n2][0] = ap[(2 * grp + 2) * 128]; ob[n2][0] = bp[(2 * grp + 2) * 128];
-                oa[n2][1] = ap[(2 * grp + 3) * 128]; ob[n2][1] = bp[(2 * grp + 3) * 128];
+                oa[n2][0] = ap[(2 * grp + 2) * kWwPos]; ob[n2][0] = bp[(2 * grp + 2) * kWwPos];
+                oa[n2][1] = ap[(2 * grp + 3) * kWwPos]; ob[n2][1] = bp[(2 * grp + 3) * kWwPos];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -289,7 +295,8 @@ int launch_wgrad_wino(const float* X, const float* G, float* dW, float* dbias, i
     g.remap = options().xcd_remap;
     g.x_bytes = static_cast<unsigned>(B * C * H * W * 4);
     g.g_bytes = static_cast<unsigned>(B * K * H * W * 4);
-    const size_t lds = 64 * 576 * sizeof(float);                    // >= the 128 KB of operand buffers
+    const size_t lds = 64 * 576 * sizeof(float);                    // the epilogue's staging = the 2 x 2 padded operand buffers (144 KiB)
+    static_assert(4 * kWwOperand * 16 <= 64 * 576 * 4, "operand buffers exceed the LDS request");
     allow_large_lds(reinterpret_cast<const void*>(conv3x3_wgrad_wino_kernel));
     const double kk = static_cast<double>(k_end - k_begin), cc = static_cast<double>(c_end - c_begin);
     // flops = the multiplications the MFMAs execute, as for the forward kernel's scope (the direct sum this call replaces has 2.25 x as many)
