@@ -258,12 +258,17 @@ class FFWMTrainer(object):
         # FFWM_STREAM_LAYOUT=5 restores one stream per branch for an A/B.
         multi = os.environ.get("FFWM_STREAMS", os.environ.get("FFWM_FLOW_STREAMS", "1" if capturable else "0")) == "1"
         multi = multi and self.device.type == "cuda"
-        five = os.environ.get("FFWM_STREAM_LAYOUT", "3") == "5"
+        # Round 4: on one GPU the D step gets a THIRD side stream of its own (layout 4: four streams = the four hardware queues; 8 of 8
+        # processes 38.9-39.1 ms against 39.3-39.5 with two side streams, profiles/r04_stream_experiments.txt); with several ranks RCCL's
+        # stream is the fourth, so the D step keeps sharing LightCNN's (layout 3).
+        layout = os.environ.get("FFWM_STREAM_LAYOUT", "3" if self.dp_active else "4")
+        five = layout == "5"
         self.loss_streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)] if multi else None
         self.flow_stream = (torch.cuda.Stream(self.device) if five else self.loss_streams[0]) if multi else None
         self.d_stream = None
         if multi and os.environ.get("FFWM_D_STREAM", "1") == "1":
-            self.d_stream = torch.cuda.Stream(self.device) if five else self.loss_streams[1]
+            # (FFWM_STREAM_LAYOUT=4: the D step on a third side stream of its own -- four streams = the four hardware queues)
+            self.d_stream = torch.cuda.Stream(self.device) if (five or layout == "4") else self.loss_streams[1]
         # flowNetF on the SECOND side stream (idle until the D step forks, and idle again once LightCNN's backward is through), beside
         # netG's encoder: e0-e3 need no flow, so the step's stream runs them while both flow nets -- ~3 ms of 2 x 2 ... 64 x 64 plane
         # kernels each -- run beside it, and in the backward flowNetF's pass (the tail of the step: it waits for d(flow) from the
