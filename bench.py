@@ -74,9 +74,49 @@ def _slim_roofline(r):
     return {k: r[k] for k in keep if k in r}
 
 
+# The per-config operator figures of the final line (SURVEY 8(d) scopes i-ii; BASELINE configs[0], [1], [4]): key -> (kernel scope,
+# substring of the row's `where`).  Each value is [avg us, fraction of the 8 TB/s HBM peak] of ONE stand-alone launch at the named
+# configuration, HIP-event timed by the library profiler on the launch stream; cfg5 rows at the per-GPU shape, bench flow ~ U[-2, 2).
+OPS_ROWS = (
+    ("cfg1_rs_fwd", "resample2d_fwd_lds", "cfg1 resample2d ks=4 [1,64"),
+    ("cfg1_rs_bwd1", "resample2d_bwd_input1_taplane", "cfg1 resample2d ks=4 backward"),
+    ("cfg1_rs_bwd2", "resample2d_bwd_input2_lds", "cfg1 resample2d ks=4 backward"),
+    ("rs_fwd@512", "resample2d_fwd_lds", "HBM-resident resample2d ks=4 [8,64,512,512] flow"),
+    ("rs_bwd1@512", "resample2d_bwd_input1_auto", "backward, flow~U[-3,3)"),
+    ("rs_bwd1@512_smooth", "resample2d_bwd_input1_auto", "backward, smooth flow"),
+    ("rs_bwd2@512", "resample2d_bwd_input2_lds", "backward, flow~U[-3,3)"),
+    ("cfg5_be_fwd", "block_extractor_fwd_lds", "src[4,128,256,256] flow~U[-2,2)"),
+    ("cfg5_be_bwd", "block_extractor_bwd_tile2", "block_extractor k=3 backward"),
+    ("cfg5_be_bwd_smooth", "block_extractor_bwd_tile2", "backward, smooth flow"),
+    ("cfg5_lar", "local_attn_reshape_fwd", "cfg5/GPU local_attn_reshape"),
+    ("cfg5_lar_bwd", "local_attn_reshape_bwd", "cfg5/GPU local_attn_reshape"),
+    ("cfg5_battn_fwd", "block_attention_fwd_lds", "block attention"),
+    ("cfg5_battn_bwd", "block_attention_bwd_tile2", "block attention"),
+    ("warp_fwd@256", "warp_flipcat_fwd@256", "HBM-resident warp"),
+    ("warp_bwd_flow@256", "warp_flipcat_bwd_flow@256", "HBM-resident warp"),
+    ("warp_bwd_feat@256", "warp_flipcat_bwd_feat_tile@256", "HBM-resident warp"),
+)
+
+
+def ops_summary(kernels, subpaths=None):
+    """{key: [avg_us, frac of HBM peak]} for the rows of OPS_ROWS found among `kernels` (first match; the rows of the timed region are
+    skipped), plus flownet_fwd_cfg2 = [us per forward of batch 6, fraction of the fp32 MFMA peak] (BASELINE configs[1])."""
+    out = {}
+    for key, scope, where in OPS_ROWS:
+        for r in kernels:
+            if r.get("kernel") == scope and where in r.get("where", "") and r.get("where") != "timed region":
+                out[key] = [r["avg_us"], r["frac_hbm_peak"]]
+                break
+    fl = (subpaths or {}).get("flownet_fwd_cfg2")
+    if isinstance(fl, dict) and "ms_per_fwd" in fl:
+        out["flownet_fwd_cfg2"] = [round(fl["ms_per_fwd"] * 1e3, 1), fl.get("fp32_flop_frac")]
+    return out
+
+
 def emit_lines(result):
     """The stdout lines of one bench run: verbose lines first, the compact judged line LAST."""
     result = dict(result)
+    ops_rows = ops_summary(result.get("kernels", []), result.get("subpaths"))
     lines = [json.dumps({"kernels": result.pop("kernels", [])})]
     detail_keys = [k for k in result if k not in FINAL_KEYS]
     detail = {k: result[k] for k in detail_keys}
@@ -105,8 +145,14 @@ def emit_lines(result):
     wa = (result.get("subpaths") or {}).get("warp_attention_path") or result.get("warp_attention_path")
     if isinstance(wa, dict):
         final["warp_attention_path"] = {k: wa[k] for k in ("fwd_img_per_s", "fwd_bwd_img_per_s", "fp32_ceiling_img_per_s") if k in wa}
+    if ops_rows:
+        # [us, fraction of the roofline] per stand-alone operator launch at BASELINE's configurations (OPS_ROWS)
+        final["ops"] = ops_rows
+        final["ops_note"] = "[avg us, frac of 8 TB/s] per stand-alone launch (flownet: [us/fwd bs6, frac of 157 TF]); HIP events"
+    if isinstance(final.get("roofline"), dict) and result.get("kernel_rows_from"):
+        final["roofline"]["rows_from"] = result["kernel_rows_from"]
     line = json.dumps(final)
-    for k in ("allreduce", "roofline_hbm_other", "roofline_mfma_2nd", "cpu_baseline_n4", "roofline_mfma"):   # never exceed the limit
+    for k in ("allreduce", "roofline_hbm_other", "roofline_mfma_2nd", "cpu_baseline_n4", "ops_note", "roofline_mfma"):   # never exceed the limit
         if len(line) < FINAL_LIMIT:
             break
         final.pop(k, None)
@@ -564,7 +610,7 @@ def main():
             del tc
         else:
             step_flops = flops.count_step(nets_all, lambda: t.step(batch, batch_increment=0))       # one untimed eager step
-        capture_mode, d_side = None, False
+        capture_mode, d_side, dp_spread = None, False, None
         if graphed:
             # several ranks: the capture modes of FFWMTrainer.capture, best first -- "ingraph" (RCCL captured into ONE graph, every
             # bucket's all-reduce overlapping backward; chosen by a probe graph every rank must replay correctly), then "serial" (three
@@ -572,7 +618,9 @@ def main():
             # RCCL ranks cannot be tried on the one-GPU development box), the ranks agree on it and try the next mode on a fresh
             # trainer; the last resort is the eager step with hook-launched, overlapped all-reduces.
             forced = os.environ.get("FFWM_DP_CAPTURE")
-            modes = [None] if world == 1 else ([forced] if forced else ["auto", "serial"])
+            # (round 5, ADVICE r4: "serial" first -- the in-graph capture of the collectives is opt-in, FFWM_DP_CAPTURE=ingraph, until it
+            # has run between >= 2 real RCCL ranks; "auto" = probe, then ingraph)
+            modes = [None] if world == 1 else ([forced, "serial"] if forced else ["serial"])
             tried, captured = [], False
             for m in modes:
                 mode = m
@@ -588,9 +636,14 @@ def main():
                 ok = True
                 try:
                     t.capture(batch, warmup=max(2, args.warmup), mode=mode)
-                    if world > 1:                       # one replay must run before the mode counts as working
-                        t.step(batch, batch_increment=0)
+                    if world > 1:                       # replays must run -- and leave the ranks in lock step -- before the mode counts as working
+                        for _ in range(2):
+                            t.step(batch, batch_increment=0)
                         torch.cuda.synchronize()
+                        spread = t.rank_spread()
+                        dp_spread = spread
+                        if not all(v == v and v <= 1e-5 for v in spread.values()):
+                            raise RuntimeError("the ranks' weights differ after two replays: %r" % (spread,))
                 except Exception as e:
                     if world == 1:
                         raise
@@ -624,6 +677,7 @@ def main():
             t.set_side_streams(False)
             _, rows = timed(lambda: t.step(batch, batch_increment=0), 2, 1, world)
             t.set_side_streams(True)
+            result["kernel_rows_from"] = "2 eager single-stream steps after the timed region (events cannot bracket kernels of a replayed graph)"
         imgs = bs * world * args.steps
         own = step_flops["total"] / bs
         result.update({"metric": "train img/s (128x128, full FFWM GAN step)", "value": round(imgs / dt, 2),
@@ -642,6 +696,7 @@ def main():
                                              + (" (%d side streams)" % len({id(x) for x in [t.flow_stream, t.d_stream if d_side else None] + list(t.loss_streams or []) if x is not None}) if t.flow_stream is not None else ""))
                                   if graphed else "eager (hook-launched all-reduces overlap backward)" if world > 1 else "eager",
                                   "dp_capture_mode": capture_mode if graphed and world > 1 else None,
+                                  "dp_rank_spread_after_2_replays": dp_spread,
                                   "miopen": "immediate mode%s" % (" + in-tree find-db (ffwm_amd/miopen_db)" if miopen_db else ", heuristic solver choice"),
                                   "conv_wgrad": ("MFMA kernel for %d netG layers" % getattr(t, "mfma_wgrad_layers", 0))
                                   if args.mfma_wgrad == "on" else "vendor library",

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libffwm_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -73,6 +73,7 @@ _SIGNATURES = {
     "ffwm_prof_get_bound": [_i, ctypes.POINTER(ctypes.c_double)],
     "ffwm_prof_reset": [],
     "ffwm_set_option": [ctypes.c_char_p, _i],
+    "ffwm_zero_fill": [_p, _i64, _p],
     "ffwm_abi_version": [],
 }
 

@@ -50,10 +50,10 @@ adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
 
 // The step counter on the DEVICE (a step that sits inside a captured hipGraph: a replay runs no host code, so the bias corrections
 // cannot come from a host integer).  state[0] = steps taken so far, state[1] = lr / bc1, state[2] = sqrt(bc2) of the current step,
-// state[3] = learning-rate override (> 0: replaces the kernel argument).
+// state[3] = learning-rate override (>= 0: replaces the kernel argument -- 0.0 freezes the weights; negative: none).
 __global__ void adam_advance_kernel(double* __restrict__ state, double lr, double beta1, double beta2) {
     const double step = state[0] + 1.0;
-    if (state[3] > 0.0) lr = state[3];          // the host's current learning rate (a schedule under hipGraph replay)
+    if (state[3] >= 0.0) lr = state[3];          // the host's current learning rate (a schedule under hipGraph replay)
     state[0] = step;
     state[1] = lr / (1.0 - pow(beta1, step));
     state[2] = sqrt(1.0 - pow(beta2, step));

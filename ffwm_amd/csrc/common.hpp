@@ -20,6 +20,13 @@ void allow_large_lds(const void* kernel);
 // A 256-byte device scratch that belongs to (device, stream): counters a launch sequence hands from one kernel to the next without
 // a host round trip.  NULL when it cannot be had (allocation failure, or first use on a stream that is being captured).
 void* stream_scratch(hipStream_t st);
+// Compute units of the CURRENT device (the tensors' device: every entry point runs under the caller's device guard), cached per device.
+int device_cus();
+// Zero-fill of `bytes` bytes (a multiple of 4, `p` 4-byte aligned) by a KERNEL of this library on `st`.  Not hipMemsetAsync: under
+// hipGraph capture that becomes a memset node, and on ROCm 7.0 the fill pattern of such nodes came out corrupted (garbage in fixed
+// dwords of every 16 bytes, over the whole buffer) when several graphs with side-stream branches were replayed back to back --
+// round 5, profiles/r05_wgrad_nan_root_cause.txt.  Returns a hipError_t-free status: 0 = launched.
+int zero_fill(void* p, size_t bytes, hipStream_t st);
 constexpr int kMaxLdsBytes = 160 * 1024;
 
 struct Options {
@@ -36,7 +43,7 @@ struct Options {
     int rs_bwd1_variant = 0;  // resample2d d_input1: 0 = auto (ks 4: tap-lane kernel, on calls of >= 2^18 pixels the tile kernel instead when a pre-pass finds the flow smooth; else plane kernel when a plane fits LDS, else tile kernel), 1 = round-2 auto (plane / tile), 2 = tile kernel, 5 = tap-lane kernel with 8-wave blocks (16-row tiles)
     int conv_tile_variant = 0; // conv_fwd.hip workgroup tile: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128
     int conv_wino_raw = 1;     // conv_winograd.hip: stage the input window through LDS when a workgroup covers whole tile rows
-    int conv_wino_split = 1;   // conv_winograd.hip: cut the reduction of a call with few (strip, k tile) pairs over 2 / 4 workgroups (atomics into a zeroed output)
+    int conv_wino_split = 1;   // conv_winograd.hip: cut the reduction of a call with few (strip, k tile) pairs over 2 / 4 workgroups (atomics into a zeroed output); 2 = at most two pieces (a two-term float sum does not depend on the order: bit-reproducible); 0 = never
     int conv_thin_tail = 1;    // conv_winograd.hip: 1-4 output channels past a multiple of 64 on the thin direct kernel
     int warp_nt = 0;          // warp forward (direct / multi-problem kernels): 1 = streaming (nt) stores, 2 = nt feature loads too
     int warp_pair_loads = 1;  // warp d(flow), multi-problem launch, fp32: one 8-byte load per corner ROW instead of two dword gathers
@@ -44,6 +51,8 @@ struct Options {
     int warp_multi_planes = 0; // multi-problem warp backward: 0 = d(feat) plane problems of one CG share a launch, 1 = one launch per problem
     int warp_multi_lds = 0;   // multi-problem warp launches: 0 = auto (LDS-staged tiles for float planes >= 64 x 64, C >= 32), 1 = direct gathers, 2 = LDS tiles
     int warp_multi_order = 0; // multi-problem warp launches: 0 = largest problem first, 1 = the caller's order
+    int zero_fill_memset = 0;    // 1 = zero_fill() calls hipMemsetAsync as rounds 1-4 did (diagnosis: reproduces the corrupted memset nodes)
+    int conv_wgrad_unsliced = 0; // conv_bwd.hip tiled weight gradient: 1 = never cut the pixel range into slices (no zero-fill, no atomics: a diagnosis switch)
     int ablate = 0;           // bench-only ablation bits (1 = skip source fetch, 2 = skip stores)
 };
 Options& options();

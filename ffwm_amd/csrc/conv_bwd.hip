@@ -472,7 +472,7 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     const int64_t tiles = static_cast<int64_t>(k_tiles) * n_tiles;
     int64_t slices = tiles >= 512 ? 1 : 512 / tiles;
     if (slices > g.chunks_total / 4) slices = g.chunks_total / 4;
-    if (slices < 1) slices = 1;
+    if (slices < 1 || options().conv_wgrad_unsliced) slices = 1;
     g.chunks = static_cast<int>((g.chunks_total + slices - 1) / slices);
     g.nz = (g.chunks_total + g.chunks - 1) / g.chunks;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -481,8 +481,8 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     if (g.nz > 1) {
         const size_t nw = static_cast<size_t>(g.K) * g.N;
         const bool joined = gb == dw + nw;          // one buffer (ops.conv2d_wgrad_tiled allocates them together): one memset
-        if (hipMemsetAsync(dw, 0, sizeof(float) * (nw + (joined ? static_cast<size_t>(g.K) : 0)), st) != hipSuccess) return FFWM_ERR_LAUNCH;
-        if (gb && !joined && hipMemsetAsync(gb, 0, sizeof(float) * static_cast<size_t>(g.K), st) != hipSuccess) return FFWM_ERR_LAUNCH;
+        if (zero_fill(dw, sizeof(float) * (nw + (joined ? static_cast<size_t>(g.K) : 0)), st)) return FFWM_ERR_LAUNCH;
+        if (gb && !joined && zero_fill(gb, sizeof(float) * static_cast<size_t>(g.K), st)) return FFWM_ERR_LAUNCH;
     }
     const double flops = 2.0 * B * g.P * static_cast<double>(g.K) * g.N;
     const double bytes = 4.0 * (static_cast<double>(B) * K * g.P + static_cast<double>(B) * C * H * W + static_cast<double>(K) * g.N);

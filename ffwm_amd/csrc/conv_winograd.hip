@@ -736,7 +736,7 @@ using namespace ffwm;
 // 512 -> 512 at 16 x 16 199 -> 99 us.  Only without a fused activation (the epilogue of a split cannot apply one); 1 = no split.
 static int winograd_splits(int pairs, int CH, int act, int cus) {
     if (act != 0 || !options().conv_wino_split || pairs <= 0) return 1;
-    for (int cs = 4; cs >= 2; cs -= 2) {
+    for (int cs = options().conv_wino_split == 2 ? 2 : 4; cs >= 2; cs -= 2) {          // (2: capped -- a + b is order-independent, a + b + c + d is not)
         if (pairs * cs > cus) continue;
         if (CH % cs != 0) continue;
         const int chs = CH / cs;
@@ -757,9 +757,7 @@ extern "C" int ffwm_conv3x3_winograd_splits(int64_t B, int64_t C, int64_t H, int
     const int64_t Kw = thin ? K - tail : K;
     const int64_t pairs = ((B * TH * TW + kWinoTiles - 1) / kWinoTiles) * ((Kw + 63) / 64);
     if (pairs <= 0 || pairs > 4096) return 1;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return winograd_splits(static_cast<int>(pairs), static_cast<int>((C + 7) / 8), act, cus);
+    return winograd_splits(static_cast<int>(pairs), static_cast<int>((C + 7) / 8), act, device_cus());
 }
 
 extern "C" int64_t ffwm_conv3x3_winograd_workspace_bytes(int64_t K, int64_t C) {
@@ -868,17 +866,12 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
         g.ROWS = 2 * g.R + 2;
         int split_n = 1;
         if (rawv) {
-            static const int cus0 = [] {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-                return n;
-            }();
-            split_n = winograd_splits(static_cast<int>(nblk), g.CH, act, cus0);
+            split_n = winograd_splits(static_cast<int>(nblk), g.CH, act, device_cus());
         }
         // (a split call -- zero-fill + atomics, few pairs -- is a launch configuration of its own: its own profiling scope)
         LaunchScope ls(split_n > 1 ? (data_gradient ? "conv_winograd_dgrad_split" : "conv_winograd_fwd_split")
                                 : (data_gradient ? "conv_winograd_dgrad" : "conv_winograd_fwd"), st, bytes, flops);
-        if (split_n > 1 && hipMemsetAsync(output, 0, static_cast<size_t>(B) * K * H * W * 4, st) != hipSuccess) return FFWM_ERR_LAUNCH;
+        if (split_n > 1 && zero_fill(output, static_cast<size_t>(B) * K * H * W * 4, st)) return FFWM_ERR_LAUNCH;
         if (rawv) {
             auto kern = winograd_conv_raw_kernel<0>;
             switch (options().ablate) {
@@ -890,11 +883,7 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
             }
             if (split_n > 1) kern = winograd_conv_raw_kernel<0, true>;
             allow_large_lds(reinterpret_cast<const void*>(kern));
-            static const int cus = [] {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-                return n;
-            }();
+            const int cus = device_cus();
             const unsigned units = nblk * static_cast<unsigned>(split_n);
             const unsigned pgrid = units < static_cast<unsigned>(cus) ? units : static_cast<unsigned>(cus);     // persistent: one workgroup per CU
             hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kWinoThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st, static_cast<const float*>(input), U,

@@ -1541,7 +1541,7 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                 const int segs_x = static_cast<int>((W + kWave - 1) / kWave);
                 const int64_t nseg = B * H * segs_x;
                 sel_limit = static_cast<int>(nseg / 4 > 0 ? nseg / 4 : 1);          // "smooth": fewer than a quarter of the row segments irregular
-                if (hipMemsetAsync(sel, 0, sizeof(int), st) != hipSuccess) return FFWM_ERR_LAUNCH;
+                if (zero_fill(sel, sizeof(int), st)) return FFWM_ERR_LAUNCH;
                 const int per = kBlock / kWave;
                 int64_t pre_blocks = (nseg + per - 1) / per;
                 if (pre_blocks > 1024) pre_blocks = 1024;
@@ -1607,7 +1607,7 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                 const unsigned grid = static_cast<unsigned>(B * tiles_x * tiles_y * cslabs);
                 const size_t lds = static_cast<size_t>(2) * 16 * kRsBoxW * 16;
                 if (cslabs > 1)          // the slabs' partial results are added atomically
-                    if (hipMemsetAsync(gin2, 0, sizeof(T) * static_cast<size_t>(B) * 3 * H * W, st) != hipSuccess) return FFWM_ERR_LAUNCH;
+                    if (zero_fill(gin2, sizeof(T) * static_cast<size_t>(B) * 3 * H * W, st)) return FFWM_ERR_LAUNCH;
                 const double bytes = sizeof(T) * static_cast<double>(B) * H * W * (2.0 * C + 6.0);
                 LaunchScope ls("resample2d_bwd_input2_lds", st, bytes);
 #define FFWM_RS_B2L(HH)                                                                                       \

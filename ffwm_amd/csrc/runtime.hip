@@ -75,6 +75,48 @@ void* stream_scratch(hipStream_t st) {
     return p;
 }
 
+int device_cus() {
+    static std::mutex mu;
+    static std::vector<int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) { (void)hipGetLastError(); return 256; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (static_cast<size_t>(dev) >= cache.size()) cache.resize(dev + 1, 0);
+    if (cache[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+
+namespace {
+__global__ void __launch_bounds__(256) zero_fill_kernel(unsigned* __restrict__ p, size_t n) {          // n dwords
+    const size_t mis = (16u - (reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+    size_t head = mis / 4;
+    if (head > n) head = n;
+    const size_t body = (n - head) / 4;          // 16-byte stores
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t j = i; j < body; j += stride) q[j] = make_uint4(0u, 0u, 0u, 0u);
+    const size_t done = head + body * 4;
+    if (i < head) p[i] = 0u;
+    if (i < n - done) p[done + i] = 0u;
+}
+}  // namespace
+
+int zero_fill(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (!p || (bytes & 3u) || (reinterpret_cast<uintptr_t>(p) & 3u)) return 1;
+    if (options().zero_fill_memset) return hipMemsetAsync(p, 0, bytes, st) == hipSuccess ? 0 : 1;
+    const size_t n = bytes / 4;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, static_cast<unsigned*>(p), n);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 // Channel slab per block: large enough to amortise the per-pixel set-up, small enough that the
 // grid has many blocks per CU on all 256 CUs.
 Geometry plan(int64_t B, int64_t C, int64_t H, int64_t W, int cs_default) {
@@ -229,6 +271,16 @@ int ffwm_prof_reset(void) {
     return FFWM_OK;
 }
 
+int ffwm_zero_fill(void* p, int64_t bytes, void* stream) {
+    FFWM_REQUIRE(bytes >= 0 && (bytes == 0 || p) && (bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 3u) == 0, FFWM_ERR_ARG,
+                 "ffwm_zero_fill: a 4-byte aligned address and a multiple of 4 bytes");
+    if (zero_fill(p, static_cast<size_t>(bytes), static_cast<hipStream_t>(stream))) {
+        set_error("ffwm_zero_fill: launch failed");
+        return FFWM_ERR_LAUNCH;
+    }
+    return FFWM_OK;
+}
+
 int ffwm_set_option(const char* key, int value) {
     if (!key) return FFWM_ERR_ARG;
     Options& o = options();
@@ -255,6 +307,8 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "conv_thin_tail")) slot = &o.conv_thin_tail;
     else if (!strcmp(key, "conv_wino_raw")) slot = &o.conv_wino_raw;
     else if (!strcmp(key, "conv_wino_split")) slot = &o.conv_wino_split;
+    else if (!strcmp(key, "conv_wgrad_unsliced")) slot = &o.conv_wgrad_unsliced;
+    else if (!strcmp(key, "zero_fill_memset")) slot = &o.zero_fill_memset;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;

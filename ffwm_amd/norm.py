@@ -144,7 +144,9 @@ _BN_RES = os.environ.get("FFWM_BN_RES_ACT", "1") != "0"
 
 def bn_res_act_ok(bn, x, act_code):
     """The fused tail serves: a training-mode BatchNorm2d with a fixed momentum on a contiguous float32 GPU tensor, LeakyReLU / sigmoid."""
-    return (_BN_RES and act_code is not None and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.momentum is not None and torch.is_tensor(x)
+    # (exactly a plain BatchNorm2d or its host-counted twin: a BatchNormLeakyReLU2d IS-A BatchNorm2d too, and the fused tail would
+    # silently drop its activation)
+    return (_BN_RES and act_code is not None and type(bn) in (nn.BatchNorm2d, HostCountBatchNorm2d) and bn.training and bn.momentum is not None and torch.is_tensor(x)
             and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.numel() // x.shape[1] > 1 and not torch.is_autocast_enabled()
             and (bn.weight is None or bn.weight.dtype == torch.float32))
 

@@ -453,7 +453,7 @@ def conv2d_wgrad_tiled_ok(rows):
 def conv2d_wgrad_tiled(rows, gathered, kernel, stride, pad, want_bias=False):
     """-> (grad_weight, grad_bias or None) of Conv2d (rows = grad_output, gathered = input: [K, C, k, k]; grad_bias = the row sums)
     or grad_weight [Ci, Co, 4, 4] of ConvTranspose2d(4, 2, 1) (rows = input, gathered = grad_output; no bias) on the tiled kernel of
-    csrc/conv_bwd.hip.  Both results are slices of ONE fresh buffer (the library clears it with one memset when it has to)."""
+    csrc/conv_bwd.hip.  Both results are slices of ONE fresh buffer (the library clears it with one fill launch when it has to)."""
     _check("conv2d_wgrad_tiled", rows, gathered)
     B, K, Ho, Wo = rows.shape
     Bg, C, H, W = gathered.shape
@@ -494,6 +494,7 @@ def conv3x3_winograd(x, weight, bias=None, data_gradient=False, act=0, slope=0.0
     elif tuple(out.shape) != (B, K, H, W):
         raise ValueError("conv3x3_winograd: out has the wrong shape")
     lib = _lib.load()
+    _sync_winograd_split_mode()
     mode = int(bool(data_gradient))
     ws = None
     if pre is not None:
@@ -553,8 +554,25 @@ def conv3x3_winograd_weights_multi(items):
     return out
 
 
+_WINO_SPLIT_CAPPED = None
+
+
+def _sync_winograd_split_mode():
+    """torch.use_deterministic_algorithms(True) caps the Winograd kernel's reduction split at TWO pieces: two partial sums meet in a
+    zero-filled output by float atomics, and a two-term sum does not depend on the order -- four terms do.  The library
+    option conv_wino_split follows the switch (1 = up to four pieces, 2 = capped); a value of 0 set by hand (never split) is kept."""
+    global _WINO_SPLIT_CAPPED
+    want = bool(torch.are_deterministic_algorithms_enabled())
+    if want != _WINO_SPLIT_CAPPED:
+        prev = _lib.set_option("conv_wino_split", 2 if want else 1)
+        if prev == 0:
+            _lib.set_option("conv_wino_split", 0)
+        _WINO_SPLIT_CAPPED = want
+
+
 def conv3x3_winograd_splits(B, C, H, W, K, act=0):
     """In how many pieces conv3x3_winograd will cut the reduction of this call (1, 2 or 4): ffwm_conv3x3_winograd_splits."""
+    _sync_winograd_split_mode()
     return int(_lib.load().ffwm_conv3x3_winograd_splits(int(B), int(C), int(H), int(W), int(K), int(act)))
 
 

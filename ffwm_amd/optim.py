@@ -46,16 +46,28 @@ class FlatAdam(object):
         # state[0] step counter, state[1..2] scratch, state[3] the current learning rate (csrc/adam.hip: it overrides the kernel argument
         # a captured graph has baked in)
         self.state = torch.zeros(4, device=dev, dtype=torch.float64) if self.capturable else None
+        if self.state is not None:
+            self.state[3] = -1.0          # no learning-rate override yet (0.0 is a legitimate rate: the sentinel is negative)
         # torch.optim's interface for schedulers (base_model.update_learning_rate: StepLR / lambda rules write param_groups[i]['lr'])
         self.param_groups = [{"capturable": self.capturable, "lr": self.lr, "params": params}]
         self._lr_on_device = None
+        self._lr_seen = self.lr
 
     def sync_lr(self):
-        """Take the learning rate a scheduler wrote into param_groups[0]['lr'] (or self.lr).  Eager: used by the next step() directly.
-        Capturable: written to the device state, so it also reaches the REPLAYS of a captured step -- call it (or step()) from the host
-        after the scheduler ran; a replay itself runs no Python."""
-        lr = float(self.param_groups[0]["lr"])
-        self.lr = lr
+        """The learning rate of the next step: whichever of ``self.lr`` (direct assignment) and ``param_groups[0]['lr']`` (torch.optim's
+        interface: base_model.update_learning_rate, StepLR / lambda rules) CHANGED since the last call -- the scheduler's value when both
+        did.  Eager: used by the next step() directly.  Capturable: written to the device state, so it also reaches the REPLAYS of a
+        captured step -- call it (or step()) from the host after the scheduler ran; a replay itself runs no Python.  A rate of 0.0 is a
+        rate like any other (csrc/adam.hip takes the device value whenever it is >= 0; the state starts at -1 = "no override")."""
+        g = float(self.param_groups[0]["lr"])
+        if g != self._lr_seen:
+            lr = g
+        elif float(self.lr) != self._lr_seen:
+            lr = float(self.lr)
+        else:
+            lr = self._lr_seen
+        self.lr = self._lr_seen = lr
+        self.param_groups[0]["lr"] = lr
         if self.capturable and lr != self._lr_on_device and not torch.cuda.is_current_stream_capturing():
             self.state[3:4].fill_(lr)
             self._lr_on_device = lr

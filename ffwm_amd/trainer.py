@@ -791,8 +791,7 @@ class FFWMTrainer(object):
         """Capture the train step into hipGraphs (HIP graphs through torch.cuda.CUDAGraph): the eager
         step issues ~2700 small launches and is launch-bound (SURVEY 7 'hard parts'); a replay submits
         them as pre-built graphs.  Single GPU: ONE graph for the whole step.  Data parallel, `mode`
-        (default: FFWM_DP_CAPTURE, else "ingraph" when the backend is RCCL and a probe graph with one
-        all-reduce replays correctly on every rank, else "serial"):
+        (default: FFWM_DP_CAPTURE, else "serial"; "ingraph" is opt-in until it has run on >= 2 real ranks):
           "ingraph"   ONE graph, as on one GPU, with the collectives inside it: capture runs the Python once, so red_G's
                       autograd hooks fire and launch each bucket's all-reduce the moment its last gradient is written; RCCL's
                       stream is forked from / joined to the step's streams by the events torch.distributed records, and the
@@ -800,12 +799,13 @@ class FFWMTrainer(object):
                       branch; its (4.5 MB) all-reduce and Adam are issued on the step's stream at the join in front of the
                       adversarial term.  Verified on the one-GPU box with a one-rank RCCL group (tests/test_gpu_dp.py).
           "serial"    round 3's three graphs with the two all-reduces between them, nothing overlapped: the fallback.
-          "segments"  EXPERIMENTAL, never chosen automatically: backward_G cut where a network's gradients are complete (loss networks +
-                      flowNetB | netG | flowNetF), one graph per segment, the finished network's buckets reduced asynchronously while
-                      the next segment replays.  The segmented backward itself is exact (tests/test_dp_gloo.py: bit-equal to the
-                      unsegmented step, eager), but the five-graph REPLAY produced non-finite weight gradients on the MI355X box in a
-                      timing-dependent way (side streams on: three netG layers every time; side streams off: one of four two-rank runs
-                      -- profiles/r04_dp_capture_modes.txt); cause not found, so it stays opt-in.
+          "segments"  opt-in: backward_G cut where a network's gradients are complete (loss networks + flowNetB | netG | flowNetF),
+                      one graph per segment, the finished network's buckets reduced asynchronously while the next segment replays.
+                      The segmented backward is exact (tests/test_dp_gloo.py: bit-equal to the unsegmented step, eager).  Round 4 saw
+                      non-finite weight gradients in this mode's replay; round 5 found the cause outside it -- hipMemsetAsync nodes whose
+                      fill pattern the runtime corrupts when graphs with side branches are replayed back to back
+                      (profiles/r05_wgrad_nan_root_cause.txt); the library zero-fills with its own kernel since, and the mode keeps the
+                      side streams (FFWM_SEG_STREAMS=0: without them).
         The batch is copied into static device buffers before every replay; the `titers` branch
         (< 20000 / >= 20000) is frozen at capture time -- re-capture when it flips."""
         assert self.device.type == "cuda" and self._graphs is None
@@ -813,7 +813,9 @@ class FFWMTrainer(object):
                    for g in getattr(o, "param_groups", [{}])):
             raise RuntimeError("capture() needs FFWMTrainer(..., capturable=True)")
         if self.dp_active:
-            mode = mode or os.environ.get("FFWM_DP_CAPTURE") or ("ingraph" if probe_collective_capture(self.device) else "serial")
+            # "serial" unless asked otherwise: "ingraph" has only ever run with ONE RCCL rank (no multi-GPU box in four rounds), and a
+            # passing probe graph says nothing about the whole step's cross-stream forks and joins between real ranks
+            mode = mode or os.environ.get("FFWM_DP_CAPTURE") or "serial"
             if mode not in ("ingraph", "segments", "serial"):
                 raise ValueError("capture mode %r" % (mode,))
         else:
@@ -824,10 +826,8 @@ class FFWMTrainer(object):
         # step on the side branch), "0" (no side branch for D)
         dside = os.environ.get("FFWM_INGRAPH_DSIDE", "main")
         self._d_side = True if mode == "single" else ({"main": "reduce_on_main", "side": True}.get(dside, False) if mode == "ingraph" else False)
-        if mode == "segments":
-            # measured (profiles/r04_dp_capture_modes.txt): with side streams inside the five-graph step the replayed weight gradients of
-            # three netG layers came out non-finite; without them the step equals the eager one.  This mode is the fallback: one stream.
-            self._streams_saved = (self.flow_stream, self.loss_streams)
+        if mode == "segments" and os.environ.get("FFWM_SEG_STREAMS", "1") == "0":
+            self._streams_saved = (self.flow_stream, self.loss_streams)          # (diagnosis: the five-graph step on one stream)
             self.flow_stream, self.loss_streams = None, None
         self._static = {k: v.clone() for k, v in b.items()}
         sb = self._static
@@ -899,7 +899,7 @@ class FFWMTrainer(object):
                 self.red_D.pack_all()
             self.red_D.finish()
             torch.cuda.synchronize(self.device)
-            pool = gs[0].pool()
+            pool = gs[0].pool() if os.environ.get("FFWM_SEG_OWN_POOLS", "0") != "1" else None          # (1: every graph its own pool, a diagnosis switch)
             with torch.cuda.graph(gs[1], pool=pool):       # D's Adam, the loss passes, backward down to the generated images + flowNetB
                 self._seg_stepD_and_G(sb)
                 self.red_G.pack_all(self.G_B)
@@ -970,6 +970,11 @@ class FFWMTrainer(object):
         self._graphs = None
         self._static = None
         self.segmented = False
+        # the eager step that follows must not take the paths that are valid only inside an in-graph capture (event joins, the
+        # ground-truth prefetch on side streams), and scratch buffers whose zero-fill was only CAPTURED must not be found in the cache
+        self.capture_mode = None
+        from .norm import reset_scratch
+        reset_scratch()
         self._d_side = not self.dp_active
         if getattr(self, "_streams_saved", None) is not None:
             self.flow_stream, self.loss_streams = self._streams_saved
@@ -994,6 +999,26 @@ class FFWMTrainer(object):
 
     def loss_values(self):
         return {k: float(v.detach()) for k, v in self.losses.items()}
+
+    def rank_spread(self):
+        """max over the ranks of |weights - rank 0's weights|, per network (0.0 everywhere = the ranks are in lock step).  Two
+        collectives per network over its flat parameter vector -- a check for after the first replays of a captured data-parallel step
+        (bench.py), not for the timed region."""
+        import torch.distributed as dist
+        out = {}
+        for name in self.MODEL_NAMES:
+            net = getattr(self, name)
+            flat = torch.cat([p.detach().flatten().float() for p in net.parameters()])
+            if self.world_size > 1 and dist.is_available() and dist.is_initialized():
+                hi, lo = flat.clone(), flat.clone()
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                out[name] = float((hi - lo).abs().max())
+            else:
+                out[name] = 0.0
+            if not bool(torch.isfinite(flat).all()):
+                out[name] = float("nan")
+        return out
 
     # ------------------------------------------------------------------ checkpoint interchange / evaluation forward
     MODEL_NAMES = ("netG", "netD", "flowNetF", "flowNetB")      # ffwm_model.py:20-24
@@ -1166,6 +1191,8 @@ class FlowNetTrainer(object):
     def release_graphs(self):
         self._graphs = None
         self._static = None
+        from .norm import reset_scratch
+        reset_scratch()                      # (scratch buffers first made inside the capture: their zero-fill was only captured)
         self.reducer.set_overlap(True)
         self.reducer.set_gather(True)
 

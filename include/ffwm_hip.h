@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FFWM_ABI_VERSION 3
+#define FFWM_ABI_VERSION 4
 
 typedef enum {
     FFWM_OK = 0,
@@ -442,8 +442,9 @@ int ffwm_adam_step(void* params, const void* grads, void* exp_avg, void* exp_avg
 
 /* The same step with the step counter in DEVICE memory (a step inside a captured hipGraph: a replay runs no host code).  state:
  * FOUR doubles (ABI 3; three before): state[0] = steps taken so far (start it at 0), state[1] and state[2] are scratch,
- * state[3] = learning-rate override -- when > 0 it replaces `lr`, so that a learning-rate schedule reaches a captured step
- * (`lr` is baked into the graph as a kernel argument; the host writes state[3] between replays).  Two launches. */
+ * state[3] = learning-rate override -- when >= 0 it replaces `lr`, so that a learning-rate schedule reaches a captured step
+ * (`lr` is baked into the graph as a kernel argument; the host writes state[3] between replays); start it at a NEGATIVE value for
+ * "no override" (ABI 4; ABI 3 took 0 for "none", so a schedule that reached 0.0 could not freeze the weights).  Two launches. */
 int ffwm_adam_step_device(void* params, const void* grads, void* exp_avg, void* exp_avg_sq, int64_t n, double lr, double beta1,
                           double beta2, double eps, void* state, int dtype, void* stream);
 
@@ -469,6 +470,12 @@ int ffwm_prof_reset(void);
  * "channel_slab", "xcd_remap", "ablate", "rows_per_thread",
  * "scatter_variant". */
 int ffwm_set_option(const char* key, int value);
+
+/* Zero-fill `bytes` bytes (a multiple of 4) at the 4-byte aligned device address `p` with a KERNEL on `stream` -- what the
+ * caller-zero-fills contract of the backward entry points (external_function.py:49-50,96,137-138) needs under hipGraph capture, where
+ * hipMemsetAsync becomes a memset node: on ROCm 7.0 such nodes were executed with a corrupted fill pattern when several graphs with
+ * side-stream branches were replayed back to back (profiles/r05_wgrad_nan_root_cause.txt). */
+int ffwm_zero_fill(void* p, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

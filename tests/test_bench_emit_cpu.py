@@ -55,3 +55,37 @@ def test_oversized_fields_never_push_the_last_line_over_the_limit():
     last = bench.emit_lines(stub)[-1]
     assert len(last) < 4096
     assert tuple(json.loads(last))[:len(CONTRACT)] == CONTRACT
+
+
+def _r04_rows():
+    """round 4's kernel rows and sub-path figures (the verbose lines of profiles/r04_bench_default.json)"""
+    with open(os.path.join(ROOT, "profiles", "r04_bench_default.json")) as f:
+        lines = [ln for ln in f if ln.strip()]
+    return json.loads(lines[0])["kernels"], json.loads(lines[1])["detail"]["subpaths"]
+
+
+def test_last_line_carries_the_per_config_operator_rows():
+    """BASELINE configs[0], [1], [4] must be visible in the line the driver parses."""
+    stub = _stub()
+    stub["kernels"], stub["subpaths"] = _r04_rows()
+    stub["kernel_rows_from"] = "2 eager single-stream steps after the timed region"
+    last = bench.emit_lines(stub)[-1]
+    assert len(last) < 4096, len(last)
+    d = json.loads(last)
+    assert tuple(d)[:len(CONTRACT)] == CONTRACT
+    ops = d["ops"]
+    for k in ("cfg1_rs_fwd", "cfg1_rs_bwd1", "cfg1_rs_bwd2", "cfg5_be_fwd", "cfg5_be_bwd", "cfg5_lar", "warp_fwd@256", "warp_bwd_flow@256",
+              "flownet_fwd_cfg2", "cfg5_battn_bwd", "rs_bwd1@512", "warp_bwd_feat@256"):
+        assert k in ops and len(ops[k]) == 2 and ops[k][0] > 0, (k, ops.get(k))
+    # the figures are the rows' own: round 4's cfg-5 extractor forward (211 us = 0.80 by HIP events), backward 596 us = 0.31
+    assert abs(ops["cfg5_be_fwd"][0] - 211.05) < 0.01 and abs(ops["cfg5_be_bwd"][1] - 0.3105) < 1e-4
+    assert abs(ops["flownet_fwd_cfg2"][0] - 897.2) < 0.1
+    assert "after the timed region" in d["roofline"]["rows_from"]
+
+
+def test_operator_rows_survive_the_size_limit_longer_than_the_optional_objects():
+    stub = _stub()
+    stub["kernels"], stub["subpaths"] = _r04_rows()
+    stub["allreduce"] = {"note": "z" * 3000}
+    d = json.loads(bench.emit_lines(stub)[-1])
+    assert "ops" in d and "allreduce" not in d

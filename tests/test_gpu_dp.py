@@ -190,7 +190,7 @@ def _worker_ingraph(rank, world, port, ret):
         tp = trainer.FFWMTrainer(dev, world_size=1, seed=50, ngf=16, bucket_bytes=4 << 20, capturable=True)
         assert tg.red_G.active and tg.dp_active and not tp.red_G.active
         batch = trainer.synthetic_batch(2, dev, seed=1000)
-        tg.capture(batch, warmup=2)
+        tg.capture(batch, warmup=2, mode="ingraph")          # opt-in since round 5 (the default for several ranks is "serial")
         tp.capture(batch, warmup=2)
         assert tg.capture_mode == "ingraph" and len(tg._graphs) == 1
         log_D, log_G = tg._captured_launch_log
@@ -199,17 +199,31 @@ def _worker_ingraph(rank, world, port, ret):
         assert sum(1 for _, w in log_G if w == "hook") >= n - 2, log_G
         assert tg._d_side == "reduce_on_main" and log_D and all(w == "finish" for _, w in log_D), log_D
 
-        def flat(t):
-            return torch.cat([p.detach().flatten().float() for m in (t.flowNetF, t.flowNetB, t.netG, t.netD) for p in m.parameters()])
+        # Two trainers of one seed, fed the same batches.  Float atomics make their gradients differ in the last bits and the GAN step of
+        # these narrow nets (Adam normalises noise-level gradients to full-size updates) amplifies that from the first warm-up step on:
+        # over 10 processes x 10 replays (profiles/r05_ingraph_repeat.txt) the relative loss difference between the two was 0.2-1.2 %
+        # at the first replay and wandered between 0.3 % and 14 % afterwards, without trend.  Round 4 asserted 5 % on the values after
+        # the tenth replay and failed 1 run in 15 -- that assertion, not the captured collectives, was the failure (the retry it was
+        # wrapped in is gone).  Asserted now: finite losses and gradients at every replay, the first replay within 3 %, every replay
+        # within 30 % (an all-reduce that was lost, doubled or applied to the wrong bucket moves the losses by far more: the D / G
+        # gradients would be zero or twice their size).
+        diag = []
         for i in range(10):
             bi = batch if i % 2 == 0 else trainer.synthetic_batch(2, dev, seed=1100 + i)
             tg.step(bi)
             tp.step(bi)
-        torch.cuda.synchronize()
-        vg, vp = tg.loss_values(), tp.loss_values()
-        assert all(torch.isfinite(torch.tensor(v)) for v in vg.values()), vg
-        for k in ("G", "D", "l1", "illu"):
-            assert abs(vg[k] - vp[k]) <= 5e-2 * (1 + abs(vp[k])), (k, vg[k], vp[k])
+            torch.cuda.synchronize()
+            vg, vp = tg.loss_values(), tp.loss_values()
+            assert all(torch.isfinite(torch.tensor(v)) for v in vg.values()), (i, vg)
+            gg, gp = tg.red_G.flat, tp.red_G.flat
+            assert bool(torch.isfinite(gg).all()) and bool(torch.isfinite(tg.red_D.flat).all()), "non-finite gradients at replay %d" % i
+            rel_g = float((gg - gp).norm() / (gp.norm() + 1e-30))
+            rel_l = max(abs(vg[k] - vp[k]) / (1 + abs(vp[k])) for k in ("G", "D", "l1", "illu"))
+            diag.append((round(rel_l, 5), round(rel_g, 5)))
+            if i == 0:
+                assert rel_l <= 3e-2, ("first replay", diag)
+        ret["diag"] = diag
+        assert max(d[0] for d in diag) <= 0.30, ("losses drifted apart", diag)
         ret[rank] = "ok"
     except Exception as e:
         import traceback
@@ -219,20 +233,10 @@ def _worker_ingraph(rank, world, port, ret):
 
 
 def test_dp_collectives_captured_into_the_step_graph_one_rank_rccl():
-    # (one retry: in ~1 of 15 runs on a fresh box this test failed once and passed on every repetition -- 13 of 13 -- with the same
-    # binary; the first attempt's message is kept so that a real regression still shows what broke)
-    first = None
-    for attempt in range(2):
-        mgr = mp.Manager()
-        ret = mgr.dict()
-        mp.spawn(_worker_ingraph, args=(1, _free_port(), ret), nprocs=1, join=True)
-        if dict(ret) == {0: "ok"}:
-            if first is not None:
-                import warnings
-                warnings.warn("first attempt failed: %s" % first)
-            return
-        first = first or dict(ret)
-    assert False, (first, dict(ret))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_ingraph, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret.get(0) == "ok", dict(ret)
 
 
 def test_dp_captured_three_graph_step_two_ranks_on_one_gpu():
@@ -281,3 +285,90 @@ def test_bench_launch_path_two_ranks_gloo():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["grad_bytes_per_step"] > 400e6 and out["config"]["grad_buckets"] >= 2
+
+
+def _worker_segments(rank, world, port, ret):
+    """The five-graph ("segments") replay WITH its side streams -- the configuration in which round 4 saw non-finite weight gradients
+    of netG's 256 / 384-channel 3x3 layers.  Cause (round 5, profiles/r05_wgrad_nan_root_cause.txt): hipMemsetAsync nodes whose fill
+    pattern the runtime corrupted; the library's own zero-fill kernel replaced them.  Two gloo ranks share the GPU; asserted over 12
+    replays: finite losses, weights and gradient buckets, and the ranks' weights in lock step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ffwm_amd import trainer
+        torch.backends.cudnn.benchmark = False
+        dev = torch.device("cuda", 0)
+        t = trainer.FFWMTrainer(dev, world_size=world, seed=60 + rank, ngf=16, bucket_bytes=8 << 20, capturable=True)
+        batch = trainer.synthetic_batch(2, dev, seed=1300 + rank)
+        t.capture(batch, warmup=2, mode="segments")
+        assert len(t._graphs) == 5 and t.flow_stream is not None and t.loss_streams is not None        # the side streams stayed
+        for i in range(12):
+            t.step(batch if i % 2 == 0 else trainer.synthetic_batch(2, dev, seed=1400 + 10 * i + rank))
+            torch.cuda.synchronize()
+            vals = t.loss_values()
+            assert all(torch.isfinite(torch.tensor(v)) for v in vals.values()), (i, vals)
+            assert bool(torch.isfinite(t.red_G.flat).all()) and bool(torch.isfinite(t.red_D.flat).all()), "non-finite gradients at replay %d" % i
+        spread = t.rank_spread()
+        assert all(v <= 1e-6 for v in spread.values()), spread
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "FAIL: %s\n%s" % (e, traceback.format_exc()[-1800:])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_five_graph_replay_with_side_streams_two_ranks_on_one_gpu():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_segments, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def _worker_full_size(rank, world, port, ret):
+    """BASELINE configs[3]'s per-rank workload with world > 1 for the first time: ngf 64 flow nets, batch 8 per
+    rank, 64 MiB buckets (428 MB of G gradients), the capture mode bench.py uses for several ranks ("serial": three graphs, the two
+    all-reduces between them) -- two gloo ranks share the GPU.  Three replays on per-rank data; asserted: finite losses, every bucket
+    reduced once per step, the ranks' weights in lock step (identical averaged gradients -> identical Adam updates)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ffwm_amd import miopen_tuning, trainer
+        torch.backends.cudnn.benchmark = False
+        miopen_tuning.install()
+        dev = torch.device("cuda", 0)
+        t = trainer.FFWMTrainer(dev, world_size=world, seed=0, bucket_bytes=64 << 20, capturable=True)
+        assert t.red_G.grad_bytes() > 400e6 and len(t.red_G.buckets) >= 6
+        batch = trainer.synthetic_batch(8, dev, seed=1 + rank)
+        t.capture(batch, warmup=2)
+        assert t.capture_mode == "serial" and len(t._graphs) == 3          # the default for several ranks
+        nb = len(t.red_G.buckets)
+        for i in range(3):
+            t.step(batch if i != 1 else trainer.synthetic_batch(8, dev, seed=50 + rank))
+            torch.cuda.synchronize()
+            assert sorted(b for b, _ in t.red_G.launch_log) == list(range(nb)), t.red_G.launch_log
+            vals = t.loss_values()
+            assert all(torch.isfinite(torch.tensor(v)) for v in vals.values()), (i, vals)
+        spread = t.rank_spread()
+        assert all(v <= 1e-6 for v in spread.values()), spread
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "FAIL: %s\n%s" % (e, traceback.format_exc()[-1800:])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_full_size_step_bs8_per_rank_ngf64_two_ranks_on_one_gpu():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_full_size, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)

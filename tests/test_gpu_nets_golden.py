@@ -440,3 +440,40 @@ def test_winograd_transforms_prepared_with_the_spectral_norm_equal_the_per_call_
             thin = (Kc > 64 or Kc <= 4) and 1 <= tail <= 4 and W % 4 == 0
             n = -(-(Kc - tail if thin else Kc) // 64) * -(-Cc // 8) * 8192 + (Cc * 36 if thin else 0)
             assert n <= ws.numel() and torch.equal(ws[:n], percall[:n]), (K, C, W, dg)
+
+
+def test_reference_written_checkpoint_and_composed_test_forward_on_the_gpu(tmp_path):
+    """SURVEY 8(f) rank 4 / VERDICT r4 next 8, on the product path: FFWMTrainer on the GPU (HIP warp kernels, routed convolutions,
+    batched spectral norm, guided-filter kernel) loads a checkpoint directory in the reference's layout -- flowNetF from the file the
+    REFERENCE's FlowNet(4) wrote (tests/golden/ckpt), netG / netD re-derived under the reference's key names and held to the
+    reference's per-tensor checksums -- and its test_forward (models/ffwm_model.py:183-189) reproduces the reference's composed
+    flowNetF -> WarpNet -> netG -> GuidedFilter(32) outputs (tests/golden/reference_eval.pt) to 1e-4 of their scale."""
+    import test_trainer_cpu as tc
+    from ffwm_amd import trainer
+    gold_eval, ckpt_dir = tc._eval_golden()
+    ep = tc._prepare_reference_checkpoints(tmp_path, gold_eval, ckpt_dir)
+    t = trainer.FFWMTrainer(torch.device(DEV), seed=5, ngf=4)
+    t.load_networks(str(tmp_path), ep, names=("flowNetF", "netG", "netD"))
+    ref_sd = torch.load(os.path.join(ckpt_dir, "%s_net_flowNetF.pth" % ep))
+    for k, v in t.flowNetF.state_dict().items():
+        assert torch.equal(v.cpu(), ref_sd[k]), k
+    for n in t.MODEL_NAMES:
+        getattr(t, n).eval()
+    b = {"img_S": fill.image(2, 3, 128, 128, "eval_img_S").to(DEV), "img_F": fill.image(2, 3, 128, 128, "eval_img_F").to(DEV)}
+    fake, gf, warped, att = t.test_forward(b)
+    tf = gold_eval["test_forward"]
+    with torch.no_grad():
+        flows = t.flowNetF(b["img_S"])
+    worst = {}
+    for got, key in zip(flows, ("flow_F128", "flow_F64", "flow_F32")):
+        worst[key] = tc._packed_close(got, tf[key], 1e-4)
+    worst["img_S_warp"] = tc._packed_close(warped, tf["img_S_warp"], 1e-4)
+    worst["fake_F128"] = tc._packed_close(fake, tf["fake_F128"], 1e-4)
+    worst["att"] = tc._packed_close(att, tf["att"], 1e-4)
+    worst["img_GF128"] = tc._packed_close(gf, tf["img_GF128"], 1e-4)
+    with torch.no_grad():
+        score = t.netD(fake)
+    ref_score = gold_eval["netD_score_of_fake"]
+    assert float((score.cpu() - ref_score).abs().max()) <= 1e-4 * (1 + float(ref_score.abs().max()))
+    # the identity feature of the evaluation path (ffwm_model.py:191-202) runs on the loaded generator's output
+    assert t.identity_feature(fake).shape[0] == 2

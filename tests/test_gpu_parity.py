@@ -1437,6 +1437,49 @@ def test_flat_adam_follows_a_learning_rate_schedule_eagerly_and_under_replay():
         assert opt_ref.param_groups[0]["lr"] < 5e-6                         # the schedule did decay (twice: 4e-4 -> 4e-6)
 
 
+def test_flat_adam_honours_a_zero_rate_and_direct_assignment_eager_and_replayed():
+    """`opt.lr = x` must not be overwritten by the stale param_groups value, and a rate of 0.0 must reach a REPLAYED step
+    (the device override used `> 0` as its sentinel: a schedule that reached zero kept the rate baked into the graph)."""
+    import torch.nn as nn
+    from ffwm_amd.dp import BucketedGradReducer
+    from ffwm_amd.optim import FlatAdam
+    for capturable in (False, True):
+        torch.manual_seed(7)
+        net = nn.Linear(24, 8).to(DEV)
+        red = BucketedGradReducer(net.parameters())
+        opt = FlatAdam(list(net.parameters()), red, lr=1e-2, betas=(0.5, 0.999), capturable=capturable)
+        red.flat.normal_()
+        graph = None
+        if capturable:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                opt.step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                opt.step()
+
+        def one_step():
+            if graph is None:
+                opt.step()
+            else:
+                opt.sync_lr()
+                graph.replay()
+            torch.cuda.synchronize()
+        w0 = net.weight.detach().clone()
+        one_step()
+        assert not torch.equal(net.weight.detach(), w0)              # the rate of the constructor moves the weights
+        opt.lr = 0.0                                                 # direct assignment (tools/two_stream_check.py)
+        w1 = net.weight.detach().clone()
+        one_step()
+        assert torch.equal(net.weight.detach(), w1), "lr = 0.0 must freeze the weights (capturable=%s)" % capturable
+        assert opt.param_groups[0]["lr"] == 0.0
+        opt.param_groups[0]["lr"] = 5e-3                             # a scheduler's write wins over the stale attribute
+        one_step()
+        assert not torch.equal(net.weight.detach(), w1) and opt.lr == 5e-3
+
+
 # ------------------------------------------------------------------------- fused BatchNorm2d + LeakyReLU
 @pytest.mark.parametrize("shape", [(8, 64, 32, 32), (4, 195, 64, 64), (8, 1024, 2, 2), (3, 37, 5, 7), (2, 16, 9, 9), (8, 5, 128, 128),
                                    (8, 64, 128, 128), (3, 130, 64, 128)])      # the last three split a channel over workgroups

@@ -9,9 +9,15 @@
 Tolerances, relative to 1 + max|reference| (north_star: <= 1e-4 max abs diff vs the reference resample2d, fp32):
   forward                 fp32 1e-6          fp64 1e-13
   d_input1 / d_source     fp32 4e-6          fp64 1e-12   (both sides accumulate in a different order)
-  d_input2 / d_flow       fp32 2e-4          fp64 1e-11   (C-channel sums + a quotient-rule difference of O(100)
-                                                           terms at sigma = 0.3; since round 3 the tap sums over the channels
-                                                           and the quotient rule are accumulated in double, fp64 2e-13)
+  d_input2 / d_flow       fp32 1e-4          fp64 1e-11   (the north_star's bound.  ONE configuration needs more, and not because of
+                                                           this library: at sigma = 0.3 (cfg1_ks4_sigma03; live test ks 4 / sigma 0.3) the
+                                                           quotient rule subtracts O(100) terms per pixel and the REFERENCE's own fp32
+                                                           kernels are 1.0e-4 away from the float64 evaluation of the same inputs
+                                                           (tests/test_oracle_ref_golden.py measures it on the golden file).  The HIP path
+                                                           accumulates the tap sums and the quotient rule in double, so it lands next to the
+                                                           float64 result and 1.0-1.6e-4 from the reference.  Those cases assert exactly
+                                                           that: |hip - fp64| <= |reference - fp64|, and |hip - reference| within the
+                                                           reference's own distance from fp64 (+ 1e-5).)
 """
 import os
 import sys
@@ -29,7 +35,8 @@ DEV = "cuda:0"
 GOLDEN = os.path.join(HERE, "golden", "reference_ops_gfx950.pt")
 FWD = {"f32": 1e-6, "f64": 1e-13}
 G1 = {"f32": 4e-6, "f64": 1e-12}
-G2 = {"f32": 2e-4, "f64": 1e-11}
+G2 = {"f32": 1e-4, "f64": 1e-11}
+G2_REFERENCE_LIMITED = {"cfg1_ks4_sigma03"}      # the reference's fp32 arithmetic is the larger error there (see above)
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +55,7 @@ def ref_mods():
 
 @pytest.mark.parametrize("dn", ["f32", "f64"])
 @pytest.mark.parametrize("name", list(cases.RS_CASES))
-def test_hip_resample2d_matches_reference_kernels(golden, name, dn):
+def test_hip_resample2d_matches_reference_kernels(golden, oracle, name, dn):
     from ffwm_amd import ops
     in1, in2, go, ks, dil = cases.rs_inputs(name, cases.DTYPES[dn])
     e = golden["resample2d"][name + "/" + dn]
@@ -59,7 +66,28 @@ def test_hip_resample2d_matches_reference_kernels(golden, name, dn):
     g1, g2 = torch.zeros_like(a), torch.zeros_like(b)
     ops.resample2d_backward(a, b, g, ks, dil, g1, g2)
     cases.compare(g1, e["g1"], G1[dn])
-    cases.compare(g2, e["g2"], G2[dn])
+    if dn == "f32" and name in G2_REFERENCE_LIMITED:
+        _closer_to_fp64_than_the_reference(oracle, g2, e["g2"], (in1, in2, go, ks, dil))
+    else:
+        cases.compare(g2, e["g2"], G2[dn])
+
+
+def _closer_to_fp64_than_the_reference(oracle, g2, packed, inputs):
+    """|hip - fp64| <= |reference - fp64| on the elements the golden file keeps (fp64 = the CPU oracle in double on the same fp32
+    inputs), the whole tensor within 1e-4 of the fp64 result, and the distance to the reference explained by the reference's own."""
+    in1, in2, go, ks, dil = inputs
+    truth = oracle.resample2d_backward(in1.double(), in2.double(), go.double(), ks, dil)[1]
+    got = g2.detach().cpu().double()
+    ref = (packed["full"] if "full" in packed else packed["sample"]).double().flatten()
+    pick = (lambda t: t.flatten()) if "full" in packed else (lambda t: t.flatten()[::cases.SAMPLE_STRIDE])
+    scale = 1 + float(ref.abs().max())
+    e_ref = float((ref - pick(truth)).abs().max()) / scale
+    e_hip = float((pick(got) - pick(truth)).abs().max()) / scale
+    e_all = float((got - truth).abs().max()) / scale
+    d = float((pick(got) - ref).abs().max()) / scale
+    assert e_hip <= e_ref + 1e-7, "HIP %.3e from fp64, the reference %.3e" % (e_hip, e_ref)
+    assert e_all <= 1e-4, "HIP %.3e from fp64 over the whole tensor" % e_all
+    assert d <= e_ref + 1e-5, "HIP %.3e from the reference, which is itself %.3e from fp64" % (d, e_ref)
 
 
 @pytest.mark.parametrize("dn", ["f32", "f64"])
@@ -109,7 +137,19 @@ def test_live_resample2d_cfg1_against_the_reference_extension(ref_mods, ks, sigm
     ops.resample2d_backward(in1, in2, go, ks, 1, g1, g2)
     assert float((out - o_ref).abs().max()) <= 1e-4 and _rel(out, o_ref) <= FWD["f32"]
     assert _rel(g1, g1_ref) <= G1["f32"]
-    assert _rel(g2, g2_ref) <= G2["f32"]
+    if sigma >= 1.0:
+        assert _rel(g2, g2_ref) <= G2["f32"]
+    else:
+        # sigma 0.3: the reference's fp32 kernels are the larger error (module docstring) -- the float64 result of the same inputs
+        # comes from the reference's OWN kernels run in double
+        d1, d2, dg = in1.double(), in2.double(), go.double()
+        t1, t2 = torch.zeros_like(d1), torch.zeros_like(d2)
+        rs.backward(d1, d2, dg, t1, t2, ks, 1)
+        scale = 1.0 + float(g2_ref.abs().max())
+        e_ref = float((g2_ref.double() - t2).abs().max()) / scale
+        e_hip = float((g2.double() - t2).abs().max()) / scale
+        assert e_hip <= e_ref + 1e-7 and e_hip <= 1e-4, (e_hip, e_ref)
+        assert _rel(g2, g2_ref) <= e_ref + 1e-5, (_rel(g2, g2_ref), e_ref)
 
 
 def test_live_block_extractor_and_reshape_cfg5_slice_against_the_reference_extension(ref_mods):

@@ -9,8 +9,10 @@ reference's kernels, not merely an independent restatement of them.
 Tolerances, relative to 1 + max|reference| (written here):
   forward                 fp32 1e-6          fp64 1e-13   (same operation order; the reference's FMA contraction)
   d_input1 / d_source     fp32 4e-6          fp64 1e-12   (the reference accumulates with float atomics: order varies)
-  d_input2 / d_flow       fp32 2e-4          fp64 1e-11   (sums over C channels and a quotient-rule difference of
-                                                           O(100) terms at sigma = 0.3; measured 2.6e-5 worst)
+  d_input2 / d_flow       fp32 1e-4          fp64 1e-11   (the north_star's bound; sums over C channels and a quotient-rule
+                                                           difference of O(100) terms at sigma = 0.3: oracle vs reference 1.4e-5 worst)
+test_reference_fp32_distance_from_fp64 measures how far the REFERENCE's fp32 kernels are from the float64 evaluation of the same
+inputs (1.0e-4 at cfg1_ks4_sigma03, <= 1.3e-5 everywhere else): the figure the GPU test's one relaxed case rests on.
 """
 import os
 import sys
@@ -25,7 +27,7 @@ import ref_ops_cases as cases  # noqa: E402
 GOLDEN = os.path.join(HERE, "golden", "reference_ops_gfx950.pt")
 FWD = {"f32": 1e-6, "f64": 1e-13}
 G1 = {"f32": 4e-6, "f64": 1e-12}
-G2 = {"f32": 2e-4, "f64": 1e-11}
+G2 = {"f32": 1e-4, "f64": 1e-11}
 
 
 @pytest.fixture(scope="module")
@@ -96,3 +98,20 @@ def test_oracle_local_attn_reshape_matches_reference_kernels(oracle, golden, nam
 def test_reference_kernel_reproduces_its_own_known_answer(golden):
     """test_local_attn_reshape.py:29-43: range(9) -> [[0,1,2],[3,4,5],[6,7,8]]; run by the reference kernel itself."""
     assert torch.equal(golden["local_attn_reshape"]["range9"].view(3, 3), torch.arange(9.0).view(3, 3))
+
+
+def test_reference_fp32_distance_from_fp64(oracle, golden):
+    """d_input2 of the reference's fp32 kernels against the float64 evaluation (the oracle in double) of the SAME fp32 inputs, on the
+    elements the golden file keeps: <= 1.5e-5 of 1 + max|ref| for every case but cfg1_ks4_sigma03, where the reference itself is
+    ~1.0e-4 away (sigma 0.3: the quotient rule subtracts two sums of O(100) terms per pixel).  A HIP path that accumulates in double
+    cannot be closer than that to the reference there -- tests/test_gpu_ref_golden.py asserts it is closer to fp64 instead."""
+    worst = {}
+    for name in cases.RS_CASES:
+        in1, in2, go, ks, dil = cases.rs_inputs(name, torch.float32)
+        p = golden["resample2d"][name + "/f32"]["g2"]
+        truth = oracle.resample2d_backward(in1.double(), in2.double(), go.double(), ks, dil)[1]
+        ref = (p["full"] if "full" in p else p["sample"]).double().flatten()
+        tr = truth.flatten() if "full" in p else truth.flatten()[::cases.SAMPLE_STRIDE]
+        worst[name] = float((ref - tr).abs().max()) / (1 + float(ref.abs().max()))
+    assert 5e-5 <= worst["cfg1_ks4_sigma03"] <= 2e-4, worst
+    assert all(v <= 1.5e-5 for k, v in worst.items() if k != "cfg1_ks4_sigma03"), worst

@@ -115,3 +115,81 @@ def test_checkpoint_interchange_roundtrip_and_reference_key_names(tmp_path):
     assert all(torch.allclose(x, y, atol=1e-5, equal_nan=True) for x, y in zip(fa, fb))
     assert fa[0].shape == (1, 3, 128, 128) and fa[3].shape == (1, 1, 128, 128)
     assert a.identity_feature(fa[0]).shape[0] == 1
+
+
+def _eval_golden():
+    here = os.path.dirname(os.path.abspath(__file__))
+    return torch.load(os.path.join(here, "golden", "reference_eval.pt"), weights_only=False), os.path.join(here, "golden", "ckpt")
+
+
+def _packed_close(got, p, tol):
+    got = got.detach().cpu()
+    assert tuple(got.shape) == p["shape"], (tuple(got.shape), p["shape"])
+    s = p["step"]
+    scale = 1.0 + float(p["sample"].abs().max())
+    d = float((got[..., ::s, ::s] - p["sample"]).abs().max())
+    assert d <= tol * scale, "max abs diff %.3e > %.3e" % (d, tol * scale)
+    n = got.numel()
+    assert abs(float(got.double().sum()) - p["sum"]) / n <= tol * scale, "mean drift"
+    assert abs(float(got.double().abs().sum()) - p["abs_sum"]) / n <= tol * scale, "mean |.| drift"
+    return d / scale
+
+
+def _prepare_reference_checkpoints(tmp_path, gold, ckpt_dir):
+    """A checkpoint directory as the reference's BaseModel.save_networks leaves it: flowNetF = the file the REFERENCE's FlowNet(4) wrote
+    (tests/golden/ckpt, committed); netG / netD (65 MB / 4.5 MB: they do not travel) re-derived with the closed form the reference's
+    modules were filled with, under the reference's key names -- and held, key by key, to the shapes and float64 checksums of the
+    reference's own state dicts."""
+    import shutil
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fill
+    from ffwm_amd import nets
+    ep = gold["epoch"]
+    shutil.copy(os.path.join(ckpt_dir, "%s_net_flowNetF.pth" % ep), str(tmp_path))
+    for name, mod in (("netG", nets.FFWM(sn=True)), ("netD", nets.MSDiscriminator(128, sigmoid=False))):
+        sd = fill.fill_module(mod).state_dict()
+        ref = gold["state"][name]
+        assert list(sd.keys()) == list(ref.keys()), name          # the reference's names in the reference's ORDER
+        for k, v in sd.items():
+            shape, ssum, sabs = ref[k]
+            assert tuple(v.shape) == shape, (name, k)
+            assert abs(float(v.double().sum()) - ssum) <= 1e-6 * (1 + sabs) and abs(float(v.double().abs().sum()) - sabs) <= 1e-6 * (1 + sabs), (name, k)
+        torch.save({k: v.detach().cpu() for k, v in sd.items()}, os.path.join(str(tmp_path), "%s_net_%s.pth" % (ep, name)))
+    return ep
+
+
+def test_a_checkpoint_written_by_the_reference_loads_and_test_forward_matches_the_reference(tmp_path):
+    """(1) '7_net_flowNetF.pth' was written by the REFERENCE's FlowNet(4) through the code of BaseModel.save_networks
+    (tests/golden/make_eval_golden.py); load_networks must take it as it is.  (2) The composed FFWMModel.test_forward
+    (models/ffwm_model.py:183-189: flowNetF -> WarpNet -> netG -> GuidedFilter(32)) of the reference's modules is a committed fixture;
+    FFWMTrainer.test_forward on the loaded networks must reproduce it (CPU here, torch stand-ins for the warps; the GPU twin of this
+    test runs the HIP kernels: tests/test_gpu_nets_golden.py)."""
+    from ffwm_amd import trainer
+    torch.set_num_threads(8)
+    gold, ckpt_dir = _eval_golden()
+    ep = _prepare_reference_checkpoints(tmp_path, gold, ckpt_dir)
+    ref_sd = torch.load(os.path.join(ckpt_dir, "%s_net_flowNetF.pth" % ep))
+    assert {k: (tuple(v.shape), float(v.double().sum())) for k, v in ref_sd.items()} == \
+           {k: (s, x) for k, (s, x, _) in gold["state"]["flowNetF"].items()}          # the committed file IS the reference's state
+    t = trainer.FFWMTrainer("cpu", seed=5, ngf=4, warp=torch_refs.warp, warp_flipcat=torch_refs.warp_flipcat)
+    t.load_networks(str(tmp_path), ep, names=("flowNetF", "netG", "netD"))
+    for k, v in t.flowNetF.state_dict().items():
+        assert torch.equal(v.cpu(), ref_sd[k]), k
+    for n in t.MODEL_NAMES:
+        getattr(t, n).eval()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import fill
+    b = {"img_S": fill.image(2, 3, 128, 128, "eval_img_S"), "img_F": fill.image(2, 3, 128, 128, "eval_img_F")}
+    fake, gf, warped, att = t.test_forward(b)
+    tf = gold["test_forward"]
+    with torch.no_grad():
+        flows = t.flowNetF(b["img_S"])
+    for got, key in zip(flows, ("flow_F128", "flow_F64", "flow_F32")):
+        _packed_close(got, tf[key], 1e-5)
+    _packed_close(warped, tf["img_S_warp"], 1e-5)
+    _packed_close(fake, tf["fake_F128"], 1e-4)
+    _packed_close(att, tf["att"], 1e-4)
+    _packed_close(gf, tf["img_GF128"], 1e-4)
+    with torch.no_grad():
+        score = t.netD(fake)
+    assert float((score - gold["netD_score_of_fake"]).abs().max()) <= 1e-4 * (1 + float(gold["netD_score_of_fake"].abs().max()))
