@@ -19,6 +19,7 @@
 //     per neighbourhood cell in registers before the atomics ((k+1)^2 instead of 4*k^2).
 //   * blockIdx -> tile mapping is XCD-aware (common.hpp:xcd_remap).
 #include "common.hpp"
+#include <type_traits>
 
 namespace ffwm {
 namespace {
@@ -1152,8 +1153,20 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
 // FUSED (block attention backward): gout is the gradient of the attention output, [B, C, Hf, Wf], and the
 // k x k grad_output window of a pixel is (g / k^2) * w_ij with the attention weights w [B, k^2, Hf, Wf]
 // (what avg_pool2d's and the product's backward hand to the extractor) -- formed in registers, never stored.
-template <int K, int RH, int H, bool FUSED = false, bool ABL = false>
-__global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 && H <= 4 ? 4 : 2))
+// FIXED (round 5): the accumulator box holds 32-bit FIXED-POINT cells instead of doubles.  ds_add_u32 retires in half the LDS time of
+// ds_add_f64 (4.3 vs 8.6 clk per conflict-free wave instruction, tools/ubench/atomics.hip), a 4-byte cell spreads a wave's lanes over
+// twice as many banks, and the box is half the size (more resident blocks).  What makes it safe:
+//   * scale: per block and channel, 2^e with |v| 2^e < 2^23 for every contribution below thr = 4 x (the maximum of a 1-in-K^2 sample
+//     of the tile's grad_output window values, reduced over the block before the channel's pixels are visited);
+//   * a pixel whose own window holds a value >= thr ("big": the sample missed the tail, or NaN / Inf) does not use the box at all:
+//     its taps go to grad_source with global float atomics, exactly like a pixel of be_bwd_far2_kernel -- so a bad estimate costs
+//     time, never correctness, and non-finite gradients propagate as in the reference;
+//   * overflow is impossible: every contribution is a convex combination of window values (|v| <= max|g| < thr), and a cell of the
+//     box can only be reached by `fit` pixels within H of it -- at most (2 H + K + 1)^2 = 144 of them per channel: 144 x 2^23 < 2^31;
+//   * rounding: one unit = 2^-e <= thr / 2^22, i.e. <= 1e-6 of the tile's largest gradient per contribution (the reference's own
+//     float atomics round each partial sum to 6e-8 of ITS magnitude -- the same order once a cell has a few contributions).
+template <int K, int RH, int H, bool FUSED = false, bool ABL = false, int FIXED = 0>          // FIXED: 0 double cells, 1 fixed-point, 2 fixed-point at 5 waves per SIMD
+__global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 && H <= 4 ? (FIXED == 2 ? 5 : 4) : 2))
 be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
                    float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
                    int ntx, int nty, int cslabs, int cs, int remap, const float* __restrict__ attn = nullptr, int ablate_arg = 0) {
@@ -1174,7 +1187,9 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
     // Compared with the owned-tile kernel no pixel is visited twice (x1.0 instead of x1.52 pixel visits),
     // at the price of ~1.4 coalesced global atomics per pixel and channel.
     // DOUBLE on purpose: ds_add_f64 ~9 clk per wave, ds_add_f32 ~190 on gfx950 (tools/ubench/atomics.hip).
-    __shared__ double A[NA];
+    using AccT = typename std::conditional<FIXED != 0, int, double>::type;          // (FIXED: int cells)
+    __shared__ AccT A[NA];
+    __shared__ float red[NW];                              // FIXED: the waves' sampled maxima of the current channel
     unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
     const int tx = t % ntx;
     t /= ntx;
@@ -1241,11 +1256,67 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
     T gxa[PPT], gya[PPT];
 #pragma unroll
     for (int r = 0; r < PPT; ++r) gxa[r] = gya[r] = 0;
+    // FIXED: one grad_output window value per pixel of this lane's rows (the centre element), as loads in flight: sample_issue() requests
+    // them for channel plane `opc`, sample_max() folds them -- called around the flush of the previous channel, which hides their latency
+    constexpr int SSTEP = FUSED ? 2 : 1;          // (FUSED holds two loads per sample: every second row, to stay within the registers)
+    T smp[FIXED != 0 ? PPT : 1], smw[(FIXED != 0 && FUSED) ? PPT : 1];
+    T m_pre = 0;
+    auto sample_issue = [&](const T* opc) {
+        if constexpr (FIXED != 0) {
+            const rsrc_t rgs = make_rsrc(opc, obytes);
+            const int xs = min(max(xf, 0), Wf - 1);
+#pragma unroll
+            for (int r = 0; r < PPT; r += SSTEP) {
+                const int ys = min(max(y0 + wave + r * NW, 0), Hf - 1);
+                if constexpr (FUSED) {
+                    const unsigned fo = (static_cast<unsigned>(ys) * Wf + xs) * E;
+                    smp[r] = buf_ld<T>(rgs, fo);
+                    smw[r] = buf_ld<T>(ratt, fo + static_cast<unsigned>((K / 2 * K + K / 2) * fplane * E));
+                } else {
+                    smp[r] = buf_ld<T>(rgs, (static_cast<unsigned>(ys) * K * W + static_cast<unsigned>(xs) * K) * E + (K / 2) * orow + (K / 2) * E);
+                }
+            }
+        }
+    };
+    auto sample_max = [&]() {
+        if constexpr (FIXED != 0) {
+            T m = 0;
+#pragma unroll
+            for (int r = 0; r < PPT; r += SSTEP) {
+                const T v = FUSED ? (smp[r] / static_cast<T>(K * K)) * smw[r] : smp[r];
+                m = fmaxf(m, fabsf(v));                     // (fmaxf drops a NaN sample: such a pixel is "big" below)
+            }
+            m_pre = m;
+        }
+    };
+    sample_issue(op);
+    sample_max();
 
     for (int c = c0; c < c1; ++c, op += oplane) {
         const bool more = c + 1 < c1;
         const rsrc_t rg = make_rsrc(op, obytes);
         const rsrc_t rs = make_rsrc(sp + static_cast<size_t>(c - c0) * splane, sbytes);
+        // FIXED: this channel's scale (see the kernel's head) from one window value per pixel -- requested while the previous channel was
+        // flushed (`m_pre`), reduced over the block here
+        T thr = 0, fx_scale = 0, fx_inv = 0;
+        if constexpr (FIXED != 0) {
+            T m = wave_max(m_pre);
+            if (lane == 0) red[wave] = m;
+            __syncthreads();
+            T mm = red[0];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) mm = fmaxf(mm, red[w2]);
+            thr = 4 * mm;
+            int ex = 0;
+            (void)frexpf(thr, &ex);                          // thr = f 2^ex, f in [0.5, 1)
+            if (!(thr > 0) || !(thr < 1e37f) || ex < -100) {
+                thr = 0;                                    // nothing usable (all zeros, Inf): every pixel takes the exact per-tap path
+                fx_scale = fx_inv = 1;
+            } else {
+                fx_scale = ldexpf(1.f, 23 - ex);
+                fx_inv = ldexpf(1.f, ex - 23);
+            }
+        }
         // software pipeline: the flow vector and the k x k grad_output window of pixel row r+1 are
         // requested before row r is processed (their addresses do not depend on the flow), so the
         // ~300 instructions of one row cover the latency of the next one's loads
@@ -1319,11 +1390,31 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                                  (static_cast<unsigned>(av) <= static_cast<unsigned>(AH - 1 - K));
                 const bool sfit = fit;
                 const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
+                bool big = false;
+                T inv_pix = 1;
+                if constexpr (FIXED != 0) {
+                    // "big": a window value >= thr, a NaN or an Inf -- one unsigned maximum over the values' magnitude bits (for
+                    // non-negative floats the bit patterns order like the values, NaN / Inf patterns lie above every finite one;
+                    // thr == 0 makes every pixel big).  A small pixel's window is pre-scaled by 2^e (exact): the contributions come
+                    // out as integers-to-be, d(flow) is scaled back once per pixel.
+                    unsigned mb = 0;
+#pragma unroll
+                    for (int i = 0; i < K; ++i)
+#pragma unroll
+                        for (int j = 0; j < K; ++j) mb = max(mb, __float_as_uint(cur.g[i].v[j]) & 0x7FFFFFFFu);
+                    big = mb >= __float_as_uint(thr);
+                    const T sc_pix = big ? static_cast<T>(1) : fx_scale;
+                    inv_pix = big ? static_cast<T>(1) : fx_inv;
+#pragma unroll
+                    for (int i = 0; i < K; ++i)
+#pragma unroll
+                        for (int j = 0; j < K; ++j) cur.g[i].v[j] *= sc_pix;
+                }
                 if (fit & (!owned | sfit)) {
                     // hot path: dense (K+1)^2 neighbourhood at one LDS address + immediates, no masks.
                     // A pixel that is not owned reads an arbitrary valid source neighbourhood: its d(flow)
                     // is never written.
-                    double* ap = A + av * AP + au;
+                    AccT* ap = A + av * AP + au;
                     // d(source): the (K+1)^2 contributions are the separable product Wy^T G Wx of the K x K window
                     // (block_extractor_kernel.cu:158-161 summed over the window): columns first (tx[i][c]),
                     // then rows, one accumulator row at a time -> 4K(K+1)/... fmas instead of 6 K^2 operations
@@ -1352,8 +1443,41 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                             if (r2 < K) v = tx[r2][c2] * yt[r2];
                             if (r2 > 0) v = (r2 < K) ? fma_t<T>(tx[r2 - 1][c2], wyb[r2 - 1], v) : tx[r2 - 1][c2] * wyb[r2 - 1];
                             if (ablate & 1) { if (v == 12345.f) A[0] = 1; continue; }            // bench-only: no LDS atomics
-                            __hip_atomic_fetch_add(ap + r2 * AP + c2, static_cast<double>(v), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if constexpr (FIXED != 0) {
+                                // (a big pixel scatters below instead: the box never sees a value it cannot hold)
+                                if (!big)
+                                    __hip_atomic_fetch_add(ap + r2 * AP + c2, __float2int_rn(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            } else {
+                                __hip_atomic_fetch_add(ap + r2 * AP + c2, static_cast<double>(v), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                    if constexpr (FIXED != 0) {
+                        if (big) {
+                            // the exact per-tap scatter of be_bwd_far2_kernel for this pixel and channel (rare: the sampled maximum
+                            // missed this window by more than 4 x, or a non-finite gradient)
+                            T* gplane_c = gp + static_cast<size_t>(c - c0) * splane;
+#pragma unroll 1
+                            for (int i = 0; i < K; ++i) {
+                                const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
+#pragma unroll 1
+                                for (int j = 0; j < K; ++j) {
+                                    const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
+                                    T gv = cur.g[0].v[0];
+#pragma unroll
+                                    for (int i2 = 0; i2 < K; ++i2)
+#pragma unroll
+                                        for (int j2 = 0; j2 < K; ++j2)
+                                            if (i2 == i && j2 == j) gv = cur.g[i2].v[j2];
+                                    const unsigned rT = ty1.lo * static_cast<unsigned>(Ws) * E, rB = ty1.hi * static_cast<unsigned>(Ws) * E;
+                                    const unsigned cL = tx1.lo * E, cR = tx1.hi * E;
+                                    atomic_add_off(gplane_c, rT + cL, gv * tx1.wlo * ty1.wlo);
+                                    atomic_add_off(gplane_c, rT + cR, gv * tx1.whi * ty1.wlo);
+                                    atomic_add_off(gplane_c, rB + cL, gv * tx1.wlo * ty1.whi);
+                                    atomic_add_off(gplane_c, rB + cR, gv * tx1.whi * ty1.whi);
+                                }
+                            }
                         }
                     }
                     // d(flow) (:163-164), only where this wave's row belongs to the tile (wave-uniform) and for
@@ -1379,6 +1503,10 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                             for (int c2 = 0; c2 <= K; ++c2) gy = fma_t<T>(tx[i][c2], sc[c2] - sp[c2], gy);   // vertical differences
 #pragma unroll
                             for (int j = 0; j <= K; ++j) sp[j] = sc[j];
+                        }
+                        if constexpr (FIXED != 0) {
+                            gx *= inv_pix;
+                            gy *= inv_pix;
                         }
                     }
                 } else {
@@ -1418,14 +1546,14 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
         // first (one thread per accumulator row), then rows (one thread per column)
         if (foldL || foldR) {
             if (threadIdx.x < AH) {
-                double* arow = A + threadIdx.x * AP;
+                AccT* arow = A + threadIdx.x * AP;
                 if (foldL) {
-                    double s = 0;
+                    AccT s = 0;
                     for (int u = 0; u < -ax0; ++u) s += arow[u];
                     arow[-ax0] += s;
                 }
                 if (foldR) {
-                    double s = 0;
+                    AccT s = 0;
                     for (int u = Ws - ax0; u < AP; ++u) s += arow[u];
                     arow[Ws - 1 - ax0] += s;
                 }
@@ -1434,14 +1562,14 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
         }
         if (foldT || foldB) {
             if (threadIdx.x < AP) {
-                double* acol = A + threadIdx.x;
+                AccT* acol = A + threadIdx.x;
                 if (foldT) {
-                    double s = 0;
+                    AccT s = 0;
                     for (int v = 0; v < -ay0; ++v) s += acol[v * AP];
                     acol[-ay0 * AP] += s;
                 }
                 if (foldB) {
-                    double s = 0;
+                    AccT s = 0;
                     for (int v = Hs - ay0; v < AH; ++v) s += acol[v * AP];
                     acol[(Hs - 1 - ay0) * AP] += s;
                 }
@@ -1454,6 +1582,7 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
             // source goes into S -- an in-image cell has the same plane offset in both
             T* gplane = gp + static_cast<size_t>(c - c0) * splane;
             const rsrc_t rn = make_rsrc(sp + static_cast<size_t>(more ? c + 1 - c0 : c - c0) * splane, more ? sbytes : 0u);
+            if (more) sample_issue(op + oplane);
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
 #pragma unroll 1
@@ -1474,7 +1603,7 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                 for (int q = 0; q < 4; ++q) {
                     const int idx = i0 + q * kBlock + tid;
                     if (idx < NA) {
-                        const T v = static_cast<T>(A[idx]);
+                        const T v = FIXED != 0 ? static_cast<T>(A[idx]) * fx_inv : static_cast<T>(A[idx]);
                         A[idx] = 0;
                         // (measured, round 4: a plain read-modify-write for the 56 x 24 cells no other block can reach is SLOWER than the
                         // return-less atomic -- 679 vs 597 us: the atomic is one write transaction resolved at L2, the RMW a round trip)
@@ -1483,6 +1612,7 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                     }
                 }
             }
+            if (more) sample_max();
         }
         __syncthreads();
     }
@@ -1495,374 +1625,6 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                 const size_t fo = static_cast<size_t>(b) * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
                 atomic_add(gflow + fo, gxa[r]);
                 atomic_add(gflow + fo + fplane, gya[r]);
-            }
-        }
-    }
-}
-
-// ---- round 5: the shared-cell tile kernel on channel PAIRS ------------------------------------------------------------------------
-// be_bwd_tile2_kernel walks one channel at a time: every pixel-channel visit recomputes the taps (~45 vector instructions), copies the
-// software pipeline's registers, forms the separable products and reads the 4 x 4 source neighbourhood for d(flow) with scalar
-// fp32 instructions -- ~300 VALU instructions per pixel and channel; round 4's ablation put ~290 us of its 420-600 us in exactly that.
-// Here a block visits its pixels once per PAIR of channels:
-//   * taps, fit test, box addresses: once per pixel for two channels;
-//   * everything per channel is a 2-vector (channel c, channel c + 1) on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32:
-//     two IEEE fp32 operations per lane and instruction, the same roundings as the scalar forms);
-//   * the clamp-extended source box is staged channel-INTERLEAVED (one 8-byte cell = the same source pixel of both channels): one
-//     ds_read_b64 serves both channels' d(flow) arithmetic;
-//   * two accumulator planes (double cells, as before: ds_add_f64), the second at a fixed byte offset from the first: one address
-//     computation, immediates for the rest;
-//   * 8 waves per block (4 rows per wave, the row loop fully unrolled: no pipeline copies), 69 KB of LDS: two blocks = 16 waves per CU.
-// Same tile geometry (64 x RH pixels, halo H), same `fit` predicate, same fold / flush as the one-channel kernel: be_bwd_far2_kernel
-// stays its complement.  FUSED as there (block attention backward).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
-
-constexpr int kPairThreads = 512;
-
-template <int K, int RH, int H, bool FUSED = false>
-__global__ void __launch_bounds__(kPairThreads, 2)
-be_bwd_pair_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
-                   float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
-                   int ntx, int nty, int cslabs, int cs, int remap, const float* __restrict__ attn = nullptr) {
-    using T = float;
-    constexpr int RW = kTileRW, NW = kPairThreads / kWave, PPT = RH / NW;
-    constexpr int TW = RW, TH = RH;
-    constexpr int AP = RW + 2 * H, AH = RH + 2 * H;
-    constexpr int NA = AP * AH;
-    constexpr unsigned E = sizeof(T);
-    static_assert(RH % NW == 0, "rows per wave");
-    extern __shared__ __attribute__((aligned(16))) unsigned char be_pair_smem[];
-    double* A0 = reinterpret_cast<double*>(be_pair_smem);          // accumulator plane of the pair's first channel; the second: A0 + NA
-    f32x2* S2 = reinterpret_cast<f32x2*>(A0 + 2 * NA);             // clamp-extended source box, the two channels interleaved
-    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
-    const int tx_ = t % ntx;
-    t /= ntx;
-    const int ty_ = t % nty;
-    t /= nty;
-    const int slab = t % cslabs;
-    const int b = t / cslabs;
-    const int x0 = tx_ * TW, y0 = ty_ * TH;
-    const int ax0 = x0 - H, ay0 = y0 - H;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int xf = x0 + lane;
-    const bool xin = xf >= 0 && xf < Wf;
-
-    const int c0 = slab * cs;
-    const int c1 = (c0 + cs < C) ? c0 + cs : C;
-    const int W = K * Wf;
-    const size_t splane = static_cast<size_t>(Hs) * Ws;
-    const size_t fplane = static_cast<size_t>(Hf) * Wf;
-    const size_t oplane = FUSED ? fplane : static_cast<size_t>(K) * Hf * W;
-    const unsigned sbytes = static_cast<unsigned>(splane * E);
-    const unsigned obytes = static_cast<unsigned>(oplane * E);
-    const unsigned orow = static_cast<unsigned>(W) * E;
-    const T* sp = src + (static_cast<size_t>(b) * C + c0) * splane;
-    T* gp = gsrc + (static_cast<size_t>(b) * C + c0) * splane;
-    const T* op = gout + (static_cast<size_t>(b) * C + c0) * oplane;
-    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, static_cast<unsigned>(2 * fplane * E));
-    const rsrc_t ratt = make_rsrc(FUSED ? attn + static_cast<size_t>(b) * K * K * fplane : src,
-                                  FUSED ? static_cast<unsigned>(K * K * fplane * E) : 0u);
-
-    const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;
-    const bool foldL = ax0 < 0, foldR = Ws - ax0 < AP;
-    const bool foldT = ay0 < 0, foldB = Hs - ay0 < AH;
-
-    // a pair's second channel may not exist (odd slab tail): its planes are addressed through ZERO-SIZED buffer resources -- every
-    // load returns 0, so its gradients, its source box and with them all of its contributions are exact zeros
-    auto stage = [&](const T* plane0, bool two) {
-        const rsrc_t r0 = make_rsrc(plane0, sbytes);
-        const rsrc_t r1 = make_rsrc(plane0 + (two ? splane : 0), two ? sbytes : 0u);
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-#pragma unroll 1
-        for (int i0 = 0; i0 < NA; i0 += 2 * kPairThreads) {
-            f32x2 st[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int idx = i0 + q * kPairThreads + tid;
-                const int arow = idx / AP, acol = idx - arow * AP;
-                const int gy = min(max(ay0 + arow, 0), Hs - 1), gx = min(max(ax0 + acol, 0), Ws - 1);
-                const unsigned off = idx < NA ? (static_cast<unsigned>(gy) * Ws + gx) * E : 0xFFFFFFF0u;
-                st[q].x = buf_ld<T>(r0, off);
-                st[q].y = buf_ld<T>(r1, off);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int idx = i0 + q * kPairThreads + tid;
-                if (idx < NA) S2[idx] = st[q];
-            }
-        }
-    };
-    for (int i = threadIdx.x; i < 2 * NA; i += kPairThreads) A0[i] = 0;
-    stage(sp, c0 + 1 < c1);
-    __syncthreads();
-
-    f32x2 gxa[PPT], gya[PPT];          // d(flow) per owned pixel row, the two channels' shares apart until the end
-#pragma unroll
-    for (int r = 0; r < PPT; ++r) gxa[r] = gya[r] = splat2(0.f);
-
-    const int xfc = min(max(xf, 0), Wf - 1);
-    for (int c = c0; c < c1; c += 2, op += 2 * oplane) {
-        const bool two = c + 1 < c1;
-        const bool more = c + 2 < c1;
-        const rsrc_t rg0 = make_rsrc(op, obytes);
-        const rsrc_t rg1 = make_rsrc(op + (two ? oplane : 0), two ? obytes : 0u);
-        const rsrc_t rs0 = make_rsrc(sp + static_cast<size_t>(c - c0) * splane, sbytes);
-        const rsrc_t rs1 = make_rsrc(sp + static_cast<size_t>(c - c0 + (two ? 1 : 0)) * splane, two ? sbytes : 0u);
-        struct PixLoad {
-            T fx, fy;
-            f32x2 gs;                  // FUSED: the pixel's upstream gradient of both channels
-            ElemRow<T, K> g0[K], g1[K];      // grad_output windows of the two channels (FUSED: g0 = the attention weights)
-        };
-        auto request = [&](int r, PixLoad& d) {
-            int yfc = y0 + wave + r * NW;
-            yfc = min(max(yfc, 0), Hf - 1);
-            const unsigned fo = (static_cast<unsigned>(yfc) * Wf + xfc) * E;
-            d.fx = buf_ld<T>(rfl, fo);
-            d.fy = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
-            if constexpr (FUSED) {
-                ElemRow<T, 1> a, bq;
-                buf_load_row_nt<T, 1>(rg0, fo, a);
-                buf_load_row_nt<T, 1>(rg1, fo, bq);
-                d.gs = f32x2{a.v[0], bq.v[0]};
-#pragma unroll
-                for (int i = 0; i < K; ++i)
-#pragma unroll
-                    for (int j = 0; j < K; ++j)
-                        d.g0[i].v[j] = buf_ld<T>(ratt, fo + static_cast<unsigned>((i * K + j) * fplane * E));
-            } else {
-                d.gs = splat2(0.f);
-                const unsigned ob = (static_cast<unsigned>(yfc) * K * W + static_cast<unsigned>(xfc) * K) * E;
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    buf_load_row_nt<T, K>(rg0, ob + i * orow, d.g0[i]);
-                    buf_load_row_nt<T, K>(rg1, ob + i * orow, d.g1[i]);
-                }
-            }
-        };
-        PixLoad pl[2];
-        request(0, pl[0]);
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            const int row = wave + r * NW;
-            const int yf = y0 + row;
-            PixLoad& cur = pl[r & 1];
-            if (r + 1 < PPT) request(r + 1, pl[(r + 1) & 1]);
-            // the pair's grad_output window as 2-vectors
-            f32x2 g2[K][K];
-            if constexpr (FUSED) {
-                const f32x2 gd = cur.gs / splat2(static_cast<T>(K * K));
-#pragma unroll
-                for (int i = 0; i < K; ++i)
-#pragma unroll
-                    for (int j = 0; j < K; ++j) g2[i][j] = gd * cur.g0[i].v[j];
-            } else {
-#pragma unroll
-                for (int i = 0; i < K; ++i)
-#pragma unroll
-                    for (int j = 0; j < K; ++j) g2[i][j] = f32x2{cur.g0[i].v[j], cur.g1[i].v[j]};
-            }
-            const bool row_owned = gflow != nullptr;
-            f32x2 gx = splat2(0.f), gy = splat2(0.f);
-            if (xin && yf >= 0 && yf < Hf) {
-                const T fx0 = cur.fx, fy0 = cur.fy;
-                // taps, the reference's arithmetic (block_extractor_kernel.cu:117-135) -- once for both channels
-                T wxr[K], wyb[K];
-                T flx0 = 0, fly0 = 0;
-                bool regular = true;
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
-                    const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
-                    const T fxl = floor_t(dx), fyl = floor_t(dy);
-                    if (j == 0) { flx0 = fxl; fly0 = fyl; }
-                    regular = regular & (fxl == flx0 + static_cast<T>(j)) & (fyl == fly0 + static_cast<T>(j));
-                    wxr[j] = dx - fxl;
-                    wyb[j] = dy - fyl;
-                }
-                const T lim = static_cast<T>(1 << 20);
-                regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);   // rejects NaN too
-                const int u0 = regular ? static_cast<int>(flx0) : 0, v0 = regular ? static_cast<int>(fly0) : 0;
-                const int au = u0 - ax0, av = v0 - ay0;
-                const bool fit = inside & regular & (static_cast<unsigned>(au) <= static_cast<unsigned>(AP - 1 - K)) &
-                                 (static_cast<unsigned>(av) <= static_cast<unsigned>(AH - 1 - K));
-                if (fit) {
-                    double* ap = A0 + av * AP + au;
-                    T xl[K], yt[K];
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        xl[j] = 1 - wxr[j];
-                        yt[j] = 1 - wyb[j];
-                    }
-                    // d(source): Wy^T G Wx of the K x K window (block_extractor_kernel.cu:158-161 summed over the window), columns first
-                    f32x2 tx[K][K + 1];
-#pragma unroll
-                    for (int i = 0; i < K; ++i) {
-#pragma unroll
-                        for (int c2 = 0; c2 <= K; ++c2) {
-                            f32x2 v = splat2(0.f);
-                            if (c2 < K) v = g2[i][c2] * xl[c2];
-                            if (c2 > 0) v = (c2 < K) ? fma2(g2[i][c2 - 1], splat2(wxr[c2 - 1]), v) : g2[i][c2 - 1] * wxr[c2 - 1];
-                            tx[i][c2] = v;
-                        }
-                    }
-#pragma unroll
-                    for (int r2 = 0; r2 <= K; ++r2) {
-#pragma unroll
-                        for (int c2 = 0; c2 <= K; ++c2) {
-                            f32x2 v = splat2(0.f);
-                            if (r2 < K) v = tx[r2][c2] * yt[r2];
-                            if (r2 > 0) v = (r2 < K) ? fma2(tx[r2 - 1][c2], splat2(wyb[r2 - 1]), v) : tx[r2 - 1][c2] * wyb[r2 - 1];
-                            __hip_atomic_fetch_add(ap + r2 * AP + c2, static_cast<double>(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_add(ap + NA + r2 * AP + c2, static_cast<double>(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                    // d(flow) (:163-164): products regrouped into source differences, both channels per instruction
-                    if (row_owned) {
-                        const f32x2* nb = S2 + av * AP + au;
-                        f32x2 spv[K + 1], scv[K + 1];
-#pragma unroll
-                        for (int j = 0; j <= K; ++j) spv[j] = nb[j];
-#pragma unroll
-                        for (int i = 0; i < K; ++i) {
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) scv[j] = nb[(i + 1) * AP + j];
-                            f32x2 hx = splat2(0.f), hy = splat2(0.f);
-#pragma unroll
-                            for (int j = 0; j < K; ++j) {
-                                hx = fma2(g2[i][j], spv[j + 1] - spv[j], hx);
-                                hy = fma2(g2[i][j], scv[j + 1] - scv[j], hy);
-                            }
-                            gx = fma2(splat2(yt[i]), hx, fma2(splat2(wyb[i]), hy, gx));
-#pragma unroll
-                            for (int c2 = 0; c2 <= K; ++c2) gy = fma2(tx[i][c2], scv[c2] - spv[c2], gy);
-#pragma unroll
-                            for (int j = 0; j <= K; ++j) spv[j] = scv[j];
-                        }
-                    }
-                } else if (row_owned) {
-                    // a tap outside the accumulator box, a floor that disagrees between neighbouring taps, NaN or huge flow: d(source) of
-                    // this pixel is be_bwd_far2_kernel's; its d(flow) per tap like the reference, clamped cells, straight from memory
-                    const unsigned ob = (static_cast<unsigned>(yf) * K * W + static_cast<unsigned>(xf) * K) * E;
-#pragma unroll 1
-                    for (int i = 0; i < K; ++i) {
-                        const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
-#pragma unroll 1
-                        for (int j = 0; j < K; ++j) {
-                            const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
-                            f32x2 gv;
-                            if constexpr (FUSED) {
-                                const T wv = buf_ld<T>(ratt, (static_cast<unsigned>(yf) * Wf + xf) * E + static_cast<unsigned>((i * K + j) * fplane * E));
-                                gv = (cur.gs / splat2(static_cast<T>(K * K))) * wv;
-                            } else {
-                                gv = f32x2{buf_ld<T>(rg0, ob + i * orow + j * E), buf_ld<T>(rg1, ob + i * orow + j * E)};
-                            }
-                            const unsigned rT = ty1.lo * static_cast<unsigned>(Ws) * E, rB = ty1.hi * static_cast<unsigned>(Ws) * E;
-                            const f32x2 sTL = {buf_ld<T>(rs0, rT + tx1.lo * E), buf_ld<T>(rs1, rT + tx1.lo * E)};
-                            const f32x2 sTR = {buf_ld<T>(rs0, rT + tx1.hi * E), buf_ld<T>(rs1, rT + tx1.hi * E)};
-                            const f32x2 sBL = {buf_ld<T>(rs0, rB + tx1.lo * E), buf_ld<T>(rs1, rB + tx1.lo * E)};
-                            const f32x2 sBR = {buf_ld<T>(rs0, rB + tx1.hi * E), buf_ld<T>(rs1, rB + tx1.hi * E)};
-                            gy += gv * (-tx1.wlo * sTL - tx1.whi * sTR + tx1.wlo * sBL + tx1.whi * sBR);
-                            gx += gv * (-ty1.wlo * sTL - ty1.whi * sBL + ty1.wlo * sTR + ty1.whi * sBR);
-                        }
-                    }
-                }
-            }
-            gxa[r] += gx;
-            gya[r] += gy;
-        }
-        __syncthreads();                       // every contribution of the pair is in A0 / A0 + NA
-        // border tiles: fold the out-of-image cells onto the border cell they clamp to -- columns first (one thread per accumulator
-        // row and plane), then rows (one thread per column and plane)
-        if (foldL || foldR) {
-            const int pl_ = threadIdx.x / 256, rr = threadIdx.x & 255;
-            if (rr < AH) {
-                double* arow = A0 + pl_ * NA + rr * AP;
-                if (foldL) {
-                    double s = 0;
-                    for (int u = 0; u < -ax0; ++u) s += arow[u];
-                    arow[-ax0] += s;
-                }
-                if (foldR) {
-                    double s = 0;
-                    for (int u = Ws - ax0; u < AP; ++u) s += arow[u];
-                    arow[Ws - 1 - ax0] += s;
-                }
-            }
-            __syncthreads();
-        }
-        if (foldT || foldB) {
-            const int pl_ = threadIdx.x / 256, cc = threadIdx.x & 255;
-            if (cc < AP) {
-                double* acol = A0 + pl_ * NA + cc;
-                if (foldT) {
-                    double s = 0;
-                    for (int v = 0; v < -ay0; ++v) s += acol[v * AP];
-                    acol[-ay0 * AP] += s;
-                }
-                if (foldB) {
-                    double s = 0;
-                    for (int v = Hs - ay0; v < AH; ++v) s += acol[v * AP];
-                    acol[(Hs - 1 - ay0) * AP] += s;
-                }
-            }
-            __syncthreads();
-        }
-        {
-            // flush + restage in one sweep: one global atomic per non-zero in-image cell and channel, the cell is cleared, and the same
-            // cell of the NEXT pair's clamp-extended source goes into S2
-            T* gplane0 = gp + static_cast<size_t>(c - c0) * splane;
-            T* gplane1 = gplane0 + splane;                                  // (touched only when the pair has a second channel: its cells are 0 otherwise)
-            const bool two_next = c + 3 < c1;
-            const T* nplane = sp + static_cast<size_t>(more ? c + 2 - c0 : c - c0) * splane;
-            const rsrc_t rn0 = make_rsrc(nplane, more ? sbytes : 0u);
-            const rsrc_t rn1 = make_rsrc(nplane + (two_next ? splane : 0), two_next ? sbytes : 0u);
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-#pragma unroll 1
-            for (int i0 = 0; i0 < NA; i0 += 2 * kPairThreads) {
-                f32x2 st[2];
-                unsigned off[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int idx = i0 + q * kPairThreads + tid;
-                    const int arow = idx / AP, acol = idx - arow * AP;
-                    const int cx = ax0 + acol, cy = ay0 + arow;
-                    const int gy_ = min(max(cy, 0), Hs - 1), gx_ = min(max(cx, 0), Ws - 1);
-                    off[q] = static_cast<unsigned>(gy_) * Ws + gx_;
-                    const unsigned lo = idx < NA ? off[q] * E : 0xFFFFFFF0u;
-                    st[q].x = buf_ld<T>(rn0, lo);
-                    st[q].y = buf_ld<T>(rn1, lo);
-                    if (gy_ != cy || gx_ != cx) off[q] = 0xFFFFFFFFu;
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int idx = i0 + q * kPairThreads + tid;
-                    if (idx < NA) {
-                        const T v0 = static_cast<T>(A0[idx]), v1 = static_cast<T>(A0[NA + idx]);
-                        A0[idx] = 0;
-                        A0[NA + idx] = 0;
-                        if (off[q] != 0xFFFFFFFFu) {
-                            if (v0 != 0) atomic_add(gplane0 + off[q], v0);
-                            if (v1 != 0) atomic_add(gplane1 + off[q], v1);
-                        }
-                        if (more) S2[idx] = st[q];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (gflow) {
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            const int yf = y0 + wave + r * NW;
-            if (xin && yf >= 0 && yf < Hf) {
-                const size_t fo = static_cast<size_t>(b) * 2 * fplane + static_cast<size_t>(yf) * Wf + xf;
-                atomic_add(gflow + fo, gxa[r].x + gxa[r].y);
-                atomic_add(gflow + fo + fplane, gya[r].x + gya[r].y);
             }
         }
     }
@@ -2160,21 +1922,10 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
                 }
             }
             if (int rc = check_launch("ffwm_block_extractor_backward(far)")) return rc;
-            if (shared_cells && variant == 0 && h == 4 && k == 3 && RH == 32 && options().ablate == 0) {
-                // round 5: two channels per pixel visit on the packed fp32 pipe (be_bwd_pair_kernel); variant 3 keeps the one-channel kernel
-                LaunchScope ls("block_extractor_bwd_tile2", st, bytes);
-                const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-                auto kfn = be_bwd_pair_kernel<3, 32, 4, false>;
-                constexpr size_t lds = static_cast<size_t>((kTileRW + 8) * (32 + 8)) * 24;
-                allow_large_lds(reinterpret_cast<const void*>(kfn));
-                hipLaunchKernelGGL(kfn, dim3(grid), dim3(kPairThreads), lds, st, (const float*)src, (const float*)flow, (const float*)gout,
-                                   (float*)gsrc, (float*)gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap,
-                                   (const float*)nullptr);
-                return check_launch("ffwm_block_extractor_backward(pair tile)");
-            }
             {
                 LaunchScope ls(shared_cells ? "block_extractor_bwd_tile2" : "block_extractor_bwd_tile", st, bytes);
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
+                const bool fixed_cells = options().be_bwd_fixed != 2;        // 32-bit fixed-point accumulator cells (round 5); 2 = the double cells of rounds 2-4
 #define FFWM_BE_TILE(KERNEL, KK, RR, HH)                                                                      \
     hipLaunchKernelGGL((KERNEL<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,              \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
@@ -2183,10 +1934,15 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
     hipLaunchKernelGGL((be_bwd_tile2_kernel<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src, \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
                        (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, 0)
+#define FFWM_BE_TILE2F(KK, RR, HH)                                                                            \
+    hipLaunchKernelGGL((be_bwd_tile2_kernel<KK, RR, HH, false, false, 1>), dim3(grid), dim3(kBlock), 0, st, (const float*)src, \
+                       (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
+                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, 0)
 #define FFWM_BE_TILE_K(KK)                                                                                    \
     case KK:                                                                                                  \
         if (shared_cells) {                                                                                   \
             if (h == 8) FFWM_BE_TILE2(KK, 32, 8);                                                             \
+            else if (fixed_cells) FFWM_BE_TILE2F(KK, 32, 4);                                                  \
             else FFWM_BE_TILE2(KK, 32, 4);                                                                    \
         } else {                                                                                              \
             if (h == 8) FFWM_BE_TILE(be_bwd_tile_kernel, KK, 32, 8);                                          \
@@ -2196,13 +1952,19 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
                 if (RH == 64) {
                     FFWM_BE_TILE(be_bwd_tile_kernel, 3, 64, 4);
                 } else if (shared_cells && k == 3 && h == 4 && options().ablate != 0) {
-                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, false, true>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,
-                                       (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs, (int)Ws, (int)Hf,
-                                       (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate);
+                    if (fixed_cells)
+                        hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, false, true, 1>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,
+                                           (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs, (int)Ws, (int)Hf,
+                                           (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate);
+                    else
+                        hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, false, true, 0>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,
+                                           (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs, (int)Ws, (int)Hf,
+                                           (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate);
                 } else {
                     switch (k) { FFWM_BE_TILE_K(1) FFWM_BE_TILE_K(2) FFWM_BE_TILE_K(3) FFWM_BE_TILE_K(4) }
                 }
 #undef FFWM_BE_TILE_K
+#undef FFWM_BE_TILE2F
 #undef FFWM_BE_TILE2
 #undef FFWM_BE_TILE
             }
@@ -2394,16 +2156,14 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
             {
                 LaunchScope ls("block_attention_bwd_tile2", st, bytes);
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-                if (h == 4 && options().be_bwd_variant == 0) {
-                    auto kfn = be_bwd_pair_kernel<3, 32, 4, true>;
-                    constexpr size_t lds = static_cast<size_t>((kTileRW + 8) * (32 + 8)) * 24;
-                    allow_large_lds(reinterpret_cast<const void*>(kfn));
-                    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kPairThreads), lds, st, src, flow, gout, gsrc, gflow, (int)C, (int)Hs, (int)Ws,
-                                       (int)Hf, (int)Wf, ntx, nty, cslabs, cs, options().xcd_remap, wts);
-                } else if (h == 8)
+                if (h == 8)
                     hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 8, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
                                        gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
                                        options().xcd_remap, wts);
+                else if (options().be_bwd_fixed != 2)
+                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, true, false, 1>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
+                                       gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
+                                       options().xcd_remap, wts, 0);
                 else
                     hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
                                        gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,

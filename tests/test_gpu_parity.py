@@ -311,6 +311,60 @@ def test_block_extractor_backward_owned_tiles_accumulates_and_handles_irregular_
     assert (gf.cpu()[ok] - gf_ref[ok]).abs().max().item() <= BWD_TOL[torch.float32] * (1 + gf_ref[ok].abs().max().item())
 
 
+@pytest.mark.parametrize("fixed", [0, 2])
+@pytest.mark.parametrize("kind", ["heavy_tail", "zeros", "one_spike_per_tile", "nonfinite", "tiny", "huge"])
+def test_block_extractor_backward_fixed_point_cells_tail_cases(oracle, kind, fixed):
+    """Round 5: the shared-cell tile kernel accumulates in 32-bit FIXED-POINT LDS cells (be_bwd_fixed = 0; 2 = the double cells of rounds
+    2-4), scaled per block and channel by a SAMPLED maximum of the grad_output windows.  A window the sample under-estimates by more
+    than 4 x -- or one that holds a NaN / Inf -- must take the exact per-tap path, never the box: gradients with a heavy tail, an
+    all-zero gradient (no scale at all), a single spike per tile (off the sampled centre element), non-finite values (which must
+    land exactly where the reference's float atomics put them), and magnitudes at both ends of the float range."""
+    from ffwm_amd import ops, _lib
+    g = _gen(40)
+    B, C, H, W = 1, 5, 150, 200
+    src = torch.rand(B, C, H, W, generator=g)
+    flow = (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * 2.0
+    go = torch.rand(B, C, 3 * H, 3 * W, generator=g)
+    if kind == "heavy_tail":
+        go = go * torch.exp(4 * torch.randn(B, C, 3 * H, 3 * W, generator=g))          # log-normal: maxima 1e5 x the median
+    elif kind == "zeros":
+        go.zero_()
+        go[0, 1, 7, 11] = 3.0                                                            # one value, off every sampled centre
+    elif kind == "one_spike_per_tile":
+        go = go * 1e-3
+        go[:, :, 0::96, 0::192] = 1e3                                                    # window corner elements only
+    elif kind == "nonfinite":
+        go[0, 0, 10, 10] = float("nan")
+        go[0, 2, 100, 301] = float("inf")
+        go[0, 3, 200, 5] = -float("inf")
+    elif kind == "tiny":
+        go = go * 1e-30
+    elif kind == "huge":
+        go = go * 1e30
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go, 3)
+    gs, gf = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV)
+    _lib.set_option("be_bwd_fixed", fixed)
+    try:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), 3, gs, gf)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        assert "block_extractor_bwd_tile2" in _lib.prof_collect()
+    finally:
+        _lib.set_option("be_bwd_fixed", 0)
+    for got, ref in ((gs.cpu(), gs_ref), (gf.cpu(), gf_ref)):
+        fin = torch.isfinite(ref)
+        # non-finite results at exactly the reference's places (NaN against Inf is a matter of how inf * 0 groups: the kernels sum
+        # source differences, the reference products)
+        assert torch.equal(torch.isfinite(got), fin), "%d / %d non-finite elements, the reference has %d" % (
+            int((~torch.isfinite(got)).sum()), got.numel(), int((~fin).sum()))
+        if fin.any():
+            scale = 1e-30 + float(ref[fin].abs().max())
+            # relative to the LARGEST gradient: what a fixed-point cell resolves (and what float atomics in another order lose)
+            assert float((got[fin] - ref[fin]).abs().max()) <= 2e-5 * scale, (kind, float((got[fin] - ref[fin]).abs().max()) / scale)
+
+
 def test_block_extractor_generic_kernel_matches_tiled(oracle):
     from ffwm_amd import ops, _lib
     src, flow, go, k = _be_inputs(BE_CASES[1], torch.float32)

@@ -137,19 +137,20 @@ def test_live_resample2d_cfg1_against_the_reference_extension(ref_mods, ks, sigm
     ops.resample2d_backward(in1, in2, go, ks, 1, g1, g2)
     assert float((out - o_ref).abs().max()) <= 1e-4 and _rel(out, o_ref) <= FWD["f32"]
     assert _rel(g1, g1_ref) <= G1["f32"]
-    if sigma >= 1.0:
-        assert _rel(g2, g2_ref) <= G2["f32"]
-    else:
-        # sigma 0.3: the reference's fp32 kernels are the larger error (module docstring) -- the float64 result of the same inputs
-        # comes from the reference's OWN kernels run in double
+    d = _rel(g2, g2_ref)
+    if d > G2["f32"]:
+        # beyond the north_star's 1e-4 only where the REFERENCE's fp32 kernels are the larger error (module docstring: sharp Gaussians /
+        # many taps -- sigma 0.3 at ks 4: 1.0e-4, sigma 1 at ks 6: ~1.5e-4 -- the quotient rule subtracts sums of O(100) terms per
+        # pixel).  The float64 result of the same inputs comes from the reference's OWN kernels run in double: the HIP path must be
+        # closer to it than the reference's fp32 run is, within 1e-4 of it, and its distance to the reference explained by that.
         d1, d2, dg = in1.double(), in2.double(), go.double()
         t1, t2 = torch.zeros_like(d1), torch.zeros_like(d2)
         rs.backward(d1, d2, dg, t1, t2, ks, 1)
         scale = 1.0 + float(g2_ref.abs().max())
         e_ref = float((g2_ref.double() - t2).abs().max()) / scale
         e_hip = float((g2.double() - t2).abs().max()) / scale
-        assert e_hip <= e_ref + 1e-7 and e_hip <= 1e-4, (e_hip, e_ref)
-        assert _rel(g2, g2_ref) <= e_ref + 1e-5, (_rel(g2, g2_ref), e_ref)
+        assert e_hip <= e_ref + 1e-7 and e_hip <= 1e-4, (ks, sigma, e_hip, e_ref)
+        assert d <= e_ref + 1e-5, (ks, sigma, d, e_ref)
 
 
 def test_live_block_extractor_and_reshape_cfg5_slice_against_the_reference_extension(ref_mods):

@@ -13,7 +13,10 @@ sm = torch.stack((2 * torch.sin(3.1 * yy + 0.3) * torch.cos(2.3 * xx), 2 * torch
 go = torch.rand(4, 128, 768, 768, generator=g).to(dev)
 gs, gf = torch.zeros_like(src), torch.zeros_like(rnd)
 lib = _lib.load()
-for ab in [int(a) for a in (sys.argv[1:] or ["0", "1", "2", "4", "3", "7"])]:
+fixed = int(os.environ.get("BE_BWD_FIXED", "0"))          # 0 = 32-bit fixed-point cells (round 5), 2 = double cells
+lib.ffwm_set_option(b"be_bwd_fixed", fixed)
+print("accumulator cells:", "fixed-point" if fixed != 2 else "double", "(ablate 8 = the ablation instantiation with nothing switched off)")
+for ab in [int(a) for a in (sys.argv[1:] or ["0", "8", "1", "2", "4", "3", "7"])]:
     lib.ffwm_set_option(b"ablate", ab)
     for name, fl in (("random", rnd), ("smooth", sm)):
         for _ in range(2):

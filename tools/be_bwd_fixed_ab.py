@@ -1,6 +1,6 @@
-"""A/B of the block_extractor / block attention backward at cfg-5 per GPU ([4,128,256,256], k = 3): the one-channel shared-cell tile
-kernel (be_bwd_variant=3) against the channel-pair kernel of round 5 (be_bwd_variant=0), random U[-2,2) and smooth flow, HIP-event
-time of the launches; and the two against each other / the float64 atomics-free reference of a small case for correctness."""
+"""A/B of the block_extractor / block attention backward at cfg-5 per GPU ([4,128,256,256], k = 3): the shared-cell tile kernel with
+double accumulator cells (be_bwd_fixed=2, rounds 2-4) against 32-bit fixed-point cells (be_bwd_fixed=0, round 5), random U[-2,2) and
+smooth flow, HIP-event time of the launches; and the two results against each other."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ffwm_amd import _lib, ops
@@ -14,8 +14,8 @@ go = torch.rand(4, 128, 768, 768, generator=g).to(dev)
 wts = torch.rand(4, 9, 256, 256, generator=g).to(dev)
 bo = torch.rand(4, 128, 256, 256, generator=g).to(dev)
 res = {}
-for variant in (3, 0):
-    _lib.set_option("be_bwd_variant", variant)
+for variant in (2, 0):
+    _lib.set_option("be_bwd_fixed", variant)
     for name, fl in (("random", rnd), ("smooth", sm)):
         gs, gf = torch.zeros_like(src), torch.zeros_like(fl)
         for _ in range(2):
@@ -39,6 +39,6 @@ for variant in (3, 0):
         res[("ba", name, variant)] = (gs / 5, gf / 5)
 for kind in ("be", "ba"):
     for name in ("random", "smooth"):
-        a, b = res[(kind, name, 3)], res[(kind, name, 0)]
-        print(kind, name, "pair vs one-channel kernel: d(source) %.3g  d(flow) %.3g  (max abs diff / (1 + max|ref|))" % (
+        a, b = res[(kind, name, 2)], res[(kind, name, 0)]
+        print(kind, name, "fixed-point vs double cells: d(source) %.3g  d(flow) %.3g  (max abs diff / (1 + max|ref|))" % (
             float((a[0] - b[0]).abs().max() / (1 + a[0].abs().max())), float((a[1] - b[1]).abs().max() / (1 + a[1].abs().max()))), flush=True)
