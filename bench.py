@@ -82,8 +82,8 @@ OPS_ROWS = (
     ("cfg1_rs_bwd1", "resample2d_bwd_input1_taplane", "cfg1 resample2d ks=4 backward"),
     ("cfg1_rs_bwd2", "resample2d_bwd_input2_lds", "cfg1 resample2d ks=4 backward"),
     ("rs_fwd@512", "resample2d_fwd_lds", "HBM-resident resample2d ks=4 [8,64,512,512] flow"),
-    ("rs_bwd1@512", "resample2d_bwd_input1_auto", "backward, flow~U[-3,3)"),
-    ("rs_bwd1@512_smooth", "resample2d_bwd_input1_auto", "backward, smooth flow"),
+    ("rs_bwd1@512", ("resample2d_bwd_input1_tile", "resample2d_bwd_input1_auto"), "backward, flow~U[-3,3)"),          # (auto: rounds 3-4)
+    ("rs_bwd1@512_smooth", ("resample2d_bwd_input1_tile", "resample2d_bwd_input1_auto"), "backward, smooth flow"),
     ("rs_bwd2@512", "resample2d_bwd_input2_lds", "backward, flow~U[-3,3)"),
     ("cfg5_be_fwd", "block_extractor_fwd_lds", "src[4,128,256,256] flow~U[-2,2)"),
     ("cfg5_be_bwd", "block_extractor_bwd_tile2", "block_extractor k=3 backward"),
@@ -104,7 +104,7 @@ def ops_summary(kernels, subpaths=None):
     out = {}
     for key, scope, where in OPS_ROWS:
         for r in kernels:
-            if r.get("kernel") == scope and where in r.get("where", "") and r.get("where") != "timed region":
+            if r.get("kernel") in ((scope,) if isinstance(scope, str) else scope) and where in r.get("where", "") and r.get("where") != "timed region":
                 out[key] = [r["avg_us"], r["frac_hbm_peak"]]
                 break
     fl = (subpaths or {}).get("flownet_fwd_cfg2")

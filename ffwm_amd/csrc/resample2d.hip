@@ -17,6 +17,7 @@
 #include <memory>
 
 #include "common.hpp"
+#include <type_traits>
 
 namespace ffwm {
 namespace {
@@ -878,7 +879,13 @@ rs_flow_irregular_kernel(const float* __restrict__ in2, int* __restrict__ count,
     }
 }
 
-template <int HALF, int RPT>
+// FIXED (round 5): the box holds 32-bit FIXED-POINT cells instead of doubles (ds_add_u32: half the LDS time of ds_add_f64 per
+// conflict-free instruction, a wave's lanes spread over twice as many banks, half the LDS -- see be_bwd_tile2_kernel).  The scale is
+// EXACT here: a block loads the grad_output values of its pixels for the four channels of a group before it adds anything, so the
+// group's maximum |g| is known (one unsigned maximum over the magnitude bits, reduced over the block); every contribution is
+// w / sum x g with w / sum <= 1, at most one per pixel and cell, so 64 TH contributions of < 2^(31 - log2(64 TH)) cannot overflow.
+// One unit is <= max|g| / 2^21 (TH = 16).  A group with a NaN / Inf gradient takes the per-tap global-atomic path for its channels.
+template <int HALF, int RPT, bool FIXED = false>
 __global__ void __launch_bounds__(kBlock)
 rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi,
                     int Wi, int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate,
@@ -893,8 +900,10 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
     // [4][NCELL]: one PLANE per channel of the group.  (Round 2 interleaved the four channels of a cell: a wave's 64 lanes then sat
     // 32 bytes apart and used 16 of the 64 LDS banks -- an 8-way bank conflict on every ds_add_f64.  Planar, neighbouring lanes are
     // 8 bytes apart: the 64 lanes of a smooth flow cover all banks twice, the minimum for 512 bytes.)
-    double* box = reinterpret_cast<double*>(smem_raw);
+    using AccT = typename std::conditional<FIXED, int, double>::type;
+    AccT* box = reinterpret_cast<AccT*>(smem_raw);
     __shared__ int red[4][NW];
+    __shared__ unsigned redm[NW];
     __shared__ int flag;
 
     unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
@@ -977,36 +986,117 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
     for (int r = 0; r < RPT; ++r)
         poffb[r] = live[r] ? (static_cast<unsigned>(ys[r]) * W + static_cast<unsigned>(x)) * 4u : 0xFFFFFFF0u;     // dead lanes read g = 0
 
-    if (use_lds) {
-        int lbase[RPT];
+    // per-tap global atomics through clamped offsets for the channels [cb, ce) of this block's pixels: the fallback of a block whose
+    // taps do not fit the box, and (FIXED) of a channel group with a non-finite gradient
+    auto global_taps = [&](int cb, int ce) {
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) lbase[r] = (v0[r] - vmin) * kRsBoxW + (u0[r] - umin);
-        for (int c = c0; c < c1; c += 4) {
-            if (!(ablate & 4))
-                for (int i = threadIdx.x; i < NCELL * 2; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
-            __syncthreads();
+        for (int r = 0; r < RPT; ++r) {
+            if (!live[r]) continue;
+            const float fxv = static_cast<float>(x) + fb[static_cast<size_t>(ys[r]) * W + x];
+            const float fyv = static_cast<float>(ys[r]) + fb[plane + static_cast<size_t>(ys[r]) * W + x];
+            const float flx = floor_t(fxv), fly = floor_t(fyv);
+            unsigned col[NT], row[NT];
+#pragma unroll
+            for (int f = 0; f < HALF; ++f) {
+                col[HALF - 1 - f] = static_cast<unsigned>(clamp_index(flx - static_cast<float>(f), Wi));
+                col[HALF + f] = static_cast<unsigned>(clamp_index(flx + static_cast<float>(f + 1), Wi));
+                row[HALF - 1 - f] = static_cast<unsigned>(clamp_index(fly - static_cast<float>(f), Hi)) * static_cast<unsigned>(Wi);
+                row[HALF + f] = static_cast<unsigned>(clamp_index(fly + static_cast<float>(f + 1), Hi)) * static_cast<unsigned>(Wi);
+            }
+            for (int c = cb; c < ce; ++c) {
+                const float g = gp[static_cast<size_t>(c - c0) * plane + poffb[r] / 4u];
+                float* d = dp + static_cast<size_t>(c - c0) * iplane;
+#pragma unroll
+                for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < NT; ++pc) atomic_add(d + row[pr] + col[pc], wn[r][pr * NT + pc] * g);
+            }
+        }
+    };
+    int lbase[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) lbase[r] = (v0[r] - vmin) * kRsBoxW + (u0[r] - umin);
+    // FIXED: 64 TH pixels, at most one contribution each per cell and channel, every one below 2^kShift after scaling
+    constexpr int kShift = 31 - 6 - (TH >= 16 ? 4 : (TH >= 8 ? 3 : 2));
+    // channel groups in runs of 64: a group the box cannot take (FIXED: a non-finite gradient; all of them when the block's taps do not
+    // fit the box) is noted in `exact` (block-uniform) and scattered per tap after the run -- ONE instance of that code path
+    for (int cbase = c0; cbase < c1; cbase += 256) {
+        const int cend = cbase + 256 < c1 ? cbase + 256 : c1;
+        unsigned long long exact = use_lds ? 0ull : ~0ull;
+        if (use_lds)
+        for (int c = cbase; c < cend; c += 4) {
+            if (!(ablate & 4)) {
+                if constexpr (FIXED) {
+                    for (int i = threadIdx.x; i < NCELL; i += kBlock) reinterpret_cast<int4*>(box)[i] = int4{0, 0, 0, 0};
+                } else {
+                    for (int i = threadIdx.x; i < NCELL * 2; i += kBlock) reinterpret_cast<double2*>(box)[i] = double2{0.0, 0.0};
+                }
+            }
             const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
             const rsrc_t rg0 = make_rsrc(g0, obytes);
             const rsrc_t rg1 = make_rsrc(g0 + plane, c + 1 < c1 ? obytes : 0u);
             const rsrc_t rg2 = make_rsrc(g0 + 2 * plane, c + 2 < c1 ? obytes : 0u);
             const rsrc_t rg3 = make_rsrc(g0 + 3 * plane, c + 3 < c1 ? obytes : 0u);
+            float g[RPT][4];
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                const float gx = buf_ld<float>(rg0, poffb[r]), gy = buf_ld<float>(rg1, poffb[r]);
-                const float gz = buf_ld<float>(rg2, poffb[r]), gw = buf_ld<float>(rg3, poffb[r]);
+                g[r][0] = buf_ld<float>(rg0, poffb[r]); g[r][1] = buf_ld<float>(rg1, poffb[r]);
+                g[r][2] = buf_ld<float>(rg2, poffb[r]); g[r][3] = buf_ld<float>(rg3, poffb[r]);
+            }
+            float fx_inv = 1.f;
+            bool exact_path = false;
+            if constexpr (FIXED) {
+                unsigned mb = 0;
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mb = max(mb, __float_as_uint(g[r][q]) & 0x7FFFFFFFu);
+                mb = wave_max(mb);
+                if (lane == 0) redm[wave] = mb;
+                __syncthreads();                     // (also: the box is cleared)
+#pragma unroll
+                for (int k = 0; k < NW; ++k) mb = max(mb, redm[k]);
+                exact_path = mb >= 0x7F800000u;      // a NaN / Inf gradient in the group: its channels scatter per tap, exactly
+                int ex = 0;
+                (void)frexpf(__uint_as_float(mb), &ex);          // max|g| < 2^ex
+                const bool usable = mb != 0u && ex > -90 && !exact_path;
+                const float sc = usable ? ldexpf(1.f, kShift - ex) : 0.f;
+                fx_inv = usable ? ldexpf(1.f, ex - kShift) : 0.f;
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[r][q] *= sc;          // (exact: a power of two; all zeros when there is nothing to add)
+            } else {
+                __syncthreads();
+            }
+            if (exact_path) {
+                exact |= 1ull << ((c - cbase) >> 2);
+                __syncthreads();                     // (redm is rewritten by the next group)
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const float gx = g[r][0], gy = g[r][1], gz = g[r][2], gw = g[r][3];
                 if (!live[r]) continue;
                 if (ablate & 1) { if (gx + gy + gz + gw == 12345.f) box[0] = 1; continue; }
-                double* nb = box + lbase[r];
+                AccT* nb = box + lbase[r];
 #pragma unroll
                 for (int pr = 0; pr < NT; ++pr)
 #pragma unroll
                     for (int pc = 0; pc < NT; ++pc) {
                         const float wq = wn[r][pr * NT + pc];
-                        double* cell = nb + (pr * kRsBoxW + pc);
-                        lds_add(cell, wq * gx);
-                        lds_add(cell + NCELL, wq * gy);
-                        lds_add(cell + 2 * NCELL, wq * gz);
-                        lds_add(cell + 3 * NCELL, wq * gw);
+                        AccT* cell = nb + (pr * kRsBoxW + pc);
+                        if constexpr (FIXED) {
+                            __hip_atomic_fetch_add(cell, __float2int_rn(wq * gx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(cell + NCELL, __float2int_rn(wq * gy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(cell + 2 * NCELL, __float2int_rn(wq * gz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(cell + 3 * NCELL, __float2int_rn(wq * gw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            lds_add(cell, wq * gx);
+                            lds_add(cell + NCELL, wq * gy);
+                            lds_add(cell + 2 * NCELL, wq * gz);
+                            lds_add(cell + 3 * NCELL, wq * gw);
+                        }
                     }
             }
             __syncthreads();
@@ -1019,37 +1109,15 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
                 float* dst = dp + static_cast<size_t>(c - c0) * iplane + static_cast<size_t>(gy) * Wi + gx;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = static_cast<float>(box[q * NCELL + i]);
+                    const float v = FIXED ? static_cast<float>(box[q * NCELL + i]) * fx_inv : static_cast<float>(box[q * NCELL + i]);
                     if (q < nch && v != 0.f && !(ablate & 2)) atomic_add(dst + static_cast<size_t>(q) * iplane, v);
                 }
             }
             __syncthreads();
         }
-        return;
-    }
-    // fallback: per-tap global atomics through clamped offsets
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        if (!live[r]) continue;
-        const float fxv = static_cast<float>(x) + fb[static_cast<size_t>(ys[r]) * W + x];
-        const float fyv = static_cast<float>(ys[r]) + fb[plane + static_cast<size_t>(ys[r]) * W + x];
-        const float flx = floor_t(fxv), fly = floor_t(fyv);
-        unsigned col[NT], row[NT];
-#pragma unroll
-        for (int f = 0; f < HALF; ++f) {
-            col[HALF - 1 - f] = static_cast<unsigned>(clamp_index(flx - static_cast<float>(f), Wi));
-            col[HALF + f] = static_cast<unsigned>(clamp_index(flx + static_cast<float>(f + 1), Wi));
-            row[HALF - 1 - f] = static_cast<unsigned>(clamp_index(fly - static_cast<float>(f), Hi)) * static_cast<unsigned>(Wi);
-            row[HALF + f] = static_cast<unsigned>(clamp_index(fly + static_cast<float>(f + 1), Hi)) * static_cast<unsigned>(Wi);
-        }
-        for (int c = c0; c < c1; ++c) {
-            const float g = gp[static_cast<size_t>(c - c0) * plane + poffb[r] / 4u];
-            float* d = dp + static_cast<size_t>(c - c0) * iplane;
-#pragma unroll
-            for (int pr = 0; pr < NT; ++pr)
-#pragma unroll
-                for (int pc = 0; pc < NT; ++pc) atomic_add(d + row[pr] + col[pc], wn[r][pr * NT + pc] * g);
-        }
+        if (exact != 0ull)
+            for (int c = cbase; c < cend; c += 4)
+                if ((exact >> ((c - cbase) >> 2)) & 1ull) global_taps(c, c + 4 < cend ? c + 4 : cend);
     }
 }
 
@@ -1528,7 +1596,11 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             const int variant = options().rs_bwd1_variant;
             int* sel = nullptr;
             int sel_limit = 0;
-            bool adaptive = gin1 && half == 2 && variant == 0 && B * H * W >= (1 << 18) && H >= 32;
+            // (round 5) variant 6: the tile kernel alone for every large call -- with fixed-point cells it no longer depends on the flow
+            // (the default since the box holds fixed-point cells: [8,64,512,512] 1.23 ms random / 0.91 ms smooth against the adaptive
+            // pair's 1.58 / 0.98 -- profiles/r05_rs_bwd1_fixed_point_ab.txt; rs_bwd1_fixed = 2 brings the pair of rounds 3-4 back)
+            const bool tile_only = gin1 && (variant == 6 || (variant == 0 && options().rs_bwd1_fixed != 2)) && B * H * W >= (1 << 18) && H >= 32;
+            bool adaptive = gin1 && half == 2 && variant == 0 && !tile_only && B * H * W >= (1 << 18) && H >= 32;
             if (adaptive) {
                 sel = static_cast<int*>(stream_scratch(st));
                 adaptive = sel != nullptr;
@@ -1549,8 +1621,8 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                                    (int)H, (int)W, segs_x, nseg);
                 if (int rc = check_launch("ffwm_resample2d_backward(flow regularity)")) return rc;
             }
-            const bool run_taplane = gin1 && half == 2 && (variant == 0 || variant == 5);
-            const bool run_tile = gin1 && (adaptive || (!run_taplane && (plane_lds > 131072 || variant == 2)));
+            const bool run_taplane = gin1 && half == 2 && (variant == 0 || variant == 5) && !tile_only;
+            const bool run_tile = gin1 && (adaptive || tile_only || (!run_taplane && (plane_lds > 131072 || variant == 2)));
             if (run_taplane) {
                 // one pixel's 16 taps x 4 channels per LDS atomic instruction -- bank-conflict-free for any flow
                 // default: 4 waves x 2 rows = 64 x 8 pixel tiles, two blocks per CU (56 KB box + 22 KB staging each); variant 5: 8 waves x 2 rows
@@ -1578,24 +1650,28 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
                 if (int rc = check_launch("ffwm_resample2d_backward(input1, tap-lane)")) return rc;
             }
             if (run_tile) {
-                const int rpt = H >= 32 ? 4 : 1;
+                const int rpt = H >= 32 ? (options().rs_bwd1_rpt == 2 ? 2 : 4) : 1;
                 const int tiles_y = static_cast<int>((H + 4 * rpt - 1) / (4 * rpt));
                 int cs, cslabs;
                 slabs(B * tiles_x * tiles_y, cs, cslabs);
                 const unsigned grid = static_cast<unsigned>(B * tiles_x * tiles_y * cslabs);
-                const size_t lds = static_cast<size_t>(4 * rpt + 12) * kRsBoxW * 4 * sizeof(double);
+                const bool fixed_cells = options().rs_bwd1_fixed != 2;          // 32-bit fixed-point box cells (round 5); 2 = double cells
+                const size_t lds = static_cast<size_t>(4 * rpt + 12) * kRsBoxW * 4 * (fixed_cells ? sizeof(int) : sizeof(double));
                 std::unique_ptr<LaunchScope> ls;
                 if (!adaptive) ls.reset(new LaunchScope("resample2d_bwd_input1_tile", st, bytes1));
-#define FFWM_RS_B1T(HH, RR)                                                                                   \
+#define FFWM_RS_B1T_(HH, RR, FX)                                                                              \
     do {                                                                                                      \
-        allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_tile_kernel<HH, RR>));                          \
-        hipLaunchKernelGGL((rs_bwd1_tile_kernel<HH, RR>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, \
+        allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_tile_kernel<HH, RR, FX>));                      \
+        hipLaunchKernelGGL((rs_bwd1_tile_kernel<HH, RR, FX>), dim3(grid), dim3(kBlock), lds, st, in2, gout, gin1, (int)C, \
                            (int)Hi, (int)Wi, (int)H, (int)W, quirk, tiles_x, tiles_y, cslabs, cs, remap, options().ablate, \
                            adaptive ? sel : nullptr, sel_limit, 1); \
     } while (0)
+#define FFWM_RS_B1T(HH, RR) do { if (fixed_cells) FFWM_RS_B1T_(HH, RR, true); else FFWM_RS_B1T_(HH, RR, false); } while (0)
                 if (rpt == 4) { if (half == 1) FFWM_RS_B1T(1, 4); else if (half == 2) FFWM_RS_B1T(2, 4); else FFWM_RS_B1T(3, 4); }
+                else if (rpt == 2) { if (half == 1) FFWM_RS_B1T(1, 2); else if (half == 2) FFWM_RS_B1T(2, 2); else FFWM_RS_B1T(3, 2); }
                 else { if (half == 1) FFWM_RS_B1T(1, 1); else if (half == 2) FFWM_RS_B1T(2, 1); else FFWM_RS_B1T(3, 1); }
 #undef FFWM_RS_B1T
+#undef FFWM_RS_B1T_
                 if (int rc = check_launch("ffwm_resample2d_backward(input1, tile)")) return rc;
             }
             auto_scope.reset();

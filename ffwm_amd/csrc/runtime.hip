@@ -310,6 +310,8 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "conv_wgrad_unsliced")) slot = &o.conv_wgrad_unsliced;
     else if (!strcmp(key, "zero_fill_memset")) slot = &o.zero_fill_memset;
     else if (!strcmp(key, "be_bwd_fixed")) slot = &o.be_bwd_fixed;
+    else if (!strcmp(key, "rs_bwd1_fixed")) slot = &o.rs_bwd1_fixed;
+    else if (!strcmp(key, "rs_bwd1_rpt")) slot = &o.rs_bwd1_rpt;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;

@@ -65,6 +65,14 @@ with torch.no_grad():
     _, _, fake_F128, att = netG(img_S, flow=[flow_F32, flow_F64, flow_F128], return_att=True)
     att = torch.mean(att[:, :64, :, :], (1,), keepdim=True)
     img_GF128 = gf128(fake_F128, img_F)
+    # The guided filter at the END of test_forward is ill-conditioned on this fixture: the closed-form netG produces a nearly constant
+    # image (std 0.006), a = cov / (var + 1e-8) divides by ~3e-5, and the reference's OWN fp32 result is 1.3e-2 away from its float64
+    # evaluation (a 1e-4 change of the input moves the output by 7e-2).  So the fixture also holds (a) that distance, which bounds
+    # what a comparison of img_GF128 can mean, and (b) the same GuidedFilter(32) on a well-conditioned pair (the two input images),
+    # which pins the filter itself to 1e-4.
+    gf64 = external_function.GuidedFilter(32).double()(fake_F128.double(), img_F.double())
+    out["img_GF128_ref_fp32_vs_fp64"] = float((img_GF128.double() - gf64).abs().max())
+    out["gf128_on_images"] = packed(gf128(img_S, img_F), 2)
     out["test_forward"] = {"fake_F128": packed(fake_F128, 2), "img_GF128": packed(img_GF128, 2), "img_S_warp": packed(img_S_warp, 2),
                            "att": packed(att, 2), "flow_F128": packed(flow_F128, 2), "flow_F64": packed(flow_F64, 1),
                            "flow_F32": packed(flow_F32, 1)}

@@ -189,7 +189,11 @@ def test_a_checkpoint_written_by_the_reference_loads_and_test_forward_matches_th
     _packed_close(warped, tf["img_S_warp"], 1e-5)
     _packed_close(fake, tf["fake_F128"], 1e-4)
     _packed_close(att, tf["att"], 1e-4)
-    _packed_close(gf, tf["img_GF128"], 1e-4)
+    # the guided filter: pinned on a well-conditioned pair; the composed output only within what the fixture's conditioning allows
+    # (tests/golden/make_eval_golden.py: the reference's own fp32 result is 1.3e-2 from its float64 evaluation there)
+    with torch.no_grad():
+        _packed_close(t.gf[128](b["img_S"], b["img_F"]), gold["gf128_on_images"], 1e-4)
+    _packed_close(gf, tf["img_GF128"], 10 * gold["img_GF128_ref_fp32_vs_fp64"])
     with torch.no_grad():
         score = t.netD(fake)
     assert float((score - gold["netD_score_of_fake"]).abs().max()) <= 1e-4 * (1 + float(gold["netD_score_of_fake"].abs().max()))
