@@ -1158,6 +1158,11 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
             const int groups = static_cast<int>((C + CG - 1) / CG);
             int gps = groups;                                       // channel groups per block: split until >= 3 blocks per CU
             while (gps > 1 && B * ntx * nty * ((groups + gps - 1) / gps) < 768) gps = (gps + 1) / 2;
+            // ... and on towards ~12 blocks per CU while a block keeps >= 8 groups: two 8-wave blocks are resident per CU (119 registers),
+            // so 800 blocks of 32 groups ran as two rounds with the second 44 % empty -- [32,64,256,256]: 897 -> 782 us with 8 groups
+            // per block (tools/warp_feat_gps_sweep.py, profiles/r05_warp_feat_gps_sweep.txt; 4: 806, 2: 911)
+            while (gps > 8 && B * ntx * nty * ((groups + gps - 1) / gps) < 3072) gps = (gps + 1) / 2;
+            if (options().warp_feat_gps > 0) gps = options().warp_feat_gps < groups ? options().warp_feat_gps : groups;
             const int cslabs = (groups + gps - 1) / gps;
             {
                 LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat_far" : "warp_bwd_feat_far", Hi), st, sizeof(T) * static_cast<double>(B) * 2.0 * H * W);

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+O=gpurun_out/run13
+mkdir -p $O
+timeout 600 python tools/warp_feat_gps_sweep.py 2>&1 | grep -v amdgpu.ids > $O/warp_feat_gps.txt
+cat $O/warp_feat_gps.txt
