@@ -355,8 +355,10 @@ def standalone_kernels(reps=10):
     nflow = smooth_flow(32, 256).to(dev)
     wo = torch.empty(32, 128, 256, 256, device=dev)
     run("HBM-resident warp+flip+cat [32,64,256,256], smooth flow", lambda: ops.warp_forward(feat, nflow, True, out=wo), 5)
-    gfeat, gflow = torch.zeros_like(feat), torch.zeros_like(nflow)
-    run("HBM-resident warp+flip+cat [32,64,256,256] backward, smooth flow", lambda: ops.warp_backward(feat, nflow, wo, True, gfeat, gflow), 3)
+    # (as external_function.WarpFunction.backward calls it since round 5: grad_feat handed over uninitialised and produced whole --
+    # flipcat bit 1 -- the owned tiles store instead of read-modify-write and the caller's 0.54 GB zero-fill is gone; grad_flow accumulates)
+    gfeat, gflow = torch.empty_like(feat), torch.zeros_like(nflow)
+    run("HBM-resident warp+flip+cat [32,64,256,256] backward, smooth flow", lambda: ops.warp_backward(feat, nflow, wo, True, gfeat, gflow, overwrite_feat=True), 3)
     del feat, nflow, wo, gfeat, gflow
     # the fused extractor + attention consumer at cfg-5 per GPU
     src = torch.rand(4, 128, 256, 256, generator=g).to(dev)

@@ -909,7 +909,9 @@ constexpr int kWtRegion = 64;                       // visited pixels per side
 constexpr int kWtTile = kWtRegion - 2 * kWtHalo;    // owned cells per side: 56
 constexpr int kWtRows = kWtRegion / kWtWaves;       // pixel rows per wave: 8
 
-template <bool FLIP, int CG>
+// OVW (round 5): the finished tile is STORED instead of added -- every in-image cell of grad_feat has exactly one owner, so a caller
+// that hands over an uninitialised buffer (flipcat bit 1 of ffwm_warp_backward) saves its zero-fill and this kernel the read of it.
+template <bool FLIP, int CG, bool OVW = false>
 __global__ void __launch_bounds__(kWtThreads)
 warp_bwd_feat_tile_kernel(const float* __restrict__ flow, const float* __restrict__ gout, float* __restrict__ gfeat, int C, int H,
                           int W, int ntx, int nty, int groups_per_slab, int cslabs) {
@@ -989,7 +991,8 @@ warp_bwd_feat_tile_kernel(const float* __restrict__ flow, const float* __restric
             acc[i] = 0.0;
             if (c0 + c < C && cx < W && cy < H) {
                 float* d = gfeat + (static_cast<size_t>(b) * C + c0 + c) * plane + static_cast<size_t>(cy) * W + cx;
-                *d += static_cast<float>(v);
+                if (OVW) *d = static_cast<float>(v);
+                else *d += static_cast<float>(v);
             }
         }
         __syncthreads();
@@ -1114,11 +1117,21 @@ int launch_fwd(const T* feat, const T* flow, T* out, int64_t B, int64_t C, int64
 
 template <typename T>
 int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, int64_t B, int64_t C,
-               int64_t Hi, int64_t Wi, int64_t H, int64_t W, int flip, hipStream_t st) {
+               int64_t Hi, int64_t Wi, int64_t H, int64_t W, int flipcat, hipStream_t st) {
+    const int flip = flipcat & 1;
+    // flipcat bit 1: grad_feat is UNINITIALISED and must be produced whole (no caller zero-fill).  Only the owned-tile path stores
+    // instead of adding; every other path gets the zero-fill it relies on from here.
+    bool ovw = (flipcat & 2) != 0 && gfeat != nullptr;
     const double bytes = sizeof(T) * static_cast<double>(B) *
                          (2.0 * C * Hi * Wi + 4.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W);
     const int remap = options().xcd_remap;
     const PlanePlan pp = plan_planes(B, C, Hi * Wi, H * W, sizeof(T) == 8 ? 2 : 8);
+    const bool tile_path = sizeof(T) == 4 && gfeat && !(pp.ok && options().scatter_variant != 1) && Hi == H && Wi == W &&
+                           options().scatter_variant != 1;
+    if (ovw && !tile_path) {
+        if (zero_fill(gfeat, sizeof(T) * static_cast<size_t>(B) * C * Hi * Wi, st)) return FFWM_ERR_LAUNCH;
+        ovw = false;
+    }
     if (gfeat && pp.ok && options().scatter_variant != 1) {
         {   // d(feat): LDS-resident planes, no contended global atomics
             LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat" : "warp_bwd_feat", Hi), st,
@@ -1164,22 +1177,30 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
             while (gps > 8 && B * ntx * nty * ((groups + gps - 1) / gps) < 3072) gps = (gps + 1) / 2;
             if (options().warp_feat_gps > 0) gps = options().warp_feat_gps < groups ? options().warp_feat_gps : groups;
             const int cslabs = (groups + gps - 1) / gps;
-            {
+            auto launch_far = [&]() {
                 LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat_far" : "warp_bwd_feat_far", Hi), st, sizeof(T) * static_cast<double>(B) * 2.0 * H * W);
                 const int fx = static_cast<int>((W + kTileX - 1) / kTileX), fy = static_cast<int>((H + kTileY - 1) / kTileY);
                 const unsigned fgrid = static_cast<unsigned>(B * fx * fy);
                 if (flip) hipLaunchKernelGGL((warp_bwd_feat_far_kernel<true>), dim3(fgrid), dim3(kBlock), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, fx, fy);
                 else hipLaunchKernelGGL((warp_bwd_feat_far_kernel<false>), dim3(fgrid), dim3(kBlock), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, fx, fy);
-            }
-            if (int rc = check_launch("ffwm_warp_backward(feat, far)")) return rc;
+                return check_launch("ffwm_warp_backward(feat, far)");
+            };
+            // (stream order: the far kernel ADDS with global atomics -- in front of the tiles' read-modify-write, behind their plain stores)
+            if (!ovw)
+                if (int rc = launch_far()) return rc;
             {
+                // algorithmic bytes: the overwriting variant does not read grad_feat
                 LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat_tile" : "warp_bwd_feat_tile", Hi), st,
-                               sizeof(T) * static_cast<double>(B) * (2.0 * C * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
+                               sizeof(T) * static_cast<double>(B) * ((ovw ? 1.0 : 2.0) * C * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-                if (flip) hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<true, CG>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs);
-                else hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<false, CG>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs);
+#define FFWM_WT(FL, OV) hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<FL, CG, OV>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs)
+                if (flip) { if (ovw) FFWM_WT(true, true); else FFWM_WT(true, false); }
+                else { if (ovw) FFWM_WT(false, true); else FFWM_WT(false, false); }
+#undef FFWM_WT
             }
             if (int rc = check_launch("ffwm_warp_backward(feat, tiles)")) return rc;
+            if (ovw)
+                if (int rc = launch_far()) return rc;
             if (!gflow) return FFWM_OK;
             gfeat = nullptr;
         }

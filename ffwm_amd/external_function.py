@@ -244,10 +244,10 @@ class WarpFunction(Function):
     def backward(ctx, grad_output):
         feat, flow = ctx.saved_tensors
         need_feat, need_flow = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        grad_feat = torch.zeros_like(feat) if need_feat else None
+        grad_feat = torch.empty_like(feat) if need_feat else None          # produced whole by the library (overwrite_feat)
         grad_flow = torch.zeros_like(flow) if need_flow else None
         if need_feat or need_flow:
-            ops.warp_backward(feat, flow, grad_output.contiguous(), ctx.flipcat, grad_feat, grad_flow)
+            ops.warp_backward(feat, flow, grad_output.contiguous(), ctx.flipcat, grad_feat, grad_flow, overwrite_feat=True)
         return grad_feat, grad_flow, None
 
 

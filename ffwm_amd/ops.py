@@ -258,8 +258,10 @@ def warp_forward(feat, flow, flipcat=False, out=None):
     return out
 
 
-def warp_backward(feat, flow, grad_output, flipcat=False, grad_feat=None, grad_flow=None):
-    """Both gradients accumulate (+=) into zero-filled buffers; None skips one."""
+def warp_backward(feat, flow, grad_output, flipcat=False, grad_feat=None, grad_flow=None, overwrite_feat=False):
+    """Both gradients accumulate (+=) into zero-filled buffers; None skips one.  overwrite_feat=True: grad_feat may be UNINITIALISED --
+    the library produces it whole (the owned-tile kernel stores instead of adding and the zero-fill is saved; every other path zero-fills
+    it itself: flipcat bit 1 of ffwm_warp_backward)."""
     _check("warp_backward", feat, flow, grad_output, grad_feat, grad_flow)
     B, C, Hi, Wi = feat.shape
     _, _, H, W = flow.shape
@@ -270,7 +272,7 @@ def warp_backward(feat, flow, grad_output, flipcat=False, grad_feat=None, grad_f
     with _on_device(feat) as stream:
         _lib.check(_lib.load().ffwm_warp_backward(
             _ptr(feat), _ptr(flow), _ptr(grad_output), _ptr(grad_feat), _ptr(grad_flow), B, C, Hi, Wi, H, W,
-            1 if flipcat else 0, _dtype_code(feat), stream), "ffwm_warp_backward")
+            (1 if flipcat else 0) | (2 if overwrite_feat and grad_feat is not None else 0), _dtype_code(feat), stream), "ffwm_warp_backward")
     return grad_feat, grad_flow
 
 

@@ -123,7 +123,9 @@ int ffwm_warp_forward(const void* feat, const void* flow, void* output, int64_t 
                       void* stream);
 
 /* grad_feat[B,C,Hi,Wi] += ; grad_flow[B,2,H,W] += .  Either may be NULL.  grad_output is
- * [B,C,H,W] or, with flipcat, [B,2C,H,W]. */
+ * [B,C,H,W] or, with flipcat bit 0, [B,2C,H,W].  flipcat bit 1 (value 2, ABI 4): grad_feat is UNINITIALISED memory and is produced
+ * whole -- the caller's zero-fill is saved (and, on the owned-tile path of planes beyond LDS, the read of it); grad_flow still
+ * accumulates. */
 int ffwm_warp_backward(const void* feat, const void* flow, const void* grad_output,
                        void* grad_feat, void* grad_flow, int64_t B, int64_t C, int64_t Hi,
                        int64_t Wi, int64_t H, int64_t W, int flipcat, int dtype, void* stream);

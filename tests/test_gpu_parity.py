@@ -2244,3 +2244,29 @@ def test_winograd_domain_weight_gradient_accumulates_and_blocks():
     finally:
         lib.ffwm_set_option(b"conv_wgrad_wino", 0)
     assert (once - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
+
+
+@pytest.mark.parametrize("flip", [False, True])
+@pytest.mark.parametrize("shape", [(1, 5, 150, 200), (2, 3, 40, 48), (1, 2, 130, 131)])
+def test_warp_backward_overwrite_mode_needs_no_zero_fill(oracle, shape, flip):
+    """flipcat bit 1 of ffwm_warp_backward (round 5): grad_feat handed over UNINITIALISED (NaN-filled here) comes back whole -- by plain
+    stores on the owned-tile path (planes beyond LDS), by the library's own zero-fill on every other path -- and equals the accumulate
+    mode on a zero-filled buffer and the oracle."""
+    from ffwm_amd import ops
+    B, C, H, W = shape
+    g = _gen(50 + H)
+    feat = torch.rand(B, C, H, W, generator=g)
+    flow = (torch.stack(torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")[::-1]).unsqueeze(0).repeat(B, 1, 1, 1)
+            + 0.05 * (torch.rand(B, 2, H, W, generator=g) - 0.5))
+    flow[0, :, 3, 3] = 3.0                                      # one pixel far outside: the far kernel's work
+    go = torch.rand(B, 2 * C if flip else C, H, W, generator=g)
+    gfeat_ref, gflow_ref = oracle.warp_backward(feat, flow, go, flip)
+    a = torch.zeros_like(feat, device=DEV)
+    ops.warp_backward(feat.to(DEV), flow.to(DEV), go.to(DEV), flip, a, None)
+    b = torch.full_like(feat, float("nan"), device=DEV)
+    gf = torch.zeros_like(flow, device=DEV)
+    ops.warp_backward(feat.to(DEV), flow.to(DEV), go.to(DEV), flip, b, gf, overwrite_feat=True)
+    assert bool(torch.isfinite(b).all())
+    _close(b, gfeat_ref, BWD_TOL[torch.float32], relative=True)
+    _close(b, a.cpu(), 1e-6, relative=True)
+    _close(gf, gflow_ref, BWD_TOL[torch.float32], relative=True)

@@ -28,3 +28,13 @@ for gps in (0, 32, 16, 8, 4, 2, 1):
     print("groups per block %2d" % gps, {k: round(v["avg_ms"] * 1e3, 1) for k, v in _lib.prof_collect().items()},
           "max diff vs auto %.2g" % float((out - ref).abs().max()), flush=True)
 _lib.set_option("warp_feat_gps", 0)
+# overwrite mode (flipcat bit 1): grad_feat uninitialised, the tiles store instead of read-modify-write
+gfeat.fill_(float("nan"))
+for _ in range(2):
+    ops.warp_backward(feat, nflow, wo, True, gfeat, None, overwrite_feat=True)
+torch.cuda.synchronize(); _lib.prof_reset(); _lib.prof_enable(True)
+for _ in range(3):
+    ops.warp_backward(feat, nflow, wo, True, gfeat, None, overwrite_feat=True)
+torch.cuda.synchronize(); _lib.prof_enable(False)
+print("overwrite mode      ", {k: round(v["avg_ms"] * 1e3, 1) for k, v in _lib.prof_collect().items()},
+      "max diff vs accumulate mode %.2g" % float((gfeat - ref).abs().max()), flush=True)
