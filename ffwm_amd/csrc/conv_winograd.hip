@@ -632,7 +632,7 @@ struct ThinGeo {
     unsigned x_bytes;
 };
 
-constexpr int kThinWaves = 8;
+constexpr int kThinWaves = 16;
 
 template <int KN>
 __global__ void __launch_bounds__(64 * kThinWaves)
@@ -668,12 +668,19 @@ conv3x3_thin_kernel(const float* __restrict__ x, const float* __restrict__ wt, c
         const bool cv = c < g.C;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            in[r][0] = buf_ld<float>(rx, (cv & (offm[r] != kOobOff)) ? offm[r] + co : kOobOff);
+            // The pixels left and right of the aligned four are the neighbouring LANES' (strips are consecutive along a row): two lane
+            // shuffles instead of two more gathers.  Round 5: the three loads per row cost the same in the texture-address unit (64
+            // lanes 16 bytes apart = 16 cache lines each), and that unit bounded the kernel -- ~50 us whether the plane was 128 x 128
+            // or 32 x 32 (tools/thin_tail_time.py).  Only a wave's first / last lane still loads its outer neighbour.
             unsigned q[4];           // (never __builtin_bit_cast a vector ELEMENT: clang reads the vector's first lane for each)
             buf_load_dwords<4>(rx, (cv & (off4[r] != kOobOff)) ? off4[r] + co : kOobOff, q);
+            const float edge_l = buf_ld<float>(rx, (cv & (lane == 0) & (offm[r] != kOobOff)) ? offm[r] + co : kOobOff);
+            const float edge_r = buf_ld<float>(rx, (cv & (lane == 63) & (offp[r] != kOobOff)) ? offp[r] + co : kOobOff);
             in[r][1] = __uint_as_float(q[0]); in[r][2] = __uint_as_float(q[1]);
             in[r][3] = __uint_as_float(q[2]); in[r][4] = __uint_as_float(q[3]);
-            in[r][5] = buf_ld<float>(rx, (cv & (offp[r] != kOobOff)) ? offp[r] + co : kOobOff);
+            const float from_l = __shfl_up(in[r][4], 1, 64), from_r = __shfl_down(in[r][1], 1, 64);
+            in[r][0] = offm[r] != kOobOff ? (lane == 0 ? edge_l : from_l) : 0.f;          // (offm / offp: the pixel exists in this row)
+            in[r][5] = offp[r] != kOobOff ? (lane == 63 ? edge_r : from_r) : 0.f;
         }
     };
     auto fma_all = [&](int c, const float (&in)[3][6]) {
