@@ -51,6 +51,7 @@ struct Options {
     int warp_multi_planes = 0; // multi-problem warp backward: 0 = d(feat) plane problems of one CG share a launch, 1 = one launch per problem
     int warp_multi_lds = 0;   // multi-problem warp launches: 0 = auto (LDS-staged tiles for float planes >= 64 x 64, C >= 32), 1 = direct gathers, 2 = LDS tiles
     int warp_multi_order = 0; // multi-problem warp launches: 0 = largest problem first, 1 = the caller's order
+    int conv_fwd_kfast = 1;      // conv_fwd.hip: workgroup index with the channel tiles fastest + XCD remap (round 5); 0 = pixel tiles fastest
     int warp_feat_gps = 0;       // warp d(feat) owned-tile kernel: channel groups per block, 0 = auto
     int rs_bwd1_rpt = 0;         // resample2d d_input1 tile kernel: pixel rows per thread, 0 = auto (4), 2
     int rs_bwd1_fixed = 0;       // resample2d d_input1 tile kernel: 0 = 32-bit fixed-point box cells (round 5), 2 = double cells

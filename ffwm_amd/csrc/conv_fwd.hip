@@ -39,6 +39,7 @@ struct ConvGeo {
     int Kd;                  // reduction length: C * R * S (MODE 1: C * 4)
     int N;                   // B * Ho * Wo
     int n_tiles, k_tiles;
+    int kfast;               // linear workgroup index: channel tiles fastest (1) or pixel tiles fastest (0)
     int splitk, chunks;      // chunks (of CPC input channels) per split
     long long out_bs;        // output batch stride in elements
     int oH, oW;              // output plane (MODE 1: 2H x 2W)
@@ -72,7 +73,20 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TM;
+    // Round 5: the (pixel tile, channel tile) pair comes from ONE linear index with the channel tiles fastest, XCD-remapped: the k_tiles
+    // workgroups that gather the SAME activations are dispatched together on one XCD and meet in its L2.  (With blockIdx.x = pixel tile,
+    // blockIdx.y = channel tile they ran a whole sweep of the pixels apart and every sweep re-fetched the input: PMC traffic 3.4-3.9 x
+    // the algorithmic bytes)  g.kfast == 0: the old mapping.
+    int n_tile, k_tile;
+    if (g.kfast) {
+        const unsigned t = xcd_remap(blockIdx.x, gridDim.x, 1);
+        k_tile = static_cast<int>(t % static_cast<unsigned>(g.k_tiles));
+        n_tile = static_cast<int>(t / static_cast<unsigned>(g.k_tiles));
+    } else {
+        n_tile = blockIdx.x % g.n_tiles;
+        k_tile = blockIdx.x / g.n_tiles;
+    }
+    const int n0 = n_tile * TN, k0 = k_tile * TM;
     int zz = blockIdx.z;
     const int split = zz % g.splitk;
     zz /= g.splitk;
@@ -313,7 +327,8 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
     if (needs_epilogue) *needs_epilogue = g.splitk > 1 ? 1 : 0;
     FFWM_REQUIRE(g.splitk == 1 || needs_epilogue, FFWM_ERR_ARG, "%s: a split launch needs the needs_epilogue out-parameter", fn);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(static_cast<unsigned>(g.n_tiles), static_cast<unsigned>(g.k_tiles), static_cast<unsigned>(g.splitk * classes));
+    g.kfast = options().conv_fwd_kfast;
+    const dim3 grid(static_cast<unsigned>(g.n_tiles) * static_cast<unsigned>(g.k_tiles), 1u, static_cast<unsigned>(g.splitk * classes));
     const double flops = 2.0 * B * g.Ho * g.Wo * classes * static_cast<double>(g.K) * g.Kd;
     const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(K) * g.Kd * classes + static_cast<double>(B) * K * g.oH * g.oW);
     static const char* const kScope[4] = {"conv_fwd_mfma", "conv_fwd_mfma_transposed", "conv_dgrad_mfma_3x3s2", "conv_dgrad_mfma_3x3s1"};

@@ -313,6 +313,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "rs_bwd1_fixed")) slot = &o.rs_bwd1_fixed;
     else if (!strcmp(key, "rs_bwd1_rpt")) slot = &o.rs_bwd1_rpt;
     else if (!strcmp(key, "warp_feat_gps")) slot = &o.warp_feat_gps;
+    else if (!strcmp(key, "conv_fwd_kfast")) slot = &o.conv_fwd_kfast;
     if (!slot) {
         set_error("ffwm_set_option: unknown key '%s'", key);
         return FFWM_ERR_ARG;
