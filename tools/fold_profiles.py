@@ -1,4 +1,4 @@
-"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r04_*.
+"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r05_*.
 
     python tools/fold_profiles.py [gpurun_out/refresh]
 
@@ -19,7 +19,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "bn_lrelu_bwd": "bn_lrelu_bwd_kernel<1024>",
     "bn_lrelu_fwd": "bn_lrelu_fwd_kernel<1024>",
     "block_extractor_bwd_far": "be_bwd_far2_kernel<float, 3, false>",
-    "block_extractor_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, false>",
+    "block_extractor_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, false,",
     "block_extractor_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 0>",
     "conv3x3_thin_tail": "conv3x3_thin_kernel<3>",
     "conv3x3_wgrad": "conv3x3_wgrad_kernel<false>",
@@ -66,15 +66,15 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     # (large ks-4 calls launch BOTH d_input1 kernels and one returns at once: these two per-dispatch averages include such dispatches)
     "resample2d_bwd_input1_taplane": "rs_bwd1_taplane_kernel<2,",
     "warp_flipcat_fwd@256": "warp_fwd_lds_kernel<true>",
-    "warp_flipcat_bwd_feat_tile@256": "warp_bwd_feat_tile_kernel<true, 2>",
+    "warp_flipcat_bwd_feat_tile@256": "warp_bwd_feat_tile_kernel<true, 2,",
     "warp_flipcat_bwd_feat_far@256": "warp_bwd_feat_far_kernel<true>",
     "warp_flipcat_bwd_flow@256": "warp_bwd_kernel<float, true>",
     "block_attention_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 1>",
-    "block_attention_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, true>",
+    "block_attention_bwd_tile2": "be_bwd_tile2_kernel<3, 32, 4, true,",
     "block_attention_bwd_weights": "be_fwd_lds_kernel<float, 3, 4, 2>",
 }
 FETCH_CORRECTION = 2.0
-ROUND = "r04"
+ROUND = "r05"
 
 
 def main():

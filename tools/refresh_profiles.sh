@@ -6,7 +6,7 @@
 #      that also instruments MIOpen's kernels aborts with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT): FETCH_SIZE, WRITE_SIZE
 #      and two SQ sets in SEPARATE runs (counters + --kernel-trace only)
 #   4. the default `python bench.py` line
-# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/r04_*.
+# Everything lands in gpurun_out/refresh/ (small CSV / JSON only); tools/fold_profiles.py turns it into profiles/r05_*.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/refresh
