@@ -111,10 +111,13 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
             const bool rok = live && c_ok && iy >= 0 && iy < g.H;
             const unsigned ro = rok ? (xb + static_cast<unsigned>(iy * g.W + 2 * tx)) * 4u : kWwOob;
             const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rx, ro, 0, 0);
-            R.xp[i * 4 + 0] = buf_ld<float>(rx, (rok && lcol) ? ro - 4u : kWwOob);
+            // Round 5: the patch's outer columns are the NEIGHBOURING tiles' inner ones (lanes t8 - 1 / t8 + 1 of the same channel and
+            // row): commit() takes them by DPP row shifts.  Only the chunk's first / last tile still gathers its outer column -- 4 + 8
+            // sparse loads per thread and chunk instead of 12, and no pixel of a chunk fetched twice.
+            R.xp[i * 4 + 0] = buf_ld<float>(rx, (rok && lcol && t8 == 0) ? ro - 4u : kWwOob);
             R.xp[i * 4 + 1] = __uint_as_float(m.x);
             R.xp[i * 4 + 2] = __uint_as_float(m.y);
-            R.xp[i * 4 + 3] = buf_ld<float>(rx, (rok && rcol) ? ro + 8u : kWwOob);
+            R.xp[i * 4 + 3] = buf_ld<float>(rx, (rok && rcol && t8 == 7) ? ro + 8u : kWwOob);
         }
         ++cur;
         const bool wrap_x = ctxc + 1 == g.TWC;
@@ -139,13 +142,25 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
                 A[(i * 4 + 3) * (4 * kWwPos)] = -rq[i];
             }
         }
+        // the outer columns of the 4 x 4 patch from the neighbouring lanes (row_shr:1 = lane - 1, row_shl:1 = lane + 1; t8 = lane & 7
+        // never crosses a 16-lane DPP row on the lanes that use the shifted value)
+        float xq[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float from_l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(R.xp[i * 4 + 2]), 0x111, 0xf, 0xf, true));
+            const float from_r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(R.xp[i * 4 + 1]), 0x101, 0xf, 0xf, true));
+            xq[i * 4 + 0] = t8 == 0 ? R.xp[i * 4 + 0] : from_l;
+            xq[i * 4 + 1] = R.xp[i * 4 + 1];
+            xq[i * 4 + 2] = R.xp[i * 4 + 2];
+            xq[i * 4 + 3] = t8 == 7 ? R.xp[i * 4 + 3] : from_r;
+        }
         // V = Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float r[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                r[j] = i == 0 ? R.xp[0 + j] - R.xp[8 + j] : i == 1 ? R.xp[4 + j] + R.xp[8 + j] : i == 2 ? R.xp[8 + j] - R.xp[4 + j] : R.xp[4 + j] - R.xp[12 + j];
+                r[j] = i == 0 ? xq[0 + j] - xq[8 + j] : i == 1 ? xq[4 + j] + xq[8 + j] : i == 2 ? xq[8 + j] - xq[4 + j] : xq[4 + j] - xq[12 + j];
             Bv[(i * 4 + 0) * (4 * kWwPos)] = r[0] - r[2];
             Bv[(i * 4 + 1) * (4 * kWwPos)] = r[1] + r[2];
             Bv[(i * 4 + 2) * (4 * kWwPos)] = r[2] - r[1];
