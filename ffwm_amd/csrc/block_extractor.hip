@@ -1258,7 +1258,7 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
     for (int r = 0; r < PPT; ++r) gxa[r] = gya[r] = 0;
     // FIXED: one grad_output window value per pixel of this lane's rows (the centre element), as loads in flight: sample_issue() requests
     // them for channel plane `opc`, sample_max() folds them -- called around the flush of the previous channel, which hides their latency
-    constexpr int SSTEP = FUSED ? 2 : 1;          // (FUSED holds two loads per sample: every second row, to stay within the registers)
+    constexpr int SSTEP = 2;          // every second row of the tile: 1024 samples per tile and channel (FUSED holds two loads per sample)
     T smp[FIXED != 0 ? PPT : 1], smw[(FIXED != 0 && FUSED) ? PPT : 1];
     T m_pre = 0;
     auto sample_issue = [&](const T* opc) {
