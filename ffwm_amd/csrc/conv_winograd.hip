@@ -200,7 +200,7 @@ __device__ __forceinline__ void winograd_epilogue(const f32x16 (&acc)[8], f32x4*
     }
 }
 
-template <int ABL>          // ABL: timing experiments only (bit 0 no patch loads, 1 no U loads, 2 no LDS commits, 3 no operand reads)
+template <int ABL>          // ABL: timing experiments only (bit 0 no patch loads, 1 no U loads, 2 no LDS commits, 3 no operand reads; raw variant: 4 no output stores, 5 no epilogue)
 __global__ void __launch_bounds__(kWinoThreads)
 winograd_conv_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out,
                      const WinoGeo g, int remap) {
@@ -379,19 +379,34 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     // ---- W stage role: quads q = tid, tid + 512 of the [8 channels][ROWS][W / 4] window
     const int W4 = g.W >> 2, nquads = 8 * g.ROWS * W4;
     const int strips_per_img = g.TH / g.R;
-    int qc[2], qlds[2], qrow[2], qcol[2];      // channel within the chunk; float index in the raw buffer; window row; pixel column
+    int qc[2], qlds[2];      // channel within the chunk; float index in the raw buffer
+    const int w4_shift = __builtin_ctz(static_cast<unsigned>(W4));
+    const float quad_rcp = 1.f / static_cast<float>(g.ROWS * W4);      // quads per channel <= 128, quad index < 1024: (q + 0.5) * rcp truncates exactly
+    auto quad_of = [&](int q, int& c, int& rr, int& col) {             // channel, window row, pixel column of quad q
+        c = static_cast<int>((static_cast<float>(q) + 0.5f) * quad_rcp);
+        const int rem = q - c * (g.ROWS * W4);
+        rr = rem >> w4_shift;
+        col = 4 * (rem & (W4 - 1));
+    };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = threadIdx.x + kWinoThreads * i;
-        const int c = q / (g.ROWS * W4), rem = q - c * (g.ROWS * W4);
-        const int rr = rem / W4;
+        int c, rr, col;
+        quad_of(q, c, rr, col);
         qc[i] = q < nquads ? c : 8;
-        qrow[i] = rr;
-        qcol[i] = 4 * (rem - rr * W4);
         // the rows of channel c are stored rotated by 16 c pixels: the 4 channels a wave reads patches from sit 0 (mod 64) dwords
         // apart, unrotated they would share their banks (35 % of the LDS cycles were conflicts)
-        qlds[i] = q < nquads ? (c * g.ROWS + rr) * g.W + ((qcol[i] + 16 * c) & (g.W - 1)) : -1;
+        qlds[i] = q < nquads ? (c * g.ROWS + rr) * g.W + ((col + 16 * c) & (g.W - 1)) : -1;
     }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // Per-lane values that are needed once per pair only (seat(), the output transform) are worked out THERE from the lane index, which
+    // `lane_now` reads off the hardware in two instructions the optimiser cannot hoist: kept in registers across the chunk loop they
+    // are spilled, and a scratch reload is a vector-memory load -- its wait also waits for every prefetched load in flight.
+    auto lane_now = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     // a load cursor: the (pair, chunk) a stream of loads has reached, and what depends on the pair
     struct Cursor {
         int pair, ch;
@@ -410,11 +425,15 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         const int ch0 = first_chunk(c.pair);
         const int tt = pk / g.KT, kt = pk - tt * g.KT;
         const int b = tt / strips_per_img, ty0 = (tt - b * strips_per_img) * g.R;
+        const int tid = wave_u * 64 + lane_now();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int iy = 2 * ty0 - 1 + qrow[i];
-            const bool ok = qc[i] < 8 && iy >= 0 && iy < g.H;
-            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + 8 * ch0 + qc[i]) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol[i])) * 4u : kOobOff;
+            const int q = tid + kWinoThreads * i;
+            int qch, qrow, qcol;
+            quad_of(q, qch, qrow, qcol);
+            const int iy = 2 * ty0 - 1 + qrow;
+            const bool ok = q < nquads && iy >= 0 && iy < g.H;
+            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + 8 * ch0 + qch) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol)) * 4u : kOobOff;
         }
         c.u_base = (static_cast<unsigned>(kt) * g.CH + ch0) * (kWinoChunk * 4u) + threadIdx.x * 16u;
     };
@@ -439,10 +458,12 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     const int pcm = (2 * tx - 1 + prot) & (g.W - 1), pc0 = (2 * tx + prot) & (g.W - 1), pcp = (2 * tx + 2 + prot) & (g.W - 1);
     const bool lcol = tx > 0, rcol = tx < g.TW - 1;
 
-    // two register sets each, alternating with the chunk's parity: a load has ~1.5 steps (6000+ cycles) to land
+    // the raw window has two register sets, alternating with the chunk's parity: a load (HBM for a strip's first k tile) has ~1.75 steps
+    // (9000+ cycles) to land.  The transformed weights come from L2 (every workgroup reads the same few k tiles): ONE set, each half
+    // re-loaded one group after its commit, 0.75 steps ahead of its next use
     u32x4 rq[2][2] = {};
-    u32x4 uw[2][4] = {};
-    float d[16];
+    u32x4 uw[4] = {};
+    float d[16] = {};
     auto load_raw = [&](u32x4 (&q)[2]) {             // L: the cursor's chunk, then the cursor moves on
         if (!(ABL & 1)) {
 #pragma unroll
@@ -454,7 +475,7 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         advance(cr);
     };
     auto write_raw = [&](float* raw, const u32x4 (&q)[2]) {      // W: registers -> raw window
-        if (ABL & 4) return;
+        if (ABL & (4 | 256)) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (qlds[i] >= 0) *reinterpret_cast<u32x4*>(raw + qlds[i]) = q[i];
@@ -473,16 +494,25 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
             const float* rp = raw + prow + i * g.W;
             const float a = rp[pcm], e = rp[pcp];
             const float2 m = *reinterpret_cast<const float2*>(rp + pc0);
-            d[i * 4 + 0] = lcol ? a : 0.f;
-            d[i * 4 + 1] = m.x;
+            d[i * 4 + 0] = a;                 // the columns outside the image are masked where the transform starts (commit_slice 0):
+            d[i * 4 + 1] = m.x;               // a select right behind its read would park the wave -- and its MFMAs -- on the LDS latency
             d[i * 4 + 2] = m.y;
-            d[i * 4 + 3] = rcol ? e : 0.f;
+            d[i * 4 + 3] = e;
         }
     };
     auto commit_slice = [&](f32x4* Ub, f32x4* Vb, const u32x4 (&u)[4], int s) {   // U rows 2s, 2s + 1; V rows 2s, 2s + 1
         if (ABL & 4) return;
+        if (!(ABL & 64))
 #pragma unroll
-        for (int i = 2 * s; i < 2 * s + 2; ++i) reinterpret_cast<u32x4*>(Ub)[threadIdx.x + kWinoThreads * i] = u[i];
+            for (int i = 2 * s; i < 2 * s + 2; ++i) reinterpret_cast<u32x4*>(Ub)[threadIdx.x + kWinoThreads * i] = u[i];
+        if (ABL & 128) return;
+        if (s == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i * 4 + 0] = lcol ? d[i * 4 + 0] : 0.f;
+                d[i * 4 + 3] = rcol ? d[i * 4 + 3] : 0.f;
+            }
+        }
         float* dst = reinterpret_cast<float*>(Vb) + (sh * 64 + ts) * 4 + c_lo;
 #pragma unroll
         for (int i = 2 * s; i < 2 * s + 2; ++i) {
@@ -504,118 +534,190 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     // step of chunk n (parity P): MFMAs on buffers P; T(n + 1), U(n + 1) into buffers 1 - P; W(n + 2) into raw[P];
-    // loads of U(n + 3) and raw chunk n + 4 into the register sets just emptied
+    // loads of U(n + 3) and raw chunk n + 4 into the register sets just emptied.
+    // The step's ONE barrier stands between its third and fourth group of MFMAs, not at its end: by then every wave has issued its last
+    // operand read of buffers P (the fourth group's operands are in registers) and its commits into buffers 1 - P, so the fourth group
+    // runs with the operands of the NEXT step's first group being read under it -- the MFMA pipe does not wait for an LDS round trip
+    // behind every barrier.  (Hazards: commits of chunk n + 1 [groups 0, 1 of step n] -> barrier n -> their first read [group 3 of
+    // step n]; last read of buffers P [group 2 of step n] -> barrier n -> their next commits [groups 0, 1 of step n + 1]; write of
+    // raw[P] [group 2] -> barrier n -> read_patch(raw[P]) [group 0 of step n + 1]; read_patch(raw[1 - P]) [group 0] -> barrier n ->
+    // its next write [group 2 of step n + 1].)
+    f32x4 oa[2][2] = {}, ob[2][2] = {};  // operands of the current / next group; [0] holds the first group's at a step's entry
     auto step = [&](auto parity) {
         constexpr int P = decltype(parity)::value, Q = 1 - P;
         f32x4* const Ub = smem + P * 4096;
         f32x4* const Vb = Ub + 2048;
         f32x4* const Un = smem + Q * 4096;
         f32x4* const Vn = Un + 2048;
-        const f32x4* ap = Ub + (ph * 8) * 128 + half * 64 + wm * 32 + l31;
-        const f32x4* bp = Vb + (ph * 8) * 128 + half * 64 + wn * 32 + l31;
-        f32x4 oa[2][2], ob[2][2];
-        oa[0][0] = ap[0]; ob[0][0] = bp[0]; oa[0][1] = ap[128]; ob[0][1] = bp[128];
+        const int oidx = (ph * 8) * 128 + half * 64 + l31;
+        const f32x4* ap = Ub + oidx + wm * 32;
+        const f32x4* bp = Vb + oidx + wn * 32;
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
             const int cur = grp & 1, nxt = cur ^ 1;
-            if (grp < 3 && !(ABL & 8)) {
-                oa[nxt][0] = ap[(2 * grp + 2) * 128]; ob[nxt][0] = bp[(2 * grp + 2) * 128];
-                oa[nxt][1] = ap[(2 * grp + 3) * 128]; ob[nxt][1] = bp[(2 * grp + 3) * 128];
+            if (!(ABL & 8)) {
+                if (grp < 3) {
+                    oa[nxt][0] = ap[(2 * grp + 2) * 128]; ob[nxt][0] = bp[(2 * grp + 2) * 128];
+                    oa[nxt][1] = ap[(2 * grp + 3) * 128]; ob[nxt][1] = bp[(2 * grp + 3) * 128];
+                } else {                 // behind the barrier: the next step's first operands, from the buffers committed in groups 0, 1
+                    const f32x4* an = Un + oidx + wm * 32;
+                    const f32x4* bn = Vn + oidx + wn * 32;
+                    oa[nxt][0] = an[0]; ob[nxt][0] = bn[0]; oa[nxt][1] = an[128]; ob[nxt][1] = bn[128];
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc[2 * grp] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][0][j], ob[cur][0][j], acc[2 * grp], 0, 0, 0);
                 acc[2 * grp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][1][j], ob[cur][1][j], acc[2 * grp + 1], 0, 0, 0);
             }
-            if (grp == 0) { if (!(ABL & 4)) read_patch(Q ? raw1 : raw0); commit_slice(Un, Vn, uw[Q], 0); }
-            else if (grp == 1) commit_slice(Un, Vn, uw[Q], 1);
-            else if (grp == 2) { write_raw(P ? raw1 : raw0, rq[P]); load_u(uw[Q], 0); }
-            else { load_u(uw[Q], 1); load_raw(rq[P]); }
+            // the patches of the NEXT step's transform are read behind the barrier too (the window this step's group 2 wrote): a
+            // group's side work then never waits for an LDS read it has just issued -- a wave that waits issues no MFMAs, and the two
+            // waves of a SIMD run in step
+            if (grp == 0) commit_slice(Un, Vn, uw, 0);
+            else if (grp == 1) { commit_slice(Un, Vn, uw, 1); load_u(uw, 0); }
+            else if (grp == 2) { write_raw(P ? raw1 : raw0, rq[P]); load_u(uw, 1); }
+            else { if (!(ABL & (4 | 512))) read_patch(P ? raw1 : raw0); load_raw(rq[P]); }
             #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to 6 VALU
                 __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // up to 2 LDS writes
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // up to 2 LDS reads
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // up to 2 VMEM reads
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (grp == 2) {
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __syncthreads();
+    };
+    auto first_operands = [&]() {        // of a parity-0 step, after a barrier behind the commits into buffers 0
+        if (ABL & 8) return;
+        const int oidx = (ph * 8) * 128 + half * 64 + l31;
+        const f32x4* a0 = smem + oidx + wm * 32;
+        const f32x4* b0 = smem + 2048 + oidx + wn * 32;
+        oa[0][0] = a0[0]; ob[0][0] = b0[0]; oa[0][1] = a0[128]; ob[0][1] = b0[128];
     };
 
     // prologue of the stream: chunk 0 staged and transformed, chunk 1 in raw[1], U(1), U(2) and raw chunks 2, 3 in flight
-    load_raw(rq[0]); load_u(uw[0], 0); load_u(uw[0], 1);
-    load_raw(rq[1]); load_u(uw[1], 0); load_u(uw[1], 1);
+    load_raw(rq[0]); load_u(uw, 0); load_u(uw, 1);
+    load_raw(rq[1]);
     write_raw(raw0, rq[0]);
     __syncthreads();
     read_patch(raw0);
-    commit_slice(smem, smem + 2048, uw[0], 0); commit_slice(smem, smem + 2048, uw[0], 1);
+    commit_slice(smem, smem + 2048, uw, 0); commit_slice(smem, smem + 2048, uw, 1);
     write_raw(raw1, rq[1]);
     load_raw(rq[0]); load_raw(rq[1]);
-    load_u(uw[0], 0); load_u(uw[0], 1);
+    load_u(uw, 0); load_u(uw, 1);
     __syncthreads();
+    first_operands();
+    if (!(ABL & 4)) read_patch(raw1);
 
-    // C/D layout: col = lane & 31 (tile), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (k).  A wave holds rows i = 2 ph, 2 ph + 1
-    // of the 4 x 4 products m; y = At m A: the ph = 1 waves park their share in the parity-1 operand buffers (consumed by the
-    // step that just ended, next written by the commits of the step after next... of the NEXT step: hence the second barrier)
+    // ---- output transform y = At (m A) of a pair.  C/D layout: col = lane & 31 (tile), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (k).
+    // A wave holds rows 2 ph, 2 ph + 1 of the 4 x 4 products m and forms z = m A of both (2 values per row).  y row 0 = z0 + z1 + z2 is
+    // finished and stored by the ph = 0 wave, y row 1 = z1 - z2 - z3 by its ph = 1 partner on the same SIMD: each hands the other ONE z
+    // row (32 floats per lane) through the parity-1 operand buffers (consumed by the step that just ended; next written by the commits of
+    // the NEXT step, hence the second barrier).  Nothing here touches the vector memory counter: the bias comes by scalar loads (a k
+    // index is wave-uniform up to the lane half) and the stores are buffer stores whose range check drops the channels past K -- a
+    // `bias[k]` vector load per register made every one of the 16 store groups wait for the previous group's stores AND for the prefetched
+    // loads of the next pair (vmcnt counts them all, in order): 5-7 us per pair, now ~2.
     float* const xch = reinterpret_cast<float*>(smem + 4096) + (wave & 3) * 4096 + lane;
+    const int ph_u = wave_u >> 2, wm_u = (wave_u >> 1) & 1;
+    const int tl = wn * 32 + l31;                    // tile within the strip: row tl / TW of its R tile rows
+    const unsigned out_lane = (static_cast<unsigned>(wm * 32 + 4 * half) * static_cast<unsigned>(HW) +
+                               static_cast<unsigned>((2 * (tl / g.TW) + ph) * g.W + 2 * (tl % g.TW))) * 4u;
+    const float sgn = ph ? -1.f : 1.f;
+    // the bias of a pair's output channels: lane j of every wave holds bias[k tile's first channel + 32 wm + (j & 31)], loaded a whole
+    // pair ahead; the epilogue fetches the value of a register's channel from lane jr + 4 half by ds_bpermute, so it neither issues a
+    // vector load nor waits on the vector memory counter
+    auto load_bias = [&](int pair) {
+        float v = 0.f;
+        if (bias != nullptr && pair < pair_end && (!SPLIT || (pair & (CS - 1)) == 0)) {
+            const int pk = SPLIT ? pair >> cs_shift : pair;
+            const int k = (pk % g.KT) * 64 + wm * 32 + l31;
+            if (k < g.K) v = bias[k];
+        }
+        return v;
+    };
+    float bvec = load_bias(pair_begin);
+    const int bsel = 16 * half;
     for (int pair = pair_begin; pair < pair_end; ++pair) {
         for (int ch = 0; ch < CHp; ch += 2) {
             step(std::integral_constant<int, 0>());
             step(std::integral_constant<int, 1>());
         }
-        const int pk = SPLIT ? pair >> cs_shift : pair, csplit = SPLIT ? pair & (CS - 1) : 0;
+        const int pk = SPLIT ? pair >> cs_shift : pair;
         const int tt = pk / g.KT, kt = pk - tt * g.KT;
-        if (ph == 1) {
+        if (ABL & 32) continue;          // timing experiment: no epilogue at all (the accumulators run on)
+        if (ph_u) {                      // z row 2 for the partner's y row 0
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 2
-                const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 3
-                xch[(r * 4 + 0) * 64] = za0;             // y0 += z2, y1 += -z2 - z3
-                xch[(r * 4 + 1) * 64] = za1;
-                xch[(r * 4 + 2) * 64] = -za0 - zb0;
-                xch[(r * 4 + 3) * 64] = -za1 - zb1;
+                xch[(r * 4 + 0) * 64] = acc[0][r] + acc[1][r] + acc[2][r];
+                xch[(r * 4 + 1) * 64] = acc[1][r] - acc[2][r] - acc[3][r];
+            }
+        } else {                         // z row 1 for the partner's y row 1
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                xch[(r * 4 + 2) * 64] = acc[4][r] + acc[5][r] + acc[6][r];
+                xch[(r * 4 + 3) * 64] = acc[5][r] - acc[6][r] - acc[7][r];
             }
         }
         __syncthreads();
-        const int tg = tt * kWinoTiles + wn * 32 + l31;
-        if (ph == 0 && kt * 64 + wm * 32 < g.K && tg < g.T) {
-            const int b = tg / (g.TH * g.TW);
-            const int rem = tg - b * (g.TH * g.TW);
-            const int ty = rem / g.TW, txo = rem - ty * g.TW;
-            float* ob = out + (static_cast<size_t>(b) * g.Kout) * HW + static_cast<size_t>(2 * ty) * g.W + 2 * txo;
+        const int kq = kt * 64 + wm_u * 32;          // first output channel of this wave's quarter
+        if (kq < g.K) {
+            const int b_u = tt / strips_per_img;     // the 64 tiles of a strip are whole tile rows of ONE image
+            const int ty0 = (tt - b_u * strips_per_img) * g.R;
+            const int krem = g.K - kt * 64;
+            float* const obase = out + (static_cast<size_t>(b_u) * g.Kout + static_cast<size_t>(kt) * 64) * HW;
+            const rsrc_t ro = make_rsrc(obase, static_cast<unsigned>(krem < 64 ? krem : 64) * static_cast<unsigned>(HW) * 4u);
+            unsigned voff = out_lane + static_cast<unsigned>(2 * ty0 * g.W) * 4u;
+            asm volatile("" : "+v"(voff));           // (keeps the 16 channel offsets below as scalar addends: hoisted as 16 registers they spill)
+            const float* const rcv = xch + (ph_u ? 2 * 64 : 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = kt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (k >= g.K) continue;
-                const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // row 0
-                const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // row 1
-                const float bv = (bias && csplit == 0) ? bias[k] : 0.f;
-                float y[4] = {za0 + zb0, za1 + zb1, zb0, zb1};   // y0 = z0 + z1 (+ z2), y1 = z1 (- z2 - z3)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float t = y[v] + xch[(r * 4 + v) * 64] + bv;
-                    if (g.act == 1) t = t > 0.f ? t : t * g.slope;
-                    y[v] = t;
+                const int jr = (r & 3) + 8 * (r >> 2);                   // k = kq + jr + 4 half
+                const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];      // z of row 2 ph
+                const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];      // z of row 2 ph + 1
+                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 4 * jr, __builtin_bit_cast(int, bvec)));
+                // ph 0: (z0 + z1) + z2;  ph 1: z1 - (z2 + z3)
+                float y0 = __builtin_fmaf(sgn, za0 + zb0, rcv[(r * 4 + 0) * 64]) + bv;
+                float y1 = __builtin_fmaf(sgn, za1 + zb1, rcv[(r * 4 + 1) * 64]) + bv;
+                if (g.act == 1) {
+                    y0 = y0 > 0.f ? y0 : y0 * g.slope;
+                    y1 = y1 > 0.f ? y1 : y1 * g.slope;
                 }
-                float* o = ob + static_cast<size_t>(k) * HW;         // W and H are even here: whole 2 x 2 tiles, 8-byte aligned pairs
+                const unsigned vo = voff + static_cast<unsigned>(jr) * static_cast<unsigned>(HW) * 4u;
+                if (ABL & 16) {          // timing experiment: the epilogue without its global stores (one lane in a million keeps it alive)
+                    if (y0 + y1 != 12345.678f) continue;
+                }
                 if (SPLIT) {
                     // a split of the reduction: the output transform is linear, the splits' shares meet in the zero-filled output
                     // (the host only splits a call without an activation; the bias rides with split 0)
-                    atomic_add(o, y[0]); atomic_add(o + 1, y[1]);
-                    atomic_add(o + g.W, y[2]); atomic_add(o + g.W + 1, y[3]);
+                    if (kq + jr + 4 * half < g.K) {
+                        float* o = obase + (vo >> 2);
+                        atomic_add(o, y0); atomic_add(o + 1, y1);
+                    }
                     continue;
                 }
-                *reinterpret_cast<float2*>(o) = make_float2(y[0], y[1]);
-                *reinterpret_cast<float2*>(o + g.W) = make_float2(y[2], y[3]);
+                const u32x2 yy = {__builtin_bit_cast(unsigned, y0), __builtin_bit_cast(unsigned, y1)};
+                __builtin_amdgcn_raw_buffer_store_b64(yy, ro, vo, 0, 0);          // W is even: 8-byte aligned pairs
             }
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+        bvec = load_bias(pair + 1);
         __syncthreads();                 // the exchange is read before the next step's commits overwrite it
+    }
+    if (ABL & 32) {                      // keeps the accumulators of the epilogue-free timing variant alive
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[p][r];
+        if (t == 12345.678f) out[threadIdx.x] = t;
     }
 }
 
@@ -886,6 +988,18 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
                 case 2: kern = winograd_conv_raw_kernel<2>; break;
                 case 3: kern = winograd_conv_raw_kernel<3>; break;
                 case 7: kern = winograd_conv_raw_kernel<7>; break;
+                case 16: kern = winograd_conv_raw_kernel<16>; break;
+                case 32: kern = winograd_conv_raw_kernel<32>; break;
+                case 35: kern = winograd_conv_raw_kernel<35>; break;
+                case 36: kern = winograd_conv_raw_kernel<36>; break;
+                case 39: kern = winograd_conv_raw_kernel<39>; break;
+                case 40: kern = winograd_conv_raw_kernel<40>; break;
+                case 47: kern = winograd_conv_raw_kernel<47>; break;
+                case 99: kern = winograd_conv_raw_kernel<35 + 64>; break;
+                case 163: kern = winograd_conv_raw_kernel<35 + 128>; break;
+                case 291: kern = winograd_conv_raw_kernel<35 + 256>; break;
+                case 547: kern = winograd_conv_raw_kernel<35 + 512>; break;
+                case 227: kern = winograd_conv_raw_kernel<35 + 64 + 128>; break;
                 default: break;
             }
             if (split_n > 1) kern = winograd_conv_raw_kernel<0, true>;
