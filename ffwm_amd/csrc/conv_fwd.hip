@@ -87,6 +87,14 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
         k_tile = blockIdx.x / g.n_tiles;
     }
     const int n0 = n_tile * TN, k0 = k_tile * TM;
+    // The bias of this wave's TM / 2 output channels, one per lane, loaded HERE: the epilogue fetches a register's channel from lane
+    // a * 32 + jr + 4 half by ds_bpermute.  (A `bias[k]` load per register in the epilogue made each of its 16-64 stores wait for that
+    // load's round trip AND for the previous store's acknowledgement -- vmcnt counts both, in order.)
+    float bvec = 0.f;
+    if (bias != nullptr && g.splitk == 1) {
+        const int kb_ = k0 + (static_cast<int>(threadIdx.x) >> 7) * (TM / 2) + (static_cast<int>(threadIdx.x) & 63);
+        if ((static_cast<int>(threadIdx.x) & 63) < TM / 2 && kb_ < g.K) bvec = bias[kb_];
+    }
     int zz = blockIdx.z;
     const int split = zz % g.splitk;
     zz /= g.splitk;
@@ -245,7 +253,7 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
                 if (g.splitk > 1) {
                     atomic_add(ob + static_cast<size_t>(k) * oplane, v);
                 } else {
-                    if (bias) v += bias[k];
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * half + 4 * (a * 32 + (r & 3) + 8 * (r >> 2)), __builtin_bit_cast(int, bvec)));
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                     else if (g.act == 2) v = tanhf(v);
                     ob[static_cast<size_t>(k) * oplane] = v;
