@@ -92,32 +92,45 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
     }
     struct Regs {
         float gy[4];            // dY tile [row][col]
-        float xp[16];           // input patch rows 2ty - 1 .. 2ty + 2, cols 2tx - 1 .. 2tx + 2
+        float xp[16];           // input patch rows 2ty - 1 .. 2ty + 2: [4 i + 1], [4 i + 2] = cols 2tx, 2tx + 1; [4 i] = the gathered outer pixel
     };
     float bsum = 0.f;           // bias gradient: this thread's share of sum(dY[k0 + chn]) (the ct == 0 workgroups keep it)
+    // Round 5 (late): the addresses of a chunk's loads are a PER-THREAD constant (channel, tile t8 of the chunk) + a WAVE-UNIFORM offset
+    // (image, tile row, chunk of the row) that rides in the loads' scalar offset; what is left per chunk on the vector ALU is one select
+    // per load (a row outside the image / a chunk past the slice -> the range check's zeros).  Before, every thread worked out every
+    // address of every chunk (~60 VALU + ~80 SALU instructions per wave and chunk next to 32 MFMAs and the transforms): the step was
+    // bound by instruction issue, not by the matrix pipe.  The two outer-column gathers of a row are ONE load (tile 0 of the chunk takes
+    // the pixel on its left, tile 7 the one on its right, the others nothing): 10 loads per thread and chunk instead of 14.
+    const unsigned gv = k_ok ? (gk_base + static_cast<unsigned>(2 * t8)) * 4u : kWwOob;
+    const unsigned xv = c_ok ? (xc_base + static_cast<unsigned>(2 * t8)) * 4u : kWwOob;
+    // (through a resource that starts one float BEFORE the tensor: the range check adds the vector and the scalar offset in more than 32
+    // bits, so "- 4" as a wrapped vector offset is out of range for channel 0 -- measured, tools/ubench/buf_soffset.hip)
+    const rsrc_t rxe = make_rsrc(reinterpret_cast<const char*>(X) - 4, g.x_bytes + 4u);
+    const unsigned xe = (c_ok && (t8 == 0 || t8 == 7)) ? (xc_base + static_cast<unsigned>(2 * t8)) * 4u + (t8 == 0 ? 0u : 12u) : kWwOob;
     auto issue = [&](Regs& R) {              // loads of the cursor's chunk (zeros past the slice's end), then the cursor moves on
         const bool live = cur < ch_end;
-        const int ty = cty, tx = ctxc * 8 + t8, b = cb;
-        const unsigned go = (live && k_ok) ? (static_cast<unsigned>(b) * g.K * HW + gk_base + static_cast<unsigned>(2 * ty * g.W + 2 * tx)) * 4u : kWwOob;
-        const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(rg, go, 0, 0);
-        const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rg, go != kWwOob ? go + static_cast<unsigned>(g.W) * 4u : kWwOob, 0, 0);
+        const int ty = cty;
+        const unsigned col = static_cast<unsigned>(16 * ctxc);
+        const unsigned sg = (static_cast<unsigned>(cb) * g.K * HW + static_cast<unsigned>(2 * ty * g.W) + col) * 4u;
+        const unsigned go = live ? gv : kWwOob;
+        const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(rg, go, sg, 0);
+        const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rg, go, sg + static_cast<unsigned>(g.W) * 4u, 0);
         R.gy[0] = __uint_as_float(r0.x); R.gy[1] = __uint_as_float(r0.y);
         R.gy[2] = __uint_as_float(r1.x); R.gy[3] = __uint_as_float(r1.y);
-        const bool lcol = tx > 0, rcol = 2 * tx + 2 < g.W;
-        const unsigned xb = static_cast<unsigned>(b) * g.C * HW + xc_base;
+        // the outer column exists on the left of every chunk but a row's first, on the right of every chunk but its last (per lane: t8)
+        const bool edge_ok = t8 == 0 ? ctxc > 0 : ctxc + 1 < g.TWC;
+        const unsigned sx = (static_cast<unsigned>(cb) * g.C * HW + col) * 4u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int iy = 2 * ty - 1 + i;
-            const bool rok = live && c_ok && iy >= 0 && iy < g.H;
-            const unsigned ro = rok ? (xb + static_cast<unsigned>(iy * g.W + 2 * tx)) * 4u : kWwOob;
-            const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rx, ro, 0, 0);
-            // Round 5: the patch's outer columns are the NEIGHBOURING tiles' inner ones (lanes t8 - 1 / t8 + 1 of the same channel and
-            // row): commit() takes them by DPP row shifts.  Only the chunk's first / last tile still gathers its outer column -- 4 + 8
-            // sparse loads per thread and chunk instead of 12, and no pixel of a chunk fetched twice.
-            R.xp[i * 4 + 0] = buf_ld<float>(rx, (rok && lcol && t8 == 0) ? ro - 4u : kWwOob);
+            const bool rok = live && iy >= 0 && iy < g.H;                      // wave-uniform
+            const unsigned srow = sx + static_cast<unsigned>((rok ? iy : 0) * g.W) * 4u;
+            const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rx, rok ? xv : kWwOob, srow, 0);
+            // the patch's outer columns are the NEIGHBOURING tiles' inner ones (lanes t8 - 1 / t8 + 1 of the same channel and row):
+            // commit() takes them by DPP row shifts; only the chunk's first / last tile gathers one
+            R.xp[i * 4 + 0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rxe, (rok && edge_ok) ? xe : kWwOob, srow, 0));
             R.xp[i * 4 + 1] = __uint_as_float(m.x);
             R.xp[i * 4 + 2] = __uint_as_float(m.y);
-            R.xp[i * 4 + 3] = buf_ld<float>(rx, (rok && rcol && t8 == 7) ? ro + 8u : kWwOob);
         }
         ++cur;
         const bool wrap_x = ctxc + 1 == g.TWC;
@@ -149,10 +162,10 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
         for (int i = 0; i < 4; ++i) {
             const float from_l = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(R.xp[i * 4 + 2]), 0x111, 0xf, 0xf, true));
             const float from_r = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(R.xp[i * 4 + 1]), 0x101, 0xf, 0xf, true));
-            xq[i * 4 + 0] = t8 == 0 ? R.xp[i * 4 + 0] : from_l;
+            xq[i * 4 + 0] = t8 == 0 ? R.xp[i * 4 + 0] : from_l;          // (xp[4 i]: the gathered outer pixel of tiles 0 and 7)
             xq[i * 4 + 1] = R.xp[i * 4 + 1];
             xq[i * 4 + 2] = R.xp[i * 4 + 2];
-            xq[i * 4 + 3] = t8 == 7 ? R.xp[i * 4 + 3] : from_r;
+            xq[i * 4 + 3] = t8 == 7 ? R.xp[i * 4 + 0] : from_r;
         }
         // V = Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
 #pragma unroll
