@@ -107,24 +107,27 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
     // bits, so "- 4" as a wrapped vector offset is out of range for channel 0 -- measured, tools/ubench/buf_soffset.hip)
     const rsrc_t rxe = make_rsrc(reinterpret_cast<const char*>(X) - 4, g.x_bytes + 4u);
     const unsigned xe = (c_ok && (t8 == 0 || t8 == 7)) ? (xc_base + static_cast<unsigned>(2 * t8)) * 4u + (t8 == 0 ? 0u : 12u) : kWwOob;
+    // the scalar offsets run along with the cursor (bytes, modulo 2^32): dY row 2 ty and input row 2 ty - 1 of the chunk's first pixel
+    // column.  A chunk to the right is + 64 bytes; a tile row down + 4 W more (2 W pixels on, W back); the next image (K - 1) / (C - 1)
+    // planes more -- three scalar adds per chunk instead of the products of (image, tile row, chunk)
+    unsigned sg = (static_cast<unsigned>(cb) * g.K * HW + static_cast<unsigned>(2 * cty * g.W) + static_cast<unsigned>(16 * ctxc)) * 4u;
+    unsigned sxr = (static_cast<unsigned>(cb) * g.C * HW + static_cast<unsigned>((2 * cty - 1) * g.W) + static_cast<unsigned>(16 * ctxc)) * 4u;
+    const unsigned w4 = static_cast<unsigned>(g.W) * 4u;
+    const unsigned img_g = static_cast<unsigned>(g.K - 1) * static_cast<unsigned>(HW) * 4u, img_x = static_cast<unsigned>(g.C - 1) * static_cast<unsigned>(HW) * 4u;
     auto issue = [&](Regs& R) {              // loads of the cursor's chunk (zeros past the slice's end), then the cursor moves on
         const bool live = cur < ch_end;
-        const int ty = cty;
-        const unsigned col = static_cast<unsigned>(16 * ctxc);
-        const unsigned sg = (static_cast<unsigned>(cb) * g.K * HW + static_cast<unsigned>(2 * ty * g.W) + col) * 4u;
         const unsigned go = live ? gv : kWwOob;
         const u32x2 r0 = __builtin_amdgcn_raw_buffer_load_b64(rg, go, sg, 0);
-        const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rg, go, sg + static_cast<unsigned>(g.W) * 4u, 0);
+        const u32x2 r1 = __builtin_amdgcn_raw_buffer_load_b64(rg, go, sg + w4, 0);
         R.gy[0] = __uint_as_float(r0.x); R.gy[1] = __uint_as_float(r0.y);
         R.gy[2] = __uint_as_float(r1.x); R.gy[3] = __uint_as_float(r1.y);
         // the outer column exists on the left of every chunk but a row's first, on the right of every chunk but its last (per lane: t8)
         const bool edge_ok = t8 == 0 ? ctxc > 0 : ctxc + 1 < g.TWC;
-        const unsigned sx = (static_cast<unsigned>(cb) * g.C * HW + col) * 4u;
+        const bool top = cty > 0, bottom = cty + 1 < g.TH;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int iy = 2 * ty - 1 + i;
-            const bool rok = live && iy >= 0 && iy < g.H;                      // wave-uniform
-            const unsigned srow = sx + static_cast<unsigned>((rok ? iy : 0) * g.W) * 4u;
+            const bool rok = live && (i == 0 ? top : i == 3 ? bottom : true);  // wave-uniform: input rows 2 ty - 1 .. 2 ty + 2 (H = 2 TH)
+            const unsigned srow = sxr + static_cast<unsigned>(i) * w4;
             const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rx, rok ? xv : kWwOob, srow, 0);
             // the patch's outer columns are the NEIGHBOURING tiles' inner ones (lanes t8 - 1 / t8 + 1 of the same channel and row):
             // commit() takes them by DPP row shifts; only the chunk's first / last tile gathers one
@@ -138,6 +141,8 @@ conv3x3_wgrad_wino_kernel(const float* __restrict__ X, const float* __restrict__
         const bool wrap_y = wrap_x && cty + 1 == g.TH;
         cty = wrap_x ? (wrap_y ? 0 : cty + 1) : cty;
         cb += wrap_y ? 1 : 0;
+        sg += 64u + (wrap_x ? w4 : 0u) + (wrap_y ? img_g : 0u);
+        sxr += 64u + (wrap_x ? w4 : 0u) + (wrap_y ? img_x : 0u);
     };
     auto commit = [&](f32x4* buf, const Regs& R) {
         float* A = reinterpret_cast<float*>(buf) + wr_off;
