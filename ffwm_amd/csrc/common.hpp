@@ -152,6 +152,27 @@ __device__ __forceinline__ void lds_add(double* cell, T v) {
 }
 
 // ---- buffer addressing -------------------------------------------------------------------
+// Division of a 32-bit unsigned by a run-time divisor that is FIXED for a launch (a plane size, a row length): the host works out a
+// multiplier and two shifts (Granlund / Montgomery round-up method, exact for every 32-bit dividend and divisor >= 1), the device
+// pays a v_mul_hi and four cheap instructions instead of the ~25 of the compiler's generic sequence.
+struct FastDiv {
+    unsigned m, s1, s2, d;
+};
+inline FastDiv make_fast_div(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                     // ceil(log2 d)
+    f.m = static_cast<unsigned>(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.s1 = l < 1 ? l : 1;
+    f.s2 = l < 1 ? 0 : l - 1;
+    return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) {
+    const unsigned t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 // A tensor plane is addressed as (wave-uniform 128-bit buffer resource in SGPRs) + (32-bit
 // per-lane BYTE offset in one VGPR): `buffer_load_dword v, v_off, s[rsrc], 0 offen`.  This is the
 // CDNA way to do "uniform base + per-lane gather": no 64-bit VGPR address per tap, and the

@@ -164,6 +164,7 @@ struct Wg2Geo {
     int chunks;              // chunks per z-slice
     int nz;
     unsigned a_bytes, x_bytes;
+    FastDiv divP, divWo;     // by P (pixels of an output plane) and by Wo
 };
 
 constexpr int kW2PC = 32;        // pixels per chunk
@@ -200,7 +201,7 @@ conv_wgrad_tile_kernel(const float* __restrict__ a, const float* __restrict__ x,
     // ---- X: pixel kk of the chunk, columns (t >> 5) + 8 i
     const int kk = threadIdx.x & 31, xcol0 = threadIdx.x >> 5;
     int coloff[NXB];                     // c * HW + r * W + s of column n0 + j (elements)
-    unsigned colsh[NXB];                 // r | s << 8: shifts into the per-pixel row / column validity masks (31: no such column)
+    unsigned colsh[NXB];                 // 8 r + s: the column's bit in the per-pixel tap mask (31: no such column)
 #pragma unroll
     for (int i = 0; i < NXB; ++i) {
         const int n = n0 + xcol0 + 8 * i;
@@ -209,7 +210,7 @@ conv_wgrad_tile_kernel(const float* __restrict__ a, const float* __restrict__ x,
         const int c = nc / RS, rs = nc - c * RS;
         const int r = rs / S, sx = rs - r * S;
         coloff[i] = c * g.HW + r * g.W + sx;
-        colsh[i] = cin ? static_cast<unsigned>(r | (sx << 8)) : 31u;
+        colsh[i] = cin ? static_cast<unsigned>(8 * r + sx) : 31u;
     }
 
     const int ch_begin = blockIdx.z * g.chunks;
@@ -225,32 +226,39 @@ conv_wgrad_tile_kernel(const float* __restrict__ a, const float* __restrict__ x,
     // The addresses of a chunk are formed in two steps so that the loads can be issued in slices between the MFMA groups of the
     // previous chunk: prep() decodes the chunk's pixels (two divisions per thread), issue_a / issue_x turn them into loads.
     // Everything is integer arithmetic on masks -- no branches (an `ok ? offset : OOB` per element compiled to an exec-mask
-    // branch per load, which serialised the whole fetch in front of the MFMAs).
+    // branch per load, which serialised the whole fetch in front of the MFMAs).  Round 5 (late): the step was bound by instruction
+    // ISSUE (a 64 x 64 tile carried ~8 vector instructions of address arithmetic per MFMA and wave: two generic divisions per
+    // chunk, two shifts + and + negate + and + or + multiply per gathered element): the divisions are multiply-high by host-made
+    // constants, and a pixel's nine / sixteen taps share ONE inverted validity mask from which an element takes its bit
+    // sign-extended (v_bfe_i32: 0 or all-ones) and ORs it onto its byte offset -- all-ones is out of range, the load returns 0
+    // (tools/ubench/buf_soffset.hip, case G).  Three instructions per element.
     unsigned a_base, a_pin;              // A: element offset of the quad in row 0; all-ones when the quad exists
     int x_base;                          // X: element offset of tap (0, 0) of this lane's pixel
-    unsigned x_rmask, x_smask;
+    int x_inv;                           // bit 8 r + s CLEAR: tap (r, s) of this lane's pixel lies inside the image (bit 31 always set)
     auto prep = [&](int ch) {
         {
             const unsigned gq = static_cast<unsigned>(ch) * kW2PC + q8 * 4;
-            const unsigned b = gq / static_cast<unsigned>(g.P);
+            const unsigned b = fast_div(gq, g.divP);
             const unsigned p = gq - b * static_cast<unsigned>(g.P);
             a_pin = 0u - static_cast<unsigned>(gq < static_cast<unsigned>(g.total_px));
             a_base = b * static_cast<unsigned>(g.K) * static_cast<unsigned>(g.P) + p;
         }
         {
             const unsigned gq = static_cast<unsigned>(ch) * kW2PC + kk;
-            const unsigned b = gq / static_cast<unsigned>(g.P);
+            const unsigned b = fast_div(gq, g.divP);
             const unsigned p = gq - b * static_cast<unsigned>(g.P);
             const unsigned pin = static_cast<unsigned>(gq < static_cast<unsigned>(g.total_px));
-            const int oy = static_cast<int>(p / static_cast<unsigned>(g.Wo)), ox = static_cast<int>(p) - oy * g.Wo;
+            const int oy = static_cast<int>(fast_div(p, g.divWo)), ox = static_cast<int>(p) - oy * g.Wo;
             const int iy0 = oy * g.stride - g.pad, ix0 = ox * g.stride - g.pad;
             unsigned rmask = 0, smask = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) rmask |= static_cast<unsigned>(static_cast<unsigned>(iy0 + r) < static_cast<unsigned>(g.H)) << r;
 #pragma unroll
             for (int q = 0; q < S; ++q) smask |= static_cast<unsigned>(static_cast<unsigned>(ix0 + q) < static_cast<unsigned>(g.W)) << q;
-            x_rmask = rmask & (0u - pin);
-            x_smask = smask;
+            unsigned taps = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) taps |= (smask & (0u - ((rmask >> r) & 1u))) << (8 * r);
+            x_inv = static_cast<int>(~(taps & (0u - pin)));
             x_base = static_cast<int>(b) * g.C * g.HW + iy0 * g.W + ix0;
         }
     };
@@ -261,10 +269,8 @@ conv_wgrad_tile_kernel(const float* __restrict__ a, const float* __restrict__ x,
         va[i][0] = __uint_as_float(v.x); va[i][1] = __uint_as_float(v.y); va[i][2] = __uint_as_float(v.z); va[i][3] = __uint_as_float(v.w);
     };
     auto issue_x = [&](int i) {          // X: this lane's pixel, column i of its NXB fixed (c, r, s) columns
-        const unsigned sh = colsh[i];
-        const unsigned live = 0u - ((x_rmask >> (sh & 31u)) & (x_smask >> (sh >> 8)) & 1u);
-        const unsigned off = ((static_cast<unsigned>(x_base + coloff[i]) * 4u) & live) | (kOobOff & ~live);
-        vx[i] = buf_ld<float>(rx_, off);
+        const unsigned dead = static_cast<unsigned>(__builtin_amdgcn_sbfe(x_inv, colsh[i], 1u));      // 0, or all-ones = out of range
+        vx[i] = buf_ld<float>(rx_, (static_cast<unsigned>(x_base + coloff[i]) << 2) | dead);
     };
     auto fetch = [&](int ch) {
         prep(ch);
@@ -448,6 +454,8 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     g.chunks_total = (g.total_px + kW2PC - 1) / kW2PC;
     g.a_bytes = static_cast<unsigned>(B * K * Ho * Wo * 4);
     g.x_bytes = static_cast<unsigned>(B * C * H * W * 4);
+    g.divP = make_fast_div(static_cast<unsigned>(g.P));
+    g.divWo = make_fast_div(static_cast<unsigned>(g.Wo));
     // tile shape (64 or 128 rows x 64 or 128 columns of dW) and pixel slices: the candidate with the smallest estimated time, in
     // units of one 32 x 32 x 32-pixel MFMA block per wave (1024 cycles).  A workgroup pays ~6 units of prologue / epilogue, a
     // sliced launch pays the atomic flush of its tile, and two workgroups per CU are resident (512 per round): a launch of 567

@@ -14,6 +14,8 @@ __global__ void k(const float* p, unsigned bytes, float* out) {
     out[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 0xFFFFFFF0u, 0, 0));
     out[4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, bytes - 4u, 256, 0));
     out[5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, bytes - 260u, 256, 0));
+    out[6] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 0xFFFFFFFFu, 0, 0));
+    out[7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 0xFFFFFFFFu, 64, 0));
 }
 int main() {
     const int n = 4096;
@@ -24,13 +26,14 @@ int main() {
     hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice);
     hipMemset(o, 0, 64);
     k<<<1, 1>>>(d, 2048 * 4, o);          // the resource covers the first half of the allocation
-    float r[6];
-    hipMemcpy(r, o, 24, hipMemcpyDeviceToHost);
+    float r[8];
+    hipMemcpy(r, o, 32, hipMemcpyDeviceToHost);
     printf("A sentinel + soffset 256        : %g (0 = dropped; 1060 = wrapped to byte 240)\n", r[0]);
     printf("B voffset 16 + soffset = records: %g (0 = the check sees soffset; %g = it does not)\n", r[1], h[2048 + 4]);
     printf("C voffset 16 + soffset 256      : %g (expect %g)\n", r[2], h[(16 + 256) / 4]);
     printf("D sentinel, soffset 0           : %g (expect 0)\n", r[3]);
     printf("E voffset records-4 + soffset 256: %g (0 = the check sees soffset; %g = it does not)\n", r[4], h[2047 + 64]);
     printf("F voffset records-260 + soffset 256: %g (expect %g)\n", r[5], h[2047]);
+    printf("G unaligned sentinel 0xFFFFFFFF, soffset 0 / 64: %g %g (expect 0 0)\n", r[6], r[7]);
     return 0;
 }
