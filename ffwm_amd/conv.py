@@ -121,18 +121,67 @@ def _tiled_wgrad_wins(rows, gathered, kernel):
     return True
 
 
+class _GradArena:
+    """Weight-gradient staging of ONE train step: every hand-written weight-gradient kernel of the step adds into zeroed memory (atomics
+    of pixel slices / k tiles), and until round 5 each call cleared its own buffer -- ~270 fill launches per step (torch.zeros here, the
+    library's zero-fill in the tiled kernel), 4-8 us each for a few hundred KiB.  Inside `begin()` .. `end()` the buffers are consecutive
+    slices of one tensor that ONE launch clears at the start of the step; the slices are handed to autograd as the layers' gradients (the
+    trainers' parameters own views of flat gradient buffers, so AccumulateGrad adds -- it never keeps a slice).  The first step measures
+    the demand with the old per-call fills; a step that asks for more than the arena holds falls back per call, and the arena grows
+    behind it (never while a stream is capturing; retired buffers stay alive: a captured graph may still clear and use them)."""
+
+    def __init__(self):
+        self.buf, self.off, self.need, self.active, self.retired = None, 0, 0, False, []
+
+    def begin(self, device):
+        self.off = self.need = 0
+        if self.buf is not None and self.buf.device != device:
+            self.retired.append(self.buf)
+            self.buf = None
+        if self.buf is not None:
+            ops.zero_fill(self.buf)
+        self.active = True
+        self.device = device
+
+    def take(self, n, like):
+        if not self.active or like.device != self.device or like.dtype != torch.float32:
+            return None
+        n_al = (n + 63) & ~63
+        self.need += n_al
+        if self.buf is None or self.off + n_al > self.buf.numel():
+            return None
+        s = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return s
+
+    def end(self):
+        self.active = False
+        if (self.buf is None or self.need > self.buf.numel()) and self.need > 0 and not torch.cuda.is_current_stream_capturing():
+            if self.buf is not None:
+                self.retired.append(self.buf)
+            self.buf = torch.zeros(self.need + self.need // 8, device=self.device, dtype=torch.float32)
+
+
+GRAD_ARENA = _GradArena()
+
+
 def conv_weight_grad(x, go, weight, stride, pad, need_b):
     """-> (grad_weight, grad_bias or None) of Conv2d(C, K, k, stride, pad) from its input and grad_output."""
     k = weight.shape[2]
     if k == 3 and stride == 1 and pad == 1 and wgrad_route_ok(x, weight):
-        # grad_weight and grad_bias (a row sum of the operand the kernel streams anyway) as slices of ONE zero-filled buffer: one fill
+        # grad_weight and grad_bias (a row sum of the operand the kernel streams anyway) as slices of ONE zero-filled buffer: one fill,
+        # or none inside a trainer's step (GRAD_ARENA)
         n = weight.numel()
-        buf = torch.zeros(n + (weight.shape[0] if need_b else 0), device=go.device, dtype=go.dtype)
+        total = n + (weight.shape[0] if need_b else 0)
+        buf = GRAD_ARENA.take(total, go)
+        if buf is None:
+            buf = torch.zeros(total, device=go.device, dtype=go.dtype)
         gw, gb = buf[:n].view_as(weight), (buf[n:] if need_b else None)
         ops.conv3x3_wgrad(x, go, gw, gb)
         return gw, gb
     if _tiled_wgrad_wins(go, x, k) and weight.shape[2] == weight.shape[3]:
-        return ops.conv2d_wgrad_tiled(go, x, k, stride, pad, want_bias=bool(need_b))
+        return ops.conv2d_wgrad_tiled(go, x, k, stride, pad, want_bias=bool(need_b),
+                                      zeroed=GRAD_ARENA.take(weight.numel() + (weight.shape[0] if need_b else 0), go))
     _, gw, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[0]] if need_b else None, [stride, stride], [pad, pad],
                                                     [1, 1], False, [0, 0], 1, [False, True, bool(need_b)])
     return gw, gb
@@ -142,7 +191,7 @@ def conv_transpose_weight_grad(x, go, weight, need_b):
     """-> (grad_weight [Ci, Co, 4, 4], grad_bias or None) of ConvTranspose2d(Ci, Co, 4, 2, 1): the same pixel sum as a Conv2d weight
     gradient with the two tensors' roles swapped."""
     if _tiled_wgrad_wins(x, go, 4):
-        gw, _ = ops.conv2d_wgrad_tiled(x, go, 4, 2, 1)
+        gw, _ = ops.conv2d_wgrad_tiled(x, go, 4, 2, 1, zeroed=GRAD_ARENA.take(weight.numel(), go))
         return gw, (_bias_grad(go) if need_b else None)
     _, gw, gb = torch.ops.aten.convolution_backward(go, x, weight, [weight.shape[1]] if need_b else None, [2, 2], [1, 1], [1, 1], True,
                                                     [0, 0], 1, [False, True, bool(need_b)])

@@ -58,6 +58,7 @@ struct Options {
     int be_bwd_fixed = 0;        // block_extractor / block attention shared-cell backward: 0 = 32-bit fixed-point accumulator cells (round 5), 2 = double cells
     int zero_fill_memset = 0;    // 1 = zero_fill() calls hipMemsetAsync as rounds 1-4 did (diagnosis: reproduces the corrupted memset nodes)
     int conv_wgrad_unsliced = 0; // conv_bwd.hip tiled weight gradient: 1 = never cut the pixel range into slices (no zero-fill, no atomics: a diagnosis switch)
+    int conv_wgrad_prezeroed = 0; // conv_bwd.hip tiled weight gradient: 1 = the caller hands over ZEROED grad_weight / grad_bias (a slice of the trainer's gradient arena, cleared by one launch per step): a sliced launch skips its own zero-fill
     int ablate = 0;           // bench-only ablation bits (1 = skip source fetch, 2 = skip stores)
 };
 Options& options();

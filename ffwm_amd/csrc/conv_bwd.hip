@@ -486,7 +486,7 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* dw = static_cast<float*>(grad_weight);
     float* gb = static_cast<float*>(grad_bias);
-    if (g.nz > 1) {
+    if (g.nz > 1 && !options().conv_wgrad_prezeroed) {
         const size_t nw = static_cast<size_t>(g.K) * g.N;
         const bool joined = gb == dw + nw;          // one buffer (ops.conv2d_wgrad_tiled allocates them together): one memset
         if (zero_fill(dw, sizeof(float) * (nw + (joined ? static_cast<size_t>(g.K) : 0)), st)) return FFWM_ERR_LAUNCH;

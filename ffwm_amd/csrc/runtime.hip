@@ -308,6 +308,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "conv_wino_raw")) slot = &o.conv_wino_raw;
     else if (!strcmp(key, "conv_wino_split")) slot = &o.conv_wino_split;
     else if (!strcmp(key, "conv_wgrad_unsliced")) slot = &o.conv_wgrad_unsliced;
+    else if (!strcmp(key, "conv_wgrad_prezeroed")) slot = &o.conv_wgrad_prezeroed;
     else if (!strcmp(key, "zero_fill_memset")) slot = &o.zero_fill_memset;
     else if (!strcmp(key, "be_bwd_fixed")) slot = &o.be_bwd_fixed;
     else if (!strcmp(key, "rs_bwd1_fixed")) slot = &o.rs_bwd1_fixed;

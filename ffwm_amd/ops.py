@@ -446,28 +446,51 @@ def conv2d_wgrad(rows, gathered, kernel, stride, pad, grad_weight=None):
     return grad_weight
 
 
+def zero_fill(t):
+    """Clear a contiguous CUDA tensor with the library's own kernel (ffwm_zero_fill; never a memset node: DESIGN 5.1)."""
+    if not (t.is_cuda and t.is_contiguous()):
+        raise ValueError("zero_fill: a contiguous CUDA tensor")
+    with _on_device(t) as stream:
+        _lib.check(_lib.load().ffwm_zero_fill(_ptr(t), t.numel() * t.element_size(), stream), "ffwm_zero_fill")
+    return t
+
+
 def conv2d_wgrad_tiled_ok(rows):
     """Shapes the tiled weight-gradient kernel takes: a plane of a multiple of 4 pixels, 16-byte aligned float32 rows."""
     return (rows.is_cuda and rows.dtype == torch.float32 and rows.dim() == 4 and (rows.shape[2] * rows.shape[3]) % 4 == 0
             and rows.data_ptr() % 16 == 0 and rows.numel() < (1 << 29))
 
 
-def conv2d_wgrad_tiled(rows, gathered, kernel, stride, pad, want_bias=False):
+def conv2d_wgrad_tiled(rows, gathered, kernel, stride, pad, want_bias=False, zeroed=None):
     """-> (grad_weight, grad_bias or None) of Conv2d (rows = grad_output, gathered = input: [K, C, k, k]; grad_bias = the row sums)
     or grad_weight [Ci, Co, 4, 4] of ConvTranspose2d(4, 2, 1) (rows = input, gathered = grad_output; no bias) on the tiled kernel of
-    csrc/conv_bwd.hip.  Both results are slices of ONE fresh buffer (the library clears it with one fill launch when it has to)."""
+    csrc/conv_bwd.hip.  Both results are slices of ONE buffer: a fresh one (the library clears it with one fill launch when it has
+    to), or `zeroed` -- K C k k (+ K) ZERO floats the caller owns (a slice of the trainer's gradient arena): no fill launch at all."""
     _check("conv2d_wgrad_tiled", rows, gathered)
     B, K, Ho, Wo = rows.shape
     Bg, C, H, W = gathered.shape
     if Bg != B:
         raise ValueError("conv2d_wgrad_tiled: batch sizes differ")
     n = K * C * kernel * kernel
-    buf = rows.new_empty((n + (K if want_bias else 0),))
+    total = n + (K if want_bias else 0)
+    if zeroed is not None:
+        if not (zeroed.is_cuda and zeroed.device == rows.device and zeroed.dtype == rows.dtype and zeroed.is_contiguous() and zeroed.numel() == total):
+            raise ValueError("conv2d_wgrad_tiled: `zeroed` must be %d contiguous zero elements of the operands' device and dtype" % total)
+        buf = zeroed.view(-1)
+    else:
+        buf = rows.new_empty((total,))
     gw = buf[:n].view(K, C, kernel, kernel)
     gb = buf[n:] if want_bias else None
+    lib = _lib.load()
     with _on_device(rows) as stream:
-        _lib.check(_lib.load().ffwm_conv2d_wgrad_tiled(_ptr(rows), _ptr(gathered), _ptr(gw), _ptr(gb), B, K, Ho, Wo, C, H, W, int(kernel),
-                                                       int(stride), int(pad), _dtype_code(rows), stream), "ffwm_conv2d_wgrad_tiled")
+        if zeroed is not None:
+            lib.ffwm_set_option(b"conv_wgrad_prezeroed", 1)
+        try:
+            _lib.check(lib.ffwm_conv2d_wgrad_tiled(_ptr(rows), _ptr(gathered), _ptr(gw), _ptr(gb), B, K, Ho, Wo, C, H, W, int(kernel),
+                                                   int(stride), int(pad), _dtype_code(rows), stream), "ffwm_conv2d_wgrad_tiled")
+        finally:
+            if zeroed is not None:
+                lib.ffwm_set_option(b"conv_wgrad_prezeroed", 0)
     return gw, gb
 
 

@@ -25,9 +25,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import nets
+from . import conv, nets
 from .dp import BucketedGradReducer, broadcast_module_state
 from .external_function import WarpNet
+
+# FFWM_GRAD_ARENA=0: every weight-gradient call clears its own buffer again (conv._GradArena)
+_GRAD_ARENA_ON = os.environ.get("FFWM_GRAD_ARENA", "1") != "0"
 
 PRC_LAYERS = ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "relu5_1")
 PRC_WEIGHTS = (1.0, 1.0 / 2, 1.0 / 4, 1.0 / 4, 1.0 / 8)
@@ -704,6 +707,8 @@ class FFWMTrainer(object):
     # optimize_parameters (ffwm_model.py:151-160) in three segments, cut where data parallelism has its
     # exchange steps (gradient all-reduce of the D set, then of the G set)
     def _seg_forward_and_D(self, b):
+        if self.device.type == "cuda" and _GRAD_ARENA_ON:
+            conv.GRAD_ARENA.begin(self.device)          # ONE launch clears every weight-gradient buffer of the step (conv._GradArena)
         self.forward(b)
         for p in self.netD.parameters():
             p.requires_grad = True
@@ -769,6 +774,7 @@ class FFWMTrainer(object):
     def _seg_stepG(self):
         self.opt_G.step()
         self.opt_F.step()
+        conv.GRAD_ARENA.end()
 
     def step(self, b, batch_increment=None):
         """optimize_parameters (ffwm_model.py:151-160): forward, D step, G step."""
@@ -973,6 +979,7 @@ class FFWMTrainer(object):
         # the eager step that follows must not take the paths that are valid only inside an in-graph capture (event joins, the
         # ground-truth prefetch on side streams), and scratch buffers whose zero-fill was only CAPTURED must not be found in the cache
         self.capture_mode = None
+        conv.GRAD_ARENA.active = False
         from .norm import reset_scratch
         reset_scratch()
         self._d_side = not self.dp_active
@@ -1131,6 +1138,8 @@ class FlowNetTrainer(object):
         self._static = None
 
     def _seg_backward(self, b):
+        if self.device.type == "cuda" and _GRAD_ARENA_ON:
+            conv.GRAD_ARENA.begin(self.device)
         gate = torch.cat((b["gate"], b["gate"]), 2)
         flow, flow64, flow32 = self.flowNet(b["img_S"])
         self.fake_F = self.warp(b["img_S"], flow)
@@ -1141,6 +1150,7 @@ class FlowNetTrainer(object):
         loss = loss_cor + loss_lm + loss_reg
         self.reducer.zero_grad()
         loss.backward()
+        conv.GRAD_ARENA.end()
         self.losses = {"loss": loss.detach(), "cor": loss_cor.detach(), "reg": loss_reg.detach(), "lm": loss_lm.detach()}
         self.fake_F = self.fake_F.detach()
 
