@@ -211,7 +211,7 @@ WINOGRAD_MIN_TILES = int(_os.environ.get("FFWM_WINOGRAD_MIN_TILES", 2048))
 # 30 us); inside the captured multi-stream step 100 pairs measure 0.2-0.3 ms per step better (42.33 vs 42.60 ms) by moving 49 more
 # small launches from the vendor's kernel to this one at 0.2-0.3 of its peak -- within the noise of the step in round 4.  Round 5 (late):
 # the kernel's launches are 8-13 % shorter (epilogue, chunk loop) and 100 pairs measure 37.42 against 37.54 ms in four alternating runs on
-# one box (tools/_variants/abenv.sh) -- 0.3 % of the step, bought with 44 more launches per step at 0.2-0.3 of the kernel's peak, which drag the
+# one box (tools/ab/abenv.sh) -- 0.3 % of the step, bought with 44 more launches per step at 0.2-0.3 of the kernel's peak, which drag the
 # step-wide average of the Winograd scope (bench.py's roofline_mfma row, the number the rounds are compared on) from 0.58 to 0.53.  The
 # threshold stays at 160; FFWM_WINOGRAD_MIN_PAIRS=100 is the faster step.
 WINOGRAD_MIN_PAIRS = int(_os.environ.get("FFWM_WINOGRAD_MIN_PAIRS", 160))

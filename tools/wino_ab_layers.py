@@ -1,5 +1,5 @@
 """Times of the Winograd kernel (+ its thin tail) on the 3x3 layers of the train step, forward with bias + LeakyReLU and data gradient;
-prints a step-weighted total.  Used for same-box A/B of library variants (tools/_variants/ab.sh).   python tools/wino_ab_layers.py"""
+prints a step-weighted total.  Used for same-box A/B of library variants (tools/ab/ab.sh).   python tools/wino_ab_layers.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
