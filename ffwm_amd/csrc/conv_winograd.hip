@@ -721,6 +721,305 @@ winograd_conv_raw_kernel(const float* __restrict__ x, const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- wave-specialised variant
+// Round 5 (late).  The ablations of the kernel above (profiles/r05_winograd_pair_and_chunk_ablation.txt) say: the MFMAs with their operand
+// reads and the barrier ALONE run at 98 % of the matrix pipe's bound; what costs 25-30 % is the side work -- window loads, transforms, LDS
+// commits -- sitting in the SAME in-order instruction streams: a wave that waits for an LDS read or issues stores issues no MFMAs, and
+// ~9.4 side instructions per 64-cycle MFMA slot and SIMD is the issue limit.  Here the roles are separate waves: 8 CONSUMER waves (the
+// compute roles of the kernel above: operand reads + 32 MFMAs per chunk, nothing else) and 4 PRODUCER waves, one per SIMD, that do
+// all the staging (each of their 256 threads carries what two threads carried above).  12 waves of 168 registers = 3 per SIMD.  A
+// consumer's stream is the 98 % one; a producer has a whole chunk time for its ~200 instructions and may wait as it likes.  Same LDS
+// plan (128 KiB operands + 2 x 16 KiB raw windows), same pipeline depths, one barrier per chunk, the same epilogue (the producers only
+// pass its two barriers).  Calls with a split reduction keep the kernel above.
+constexpr int kWsThreads = 768;
+template <int ABL>
+__global__ void __launch_bounds__(kWsThreads)
+winograd_conv_ws_kernel(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias, float* __restrict__ out,
+                        const WinoGeo g, int remap) {
+    extern __shared__ f32x4 smem[];          // operands (8192 f32x4), then raw[2][kWinoRawFloats]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr unsigned kOobOff = 0xFFFFFFF0u;
+    const int HW = g.H * g.W;
+    const int npairs = g.TT * g.KT;
+    const int L = static_cast<int>(xcd_remap(blockIdx.x, gridDim.x, remap));
+    const int per = npairs / static_cast<int>(gridDim.x), extra = npairs - per * static_cast<int>(gridDim.x);
+    const int pair_begin = L * per + min(L, extra), pair_cnt = per + (L < extra ? 1 : 0);
+    const int pair_end = pair_begin + pair_cnt;
+    if (pair_cnt == 0) return;
+    const int CHn = g.CH, CHp = (CHn + 1) & ~1;      // an odd count ends with a chunk of zeros (inputs AND weights out of range: see above)
+    const int strips_per_img = g.TH / g.R;
+
+    // The two roles are two separate loops (their registers must not be live together: 128 accumulators here, 64 staging registers
+    // there); both execute the same sequence of barriers: 2 (prologue) + per pair CHp (steps) + 2 (epilogue).
+    if (wave_u < 8) {
+        // ============================================================ consumers: operand reads + MFMAs, the output transform
+        const int l31 = lane & 31, half = lane >> 5;
+        const int ph = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+        f32x16 acc[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+        auto step = [&](auto parity) {
+            constexpr int P = decltype(parity)::value;
+            if (ABL & 1) { __syncthreads(); return; }          // timing experiment: producers alone
+            const f32x4* ap = smem + P * 4096 + (ph * 8) * 128 + half * 64 + wm * 32 + l31;
+            const f32x4* bp = smem + P * 4096 + 2048 + (ph * 8) * 128 + half * 64 + wn * 32 + l31;
+            f32x4 oa[2][2], ob[2][2];
+            oa[0][0] = ap[0]; ob[0][0] = bp[0]; oa[0][1] = ap[128]; ob[0][1] = bp[128];
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                const int cur = grp & 1, nxt = cur ^ 1;
+                if (grp < 3) {
+                    oa[nxt][0] = ap[(2 * grp + 2) * 128]; ob[nxt][0] = bp[(2 * grp + 2) * 128];
+                    oa[nxt][1] = ap[(2 * grp + 3) * 128]; ob[nxt][1] = bp[(2 * grp + 3) * 128];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * grp] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][0][j], ob[cur][0][j], acc[2 * grp], 0, 0, 0);
+                    acc[2 * grp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[cur][1][j], ob[cur][1][j], acc[2 * grp + 1], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        };
+        __syncthreads();
+        __syncthreads();
+        float* const xch = reinterpret_cast<float*>(smem + 4096) + (wave & 3) * 4096 + lane;
+        const int ph_u = wave_u >> 2, wm_u = (wave_u >> 1) & 1;
+        const int tl = wn * 32 + l31;
+        const unsigned out_lane = (static_cast<unsigned>(wm * 32 + 4 * half) * static_cast<unsigned>(HW) +
+                                   static_cast<unsigned>((2 * (tl / g.TW) + ph) * g.W + 2 * (tl % g.TW))) * 4u;
+        const float sgn = ph ? -1.f : 1.f;
+        auto load_bias = [&](int pair) {
+            float v = 0.f;
+            if (bias != nullptr && pair < pair_end) {
+                const int k = (pair % g.KT) * 64 + wm * 32 + l31;
+                if (k < g.K) v = bias[k];
+            }
+            return v;
+        };
+        float bvec = load_bias(pair_begin);
+        const int bsel = 16 * half;
+        for (int pair = pair_begin; pair < pair_end; ++pair) {
+            for (int ch = 0; ch < CHp; ch += 2) {
+                step(std::integral_constant<int, 0>());
+                step(std::integral_constant<int, 1>());
+            }
+            const int tt = pair / g.KT, kt = pair - tt * g.KT;
+            if (ph_u) {                  // z row 2 for the partner's y row 0 (the exchange of the kernel above)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    xch[(r * 4 + 0) * 64] = acc[0][r] + acc[1][r] + acc[2][r];
+                    xch[(r * 4 + 1) * 64] = acc[1][r] - acc[2][r] - acc[3][r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    xch[(r * 4 + 2) * 64] = acc[4][r] + acc[5][r] + acc[6][r];
+                    xch[(r * 4 + 3) * 64] = acc[5][r] - acc[6][r] - acc[7][r];
+                }
+            }
+            __syncthreads();
+            const int kq = kt * 64 + wm_u * 32;
+            if (kq < g.K) {
+                const int b_u = tt / strips_per_img;
+                const int ty0 = (tt - b_u * strips_per_img) * g.R;
+                const int krem = g.K - kt * 64;
+                float* const obase = out + (static_cast<size_t>(b_u) * g.Kout + static_cast<size_t>(kt) * 64) * HW;
+                const rsrc_t ro = make_rsrc(obase, static_cast<unsigned>(krem < 64 ? krem : 64) * static_cast<unsigned>(HW) * 4u);
+                unsigned voff = out_lane + static_cast<unsigned>(2 * ty0 * g.W) * 4u;
+                asm volatile("" : "+v"(voff));
+                const float* const rcv = xch + (ph_u ? 2 * 64 : 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jr = (r & 3) + 8 * (r >> 2);
+                    const float za0 = acc[0][r] + acc[1][r] + acc[2][r], za1 = acc[1][r] - acc[2][r] - acc[3][r];
+                    const float zb0 = acc[4][r] + acc[5][r] + acc[6][r], zb1 = acc[5][r] - acc[6][r] - acc[7][r];
+                    const float bv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bsel + 4 * jr, __builtin_bit_cast(int, bvec)));
+                    float y0 = __builtin_fmaf(sgn, za0 + zb0, rcv[(r * 4 + 0) * 64]) + bv;
+                    float y1 = __builtin_fmaf(sgn, za1 + zb1, rcv[(r * 4 + 1) * 64]) + bv;
+                    if (g.act == 1) {
+                        y0 = y0 > 0.f ? y0 : y0 * g.slope;
+                        y1 = y1 > 0.f ? y1 : y1 * g.slope;
+                    }
+                    const unsigned vo = voff + static_cast<unsigned>(jr) * static_cast<unsigned>(HW) * 4u;
+                    const u32x2 yy = {__builtin_bit_cast(unsigned, y0), __builtin_bit_cast(unsigned, y1)};
+                    __builtin_amdgcn_raw_buffer_store_b64(yy, ro, vo, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+            bvec = load_bias(pair + 1);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================================================ producers (threads 512 .. 767): every load, transform and LDS commit
+    __builtin_amdgcn_s_setprio(3);           // the youngest waves of the workgroup lose every issue arbitration at equal priority -- and the barrier waits for them
+    const rsrc_t rx = make_rsrc(x, g.x_bytes);
+    const rsrc_t ru = make_rsrc(U, g.u_bytes);
+    float* const raw0 = reinterpret_cast<float*>(smem + 8192);
+    float* const raw1 = raw0 + kWinoRawFloats;
+    const int pt = static_cast<int>(threadIdx.x) - 512;
+    const int W4 = g.W >> 2, nquads = 8 * g.ROWS * W4;
+    const int w4_shift = __builtin_ctz(static_cast<unsigned>(W4));
+    const float quad_rcp = 1.f / static_cast<float>(g.ROWS * W4);
+    auto quad_of = [&](int q, int& c, int& rr, int& col) {
+        c = static_cast<int>((static_cast<float>(q) + 0.5f) * quad_rcp);
+        const int rem = q - c * (g.ROWS * W4);
+        rr = rem >> w4_shift;
+        col = 4 * (rem & (W4 - 1));
+    };
+    int qc[4], qlds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = pt + 256 * i;
+        int c, rr, col;
+        quad_of(q, c, rr, col);
+        qc[i] = q < nquads ? c : 8;
+        qlds[i] = q < nquads ? (c * g.ROWS + rr) * g.W + ((col + 16 * c) & (g.W - 1)) : -1;
+    }
+    struct Cursor {
+        int pair, ch;
+        unsigned qoff[4];
+        unsigned u_base;
+    };
+    auto seat = [&](Cursor& c) {
+        if (c.pair >= pair_end) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c.qoff[i] = kOobOff;
+            c.u_base = kOobOff;
+            return;
+        }
+        const int tt = c.pair / g.KT, kt = c.pair - tt * g.KT;
+        const int b = tt / strips_per_img, ty0 = (tt - b * strips_per_img) * g.R;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = pt + 256 * i;
+            int qch, qrow, qcol;
+            quad_of(q, qch, qrow, qcol);
+            const int iy = 2 * ty0 - 1 + qrow;
+            const bool ok = q < nquads && iy >= 0 && iy < g.H;
+            c.qoff[i] = ok ? ((static_cast<unsigned>(b) * g.C + qch) * static_cast<unsigned>(HW) + static_cast<unsigned>(iy * g.W + qcol)) * 4u : kOobOff;
+        }
+        c.u_base = (static_cast<unsigned>(kt) * g.CH) * (kWinoChunk * 4u) + static_cast<unsigned>(pt) * 16u;
+    };
+    auto advance = [&](Cursor& c) {
+        if (++c.ch == CHp) {
+            c.ch = 0;
+            ++c.pair;
+            seat(c);
+        }
+    };
+    Cursor cr, cu;
+    cr.pair = cu.pair = pair_begin;
+    cr.ch = cu.ch = 0;
+    seat(cr);
+    cu = cr;
+    // patches: tile ts, channels c_lo and 4 + c_lo of the chunk
+    const int c_lo = lane & 3, ts = (wave & 3) * 16 + (lane >> 2);
+    const int tr = ts / g.TW, tx = ts - tr * g.TW;
+    const bool lcol = tx > 0, rcol = tx < g.TW - 1;
+    int prow[2], pcm[2], pc0[2], pcp[2];
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) {
+        prow[sh] = ((4 * sh + c_lo) * g.ROWS + 2 * tr) * g.W;
+        const int prot = 16 * (4 * sh + c_lo);
+        pcm[sh] = (2 * tx - 1 + prot) & (g.W - 1);
+        pc0[sh] = (2 * tx + prot) & (g.W - 1);
+        pcp[sh] = (2 * tx + 2 + prot) & (g.W - 1);
+    }
+    u32x4 rq[2][4] = {};
+    u32x4 uw[8] = {};
+    auto load_raw = [&](u32x4 (&q)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool cin = cr.ch * 8 + qc[i] < g.C;
+            q[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (cin & (cr.qoff[i] != kOobOff)) ? cr.qoff[i] + static_cast<unsigned>(cr.ch) * (32u * HW) : kOobOff, 0, 0);
+        }
+        advance(cr);
+    };
+    auto write_raw = [&](float* raw, const u32x4 (&q)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (qlds[i] >= 0) *reinterpret_cast<u32x4*>(raw + qlds[i]) = q[i];
+    };
+    auto load_u = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            uw[i] = __builtin_amdgcn_raw_buffer_load_b128(ru, (cu.u_base != kOobOff && cu.ch < CHn) ? cu.u_base + static_cast<unsigned>(cu.ch) * (kWinoChunk * 4u) + i * 4096u : kOobOff, 0, 0);
+        advance(cu);
+    };
+    auto commit_u = [&](f32x4* Ub) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) reinterpret_cast<u32x4*>(Ub)[pt + 256 * i] = uw[i];
+    };
+    auto transform = [&](const float* raw, f32x4* Vb) {      // both patches of this thread: raw window -> Bt d B -> V
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+            float d[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* rp = raw + prow[sh] + i * g.W;
+                const float a = rp[pcm[sh]], e = rp[pcp[sh]];
+                const float2 m = *reinterpret_cast<const float2*>(rp + pc0[sh]);
+                d[i * 4 + 0] = lcol ? a : 0.f;
+                d[i * 4 + 1] = m.x;
+                d[i * 4 + 2] = m.y;
+                d[i * 4 + 3] = rcol ? e : 0.f;
+            }
+            float* dst = reinterpret_cast<float*>(Vb) + (sh * 64 + ts) * 4 + c_lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    r[j] = i == 0 ? d[0 + j] - d[8 + j] : i == 1 ? d[4 + j] + d[8 + j] : i == 2 ? d[8 + j] - d[4 + j] : d[4 + j] - d[12 + j];
+                dst[(i * 4 + 0) * 512] = r[0] - r[2];
+                dst[(i * 4 + 1) * 512] = r[1] + r[2];
+                dst[(i * 4 + 2) * 512] = r[2] - r[1];
+                dst[(i * 4 + 3) * 512] = r[1] - r[3];
+            }
+        }
+    };
+    // step of chunk n (parity P) while the consumers run their MFMAs on buffers P: U(n + 1) -> U buffer 1 - P and the load of U(n + 2);
+    // the patches of chunk n + 1 from raw[1 - P] -> V buffer 1 - P; the window of chunk n + 2 (registers) -> raw[P] and the load of
+    // chunk n + 4 into those registers
+    auto pstep = [&](auto parity) {
+        constexpr int P = decltype(parity)::value, Q = 1 - P;
+        f32x4* const Un = smem + Q * 4096;
+        if (ABL & 2) { __syncthreads(); return; }              // timing experiment: consumers alone
+        if (!(ABL & 4)) commit_u(Un);
+        if (!(ABL & 32)) load_u();
+        if (!(ABL & 8)) transform(Q ? raw1 : raw0, Un + 2048);
+        if (!(ABL & 16)) write_raw(P ? raw1 : raw0, rq[P]);
+        if (!(ABL & 32)) load_raw(rq[P]);
+        __syncthreads();
+    };
+    // prologue: chunk 0 staged and transformed into buffers 0, chunk 1's window in raw[1], U(1) and the windows of chunks 2, 3 in flight
+    load_raw(rq[0]); load_u(); load_raw(rq[1]);
+    write_raw(raw0, rq[0]);
+    __syncthreads();
+    transform(raw0, smem + 2048);
+    commit_u(smem);
+    write_raw(raw1, rq[1]);
+    load_raw(rq[0]); load_raw(rq[1]);
+    load_u();
+    __syncthreads();
+    for (int pair = pair_begin; pair < pair_end; ++pair) {
+        for (int ch = 0; ch < CHp; ch += 2) {
+            pstep(std::integral_constant<int, 0>());
+            pstep(std::integral_constant<int, 1>());
+        }
+        __syncthreads();                 // the consumers' exchange of the output transform ...
+        __syncthreads();                 // ... lives in the parity-1 buffers: no commit before they have read it
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- thin tail
 // The last 1-4 output channels of a layer whose channel count is just past a multiple of 64 (netG's residual blocks: 195 =
 // 3 * 64 + 3) would cost a whole 64-channel tile of the Winograd kernel (a quarter of the launch).  They are a direct sum
@@ -1003,14 +1302,30 @@ extern "C" int ffwm_conv3x3_winograd_forward(const void* input, const void* weig
                 default: break;
             }
             if (split_n > 1) kern = winograd_conv_raw_kernel<0, true>;
-            allow_large_lds(reinterpret_cast<const void*>(kern));
             const int cus = device_cus();
             const unsigned units = nblk * static_cast<unsigned>(split_n);
             const unsigned pgrid = units < static_cast<unsigned>(cus) ? units : static_cast<unsigned>(cus);     // persistent: one workgroup per CU
+            if (split_n == 1 && options().conv_wino_ws) {
+                auto wsk = winograd_conv_ws_kernel<0>;
+                if (options().ablate == 1) wsk = winograd_conv_ws_kernel<1>;
+                if (options().ablate == 2) wsk = winograd_conv_ws_kernel<2>;
+                if (options().ablate == 4) wsk = winograd_conv_ws_kernel<4>;
+                if (options().ablate == 8) wsk = winograd_conv_ws_kernel<8>;
+                if (options().ablate == 16) wsk = winograd_conv_ws_kernel<16>;
+                if (options().ablate == 32) wsk = winograd_conv_ws_kernel<32>;
+                if (options().ablate == 28) wsk = winograd_conv_ws_kernel<28>;
+                allow_large_lds(reinterpret_cast<const void*>(wsk));
+                hipLaunchKernelGGL(wsk, dim3(pgrid), dim3(kWsThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st,
+                                   static_cast<const float*>(input), U, static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap);
+                const int rc = check_launch(fn);
+                if (rc || !thin) return rc;
+            } else {
+            allow_large_lds(reinterpret_cast<const void*>(kern));
             hipLaunchKernelGGL(kern, dim3(pgrid), dim3(kWinoThreads), 4 * kWinoChunk * 4 + 2 * kWinoRawFloats * 4, st, static_cast<const float*>(input), U,
                                static_cast<const float*>(bias), static_cast<float*>(output), g, options().xcd_remap, split_n, g.CH / split_n);
             const int rc = check_launch(fn);
             if (rc || !thin) return rc;
+            }
         } else {
         auto kern = winograd_conv_kernel<0>;
         switch (options().ablate) {

@@ -2008,6 +2008,35 @@ def test_conv3x3_winograd_ignores_what_lies_behind_the_transformed_weights():
             assert (dx.cpu().double() - dref).abs().max().item() <= 2e-5 * (1 + dref.abs().max().item())
 
 
+
+@pytest.mark.parametrize("shape", [(2, 64, 32, 64, 0), (2, 195, 64, 195, 1), (3, 72, 16, 130, 0), (4, 200, 128, 96, 1)])
+def test_winograd_wave_specialised_variant_equals_the_standard_kernel(shape):
+    """csrc/conv_winograd.hip, winograd_conv_ws_kernel (library option conv_wino_ws, off by default: it measured slower --
+    profiles/r05_winograd_wave_specialised_negative.txt): 8 MFMA waves + 4 staging waves run the same MFMA order and the same output
+    transform as the standard persistent kernel, so the results are the same bits; both against ATen float64."""
+    from ffwm_amd import _lib, ops
+    B, C, H, K, act = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, C, H, H, generator=g).to(DEV)
+    w = (torch.randn(K, C, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(K, generator=g).to(DEV)
+    std = ops.conv3x3_winograd(x, w, b, act=act, slope=0.2).clone()
+    std_d = ops.conv3x3_winograd(x, w.transpose(0, 1).contiguous(), None, data_gradient=True).clone() if C == K else None
+    prev = _lib.set_option("conv_wino_ws", 1)
+    try:
+        ws = ops.conv3x3_winograd(x, w, b, act=act, slope=0.2).clone()
+        ws_d = ops.conv3x3_winograd(x, w.transpose(0, 1).contiguous(), None, data_gradient=True).clone() if C == K else None
+    finally:
+        _lib.set_option("conv_wino_ws", prev)
+    assert torch.equal(std, ws)
+    if std_d is not None:
+        assert torch.equal(std_d, ws_d)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if act:
+        ref = torch.nn.functional.leaky_relu(ref, 0.2)
+    assert float((ws.double() - ref).abs().max() / ref.abs().max()) <= 2e-5
+
+
 @pytest.mark.parametrize("min_pairs", [1, 64])
 def test_winograd_routing_matches_aten_autograd(min_pairs, monkeypatch):
     """conv.route_conv_winograd: re-classed 3x3 / stride-1 Conv2d layers (forward + data gradient on csrc/conv_winograd.hip,

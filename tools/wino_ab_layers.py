@@ -7,6 +7,8 @@ from ffwm_amd import ops, _lib
 # (B, C, H, K, forward calls, data-gradient calls) per step (profiles/r05_winograd_layers_of_the_step.txt)
 LAYERS = [(8, 195, 128, 195, 4, 4), (8, 128, 128, 128, 3, 3), (8, 195, 64, 195, 4, 4), (8, 384, 32, 384, 4, 4), (8, 128, 64, 128, 5, 4),
           (8, 195, 64, 256, 1, 1), (8, 256, 32, 256, 3, 3), (8, 64, 128, 64, 4, 3), (8, 384, 32, 256, 1, 1), (8, 64, 64, 128, 4, 0), (40, 64, 32, 64, 2, 1)]
+if os.environ.get("FFWM_WINO_WS"):
+    _lib.set_option("conv_wino_ws", int(os.environ["FFWM_WINO_WS"]))
 # the first measurements of a process run on cold clocks (195 -> 195 @128 read 460 us first and 376 us a second later): warm up
 _x = torch.randn(8, 256, 128, 128, device="cuda"); _w = torch.randn(256, 256, 3, 3, device="cuda") * 0.05
 for _ in range(300): ops.conv3x3_winograd(_x, _w, None)
