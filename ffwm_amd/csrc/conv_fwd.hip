@@ -324,7 +324,11 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
     const int64_t tiles = static_cast<int64_t>(g.n_tiles) * g.k_tiles * classes;
     int splitk = 1;
     if (allow_split && tiles < 256) {
-        splitk = static_cast<int>((768 + tiles - 1) / tiles);
+        // 768 workgroups; 384 for the transposed convolutions and for <= 32 output pixels: there every slice's atomics land on the same few
+        // thousand output elements and half as many slices cost less than they save (FlowNet(64), batch 6: deconv1 35 -> 24 us, deconv4 48 -> 38,
+        // conv6 28 -> 23, conv6_1 34 -> 29; the other layers lose with fewer slices -- profiles/r05_conv_fwd_split_target.txt)
+        const int target = options().conv_fwd_split_target > 0 ? options().conv_fwd_split_target : ((mode == 1 || g.N <= 32) ? 384 : 768);
+        splitk = static_cast<int>((target + tiles - 1) / tiles);
         if (splitk > chunks_total) splitk = chunks_total;
         if (splitk < 1) splitk = 1;
     }

@@ -12,6 +12,8 @@ def t(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 B = int(os.environ.get("B", 6))
+if os.environ.get("FFWM_SPLIT_TARGET"):
+    _lib.set_option("conv_fwd_split_target", int(os.environ["FFWM_SPLIT_TARGET"]))
 layers = [("conv1", 64, 128, 64, 3, 2, False), ("conv2", 128, 64, 128, 3, 2, False), ("conv3", 128, 32, 256, 3, 2, False),
           ("conv4", 256, 16, 512, 3, 2, False), ("conv4_1", 512, 8, 512, 3, 1, False), ("conv5", 512, 8, 512, 3, 2, False),
           ("conv5_1", 512, 4, 512, 3, 1, False), ("conv6", 512, 4, 1024, 3, 2, False), ("conv6_1", 1024, 2, 1024, 3, 1, False),
