@@ -44,6 +44,7 @@ struct Options {
     int conv_tile_variant = 0; // conv_fwd.hip workgroup tile: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128
     int conv_wino_raw = 1;     // conv_winograd.hip: stage the input window through LDS when a workgroup covers whole tile rows
     int conv_fwd_split_target = 0; // conv_fwd.hip: workgroups a launch with < 256 tiles is cut into along the reduction (each slice adds its tile by atomics); 0 = by shape (768 / 384)
+    int conv_wgrad_slice_target = 0; // conv_bwd.hip tiled weight gradient: workgroups a launch is cut into along the pixels (0 = 512)
     int conv_wino_ws = 0;      // conv_winograd.hip: the wave-specialised variant (8 MFMA waves + 4 staging waves) for calls without a split reduction
     int conv_wino_split = 1;   // conv_winograd.hip: cut the reduction of a call with few (strip, k tile) pairs over 2 / 4 workgroups (atomics into a zeroed output); 2 = at most two pieces (a two-term float sum does not depend on the order: bit-reproducible); 0 = never
     int conv_thin_tail = 1;    // conv_winograd.hip: 1-4 output channels past a multiple of 64 on the thin direct kernel

@@ -461,13 +461,14 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     // sliced launch pays the atomic flush of its tile, and two workgroups per CU are resident (512 per round): a launch of 567
     // workgroups runs as long as one of 1024, and FlowNet's 8 x 8 layers (16 chunks in all) are better off with 288 unsliced
     // 64 x 128 tiles than with 432 slices of three 128 x 128 chunks each.
+    const int64_t wg_target = options().conv_wgrad_slice_target > 0 ? options().conv_wgrad_slice_target : 512;
     int wmt = 1, wnt = 1;
     double best = 1e30;
     for (int cm = 1; cm <= 2; ++cm)
         for (int cn = 1; cn <= 2; ++cn) {
             if ((cm == 2 && g.K <= 64) || (cn == 2 && g.N <= 64)) continue;
             const int64_t t = static_cast<int64_t>((g.K + 64 * cm - 1) / (64 * cm)) * ((g.N + 64 * cn - 1) / (64 * cn));
-            int64_t sl = t >= 512 ? 1 : 512 / t;
+            int64_t sl = t >= wg_target ? 1 : wg_target / t;
             if (sl > g.chunks_total / 4) sl = g.chunks_total / 4;
             if (sl < 1) sl = 1;
             const int64_t per = (g.chunks_total + sl - 1) / sl;
@@ -478,7 +479,7 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
         }
     const int k_tiles = (g.K + 64 * wmt - 1) / (64 * wmt), n_tiles = (g.N + 64 * wnt - 1) / (64 * wnt);
     const int64_t tiles = static_cast<int64_t>(k_tiles) * n_tiles;
-    int64_t slices = tiles >= 512 ? 1 : 512 / tiles;
+    int64_t slices = tiles >= wg_target ? 1 : wg_target / tiles;
     if (slices > g.chunks_total / 4) slices = g.chunks_total / 4;
     if (slices < 1 || options().conv_wgrad_unsliced) slices = 1;
     g.chunks = static_cast<int>((g.chunks_total + slices - 1) / slices);

@@ -307,6 +307,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "conv_thin_tail")) slot = &o.conv_thin_tail;
     else if (!strcmp(key, "conv_wino_raw")) slot = &o.conv_wino_raw;
     else if (!strcmp(key, "conv_wino_ws")) slot = &o.conv_wino_ws;
+    else if (!strcmp(key, "conv_wgrad_slice_target")) slot = &o.conv_wgrad_slice_target;
     else if (!strcmp(key, "conv_fwd_split_target")) slot = &o.conv_fwd_split_target;
     else if (!strcmp(key, "conv_wino_split")) slot = &o.conv_wino_split;
     else if (!strcmp(key, "conv_wgrad_unsliced")) slot = &o.conv_wgrad_unsliced;

@@ -6,6 +6,8 @@ import torch
 from ffwm_amd import ops, _lib
 SHAPES = [(8, 256, 32, 256, 3, 1), (8, 384, 32, 384, 3, 1), (8, 128, 32, 128, 3, 1), (8, 512, 16, 512, 3, 1), (8, 64, 128, 128, 3, 2), (8, 128, 64, 256, 3, 2),
           (8, 256, 32, 512, 3, 2), (6, 512, 8, 512, 3, 1), (6, 1024, 2, 1024, 3, 1), (8, 64, 64, 64, 3, 1), (8, 3, 128, 64, 3, 1), (8, 195, 64, 195, 4, 2)]
+if os.environ.get("FFWM_SLICE_TARGET"):
+    _lib.set_option("conv_wgrad_slice_target", int(os.environ["FFWM_SLICE_TARGET"]))
 g = torch.Generator().manual_seed(0)
 tot = 0.0
 for B, C, H, K, k, s in SHAPES:
