@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libffwm_hip.so")
 
 F32, F64 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -38,7 +38,7 @@ _SIGNATURES = {
     "ffwm_flow_up_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_flow_head_backward": [_p, _p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_flow_up_backward": [_p, _p, _p] + [_i64] * 4 + [_i, _p],
-    "ffwm_conv2d_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, _i, _i, _i, _i64, _i, ctypes.c_double, _i, ctypes.POINTER(_i), _i, _p],
+    "ffwm_conv2d_forward": [_p, _p, _p, _p, _p] + [_i64] * 5 + [_i, _i, _i, _i, _i64, _i64, _i, ctypes.c_double, _p, _i64, _i, _p],
     "ffwm_conv2d_wgrad": [_p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
     "ffwm_conv2d_wgrad_tiled": [_p, _p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
     "ffwm_conv3x3_winograd_forward": [_p, _p, _p, _p, _p] + [_i64] * 5 + [_i, _i, ctypes.c_double, _i, _p],
@@ -77,7 +77,8 @@ _SIGNATURES = {
     "ffwm_abi_version": [],
 }
 
-EXPORTS = sorted(list(_SIGNATURES) + ["ffwm_last_error", "ffwm_conv3x3_winograd_workspace_bytes", "ffwm_conv3x3_winograd_splits"])
+EXPORTS = sorted(list(_SIGNATURES) + ["ffwm_last_error", "ffwm_conv3x3_winograd_workspace_bytes", "ffwm_conv3x3_winograd_splits",
+                                      "ffwm_conv2d_forward_workspace"])
 
 
 class FFWMError(RuntimeError):
@@ -102,6 +103,8 @@ def load():
     lib.ffwm_conv3x3_winograd_workspace_bytes.restype = _i64
     lib.ffwm_conv3x3_winograd_splits.argtypes = [_i64, _i64, _i64, _i64, _i64, _i]
     lib.ffwm_conv3x3_winograd_splits.restype = _i
+    lib.ffwm_conv2d_forward_workspace.argtypes = [_i64] * 5 + [_i] * 4
+    lib.ffwm_conv2d_forward_workspace.restype = _i64
     lib.ffwm_last_error.argtypes = []
     lib.ffwm_last_error.restype = ctypes.c_char_p
     got = lib.ffwm_abi_version()

@@ -22,9 +22,12 @@
 //   and plane) and walks kd in chunks of 32: weights [64 x 32] and gathered activations [32 x 64] are staged in LDS
 //   (global loads of chunk i+1 in flight under the 16 MFMAs per wave of chunk i), operands are ds_read_b32 at
 //   conflict-free pitches.  Layers with few output pixels (the tail) are cut along kd (split-K over blockIdx.z) until the
-//   chip is full: each slice adds its partial tile atomically into the zero-filled output and the bias / activation
-//   epilogue runs as ffwm_bias_act_forward; otherwise the epilogue (bias + LeakyReLU / tanh, optional write into a channel
-//   slice of a concatenation buffer) is fused here.
+//   chip is full.  Round 6: a slice STORES its partial tile into its own slot of a caller-provided workspace
+//   ([splitk][B][K][oH * oW], nothing to zero-fill) and conv_split_reduce_kernel adds the slots in slice order, applies bias +
+//   activation and writes the destination(s) -- no float atomics, so the result is bit-reproducible run to run (rounds 2-5 added
+//   the slices atomically into a zero-filled output: 18 of 38 us of a tail layer were those atomics meeting on a few thousand
+//   addresses).  Unsplit launches fuse the epilogue (bias + LeakyReLU / tanh, written to one or two destinations: channel
+//   slices of concatenation buffers are valid) here.
 #include "common.hpp"
 
 namespace ffwm {
@@ -41,7 +44,9 @@ struct ConvGeo {
     int n_tiles, k_tiles;
     int kfast;               // linear workgroup index: channel tiles fastest (1) or pixel tiles fastest (0)
     int splitk, chunks;      // chunks (of CPC input channels) per split
-    long long out_bs;        // output batch stride in elements
+    long long out_bs;        // output batch stride in elements (split launch: K * oH * oW, the workspace slot's)
+    long long out2_bs;       // second destination's batch stride (unsplit launches with out2 != NULL)
+    long long slot;          // split launch: elements per workspace slot = B * K * oH * oW
     int oH, oW;              // output plane (MODE 1: 2H x 2W)
     int act;
     float slope;
@@ -59,7 +64,7 @@ struct ConvGeo {
 template <int MODE, int R, int S, int TM, int TN>
 __global__ void __launch_bounds__(kBlock)
 conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
-                const ConvGeo g) {
+                float* __restrict__ out2, const ConvGeo g) {
     constexpr bool PARITY = MODE == 1 || MODE == 2;          // four output-parity classes over the input grid
     constexpr int RS = PARITY ? 4 : R * S;
     constexpr int CPC = RS == 9 ? 4 : (RS == 16 ? 2 : 8);       // channels per chunk
@@ -227,14 +232,20 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
         compute();
     }
 
-    // ---- epilogue.  C/D layout: col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+    // ---- epilogue.  C/D layout: col = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel).
+    // The bias fetch (ds_bpermute reads the SOURCE lane's register only while that lane is enabled) runs in uniform control flow, in
+    // front of the per-lane range tests: round 5 had it behind `if (n >= N) continue; if (k >= K) continue;`, so a ragged last pixel
+    // block (B * Ho * Wo % 32 != 0) or a ragged channel tile lost the bias of every channel whose source lane was masked off.
     const size_t oplane = static_cast<size_t>(g.oH) * g.oW;
+    float* ob[WNT];
+    float* ob2[WNT];
+    bool nok[WNT];
 #pragma unroll
     for (int bq = 0; bq < WNT; ++bq) {
         const int n = n0 + wn * (TN / 2) + bq * 32 + l31;
-        if (n >= g.N) continue;
-        const int b = n / plane_o;
-        const int p = n - b * plane_o;
+        nok[bq] = n < g.N;
+        const int b = nok[bq] ? n / plane_o : 0;
+        const int p = nok[bq] ? n - b * plane_o : 0;
         size_t pix;
         if constexpr (!PARITY) {
             pix = static_cast<size_t>(p);
@@ -242,23 +253,76 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
             const int oy = p / g.Wo, ox = p - oy * g.Wo;
             pix = static_cast<size_t>(2 * oy + py) * g.oW + (2 * ox + px);
         }
-        float* ob = out + static_cast<size_t>(b) * g.out_bs + pix;
+        ob[bq] = out + (g.splitk > 1 ? static_cast<size_t>(split) * g.slot : 0) + static_cast<size_t>(b) * g.out_bs + pix;
+        ob2[bq] = out2 ? out2 + static_cast<size_t>(b) * g.out2_bs + pix : nullptr;
+    }
+    const bool fused = g.splitk == 1;
 #pragma unroll
-        for (int a = 0; a < WMT; ++a)
+    for (int a = 0; a < WMT; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wm * (TM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (k >= g.K) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int kr = a * 32 + (r & 3) + 8 * (r >> 2);
+            const int k = k0 + wm * (TM / 2) + kr + 4 * half;
+            const float bk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * half + 4 * kr, __builtin_bit_cast(int, bvec)));   // all lanes on
+#pragma unroll
+            for (int bq = 0; bq < WNT; ++bq) {
+                if (!nok[bq] || k >= g.K) continue;
                 float v = acc[a][bq][r];
-                if (g.splitk > 1) {
-                    atomic_add(ob + static_cast<size_t>(k) * oplane, v);
-                } else {
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * half + 4 * (a * 32 + (r & 3) + 8 * (r >> 2)), __builtin_bit_cast(int, bvec)));
+                if (fused) {
+                    v += bk;
                     if (g.act == 1) v = v > 0.f ? v : v * g.slope;
                     else if (g.act == 2) v = tanhf(v);
-                    ob[static_cast<size_t>(k) * oplane] = v;
+                    if (ob2[bq]) ob2[bq][static_cast<size_t>(k) * oplane] = v;
                 }
+                ob[bq][static_cast<size_t>(k) * oplane] = v;        // split launch: the slice's own workspace slot, plain store
             }
+        }
+}
+
+// The second half of a split launch: y[b, k, p] = act(bias[k] + slot_0 + slot_1 + ... ) in slice order (a fixed-order float sum:
+// bit-reproducible), written to one or two destinations with their own batch strides.  One thread per 4 consecutive pixels when
+// the plane allows, else per pixel.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+conv_split_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ y2,
+                         int64_t total, int splitk, int64_t slot, int K, int HW, int64_t ybs, int64_t y2bs, int act, float slope) {
+    const int hwv = HW / VEC;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const int64_t plane = i / hwv;
+        const int p = static_cast<int>(i - plane * hwv) * VEC;
+        const int k = static_cast<int>(plane % K);
+        const int64_t b = plane / K;
+        const float* src = ws + plane * HW + p;
+        float v[VEC];
+        if constexpr (VEC == 4) {
+            float4 s4 = *reinterpret_cast<const float4*>(src);
+            for (int s = 1; s < splitk; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(src + s * slot);
+                s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
+            }
+            v[0] = s4.x; v[1] = s4.y; v[2] = s4.z; v[3] = s4.w;
+        } else {
+            float a = src[0];
+            for (int s = 1; s < splitk; ++s) a += src[s * slot];
+            v[0] = a;
+        }
+        const float bk = bias ? bias[k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = v[j] + bk;
+            if (act == 1) t = t > 0.f ? t : t * slope;
+            else if (act == 2) t = tanhf(t);
+            v[j] = t;
+        }
+        const int64_t o = static_cast<int64_t>(k) * HW + p;
+        if constexpr (VEC == 4) {
+            const float4 o4 = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4*>(y + b * ybs + o) = o4;
+            if (y2) *reinterpret_cast<float4*>(y2 + b * y2bs + o) = o4;
+        } else {
+            y[b * ybs + o] = v[0];
+            if (y2) y2[b * y2bs + o] = v[0];
+        }
     }
 }
 
@@ -267,22 +331,29 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
 
 using namespace ffwm;
 
-// Returns 1 through *needs_epilogue when the launch was cut along the reduction: the caller must have ZERO-FILLED the
-// output and must apply bias / activation afterwards (ffwm_bias_act_forward).
-extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const void* bias, void* output, int64_t B, int64_t C,
-                                   int64_t H, int64_t W, int64_t K, int kernel, int stride, int pad, int transposed,
-                                   int64_t out_batch_stride, int act, double negative_slope, int allow_split,
-                                   int* needs_epilogue, int dtype, void* stream) {
-    const char* fn = "ffwm_conv2d_forward";
-    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
-    FFWM_REQUIRE(input && weight && output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
-    FFWM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && K > 0 && act >= 0 && act <= 2, FFWM_ERR_ARG, "%s: bad sizes / activation", fn);
+namespace {
+
+unsigned ew_grid(int64_t n) {
+    const int64_t blocks = (n + kBlock - 1) / kBlock;
+    return static_cast<unsigned>(blocks > 256 * 32 ? 256 * 32 : (blocks < 1 ? 1 : blocks));
+}
+
+// Geometry, tile shape and reduction split of one call -- shared by the workspace query and the launch so that they cannot disagree.
+struct ConvPlan {
     ConvGeo g;
+    int tm, tn, classes, mode, kernel;
+    int64_t out_elems;       // B * K * oH * oW
+};
+
+int conv_plan(const char* fn, int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int kernel, int stride, int pad, int mode,
+              bool may_split, ConvPlan* pl) {
+    FFWM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && K > 0, FFWM_ERR_ARG, "%s: bad sizes", fn);
+    ConvGeo& g = pl->g;
     g.C = static_cast<int>(C); g.H = static_cast<int>(H); g.W = static_cast<int>(W); g.K = static_cast<int>(K);
     g.stride = stride; g.pad = pad;
     int classes = 1;
     int64_t w_elems;
-    const int mode = transposed;        // 0 conv, 1 ConvTranspose2d(4, 2, 1), 2 d(input) of Conv2d(3, 2, 1), 3 d(input) of Conv2d(3, 1, 1)
+    // mode: 0 conv, 1 ConvTranspose2d(4, 2, 1), 2 d(input) of Conv2d(3, 2, 1), 3 d(input) of Conv2d(3, 1, 1)
     FFWM_REQUIRE(mode >= 0 && mode <= 3, FFWM_ERR_ARG, "%s: unknown mode %d", fn, mode);
     if (mode == 1 || mode == 2) {
         FFWM_REQUIRE((mode == 1 ? kernel == 4 : kernel == 3) && stride == 2 && pad == 1, FFWM_ERR_ARG,
@@ -304,7 +375,6 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
                  FFWM_ERR_SIZE, "%s: tensor too large (input and weight must stay below 2 GiB: 32-bit buffer offsets)", fn);
     g.x_bytes = static_cast<unsigned>(B * C * H * W * 4);
     g.w_bytes = static_cast<unsigned>(w_elems * 4);
-    FFWM_REQUIRE(out_batch_stride >= K * g.oH * g.oW, FFWM_ERR_ARG, "%s: output batch stride smaller than K * Ho * Wo", fn);
     g.N = static_cast<int>(B * g.Ho * g.Wo);
     // tile (conv_tile_variant: 0 auto, 1 = 64 x 64, 2 = 128 x 64, 3 = 64 x 128, 4 = 128 x 128).  Measured per layer at batch 32
     // (tools/conv_layers.py): 64 x 128 pixels wins where >= 512 workgroups remain and on the transposed convolutions with >= 2048
@@ -323,10 +393,9 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
     const int chunks_total = (g.C + cpc - 1) / cpc;
     const int64_t tiles = static_cast<int64_t>(g.n_tiles) * g.k_tiles * classes;
     int splitk = 1;
-    if (allow_split && tiles < 256) {
-        // 768 workgroups; 384 for the transposed convolutions and for <= 32 output pixels: there every slice's atomics land on the same few
-        // thousand output elements and half as many slices cost less than they save (FlowNet(64), batch 6: deconv1 35 -> 24 us, deconv4 48 -> 38,
-        // conv6 28 -> 23, conv6_1 34 -> 29; the other layers lose with fewer slices -- profiles/r05_conv_fwd_split_target.txt)
+    if (may_split && tiles < 256) {
+        // 768 workgroups; 384 for the transposed convolutions and for <= 32 output pixels (profiles/r05_conv_fwd_split_target.txt, measured
+        // with the slices meeting by atomics; option conv_fwd_split_target overrides)
         const int target = options().conv_fwd_split_target > 0 ? options().conv_fwd_split_target : ((mode == 1 || g.N <= 32) ? 384 : 768);
         splitk = static_cast<int>((target + tiles - 1) / tiles);
         if (splitk > chunks_total) splitk = chunks_total;
@@ -334,33 +403,89 @@ extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const 
     }
     g.chunks = (chunks_total + splitk - 1) / splitk;
     g.splitk = (chunks_total + g.chunks - 1) / g.chunks;
-    g.out_bs = out_batch_stride;
+    pl->tm = tm; pl->tn = tn; pl->classes = classes; pl->mode = mode; pl->kernel = kernel;
+    pl->out_elems = B * K * g.oH * g.oW;
+    g.slot = pl->out_elems;
+    return FFWM_OK;
+}
+
+}  // namespace
+
+// Bytes of workspace with which ffwm_conv2d_forward cuts this layer along its reduction (0: the layer fills the chip unsplit).
+extern "C" int64_t ffwm_conv2d_forward_workspace(int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int kernel, int stride, int pad,
+                                                 int transposed) {
+    ConvPlan pl;
+    if (conv_plan("ffwm_conv2d_forward_workspace", B, C, H, W, K, kernel, stride, pad, transposed, true, &pl) != FFWM_OK) return -1;
+    return pl.g.splitk > 1 ? static_cast<int64_t>(pl.g.splitk) * pl.out_elems * 4 : 0;
+}
+
+extern "C" int ffwm_conv2d_forward(const void* input, const void* weight, const void* bias, void* output, void* output2, int64_t B,
+                                   int64_t C, int64_t H, int64_t W, int64_t K, int kernel, int stride, int pad, int transposed,
+                                   int64_t out_batch_stride, int64_t out2_batch_stride, int act, double negative_slope,
+                                   void* workspace, int64_t workspace_bytes, int dtype, void* stream) {
+    const char* fn = "ffwm_conv2d_forward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(input && weight && output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(act >= 0 && act <= 2, FFWM_ERR_ARG, "%s: bad activation", fn);
+    ConvPlan pl;
+    int rc = conv_plan(fn, B, C, H, W, K, kernel, stride, pad, transposed, workspace != nullptr, &pl);
+    if (rc != FFWM_OK) return rc;
+    if (pl.g.splitk > 1 && (workspace_bytes < static_cast<int64_t>(pl.g.splitk) * pl.out_elems * 4 ||
+                            reinterpret_cast<uintptr_t>(workspace) % 16 != 0)) {
+        rc = conv_plan(fn, B, C, H, W, K, kernel, stride, pad, transposed, false, &pl);        // too small a workspace: one slice
+        if (rc != FFWM_OK) return rc;
+    }
+    ConvGeo& g = pl.g;
+    const int mode = pl.mode, tm = pl.tm, tn = pl.tn, classes = pl.classes;
+    const int64_t oplane = static_cast<int64_t>(g.oH) * g.oW;
+    FFWM_REQUIRE(out_batch_stride >= K * oplane, FFWM_ERR_ARG, "%s: output batch stride smaller than K * Ho * Wo", fn);
+    FFWM_REQUIRE(!output2 || out2_batch_stride >= K * oplane, FFWM_ERR_ARG, "%s: second output's batch stride smaller than K * Ho * Wo", fn);
+    const bool split = g.splitk > 1;
+    g.out_bs = split ? K * oplane : out_batch_stride;
+    g.out2_bs = out2_batch_stride;
     g.act = act; g.slope = static_cast<float>(negative_slope);
-    if (needs_epilogue) *needs_epilogue = g.splitk > 1 ? 1 : 0;
-    FFWM_REQUIRE(g.splitk == 1 || needs_epilogue, FFWM_ERR_ARG, "%s: a split launch needs the needs_epilogue out-parameter", fn);
     hipStream_t st = static_cast<hipStream_t>(stream);
     g.kfast = options().conv_fwd_kfast;
     const dim3 grid(static_cast<unsigned>(g.n_tiles) * static_cast<unsigned>(g.k_tiles), 1u, static_cast<unsigned>(g.splitk * classes));
     const double flops = 2.0 * B * g.Ho * g.Wo * classes * static_cast<double>(g.K) * g.Kd;
     const double bytes = 4.0 * (static_cast<double>(B) * C * H * W + static_cast<double>(K) * g.Kd * classes + static_cast<double>(B) * K * g.oH * g.oW);
     static const char* const kScope[4] = {"conv_fwd_mfma", "conv_fwd_mfma_transposed", "conv_dgrad_mfma_3x3s2", "conv_dgrad_mfma_3x3s1"};
-    LaunchScope ls(kScope[mode], st, bytes, flops);
     const float* x = static_cast<const float*>(input);
     const float* wt = static_cast<const float*>(weight);
     const float* bs = static_cast<const float*>(bias);
-    float* o = static_cast<float*>(output);
+    float* o = split ? static_cast<float*>(workspace) : static_cast<float*>(output);
+    float* o2 = split ? nullptr : static_cast<float*>(output2);
+    {
+        LaunchScope ls(kScope[mode], st, bytes, flops);
 #define FFWM_CONV_LAUNCH(M, RR, SS)                                                                                          \
     do {                                                                                                                   \
-        if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 128, 128>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g); \
-        else if (tm == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 128, 64>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);          \
-        else if (tn == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 64, 128>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);          \
-        else hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 64, 64>), grid, dim3(kBlock), 0, st, x, wt, bs, o, g);                          \
+        if (tm == 128 && tn == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 128, 128>), grid, dim3(kBlock), 0, st, x, wt, bs, o, o2, g); \
+        else if (tm == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 128, 64>), grid, dim3(kBlock), 0, st, x, wt, bs, o, o2, g);          \
+        else if (tn == 128) hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 64, 128>), grid, dim3(kBlock), 0, st, x, wt, bs, o, o2, g);          \
+        else hipLaunchKernelGGL((conv_fwd_kernel<M, RR, SS, 64, 64>), grid, dim3(kBlock), 0, st, x, wt, bs, o, o2, g);                          \
     } while (0)
-    if (mode == 1) FFWM_CONV_LAUNCH(1, 2, 2);
-    else if (mode == 2) FFWM_CONV_LAUNCH(2, 2, 2);
-    else if (mode == 3) FFWM_CONV_LAUNCH(3, 3, 3);
-    else if (kernel == 3) FFWM_CONV_LAUNCH(0, 3, 3);
-    else FFWM_CONV_LAUNCH(0, 4, 4);
+        if (mode == 1) FFWM_CONV_LAUNCH(1, 2, 2);
+        else if (mode == 2) FFWM_CONV_LAUNCH(2, 2, 2);
+        else if (mode == 3) FFWM_CONV_LAUNCH(3, 3, 3);
+        else if (pl.kernel == 3) FFWM_CONV_LAUNCH(0, 3, 3);
+        else FFWM_CONV_LAUNCH(0, 4, 4);
 #undef FFWM_CONV_LAUNCH
+        rc = check_launch(fn);
+        if (rc != FFWM_OK) return rc;
+    }
+    if (!split) return FFWM_OK;
+    // fixed-order reduction of the slices + bias + activation into the destination(s)
+    float* y = static_cast<float*>(output);
+    float* y2 = static_cast<float*>(output2);
+    const bool vec = oplane % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 && out_batch_stride % 4 == 0 &&
+                     (!y2 || (reinterpret_cast<uintptr_t>(y2) % 16 == 0 && out2_batch_stride % 4 == 0));
+    const int64_t total = pl.out_elems / (vec ? 4 : 1);
+    LaunchScope ls("conv_fwd_split_reduce", st, 4.0 * pl.out_elems * (g.splitk + 1.0 + (y2 ? 1 : 0)));
+    if (vec)
+        hipLaunchKernelGGL((conv_split_reduce_kernel<4>), dim3(ew_grid(total)), dim3(kBlock), 0, st, static_cast<const float*>(workspace), bs, y, y2,
+                           total, g.splitk, pl.out_elems, static_cast<int>(K), static_cast<int>(oplane), out_batch_stride, out2_batch_stride, act, g.slope);
+    else
+        hipLaunchKernelGGL((conv_split_reduce_kernel<1>), dim3(ew_grid(total)), dim3(kBlock), 0, st, static_cast<const float*>(workspace), bs, y, y2,
+                           total, g.splitk, pl.out_elems, static_cast<int>(K), static_cast<int>(oplane), out_batch_stride, out2_batch_stride, act, g.slope);
     return check_launch(fn);
 }

@@ -77,11 +77,11 @@ def flow_up(flow, weight, bias, out):
     return out
 
 
-class ZeroArena(object):
-    """The zero-filled accumulation buffers of one forward pass as slices of ONE tensor cleared by one fill: the layers with so few
-    output pixels that the convolution kernel splits its reduction add partial tiles atomically into a zeroed output, and a
-    `torch.zeros` per layer was 17 of the 121 launches of FlowNet's eval forward (85 of 920 us).  The first pass measures, later
-    passes carve; a slice is valid until the next begin()."""
+class Arena(object):
+    """The split-launch workspaces of one forward pass as slices of ONE tensor: a layer with so few output pixels that the convolution
+    kernel cuts its reduction stores the slices' partial sums into a workspace (csrc/conv_fwd.hip: every slot is written before it is
+    read, nothing is zero-filled).  The first pass measures, later passes carve; a slice is valid until the next begin().  (Rounds 2-5
+    zero-filled accumulation buffers here for the atomics of the split: 17 fills, later one, per forward.)"""
 
     def __init__(self):
         self.buf, self.need, self.pos, self.used = None, 0, 0, 0
@@ -90,27 +90,26 @@ class ZeroArena(object):
         self.need = max(self.need, self.used)
         if self.need and (self.buf is None or self.buf.numel() < self.need or self.buf.device != device):
             self.buf = torch.empty(self.need, device=device, dtype=torch.float32)
-        if self.buf is not None:
-            self.buf.zero_()
         self.pos = self.used = 0
 
-    def take(self, *shape):
-        n = 1
-        for d in shape:
-            n *= d
+    def take(self, n, device):
         padded = (n + 63) // 64 * 64            # 256-byte aligned slices
         self.used += padded
-        if self.buf is not None and self.pos + padded <= self.buf.numel():
-            v = self.buf[self.pos:self.pos + n].view(*shape)
+        if self.buf is not None and self.buf.device == device and self.pos + padded <= self.buf.numel():
+            v = self.buf[self.pos:self.pos + n]
             self.pos += padded
             return v
-        return torch.zeros(*shape, device=self.buf.device if self.buf is not None else None, dtype=torch.float32)
+        return torch.empty(n, device=device, dtype=torch.float32)
 
 
-def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None, dst2=None, arena=None):
-    """The hand-written fp32 MFMA convolution (csrc/conv_fwd.hip) with its bias + activation epilogue: fused in the kernel,
-    or -- when the layer has so few output pixels that the launch is cut along the reduction -- as a bias_act pass over
-    the atomically accumulated result.  dst / dst2 as in bias_act (channel slices of concatenation buffers)."""
+ZeroArena = Arena          # the name rounds 2-5 used
+
+
+def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None, dst2=None, arena=None, split=True):
+    """The hand-written fp32 MFMA convolution (csrc/conv_fwd.hip) with its bias + activation epilogue: fused in the kernel, or -- when
+    the layer has so few output pixels that the launch is cut along the reduction -- applied by the fixed-order reduction of the
+    slices' workspace slots.  dst: destination instead of a fresh tensor, dst2: a second destination for the same values; both
+    4-D views whose samples are contiguous (channel slices of concatenation buffers)."""
     B, C, H, W = x.shape
     k = weight.size(2)
     mode = int(transposed)      # 0 conv, 1 ConvTranspose2d(4, 2, 1), 2 / 3: d(input) of Conv2d(3, 2, 1) / Conv2d(3, 1, 1) (x = grad_output)
@@ -122,32 +121,21 @@ def conv_mfma(x, weight, bias, stride, pad, transposed, act, slope=0.2, dst=None
         K = weight.size(0)
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     lib = _lib.load()
-    flag = ctypes.c_int(0)
-    small = B * Ho * Wo * ((K + 63) // 64) * (1 if mode in (1, 2) else 4) < 256 * 64 * 4      # fewer than 256 tiles: split the reduction
-    direct = dst is not None and dst2 is None and not small
-    if direct:
-        y = dst
-    elif not small:
-        y = torch.empty(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
-    elif arena is not None and arena.buf is not None:
-        y = arena.take(B, K, Ho, Wo)
-    else:
-        if arena is not None:
-            arena.take(B, K, Ho, Wo)             # measuring pass
-        y = torch.zeros(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
+    y = dst if dst is not None else torch.empty(B, K, Ho, Wo, device=x.device, dtype=x.dtype)
+    for d in (y, dst2):
+        if d is not None:
+            assert d.shape == (B, K, Ho, Wo) and d.stride(1) == Ho * Wo and d.stride(3) == 1 and d.stride(2) == Wo
+    ws = None
+    if split:
+        need = lib.ffwm_conv2d_forward_workspace(B, C, H, W, K, k, stride, pad, mode)
+        if need > 0:
+            ws = arena.take(need // 4, x.device) if arena is not None else torch.empty(need // 4, device=x.device, dtype=torch.float32)
     _lib.check(lib.ffwm_conv2d_forward(x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                       B, C, H, W, K, k, stride, pad, mode, y.stride(0), act, float(slope),
-                                       1 if small else 0, ctypes.byref(flag), _lib.F32, _stream(x)), "ffwm_conv2d_forward")
-    if flag.value:                       # split launch: bias + activation as a pass over the accumulated sums
-        if dst is None and dst2 is None:
-            return bias_act(y, bias, act, slope=slope)
-        bias_act(y, bias, act, y=dst if dst is not None else y, y2=dst2, slope=slope)
-        return dst if dst is not None else y
-    if direct or (dst is None and dst2 is None):
-        return y
-    # fused epilogue already applied: only the extra destination(s) remain to be written
-    bias_act(y, None, NONE, y=dst, y2=dst2)
-    return dst if dst is not None else y
+                                       None if dst2 is None else dst2.data_ptr(), B, C, H, W, K, k, stride, pad, mode, y.stride(0),
+                                       0 if dst2 is None else dst2.stride(0), act, float(slope),
+                                       None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * 4,
+                                       _lib.F32, _stream(x)), "ffwm_conv2d_forward")
+    return y
 
 
 class FoldedFlowNet(object):
@@ -156,7 +144,7 @@ class FoldedFlowNet(object):
         # layers thinner than this stay with the vendor kernel (measured slower on csrc/conv_fwd.hip); the fixture test lowers it
         # to 1 so that EVERY stride-2 / transposed / small-plane layer of a narrow FlowNet runs on the hand-written kernel
         self.mfma_min_channels = int(mfma_min_channels)
-        self.arena = ZeroArena()
+        self.arena = Arena()
         if net.training:
             raise ValueError("FoldedFlowNet folds eval-mode BatchNorm statistics: call net.eval() first")
         p = next(net.parameters())

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define FFWM_ABI_VERSION 4
+#define FFWM_ABI_VERSION 5
 
 typedef enum {
     FFWM_OK = 0,
@@ -376,15 +376,23 @@ int ffwm_flow_up_backward(const void* grad_out, const void* weight, void* grad_x
                           int64_t grad_out_batch_stride, int dtype, void* stream);
 
 /* fp32 MFMA implicit-GEMM convolution forward, NCHW, for the layers the vendor library wraps in layout transposes:
- * nn.Conv2d(C, K, kernel 3 or 4, stride 1 or 2, pad) or -- transposed != 0 -- nn.ConvTranspose2d(C, K, 4, 2, 1)
- * (weight [C, K, 4, 4]) of models/base_networks.py:12-31,64-112.  output sample b starts at output + b * out_batch_stride
- * (a channel slice of a concatenation buffer is a valid destination).  act: 0 none, 1 LeakyReLU(negative_slope), 2 tanh,
- * applied after the bias.  allow_split != 0 lets a layer with few output pixels be cut along its reduction over several
- * workgroups; *needs_epilogue is then set to 1: the caller must have ZERO-FILLED the output, and bias / activation were NOT
- * applied (run ffwm_bias_act_forward afterwards).  Exact fp32 (v_mfma_f32_32x32x2_f32). */
-int ffwm_conv2d_forward(const void* input, const void* weight, const void* bias, void* output, int64_t B, int64_t C, int64_t H,
-                        int64_t W, int64_t K, int kernel, int stride, int pad, int transposed, int64_t out_batch_stride,
-                        int act, double negative_slope, int allow_split, int* needs_epilogue, int dtype, void* stream);
+ * nn.Conv2d(C, K, kernel 3 or 4, stride 1 or 2, pad) or -- transposed == 1 -- nn.ConvTranspose2d(C, K, 4, 2, 1)
+ * (weight [C, K, 4, 4]) of models/base_networks.py:12-31,64-112; transposed == 2 / 3: the data gradient of Conv2d(3, 2, 1) /
+ * Conv2d(3, 1, 1) with `input` = grad_output and the layer's own weight tensor.  output sample b starts at
+ * output + b * out_batch_stride (a channel slice of a concatenation buffer is a valid destination); output2 (NULL: none) is a
+ * second destination that receives the same values (the decoder's concatenation slice next to the skip tensor).  act: 0 none,
+ * 1 LeakyReLU(negative_slope), 2 tanh, applied after the bias.  Exact fp32 (v_mfma_f32_32x32x2_f32).
+ * workspace (ABI 5; NULL: never split): a layer with so few output pixels that its tiles do not fill the chip is cut along its
+ * REDUCTION when `workspace_bytes >= ffwm_conv2d_forward_workspace(...)` (16-byte aligned, contents irrelevant, nothing to
+ * zero-fill): every slice stores its partial sums into its own slot and a second launch adds the slots in slice order and
+ * applies bias / activation -- no float atomics, so the output is bit-reproducible.  (ABI <= 4 added the slices atomically into
+ * a caller-zeroed output and left bias / activation to ffwm_bias_act_forward.) */
+int64_t ffwm_conv2d_forward_workspace(int64_t B, int64_t C, int64_t H, int64_t W, int64_t K, int kernel, int stride, int pad,
+                                      int transposed);
+int ffwm_conv2d_forward(const void* input, const void* weight, const void* bias, void* output, void* output2, int64_t B, int64_t C,
+                        int64_t H, int64_t W, int64_t K, int kernel, int stride, int pad, int transposed, int64_t out_batch_stride,
+                        int64_t out2_batch_stride, int act, double negative_slope, void* workspace, int64_t workspace_bytes,
+                        int dtype, void* stream);
 
 /* fp32 MFMA weight gradient of the convolutions ffwm_conv2d_forward serves, one launch, no layout transposes:
  *   grad_weight[k][(c, r, s)] += sum_{b, oy, ox} rows[b, k, oy, ox] * gathered[b, c, oy * stride + r - pad, ox * stride + s - pad]

@@ -38,7 +38,7 @@ def test_binding_table_matches_header():
 
 def test_abi_version(hiplib):
     from ffwm_amd import _lib
-    assert hiplib.ffwm_abi_version() == _lib.ABI_VERSION == 4          # round 5: ffwm_adam_step_device's learning-rate override counts from 0.0 (negative = none)
+    assert hiplib.ffwm_abi_version() == _lib.ABI_VERSION == 5          # round 6: ffwm_conv2d_forward takes a workspace (split reduction without atomics) and a second destination
 
 
 def test_argument_errors_are_reported_before_launch(hiplib):

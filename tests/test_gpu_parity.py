@@ -1788,26 +1788,59 @@ def test_ffwm_generator_levels_in_one_launch_match_the_per_level_path():
     (6, 1024, 2, 2, 512, 4, 2, 1, True),        # deconv5
     (6, 66, 32, 32, 32, 4, 2, 1, True),         # deconv1
     (2, 5, 7, 9, 3, 4, 2, 1, True),             # ragged transposed
+    (2, 8, 50, 50, 100, 3, 1, 1, False),        # fused bias, K >= 64, B * Ho * Wo % 32 != 0 (5000 pixels: 79 tiles of 64 -> unsplit)
+    (3, 16, 50, 50, 68, 3, 1, 1, False),        # K % 8 in 1..4 beside a ragged last pixel block
+    (4, 12, 45, 45, 70, 3, 2, 1, False),        # stride 2, 23 x 23 planes
+    (2, 24, 25, 25, 100, 4, 2, 1, True),        # transposed, ragged pixel blocks in every parity class
 ])
 def test_conv2d_forward_mfma_matches_aten(case):
     """csrc/conv_fwd.hip against ATen's float64 convolution: conv + bias + LeakyReLU, plain and transposed, fused and
-    split-reduction launches, and the write into a channel slice of a wider buffer."""
+    split-reduction launches (round 6: workspace slots + a fixed-order reduction instead of atomics), the write into a channel
+    slice of a wider buffer, a second destination, and bit-identical results from repeated calls."""
     from ffwm_amd import flownet_eval
     B, C, H, W, K, k, stride, pad, transposed = case
     g = _gen(sum(case[:5]))
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(*((C, K, k, k) if transposed else (K, C, k, k)), generator=g) / (C * k * k) ** 0.5
-    b = torch.randn(K, generator=g)
+    b = torch.randn(K, generator=g) * 3                 # a lost bias must be visible at the tolerance
     conv = F.conv_transpose2d if transposed else F.conv2d
     ref = F.leaky_relu(conv(x.double(), w.double(), b.double(), stride, pad), 0.2)
     xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
     y = flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2)
     tol = 2e-5 * (1 + ref.abs().max().item())
     assert (y.cpu().double() - ref).abs().max().item() <= tol
-    buf = torch.full((B, K + 5, ref.size(2), ref.size(3)), 7.0, device=DEV)
-    flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2, dst=buf[:, 2:2 + K])
-    assert (buf[:, 2:2 + K].cpu().double() - ref).abs().max().item() <= tol
-    assert (buf[:, :2] == 7).all() and (buf[:, 2 + K:] == 7).all()
+    # the same call again: no float atomics anywhere, so bit for bit the same
+    assert torch.equal(y, flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2))
+    # never split: the fused epilogue for every case (incl. the ragged tiles of the few-pixel layers)
+    y1 = flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2, split=False)
+    assert (y1.cpu().double() - ref).abs().max().item() <= tol
+    for split in (True, False):
+        buf = torch.full((B, K + 5, ref.size(2), ref.size(3)), 7.0, device=DEV)
+        buf2 = torch.full((B, K + 3, ref.size(2), ref.size(3)), 9.0, device=DEV)
+        flownet_eval.conv_mfma(xd, wd, bd, stride, pad, transposed, flownet_eval.LRELU, 0.2, dst=buf[:, 2:2 + K], dst2=buf2[:, 3:], split=split)
+        assert (buf[:, 2:2 + K].cpu().double() - ref).abs().max().item() <= tol
+        assert (buf[:, :2] == 7).all() and (buf[:, 2 + K:] == 7).all()
+        assert torch.equal(buf2[:, 3:], buf[:, 2:2 + K]) and (buf2[:, :3] == 9).all()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+def test_conv2d_forward_mfma_tile_variants_keep_the_bias_on_ragged_tiles(variant):
+    """Every workgroup tile shape (64 / 128 output channels x 64 / 128 pixels) with a fused bias on a layer whose last pixel block and
+    last channel tile are both ragged: K = 100 (TM = 128: the second accumulator's channels 100..127 are masked), 2 * 37 * 37 = 2738
+    pixels (% 32 = 18).  ADVICE r5: the bias fetch (ds_bpermute) ran behind the per-lane range tests and lost the bias of the
+    channels whose source lane was masked."""
+    from ffwm_amd import _lib, flownet_eval
+    g = _gen(500 + variant)
+    x = torch.randn(2, 20, 37, 37, generator=g)
+    w = torch.randn(100, 20, 3, 3, generator=g) / 180 ** 0.5
+    b = torch.randn(100, generator=g) * 3
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1), 0.2)
+    _lib.set_option("conv_tile_variant", variant)
+    try:
+        y = flownet_eval.conv_mfma(x.to(DEV), w.to(DEV), b.to(DEV), 1, 1, False, flownet_eval.LRELU, 0.2, split=False)
+    finally:
+        _lib.set_option("conv_tile_variant", 0)
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * (1 + ref.abs().max().item())
 
 
 @pytest.mark.parametrize("own_backward", [False, True])
