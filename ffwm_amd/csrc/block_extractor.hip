@@ -1161,15 +1161,25 @@ be_bwd_tile_kernel(const float* __restrict__ src, const float* __restrict__ flow
 //   * a pixel whose own window holds a value >= thr ("big": the sample missed the tail, or NaN / Inf) does not use the box at all:
 //     its taps go to grad_source with global float atomics, exactly like a pixel of be_bwd_far2_kernel -- so a bad estimate costs
 //     time, never correctness, and non-finite gradients propagate as in the reference;
-//   * overflow is impossible: every contribution is a convex combination of window values (|v| <= max|g| < thr), and a cell of the
-//     box can only be reached by `fit` pixels within H of it -- at most (2 H + K + 1)^2 = 144 of them per channel: 144 x 2^23 < 2^31;
-//   * rounding: one unit = 2^-e <= thr / 2^22, i.e. <= 1e-6 of the tile's largest gradient per contribution (the reference's own
-//     float atomics round each partial sum to 6e-8 of ITS magnitude -- the same order once a cell has a few contributions).
+//   * overflow: every contribution is a convex combination of window values (|v| <= max|g| < thr), i.e. below 2^bits units, and a
+//     cell (X, Y) is reached exactly by the `fit` pixels whose neighbourhood origin (u0, v0) lies in [X - K, X] x [Y - K, Y]: (K + 1)^2
+//     origins.  `fit` bounds where a pixel's taps land, NOT how far the flow carried it there, so ANY number of the tile's 64 x 32
+//     pixels can share an origin (a contracting flow): round 5 assumed <= 144 per cell and wrapped silently beyond.  The
+//     block therefore COUNTS, once (the flow is the same for all its channels), the pixels per origin in the accumulator box itself
+//     (one ds_add_u32 per pixel), takes the maximum cmax, and sizes the scale for the real population:
+//     bits = min(23, 31 - ceil_log2((K + 1)^2) - bitlength(cmax)), so that (K + 1)^2 cmax 2^bits < 2^31.  K = 3: 23 bits up to 15 pixels
+//     per origin (a random U[-2, 2) flow reaches 6-8), 22 up to 31, ... 15 when all 2048 pixels collapse onto one cell -- the sum is
+//     then that much larger, so its relative error is unchanged.  The border folds (out-of-image cells onto the clamped cell) add up
+//     to a whole box in 64-bit and send what does not fit a cell straight to grad_source;
+//   * rounding: one unit = 2^-e <= thr / 2^(bits - 1), i.e. <= 1e-6 of the tile's largest gradient per contribution at 23 bits (the
+//     reference's own float atomics round each partial sum to 6e-8 of ITS magnitude -- the same order once a cell has a few
+//     contributions).
 template <int K, int RH, int H, bool FUSED = false, bool ABL = false, int FIXED = 0>          // FIXED: 0 double cells, 1 fixed-point, 2 fixed-point at 5 waves per SIMD
 __global__ void __launch_bounds__(kBlock, (RH == 32 && K <= 3 && H <= 4 ? (FIXED == 2 ? 5 : 4) : 2))
 be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ gout,
                    float* __restrict__ gsrc, float* __restrict__ gflow, int C, int Hs, int Ws, int Hf, int Wf,
-                   int ntx, int nty, int cslabs, int cs, int remap, const float* __restrict__ attn = nullptr, int ablate_arg = 0) {
+                   int ntx, int nty, int cslabs, int cs, int remap, const float* __restrict__ attn = nullptr, int ablate_arg = 0,
+                   int flush_rmw = 0) {
     using T = float;
     // bench-only ablation (tools/be_bwd_ablate.py; profiles/r04_be_bwd_ablation.txt): 1 = no LDS atomics, 2 = no flush atomics,
     // 4 = no d(flow) arithmetic.  A compile-time zero in the product instantiations.
@@ -1253,6 +1263,52 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
     stage(sp);
     __syncthreads();
 
+    // FIXED: the population bound (kernel head).  Every `fit` pixel of the tile adds 1 to the box cell of its neighbourhood origin; the
+    // block maximum of those counts sizes the fixed-point scale of every channel.  Same `regular` / `fit` arithmetic as the hot loop.
+    int fx_bits = 23;
+    if constexpr (FIXED != 0) {
+        __shared__ int cred[NW];
+        if (inside && xin) {
+#pragma unroll 1
+            for (int r = 0; r < PPT; ++r) {
+                const int yf = y0 + wave + r * NW;
+                if (yf >= Hf) break;
+                const unsigned fo = (static_cast<unsigned>(yf) * Wf + xf) * E;
+                const T fx0 = buf_ld<T>(rfl, fo), fy0 = buf_ld<T>(rfl, fo + static_cast<unsigned>(fplane * E));
+                T flx0 = 0, fly0 = 0;
+                bool regular = true;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const T dx = (fx0 + static_cast<T>(j - K / 2)) + static_cast<T>(xf);
+                    const T dy = (fy0 + static_cast<T>(j - K / 2)) + static_cast<T>(yf);
+                    const T fxl = floor_t(dx), fyl = floor_t(dy);
+                    if (j == 0) { flx0 = fxl; fly0 = fyl; }
+                    regular = regular & (fxl == flx0 + static_cast<T>(j)) & (fyl == fly0 + static_cast<T>(j));
+                }
+                const T lim = static_cast<T>(1 << 20);
+                regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);
+                const int au = (regular ? static_cast<int>(flx0) : 0) - ax0, av = (regular ? static_cast<int>(fly0) : 0) - ay0;
+                if (regular && static_cast<unsigned>(au) <= static_cast<unsigned>(AP - 1 - K) && static_cast<unsigned>(av) <= static_cast<unsigned>(AH - 1 - K))
+                    __hip_atomic_fetch_add(A + av * AP + au, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        int cm = 0;
+        for (int i = threadIdx.x; i < NA; i += kBlock) {
+            cm = max(cm, static_cast<int>(A[i]));
+            A[i] = 0;
+        }
+        cm = wave_max(cm);
+        if (lane == 0) cred[wave] = cm;
+        __syncthreads();
+        cm = cred[0];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) cm = max(cm, cred[w2]);
+        constexpr int KB = (K + 1) * (K + 1) <= 4 ? 2 : ((K + 1) * (K + 1) <= 16 ? 4 : ((K + 1) * (K + 1) <= 32 ? 5 : 6));   // ceil_log2((K + 1)^2), K <= 7
+        const int blen = 32 - __clz(cm);                     // cm < 2^blen (cm = 0: 0)
+        fx_bits = __builtin_amdgcn_readfirstlane(min(23, 31 - KB - blen));        // block-uniform: a scalar register
+    }
+
     T gxa[PPT], gya[PPT];
 #pragma unroll
     for (int r = 0; r < PPT; ++r) gxa[r] = gya[r] = 0;
@@ -1313,8 +1369,8 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                 thr = 0;                                    // nothing usable (all zeros, Inf): every pixel takes the exact per-tap path
                 fx_scale = fx_inv = 1;
             } else {
-                fx_scale = ldexpf(1.f, 23 - ex);
-                fx_inv = ldexpf(1.f, ex - 23);
+                fx_scale = ldexpf(1.f, fx_bits - ex);        // |v| < thr = f 2^ex  ->  |v| fx_scale < 2^fx_bits
+                fx_inv = ldexpf(1.f, ex - fx_bits);
             }
         }
         // software pipeline: the flow vector and the k x k grad_output window of pixel row r+1 are
@@ -1541,37 +1597,58 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
             gxa[r] += gx;       // r is wave-uniform: indexed VGPR access (s_set_gpr_idx), no scratch
             gya[r] += gy;
         }
+        if (flush_rmw) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a "big" pixel's per-tap atomics have reached L2 before any interior cell is read back
         __syncthreads();                       // every contribution of channel c is in A
         // border tiles: fold the out-of-image cells onto the border cell they clamp to -- columns
         // first (one thread per accumulator row), then rows (one thread per column)
+        // (FIXED: the sums run in 64-bit -- a fold can collect a large part of the box -- and a total that does not fit the 32-bit cell
+        // goes straight to the clamped cell of grad_source)
+        using FoldT = typename std::conditional<FIXED != 0, long long, double>::type;
+        T* gfold = gp + static_cast<size_t>(c - c0) * splane;
+        auto fold_into = [&](AccT& cell, FoldT s, int cy, int cx) {
+            if constexpr (FIXED != 0) {
+                const long long t = static_cast<long long>(cell) + s;
+                if (t >= -2147483647LL && t <= 2147483647LL) {
+                    cell = static_cast<int>(t);
+                } else {
+                    cell = 0;
+                    const int gy = min(max(cy, 0), Hs - 1), gx = min(max(cx, 0), Ws - 1);
+                    atomic_add(gfold + static_cast<size_t>(gy) * Ws + gx, static_cast<T>(t) * fx_inv);
+                }
+            } else {
+                cell += s;
+            }
+        };
         if (foldL || foldR) {
             if (threadIdx.x < AH) {
                 AccT* arow = A + threadIdx.x * AP;
+                const int cy = ay0 + static_cast<int>(threadIdx.x);
                 if (foldL) {
-                    AccT s = 0;
+                    FoldT s = 0;
                     for (int u = 0; u < -ax0; ++u) s += arow[u];
-                    arow[-ax0] += s;
+                    fold_into(arow[-ax0], s, cy, 0);
                 }
                 if (foldR) {
-                    AccT s = 0;
+                    FoldT s = 0;
                     for (int u = Ws - ax0; u < AP; ++u) s += arow[u];
-                    arow[Ws - 1 - ax0] += s;
+                    fold_into(arow[Ws - 1 - ax0], s, cy, Ws - 1);
                 }
             }
             __syncthreads();
         }
         if (foldT || foldB) {
-            if (threadIdx.x < AP) {
+            const int cx = ax0 + static_cast<int>(threadIdx.x);
+            if (threadIdx.x < AP && cx >= 0 && cx < Ws) {       // (the out-of-image columns are already part of the border columns)
                 AccT* acol = A + threadIdx.x;
                 if (foldT) {
-                    AccT s = 0;
+                    FoldT s = 0;
                     for (int v = 0; v < -ay0; ++v) s += acol[v * AP];
-                    acol[-ay0 * AP] += s;
+                    fold_into(acol[-ay0 * AP], s, 0, cx);
                 }
                 if (foldB) {
-                    AccT s = 0;
+                    FoldT s = 0;
                     for (int v = Hs - ay0; v < AH; ++v) s += acol[v * AP];
-                    acol[(Hs - 1 - ay0) * AP] += s;
+                    fold_into(acol[(Hs - 1 - ay0) * AP], s, Hs - 1, cx);
                 }
             }
             __syncthreads();
@@ -1579,12 +1656,54 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
         {
             // flush + restage in one sweep over the box: one global atomic per non-zero in-image cell of
             // channel c (then the cell is cleared), and the same cell of channel c+1's clamp-extended
-            // source goes into S -- an in-image cell has the same plane offset in both
+            // source goes into S -- an in-image cell has the same plane offset in both.
+            // Round 6 experiment (flush_rmw, option be_bwd_flush = 1, OFF): the INTERIOR cells -- box columns [2H, TW) x rows [2H, TH), i.e.
+            // the tile shrunk by H: no other block's box reaches them, the far kernel's atomics are a finished earlier launch -- added by a
+            // plain read-modify-write, with ALL old values of a thread's cells requested up front through L2 (sc0 sc1).  Measured on one
+            // box, cfg-5 (profiles/r06_be_flush_rmw_negative.txt): 432 -> 577 us random, 414 -> 565 us smooth; block attention 401 -> 538.
+            // Like round 4's attempt (loads issued where needed: 597 -> 679): a return-less atomic is ONE write transaction resolved at
+            // L2, the read-modify-write a round trip per cell that the four resident blocks do not cover.  The atomics stay.
             T* gplane = gp + static_cast<size_t>(c - c0) * splane;
             const rsrc_t rn = make_rsrc(sp + static_cast<size_t>(more ? c + 1 - c0 : c - c0) * splane, more ? sbytes : 0u);
+            const rsrc_t rq = make_rsrc(gplane, sbytes);
             if (more) sample_issue(op + oplane);
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));
+            constexpr int NCH = (NA + kBlock - 1) / kBlock;
+            if (flush_rmw) {
+                T old[NCH];
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int idx = q * kBlock + tid;
+                    const int arow = idx / AP, acol = idx - arow * AP;
+                    const int cx = ax0 + acol, cy = ay0 + arow;
+                    const bool interior = static_cast<unsigned>(acol - 2 * H) < static_cast<unsigned>(TW - 2 * H) &&
+                                          static_cast<unsigned>(arow - 2 * H) < static_cast<unsigned>(TH - 2 * H) && cx < Ws && cy < Hs;
+                    old[q] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(
+                        rq, interior ? (static_cast<unsigned>(cy) * Ws + cx) * E : 0xFFFFFFF0u, 0, 17));
+                }
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int idx = q * kBlock + tid;
+                    if (idx < NA) {
+                        const int arow = idx / AP, acol = idx - arow * AP;
+                        const int cx = ax0 + acol, cy = ay0 + arow;
+                        const int gy = min(max(cy, 0), Hs - 1), gx = min(max(cx, 0), Ws - 1);
+                        const unsigned off = static_cast<unsigned>(gy) * Ws + gx;
+                        const bool in_img = gy == cy && gx == cx;
+                        const bool interior = static_cast<unsigned>(acol - 2 * H) < static_cast<unsigned>(TW - 2 * H) &&
+                                              static_cast<unsigned>(arow - 2 * H) < static_cast<unsigned>(TH - 2 * H);
+                        const T nx = buf_ld<T>(rn, off * E);
+                        const T v = FIXED != 0 ? static_cast<T>(A[idx]) * fx_inv : static_cast<T>(A[idx]);
+                        A[idx] = 0;
+                        if (v != 0 && in_img && !(ablate & 2)) {
+                            if (interior) gplane[off] = old[q] + v;
+                            else atomic_add(gplane + off, v);
+                        }
+                        if (more) S[idx] = nx;
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int i0 = 0; i0 < NA; i0 += 4 * kBlock) {
                 T st[4];
@@ -1605,12 +1724,11 @@ be_bwd_tile2_kernel(const float* __restrict__ src, const float* __restrict__ flo
                     if (idx < NA) {
                         const T v = FIXED != 0 ? static_cast<T>(A[idx]) * fx_inv : static_cast<T>(A[idx]);
                         A[idx] = 0;
-                        // (measured, round 4: a plain read-modify-write for the 56 x 24 cells no other block can reach is SLOWER than the
-                        // return-less atomic -- 679 vs 597 us: the atomic is one write transaction resolved at L2, the RMW a round trip)
                         if (v != 0 && off[q] != 0xFFFFFFFFu && !(ablate & 2)) atomic_add(gplane + off[q], v);
                         if (more) S[idx] = st[q];
                     }
                 }
+            }
             }
             if (more) sample_max();
         }
@@ -1926,6 +2044,7 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
                 LaunchScope ls(shared_cells ? "block_extractor_bwd_tile2" : "block_extractor_bwd_tile", st, bytes);
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
                 const bool fixed_cells = options().be_bwd_fixed != 2;        // 32-bit fixed-point accumulator cells (round 5); 2 = the double cells of rounds 2-4
+                const int flush_rmw = options().be_bwd_flush == 1 ? 1 : 0;   // 1 = interior cells by read-modify-write (round 6 experiment: SLOWER, profiles/r06_be_flush_rmw_negative.txt); 0 = every cell by a global atomic
 #define FFWM_BE_TILE(KERNEL, KK, RR, HH)                                                                      \
     hipLaunchKernelGGL((KERNEL<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,              \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
@@ -1933,11 +2052,11 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
 #define FFWM_BE_TILE2(KK, RR, HH)                                                                             \
     hipLaunchKernelGGL((be_bwd_tile2_kernel<KK, RR, HH>), dim3(grid), dim3(kBlock), 0, st, (const float*)src, \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
-                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, 0)
+                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, 0, flush_rmw)
 #define FFWM_BE_TILE2F(KK, RR, HH)                                                                            \
     hipLaunchKernelGGL((be_bwd_tile2_kernel<KK, RR, HH, false, false, 1>), dim3(grid), dim3(kBlock), 0, st, (const float*)src, \
                        (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs,  \
-                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, 0)
+                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, 0, flush_rmw)
 #define FFWM_BE_TILE_K(KK)                                                                                    \
     case KK:                                                                                                  \
         if (shared_cells) {                                                                                   \
@@ -1955,11 +2074,11 @@ int launch_bwd(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, in
                     if (fixed_cells)
                         hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, false, true, 1>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,
                                            (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs, (int)Ws, (int)Hf,
-                                           (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate);
+                                           (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate, flush_rmw);
                     else
                         hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, false, true, 0>), dim3(grid), dim3(kBlock), 0, st, (const float*)src,
                                            (const float*)flow, (const float*)gout, (float*)gsrc, (float*)gflow, (int)C, (int)Hs, (int)Ws, (int)Hf,
-                                           (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate);
+                                           (int)Wf, ntx, nty, cslabs, cs, remap, (const float*)nullptr, options().ablate, flush_rmw);
                 } else {
                     switch (k) { FFWM_BE_TILE_K(1) FFWM_BE_TILE_K(2) FFWM_BE_TILE_K(3) FFWM_BE_TILE_K(4) }
                 }
@@ -2156,18 +2275,19 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
             {
                 LaunchScope ls("block_attention_bwd_tile2", st, bytes);
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
+                const int flush_rmw = options().be_bwd_flush == 1 ? 1 : 0;
                 if (h == 8)
                     hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 8, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
                                        gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
-                                       options().xcd_remap, wts);
+                                       options().xcd_remap, wts, 0, flush_rmw);
                 else if (options().be_bwd_fixed != 2)
                     hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, true, false, 1>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
                                        gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
-                                       options().xcd_remap, wts, 0);
+                                       options().xcd_remap, wts, 0, flush_rmw);
                 else
                     hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
                                        gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
-                                       options().xcd_remap, wts);
+                                       options().xcd_remap, wts, 0, flush_rmw);
             }
             if (int rc = check_launch("ffwm_block_attention_backward(tile)")) return rc;
             if (gw) {

@@ -365,6 +365,55 @@ def test_block_extractor_backward_fixed_point_cells_tail_cases(oracle, kind, fix
             assert float((got[fin] - ref[fin]).abs().max()) <= 2e-5 * scale, (kind, float((got[fin] - ref[fin]).abs().max()) / scale)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("kind", ["tile_collapse", "row_collapse", "corner_collapse"])
+def test_block_extractor_backward_fixed_point_cells_contracting_flow(oracle, kind, fused):
+    """`fit` bounds where a pixel's taps land, not how many pixels land there.  A flow that carries every pixel of a 64 x 32
+    tile onto the tile's centre (all 2048 `fit`, all on the same 4 x 4 cells) with a one-signed grad_output wrapped round 5's int32 cells
+    (sized for <= 144 pixels per cell); the block now counts the pixels per neighbourhood origin and sizes the scale for them.
+    row_collapse: every row of a tile onto one row (32 pixels per origin); corner_collapse: towards the image corner, so that the border
+    FOLD collects the sums (64-bit, overflow straight to grad_source).  Also through the block attention backward (FUSED)."""
+    from ffwm_amd import ops, _lib
+    g = _gen(77)
+    B, C, H, W = 1, 3, 160, 192                     # tiles of 64 x 32 flow pixels: 3 x 5
+    src = torch.rand(B, C, H, W, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    jitter = torch.rand(2, H, W, generator=g) * 0.5 + 0.2                              # keep the taps off the integers
+    if kind == "tile_collapse":
+        fx = (xs // 64) * 64 + 30 - xs
+        fy = (ys // 32) * 32 + 14 - ys
+    elif kind == "row_collapse":
+        fx = torch.zeros(H, W)
+        fy = (ys // 32) * 32 + 14 - ys
+    else:
+        fx = torch.where(xs < 64, -xs - 2, torch.zeros(H, W))                          # the first tile column onto x < 0: folds onto column 0
+        fy = torch.where(ys < 32, -ys - 2, torch.zeros(H, W))
+    flow = torch.stack((fx + jitter[0], fy + jitter[1]))[None].contiguous()
+    if fused:
+        gout = torch.rand(B, C, H, W, generator=g) + 0.5
+        attn = torch.rand(B, 9, H, W, generator=g) + 0.5
+        go = (gout[:, :, :, None, :, None] / 9 * attn.view(B, 1, 3, 3, H, W).permute(0, 1, 4, 2, 5, 3)).reshape(B, C, 3 * H, 3 * W)
+    else:
+        go = torch.rand(B, C, 3 * H, 3 * W, generator=g) + 0.5                         # one sign: nothing cancels
+    gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go.contiguous(), 3)
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    if fused:
+        gs, gf = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV)
+        ops.block_attention_backward(src.to(DEV), flow.to(DEV), attn.to(DEV), gout.to(DEV), 3, gs, gf, None)
+    else:
+        gs, gf = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV)
+        ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go.to(DEV), 3, gs, gf)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    assert any("tile2" in k or "block_attention_bwd" in k for k in _lib.prof_collect())
+    for got, ref in ((gs.cpu(), gs_ref), (gf.cpu(), gf_ref)):
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-5 * scale, (kind, float((got - ref).abs().max()) / scale)
+    if kind == "tile_collapse" and not fused:
+        assert float(gs_ref.max()) > 1000.0            # a cell really collects ~2000 pixels
+
+
 def test_block_extractor_generic_kernel_matches_tiled(oracle):
     from ffwm_amd import ops, _lib
     src, flow, go, k = _be_inputs(BE_CASES[1], torch.float32)
