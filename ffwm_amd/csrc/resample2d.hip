@@ -1121,6 +1121,404 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
     }
 }
 
+// ------------------------------------------------------------------------------------ K2, owned tiles (round 6)
+// rs_bwd1_owned_kernel + rs_bwd1_far_kernel: d_input1 WITHOUT global atomics on the regular path.
+//
+// The tile kernel above lets the boxes of neighbouring blocks overlap and folds every non-zero box cell into grad_input1 with a
+// global atomic: ~1.8 per pixel and channel, which issue at about one lane per clock and CU -- 445 us of the 1.23 ms at
+// [8, 64, 512, 512] (profiles/r05_rs_bwd1_ablation.txt), an order of magnitude more per lane than an LDS atomic (4.3 clk per wave).
+// Here every cell of grad_input1 has exactly ONE owner: a block of 8 waves owns an OW x OH tile of the input plane (54 x 54 at ks 4)
+// and visits the 64 x 64 PIXELS of the tile grown by M = 3 + ks/2 -- every pixel whose floor offset is within +-3 of its own position
+// and can therefore reach the tile.  A pixel near a tile edge is visited by up to four blocks (x 1.4 pixel visits, x 1.4 LDS
+// atomics); each keeps the taps that land in ITS tile (after the reference's clamp to the image).  A tap ROW outside the tile is skipped
+// under the exec mask, a tap COLUMN outside it goes to a per-lane dump cell behind the box (a shared ring cell was the first version:
+// the 5 + 5 margin lanes of every wave row met on it and every LDS atomic paid a 5-way same-address conflict -- 2.0 ms instead of 0.9).  The box is flushed with plain coalesced
+// stores: `=` when the caller says grad_input1 is uninitialised (reference_quirk bit 1: the zero-fill of the reference's wrapper,
+// models/external_function.py:137, disappears as well), a read-modify-write otherwise.  No cell is touched by two blocks.
+// rs_bwd1_far_kernel is the exact complement, at (pixel, tap) granularity: a pair whose pixel lies OUTSIDE the region of the tap's
+// owner tile (flow wider than +-3, NaN, huge) goes out with a global atomic, after the tiles.  For a flow net's field it reads the flow
+// and returns.
+//
+// Cells: 32-bit fixed point (see rs_bwd1_tile_kernel).  The scale of a 4-channel group is 2^(bits - e) with max|g| < 2^e taken over the
+// block's pixels (all loaded before the first add) and bits = 31 - bitlength(pop): `pop` is the largest number of taps that meet on
+// one own cell, COUNTED once per block in the box itself (the flow is the same for every channel) -- so pop 2^bits < 2^31 holds for
+// any flow, contracting ones included, and a typical field gets 25-26 bits where the tile kernel's worst-case bound gives 21.
+// A group with a NaN / Inf gradient scatters its own-tile taps with global atomics behind a flush of zeros.
+// Weights: w_tap / sum = (wy / sum_y) (wx / sum_x) held as 4 + 4 factors per pixel (8 registers instead of 16): sum = sum_y sum_x up to
+// rounding (resample2d_kernel.cu:87 adds the 16 products), SAFE_DIV's zero case kept per factor.
+template <int HALF>
+struct RsOwn {
+    static constexpr int NT = 2 * HALF;
+    static constexpr int D = 3;                    // |floor offset| served on the fast path
+    static constexpr int M = D + HALF;             // margin of the pixel region around the owned tile
+    static constexpr int RW = 64, RH = 64;         // pixel region of a block
+    static constexpr int OW = RW - 2 * M, OH = RH - 2 * M;
+    static constexpr int BP = OW + 2, BH = OH + 2; // box = tile + a ring that swallows what belongs to other tiles
+    static constexpr int NCELL = BP * BH + 64;     // + one dump cell per lane: where a tap of another block's tile goes (never read)
+    static constexpr int DUMP = BP * BH;
+    static constexpr int THREADS = 512, NW = THREADS / 64, PPT = RH / NW;
+};
+
+// floor offset of a pixel's tap window: origin cell (u0, v0) of its NT x NT taps; ok = finite and small enough for int arithmetic.
+// ONE definition for the tile and the far kernel: their predicates must agree bit for bit.
+template <int HALF>
+__device__ __forceinline__ bool rs_origin(float dx, float dy, int x, int y, int& u0, int& v0) {
+    const float flx = floor_t(static_cast<float>(x) + dx), fly = floor_t(static_cast<float>(y) + dy);
+    const float lim = static_cast<float>(1 << 20);
+    const bool ok = (flx > -lim) && (flx < lim) && (fly > -lim) && (fly < lim);
+    u0 = ok ? static_cast<int>(flx) - (HALF - 1) : 0;
+    v0 = ok ? static_cast<int>(fly) - (HALF - 1) : 0;
+    return ok;
+}
+
+template <int HALF>
+__global__ void __launch_bounds__(RsOwn<HALF>::THREADS, 4)          // two 8-wave blocks per CU: 128 registers
+rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi, int Wi,
+                     int H, int W, int quirk, int overwrite, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate) {
+    using G = RsOwn<HALF>;
+    constexpr int NT = G::NT, M = G::M, OW = G::OW, OH = G::OH, BP = G::BP, NCELL = G::NCELL, NW = G::NW, PPT = G::PPT;
+    __shared__ int box[4 * NCELL];                 // [4 channels][BH][BP]
+    __shared__ unsigned redm[NW];
+    __shared__ int redp[NW];
+
+    unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = tid % tiles_x;
+    tid /= tiles_x;
+    const int ty = tid % tiles_y;
+    tid /= tiles_y;
+    const int slab = tid % cslabs;
+    const int b = tid / cslabs;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int X0 = tx * OW, Y0 = ty * OH;          // owned tile (cells of the input plane)
+    const int x = X0 - M + lane;                   // this lane's pixel column
+    const bool inx = x >= 0 && x < W;
+    // tap coordinate -> box column / row: the reference's clamp to the image, then to the tile + a one-cell ring (both are one clamp:
+    // the intervals overlap), relative to the ring's first cell: 0 and OW + 1 / OH + 1 mean "another block's"
+    const int cxlo = max(0, X0 - 1), cxhi = min(Wi - 1, X0 + OW);
+    const int cylo = max(0, Y0 - 1), cyhi = min(Hi - 1, Y0 + OH);
+    const int dump = G::DUMP + lane;
+
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fb = in2 + static_cast<size_t>(b) * 3 * plane;
+    float wyn[PPT][NT], wxn[PPT][NT];
+    int uv[PPT];                                   // (v0 << 16) | (u0 & 0xffff), both relative to the ring origin and clamped to +-2048
+    unsigned livemask = 0;
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int y = Y0 - M + wave + r * NW;
+        const bool live_px = inx && y >= 0 && y < H;
+        int u0 = 0, v0 = 0;
+        bool ok = false;
+#pragma unroll
+        for (int f = 0; f < NT; ++f) wyn[r][f] = wxn[r][f] = 0.f;
+        if (live_px) {
+            const size_t poff = static_cast<size_t>(y) * W + x;
+            const float dx = fb[poff], dy = fb[plane + poff], sgm = fb[2 * plane + poff];
+            ok = rs_origin<HALF>(dx, dy, x, y, u0, v0);
+            if (ok) {
+                RsTaps<float, HALF> t;
+                if (ablate & 8) {                      // bench-only: no Gaussian weights
+#pragma unroll
+                    for (int f = 0; f < NT; ++f) { t.wx[f] = dx; t.wy[f] = dy; }
+                } else
+                make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+                float wxp[NT], wyp[NT];
+                float sx = 0.f, sy = 0.f;
+#pragma unroll
+                for (int f = 0; f < HALF; ++f) {
+                    wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
+                    wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
+                }
+#pragma unroll
+                for (int f = 0; f < NT; ++f) { sx += wxp[f]; sy += wyp[f]; }
+#pragma unroll
+                for (int f = 0; f < NT; ++f) {
+                    wxn[r][f] = static_cast<float>(safe_div<float>(wxp[f], sx));
+                    wyn[r][f] = static_cast<float>(safe_div<float>(wyp[f], sy));
+                }
+            }
+        }
+        const bool on = live_px && ok;
+        if (on) livemask |= 1u << r;
+        // a pixel that is dead here (outside the flow grid, or irregular: the far kernel's) parks its window in the ring's corner
+        const int ur = on ? min(max(u0 - (X0 - 1), -2048), 2048) : -2048;
+        const int vr = on ? min(max(v0 - (Y0 - 1), -2048), 2048) : -2048;
+        uv[r] = (vr << 16) | (ur & 0xffff);
+        __builtin_amdgcn_sched_barrier(0);         // one pixel's double-precision exponentials at a time: interleaved, the eight chains spill
+    }
+    // box column / row of tap f of a pixel with packed origin `o`
+    auto colx = [&](int o, int f) { return min(max(static_cast<int>(static_cast<short>(o & 0xffff)) + (X0 - 1) + f, cxlo), cxhi) - (X0 - 1); };
+    auto rowy = [&](int o, int f) { return min(max((o >> 16) + (Y0 - 1) + f, cylo), cyhi) - (Y0 - 1); };
+
+    // ---- population bound: taps per own cell, counted in plane 0
+    for (int i = threadIdx.x; i < 4 * NCELL; i += G::THREADS) box[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        if (!((livemask >> r) & 1u)) continue;
+        int cx[NT], ry[NT];
+#pragma unroll
+        for (int f = 0; f < NT; ++f) { cx[f] = colx(uv[r], f); ry[f] = rowy(uv[r], f); }
+#pragma unroll
+        for (int pr = 0; pr < NT; ++pr) {
+            if (static_cast<unsigned>(ry[pr] - 1) >= static_cast<unsigned>(OH)) continue;
+#pragma unroll
+            for (int pc = 0; pc < NT; ++pc)
+                if (static_cast<unsigned>(cx[pc] - 1) < static_cast<unsigned>(OW))
+                    __hip_atomic_fetch_add(box + ry[pr] * BP + cx[pc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    int pop = 0;
+    for (int i = threadIdx.x; i < OW * OH; i += G::THREADS) {
+        const int rr = i / OW, cc = i - rr * OW;
+        pop = max(pop, box[(rr + 1) * BP + cc + 1]);
+    }
+    pop = wave_max(pop);
+    if (lane == 0) redp[wave] = pop;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) pop = max(pop, redp[k]);
+    const int bits = __builtin_amdgcn_readfirstlane(31 - (32 - __clz(pop)));          // pop 2^bits < 2^31 (pop = 0: 31, unused)
+    for (int i = threadIdx.x; i < NCELL; i += G::THREADS) box[i] = 0;                  // plane 0 again (the dump cells keep garbage later: they are never read)
+
+    const int c0 = slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const unsigned obytes = static_cast<unsigned>(plane * sizeof(float));
+    const float* gp = gout + (static_cast<size_t>(b) * C + c0) * plane;
+    float* dp = gin1 + (static_cast<size_t>(b) * C + c0) * iplane;
+    // byte offset of pixel row 0 of this lane in a grad_output plane; row r is 8 W further (dead pixels read 0 through an offset past the plane)
+    const int ybase = Y0 - M + wave;
+
+    for (int c = c0; c < c1; c += 4) {
+        const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
+        const rsrc_t rg0 = make_rsrc(g0, obytes);
+        const rsrc_t rg1 = make_rsrc(g0 + plane, c + 1 < c1 ? obytes : 0u);
+        const rsrc_t rg2 = make_rsrc(g0 + 2 * plane, c + 2 < c1 ? obytes : 0u);
+        const rsrc_t rg3 = make_rsrc(g0 + 3 * plane, c + 3 < c1 ? obytes : 0u);
+        // pass 1 over the group's gradients: max|g| of the block's pixels (the exact scale).  The values are NOT kept: 32 registers more
+        // would cost the second resident block (128 registers per thread at two 8-wave blocks per CU); pass 2 reads them again, from L2.
+        auto pix_off = [&](int r) {
+            return ((livemask >> r) & 1u) ? (static_cast<unsigned>(ybase + r * NW) * W + static_cast<unsigned>(x)) * 4u : 0xFFFFFFF0u;
+        };
+        unsigned mb = 0;
+        if (ablate & 4) mb = 0x3F800000u;              // bench-only: no first pass over the gradients
+        else {
+            float g[PPT][4];
+#pragma unroll
+            for (int r = 0; r < PPT; ++r) {
+                const unsigned po = pix_off(r);
+                g[r][0] = buf_ld<float>(rg0, po); g[r][1] = buf_ld<float>(rg1, po);
+                g[r][2] = buf_ld<float>(rg2, po); g[r][3] = buf_ld<float>(rg3, po);
+            }
+#pragma unroll
+            for (int r = 0; r < PPT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mb = max(mb, __float_as_uint(g[r][q]) & 0x7FFFFFFFu);
+        }
+        mb = wave_max(mb);
+        if (lane == 0) redm[wave] = mb;
+        __syncthreads();                               // (also: the box is clear -- the count pass / the previous group's flush)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) mb = max(mb, redm[k]);
+        const bool exact_path = mb >= 0x7F800000u;      // a NaN / Inf gradient among this group's pixels
+        int ex = 0;
+        (void)frexpf(__uint_as_float(mb), &ex);         // max|g| < 2^ex
+        const bool usable = mb != 0u && ex > -90 && !exact_path;
+        const float sc = usable ? ldexpf(1.f, bits - ex) : 0.f;
+        const float fx_inv = usable ? ldexpf(1.f, ex - bits) : 0.f;
+        if (usable) {
+            float gn[4];
+            {
+                const unsigned po = pix_off(0);
+                gn[0] = buf_ld<float>(rg0, po); gn[1] = buf_ld<float>(rg1, po); gn[2] = buf_ld<float>(rg2, po); gn[3] = buf_ld<float>(rg3, po);
+            }
+#pragma unroll
+            for (int r = 0; r < PPT; ++r) {
+                const float gx = gn[0] * sc, gy = gn[1] * sc, gz = gn[2] * sc, gw = gn[3] * sc;   // (exact: a power of two)
+                if (r + 1 < PPT) {
+                    const unsigned po = pix_off(r + 1);
+                    gn[0] = buf_ld<float>(rg0, po); gn[1] = buf_ld<float>(rg1, po); gn[2] = buf_ld<float>(rg2, po); gn[3] = buf_ld<float>(rg3, po);
+                }
+                if (!((livemask >> r) & 1u)) continue;
+                // the pixel's origin and factors pass through an opaque register copy: everything derived from them (4 + 4 box
+                // offsets, 16 weight products) is channel-invariant, and hipcc would hoist all of it out of the channel loop -- 24
+                // registers per pixel, 192 per thread, 932 bytes of scratch
+                int o = uv[r];
+                asm volatile("" : "+v"(o));
+                float wy4[NT], wx4[NT];
+#pragma unroll
+                for (int f = 0; f < NT; ++f) {
+                    wy4[f] = wyn[r][f]; wx4[f] = wxn[r][f];
+                    asm volatile("" : "+v"(wy4[f]), "+v"(wx4[f]));
+                }
+                int cx[NT], ry[NT];
+#pragma unroll
+                for (int f = 0; f < NT; ++f) {
+                    cx[f] = colx(o, f);
+                    cx[f] = static_cast<unsigned>(cx[f] - 1) < static_cast<unsigned>(OW) ? cx[f] : -1;
+                    ry[f] = rowy(o, f);
+                }
+#pragma unroll
+                for (int pr = 0; pr < NT; ++pr) {
+                    if (static_cast<unsigned>(ry[pr] - 1) >= static_cast<unsigned>(OH)) continue;          // a tap row of another tile
+                    const int rb = ry[pr] * BP;
+#pragma unroll
+                    for (int pc = 0; pc < NT; ++pc) {
+                        const float wq = wy4[pr] * wx4[pc];
+                        int* cell = box + (cx[pc] >= 0 ? rb + cx[pc] : dump);
+                        if (ablate & 1) { if (wq * gx + wq * gy + wq * gz + wq * gw == 12345.f) box[0] = 1; continue; }      // bench-only: no LDS atomics
+                        __hip_atomic_fetch_add(cell, __float2int_rn(wq * gx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(cell + NCELL, __float2int_rn(wq * gy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(cell + 2 * NCELL, __float2int_rn(wq * gz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(cell + 3 * NCELL, __float2int_rn(wq * gw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // flush the owned cells: plain coalesced stores, no other block touches them
+        const int nch = c1 - c < 4 ? c1 - c : 4;
+        for (int i = threadIdx.x; i < OW * OH; i += G::THREADS) {
+            const int rr = i / OW, cc = i - rr * OW;
+            const int gy = Y0 + rr, gx = X0 + cc;
+            const int bi = (rr + 1) * BP + cc + 1;
+            const bool in_img = gy < Hi && gx < Wi;
+            float* dst = dp + static_cast<size_t>(c - c0) * iplane + static_cast<size_t>(gy) * Wi + gx;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = static_cast<float>(box[q * NCELL + bi]) * fx_inv;
+                box[q * NCELL + bi] = 0;
+                if (q < nch && in_img && !(ablate & 2)) {
+                    float* d = dst + static_cast<size_t>(q) * iplane;
+                    if (overwrite) *d = v;
+                    else if (v != 0.f) atomic_add(d, v);        // `+=` mode: a return-less atomic (one transaction), not a read-modify-write round trip (measured: +260 us)
+                }
+            }
+        }
+        if (exact_path) {
+            // the group's own-tile taps by global atomics (this block is still the only writer of these cells: behind its own stores).
+            // Everything is re-derived from the flow in a ROLLED loop: the rare path must not touch the register arrays of the hot one
+            // (unrolled beside it, hipcc hoisted its products and offsets into 110 more registers and 900 bytes of scratch).
+            __builtin_amdgcn_s_waitcnt(0);             // vmcnt(0) expcnt(0) lgkmcnt(0): the zeros are out
+            __syncthreads();
+#pragma unroll 1
+            for (int r = 0; r < PPT; ++r) {
+                const int y = ybase + r * NW;
+                if (!(inx && y >= 0 && y < H)) continue;
+                const size_t poff = static_cast<size_t>(y) * W + x;
+                const float dx = fb[poff], dy = fb[plane + poff], sgm = fb[2 * plane + poff];
+                int u0, v0;
+                if (!rs_origin<HALF>(dx, dy, x, y, u0, v0)) continue;
+                RsTaps<float, HALF> t;
+                make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+                float wxp[NT], wyp[NT];
+                float sx = 0.f, sy = 0.f;
+#pragma unroll
+                for (int f = 0; f < HALF; ++f) {
+                    wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
+                    wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
+                }
+#pragma unroll
+                for (int f = 0; f < NT; ++f) { sx += wxp[f]; sy += wyp[f]; }
+#pragma unroll
+                for (int f = 0; f < NT; ++f) {
+                    wxp[f] = static_cast<float>(safe_div<float>(wxp[f], sx));
+                    wyp[f] = static_cast<float>(safe_div<float>(wyp[f], sy));
+                }
+                float gq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gq[q] = q < nch ? gp[static_cast<size_t>(c - c0 + q) * plane + poff] : 0.f;
+#pragma unroll
+                for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+                    for (int pc = 0; pc < NT; ++pc) {
+                        const int cc = min(max(u0 + pc, 0), Wi - 1) - X0, rr = min(max(v0 + pr, 0), Hi - 1) - Y0;
+                        if (static_cast<unsigned>(cc) >= static_cast<unsigned>(OW) || static_cast<unsigned>(rr) >= static_cast<unsigned>(OH)) continue;
+                        float* dst = dp + static_cast<size_t>(c - c0) * iplane + static_cast<size_t>(Y0 + rr) * Wi + (X0 + cc);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < nch) atomic_add(dst + static_cast<size_t>(q) * iplane, (wyp[pr] * wxp[pc]) * gq[q]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The complement of rs_bwd1_owned_kernel: (pixel, tap) pairs whose pixel is not visited by the block that owns the tap's cell.
+template <int HALF>
+__global__ void __launch_bounds__(kBlock)
+rs_bwd1_far_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi, int Wi,
+                   int H, int W, int quirk, int tiles_x, int tiles_y, int cslabs, int cs) {
+    using G = RsOwn<HALF>;
+    constexpr int NT = G::NT, M = G::M, OW = G::OW, OH = G::OH;
+    const TileCoord tc = decode_tile(tiles_x, tiles_y, cslabs, 0);
+    if (tc.xf >= W || tc.yf >= H) return;
+    const int x = tc.xf, y = tc.yf;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fb = in2 + static_cast<size_t>(tc.b) * 3 * plane;
+    const size_t poff = static_cast<size_t>(y) * W + x;
+    const float dx = fb[poff], dy = fb[plane + poff];
+    int u0, v0;
+    const bool ok = rs_origin<HALF>(dx, dy, x, y, u0, v0);
+    // which taps are far: the pixel is outside the region of the cell's owner tile (or irregular: every tap, through the reference's
+    // saturating clamp of the float coordinate)
+    unsigned farmask = 0;
+    int colc[NT], rowc[NT];
+    if (ok) {
+        bool fx[NT], fy[NT];
+#pragma unroll
+        for (int f = 0; f < NT; ++f) {
+            colc[f] = min(max(u0 + f, 0), Wi - 1);
+            rowc[f] = min(max(v0 + f, 0), Hi - 1);
+            const int ox = (colc[f] / OW) * OW, oy = (rowc[f] / OH) * OH;
+            fx[f] = x < ox - M || x >= ox - M + G::RW;
+            fy[f] = y < oy - M || y >= oy - M + G::RH;
+        }
+#pragma unroll
+        for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+            for (int pc = 0; pc < NT; ++pc)
+                if (fx[pc] || fy[pr]) farmask |= 1u << (pr * NT + pc);
+    } else {
+        farmask = NT * NT >= 32 ? 0xFFFFFFFFu : ((1u << (NT * NT)) - 1u);
+        const float flx = floor_t(static_cast<float>(x) + dx), fly = floor_t(static_cast<float>(y) + dy);
+#pragma unroll
+        for (int f = 0; f < HALF; ++f) {
+            colc[HALF - 1 - f] = clamp_index(flx - static_cast<float>(f), Wi);
+            colc[HALF + f] = clamp_index(flx + static_cast<float>(f + 1), Wi);
+            rowc[HALF - 1 - f] = clamp_index(fly - static_cast<float>(f), Hi);
+            rowc[HALF + f] = clamp_index(fly + static_cast<float>(f + 1), Hi);
+        }
+    }
+    if (farmask == 0) return;
+    const float sgm = fb[2 * plane + poff];
+    RsTaps<float, HALF> t;
+    make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+    float wxp[NT], wyp[NT];
+#pragma unroll
+    for (int f = 0; f < HALF; ++f) {
+        wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
+        wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
+    }
+    const size_t iplane = static_cast<size_t>(Hi) * Wi;
+    const int c0 = tc.slab * cs;
+    const int c1 = (c0 + cs < C) ? c0 + cs : C;
+    const float* gp = gout + (static_cast<size_t>(tc.b) * C + c0) * plane + poff;
+    float* dp = gin1 + (static_cast<size_t>(tc.b) * C + c0) * iplane;
+    for (int c = c0; c < c1; ++c, gp += plane, dp += iplane) {
+        const float g = *gp;
+#pragma unroll
+        for (int pr = 0; pr < NT; ++pr)
+#pragma unroll
+            for (int pc = 0; pc < NT; ++pc)
+                if ((farmask >> (pr * NT + pc)) & 1u)
+                    atomic_add(dp + static_cast<size_t>(rowc[pr]) * Wi + colc[pc], static_cast<float>(safe_div<float>(wyp[pr] * wxp[pc], t.sum)) * g);
+    }
+}
+
 // rs_bwd1_taplane_kernel (d_input1, ks = 4): the same LDS box accumulator, other work assignment.  The tile kernel above gives a
 // lane one PIXEL and adds one tap of 64 pixels per ds_add_f64: under a random flow the 64 target cells fall on random banks
 // (measured at cfg-1: 18 of 34 us are the LDS atomics, 5x their conflict-free time).  Here a wave-instruction adds the 16 taps x 4
@@ -1575,11 +1973,58 @@ int launch_fwd(const T* in1, const T* in2, T* out, int64_t B, int64_t C, int64_t
 
 template <typename T>
 int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int64_t B, int64_t C,
-               int64_t Hi, int64_t Wi, int64_t H, int64_t W, int ks, int dil, int quirk,
+               int64_t Hi, int64_t Wi, int64_t H, int64_t W, int ks, int dil, int quirk_flags,
                hipStream_t st) {
     const int remap = options().xcd_remap;
     const size_t plane_lds = static_cast<size_t>(Hi) * Wi * sizeof(double);     // the LDS accumulator is double
     const int half = ks / 2;
+    const int quirk = quirk_flags & 1;
+    const bool overwrite = (quirk_flags & 2) != 0 && gin1 != nullptr;           // grad_input1 arrives uninitialised
+    if constexpr (sizeof(T) == 4) {
+        // Round 6: owned tiles (rs_bwd1_owned_kernel + rs_bwd1_far_kernel) for the calls the shared-cell tile kernel served: fp32, dilation 1,
+        // kernel_size 2 / 4, >= 2^18 pixels, planes of >= 32 rows.  rs_bwd1_owned: 0 = on, 2 = off (rounds 3-5's kernels).
+        if (gin1 && dil == 1 && (half == 1 || half == 2) && options().scatter_variant == 0 && options().rs_bwd1_variant == 0 &&
+            options().rs_bwd1_owned != 2 && B * H * W >= (1 << 18) && H >= 32 && Hi >= 32 &&
+            static_cast<int64_t>(Hi) * Wi < (1LL << 29) && static_cast<int64_t>(H) * W < (1LL << 29)) {
+            const double bytes1 = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
+            const int ow = half == 1 ? RsOwn<1>::OW : RsOwn<2>::OW, oh = half == 1 ? RsOwn<1>::OH : RsOwn<2>::OH;
+            const int tiles_x = static_cast<int>((Wi + ow - 1) / ow), tiles_y = static_cast<int>((Hi + oh - 1) / oh);
+            const int64_t spatial = B * tiles_x * tiles_y;
+            int cs = static_cast<int>((C + 3) / 4 * 4);
+            // a block pays ~15 us for its pixels' weights (double-precision exponentials) and the population count before its first channel:
+            // slabs as large as two rounds of the 512 resident blocks allow ([8,64,512,512], 800 tiles: 32 channels 722 us, 16: 815, 8: 907)
+            const int min_blocks = options().rs_bwd1_owned_blocks > 0 ? options().rs_bwd1_owned_blocks : 1024;
+            while (cs > 4 && spatial * ((C + cs - 1) / cs) < min_blocks) cs = (cs / 2 + 3) / 4 * 4;
+            const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            {
+                LaunchScope ls("resample2d_bwd_input1_owned", st, bytes1);
+                const unsigned grid = static_cast<unsigned>(spatial * cslabs);
+                if (half == 1)
+                    hipLaunchKernelGGL((rs_bwd1_owned_kernel<1>), dim3(grid), dim3(RsOwn<1>::THREADS), 0, st, (const float*)in2, (const float*)gout,
+                                       (float*)gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, quirk, overwrite ? 1 : 0, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
+                else
+                    hipLaunchKernelGGL((rs_bwd1_owned_kernel<2>), dim3(grid), dim3(RsOwn<2>::THREADS), 0, st, (const float*)in2, (const float*)gout,
+                                       (float*)gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, quirk, overwrite ? 1 : 0, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
+            }
+            if (int rc = check_launch("ffwm_resample2d_backward(input1, owned tiles)")) return rc;
+            {
+                const Geometry gf = plan(B, C, H, W, 32);
+                LaunchScope ls("resample2d_bwd_input1_far", st, sizeof(T) * 3.0 * B * H * W);
+                if (half == 1)
+                    hipLaunchKernelGGL((rs_bwd1_far_kernel<1>), dim3(gf.grid), dim3(kBlock), 0, st, (const float*)in2, (const float*)gout, (float*)gin1,
+                                       (int)C, (int)Hi, (int)Wi, (int)H, (int)W, quirk, gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs);
+                else
+                    hipLaunchKernelGGL((rs_bwd1_far_kernel<2>), dim3(gf.grid), dim3(kBlock), 0, st, (const float*)in2, (const float*)gout, (float*)gin1,
+                                       (int)C, (int)Hi, (int)Wi, (int)H, (int)W, quirk, gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs);
+            }
+            if (int rc = check_launch("ffwm_resample2d_backward(input1, far)")) return rc;
+            if (!gin2) return FFWM_OK;
+            gin1 = nullptr;
+        }
+    }
+    // every other path ACCUMULATES into grad_input1: an uninitialised buffer is cleared here
+    if (overwrite && gin1)
+        if (zero_fill(gin1, sizeof(T) * static_cast<size_t>(B) * C * Hi * Wi, st)) return FFWM_ERR_LAUNCH;
     if constexpr (sizeof(T) == 4) {
         // fp32, dilation 1, kernel_size 2 / 4 / 6: the LDS-tile kernels (scatter_variant 1 = global atomics, 2 = plane kernel)
         if (dil == 1 && half >= 1 && half <= 3 && options().scatter_variant == 0) {
@@ -1798,6 +2243,7 @@ extern "C" int ffwm_resample2d_backward(const void* input1, const void* input2, 
     if (int rc = check_dims(fn, B, C, Hi, Wi, H, W, kernel_size, dilation, dtype)) return rc;
     if (!grad_input1 && !grad_input2) return FFWM_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    FFWM_REQUIRE(reference_quirk >= 0 && reference_quirk <= 3, FFWM_ERR_ARG, "%s: reference_quirk is a 2-bit flag word", fn);
     if (dtype == FFWM_F32)
         return launch_bwd<float>((const float*)input1, (const float*)input2, (const float*)grad_output,
                                  (float*)grad_input1, (float*)grad_input2, B, C, Hi, Wi, H, W, kernel_size,

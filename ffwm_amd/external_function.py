@@ -200,11 +200,15 @@ class Resample2dFunction(Function):
     def backward(ctx, grad_output):
         input1, input2 = ctx.saved_tensors
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        grad_input1 = torch.zeros_like(input1) if need1 else None
+        # the reference zero-fills grad_input1 for its atomics (external_function.py:137); here the library is told that the buffer is
+        # uninitialised (owned tiles store every cell once; the other paths clear it themselves) -- unless input1 has more samples than
+        # input2 (the extra ones get no gradient and must read zero)
+        fresh = need1 and input1.size(0) == input2.size(0)
+        grad_input1 = (torch.empty_like(input1) if fresh else torch.zeros_like(input1)) if need1 else None
         grad_input2 = torch.empty_like(input2) if need2 else None
         if need1 or need2:
             ops.resample2d_backward(input1, input2, grad_output.contiguous(), ctx.kernel_size, ctx.dilation,
-                                    grad_input1, grad_input2, Resample2dFunction.reference_quirk)
+                                    grad_input1, grad_input2, Resample2dFunction.reference_quirk, overwrite_input1=fresh)
         return grad_input1, grad_input2, None, None
 
 

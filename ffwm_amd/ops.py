@@ -219,8 +219,9 @@ def resample2d_forward(input1, input2, kernel_size=2, dilation=1, out=None):
 
 
 def resample2d_backward(input1, input2, grad_output, kernel_size=2, dilation=1, grad_input1=None,
-                        grad_input2=None, reference_quirk=True):
-    """grad_input1 += (zero-fill it first), grad_input2 is overwritten; None skips one."""
+                        grad_input2=None, reference_quirk=True, overwrite_input1=False):
+    """grad_input1 += (zero-fill it first) -- or, with overwrite_input1, grad_input1[:B] = (the buffer may be uninitialised: the owned-tile
+    kernel stores every cell once, any other path clears the buffer itself) --, grad_input2 is overwritten; None skips one."""
     _check("resample2d_backward", input1, input2, grad_output, grad_input1, grad_input2)
     _, C, Hi, Wi = input1.shape
     B, _, H, W = input2.shape
@@ -231,8 +232,8 @@ def resample2d_backward(input1, input2, grad_output, kernel_size=2, dilation=1, 
     with _on_device(input1) as stream:
         _lib.check(_lib.load().ffwm_resample2d_backward(
             _ptr(input1), _ptr(input2), _ptr(grad_output), _ptr(grad_input1), _ptr(grad_input2), B, C, Hi,
-            Wi, H, W, int(kernel_size), int(dilation), 1 if reference_quirk else 0, _dtype_code(input1),
-            stream), "ffwm_resample2d_backward")
+            Wi, H, W, int(kernel_size), int(dilation), (1 if reference_quirk else 0) | (2 if overwrite_input1 else 0),
+            _dtype_code(input1), stream), "ffwm_resample2d_backward")
     return grad_input1, grad_input2
 
 

@@ -108,7 +108,9 @@ int ffwm_resample2d_forward(const void* input1, const void* input2, void* output
 /* grad_input1[B,C,Hi,Wi] += scatter (resample2d_kernel.cu:98-202); grad_input2[B,3,H,W] is
  * OVERWRITTEN (resample2d_kernel.cu:204-330).  reference_quirk != 0 keeps the reference's
  * `alpha = xf - int(xf)` truncation in the grad_input1 weights (:137-138); 0 uses floor (the
- * true gradient).  Either gradient may be NULL. */
+ * true gradient).  reference_quirk bit 1 (value 2, ABI 5): grad_input1 arrives UNINITIALISED and is overwritten -- the
+ * owned-tile kernels store every cell exactly once (no zero-fill by the caller, no atomics on the regular path), every
+ * other path clears the buffer itself first.  Either gradient may be NULL. */
 int ffwm_resample2d_backward(const void* input1, const void* input2, const void* grad_output,
                              void* grad_input1, void* grad_input2, int64_t B, int64_t C,
                              int64_t Hi, int64_t Wi, int64_t H, int64_t W, int kernel_size,

@@ -651,6 +651,71 @@ def test_resample2d_backward_large_call_picks_a_kernel_by_flow_regularity(oracle
         _close(g1, g1_ref, BWD_TOL[torch.float32], relative=True)
 
 
+@pytest.mark.parametrize("owned", [0, 2])
+@pytest.mark.parametrize("kind", ["random3", "smooth", "far", "nan_flow", "nan_grad", "contract", "grid_mismatch", "ks2", "odd_channels"])
+def test_resample2d_backward_owned_tiles(oracle, kind, owned):
+    """Round 6: large d_input1 calls on OWNED tiles (rs_bwd1_owned_kernel: every cell of grad_input1 has one owner block that visits the
+    pixels within reach, drops foreign taps into a ring, and stores its tile -- no fold atomics) + the far complement at (pixel, tap)
+    granularity.  Against the oracle: the bench's random flow, a smooth field, flows far beyond the +-3 fast path (the far kernel's
+    atomics), NaN / huge flow values, non-finite gradients (the group's exact path), a flow that contracts a whole region onto one cell
+    (the counted population bound of the fixed-point scale), an input plane that differs from the flow grid, ks = 2, and a channel count
+    that is not a multiple of 4; in `+=` mode on a non-zero buffer and in overwrite mode on a NaN-poisoned one.  owned = 2: the same
+    cases through rounds 3-5's shared-cell tile kernel."""
+    from ffwm_amd import _lib, ops
+    g = _gen(60)
+    B, C, H, W, ks = 1, 6, 520, 530, 4
+    Hi, Wi = H, W
+    if kind == "grid_mismatch":
+        Hi, Wi = 480, 600
+    if kind == "ks2":
+        ks = 2
+    if kind == "odd_channels":
+        C = 7
+    fl = torch.rand(B, 2, H, W, generator=g) * 6 - 3
+    if kind == "smooth":
+        lin = torch.linspace(-1, 1, H)[:, None], torch.linspace(-1, 1, W)[None, :]
+        fl = torch.stack((3 * torch.sin(3.1 * lin[0] + 0.3) * torch.cos(2.3 * lin[1]), 3 * torch.cos(2.7 * lin[1] - 0.2) * torch.sin(1.9 * lin[0])), 0)[None].contiguous()
+    elif kind == "far":
+        fl = torch.rand(B, 2, H, W, generator=g) * 60 - 30
+        fl[:, :, ::7, ::5] = torch.rand(B, 2, (H + 6) // 7, (W + 4) // 5, generator=g) * 2000 - 1000
+    elif kind == "nan_flow":
+        fl[0, 0, 5, 5] = float("nan")
+        fl[0, 1, 100, 200] = 1e30
+        fl[0, 0, 300, 7] = -1e30
+        fl[0, 1, 519, 529] = float("inf")
+    elif kind == "contract":
+        ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        fl = torch.stack(((xs // 48) * 48 + 20.3 - xs, (ys // 48) * 48 + 21.7 - ys))[None].contiguous()      # 48 x 48 pixels onto one window
+        fl = fl.clamp(-2.9, 2.9) * 0 + fl      # (kept as is: most of these pixels are beyond +-3 -> far kernel; the inner 6 x 6 pile up in the box)
+    sg = torch.rand(B, 1, H, W, generator=g) * 2 + 0.5
+    in2 = torch.cat((fl, sg), 1).contiguous()
+    in1 = torch.rand(B, C, Hi, Wi, generator=g)
+    go = torch.rand(B, C, H, W, generator=g) + (0.5 if kind == "contract" else 0.0)
+    if kind == "nan_grad":
+        go[0, 1, 17, 300] = float("nan")
+        go[0, 4, 400, 40] = float("inf")
+    g1_ref, _ = oracle.resample2d_backward(in1, in2, go, ks, 1)
+    _lib.set_option("rs_bwd1_owned", owned)
+    try:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        acc = torch.full_like(in1, 0.25, device=DEV)
+        ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), ks, 1, acc, None)
+        fresh = torch.full_like(in1, float("nan"), device=DEV)
+        ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go.to(DEV), ks, 1, fresh, None, overwrite_input1=True)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        scopes = _lib.prof_collect()
+        assert ("resample2d_bwd_input1_owned" in scopes) == (owned == 0), sorted(scopes)
+    finally:
+        _lib.set_option("rs_bwd1_owned", 0)
+    fin = torch.isfinite(g1_ref)
+    for got in (acc.cpu() - 0.25, fresh.cpu()):
+        assert torch.equal(torch.isfinite(got), fin), (int((~torch.isfinite(got)).sum()), int((~fin).sum()))
+        scale = float(g1_ref[fin].abs().max())
+        assert float((got[fin] - g1_ref[fin]).abs().max()) <= 2e-5 * scale + (3e-7 if got is not fresh.cpu() else 0), (kind, float((got[fin] - g1_ref[fin]).abs().max()) / scale)
+
+
 def test_resample2d_backward_accumulates_into_grad_input1_and_overwrites_grad_input2(oracle):
     """The boundary's contract (external_function.py:137-138, resample2d_kernel.cu:98-330): grad_input1 is accumulated
     into (atomics), grad_input2 is written -- also when the channel slabs of the tile kernel add partial results."""
