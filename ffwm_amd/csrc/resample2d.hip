@@ -1996,8 +1996,8 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             const int min_blocks = options().rs_bwd1_owned_blocks > 0 ? options().rs_bwd1_owned_blocks : 1024;
             while (cs > 4 && spatial * ((C + cs - 1) / cs) < min_blocks) cs = (cs / 2 + 3) / 4 * 4;
             const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            LaunchScope ls("resample2d_bwd_input1_owned", st, bytes1);      // both launches: the tiles and their far complement
             {
-                LaunchScope ls("resample2d_bwd_input1_owned", st, bytes1);
                 const unsigned grid = static_cast<unsigned>(spatial * cslabs);
                 if (half == 1)
                     hipLaunchKernelGGL((rs_bwd1_owned_kernel<1>), dim3(grid), dim3(RsOwn<1>::THREADS), 0, st, (const float*)in2, (const float*)gout,
@@ -2008,8 +2008,8 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             }
             if (int rc = check_launch("ffwm_resample2d_backward(input1, owned tiles)")) return rc;
             {
-                const Geometry gf = plan(B, C, H, W, 32);
-                LaunchScope ls("resample2d_bwd_input1_far", st, sizeof(T) * 3.0 * B * H * W);
+                // one thread per pixel with ALL channels: for a flow net's field the launch reads the flow and returns
+                const Geometry gf = plan(B, C, H, W, static_cast<int>(C));
                 if (half == 1)
                     hipLaunchKernelGGL((rs_bwd1_far_kernel<1>), dim3(gf.grid), dim3(kBlock), 0, st, (const float*)in2, (const float*)gout, (float*)gin1,
                                        (int)C, (int)Hi, (int)Wi, (int)H, (int)W, quirk, gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs);

