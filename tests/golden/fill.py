@@ -64,6 +64,20 @@ def fill_module(mod, power_iters=3):
     return mod
 
 
+def boost_output_gain(mod, prefixes=("rec0", "rec1", "rec2"), gain=150.0):
+    """The evaluation fixture only (make_eval_golden.py and the tests that rebuild its networks): under `fill_module` netG's activations
+    are tiny and its sigmoid heads emit a nearly constant image (std 0.006) -- on which the guided filter at the end of test_forward is
+    ill-conditioned (round 5 could only bound that output to 0.13).  A spectrally normalised layer in eval mode divides its weight by
+    sigma = u . (W v) with the STORED u, v (torch.nn.utils.spectral_norm: no power iteration outside training), so dividing the stored
+    `weight_u` of the three image heads by `gain` multiplies their weights by it: the generated image gets a std of 0.14 (range 0.2 .. 0.88)."""
+    sd = mod.state_dict()
+    for name in list(sd):
+        if name.endswith("weight_u") and name.split(".")[0] in prefixes:
+            sd[name] = sd[name] / gain
+    mod.load_state_dict(sd)
+    return mod
+
+
 def image(b, c, h, w, name="img"):
     """Values in [0,1]."""
     return (wave((b, c, h, w), name, 0.5, freq=0.7548776662) + 0.5).contiguous()

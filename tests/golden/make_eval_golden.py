@@ -49,7 +49,7 @@ def packed(t, step):
 out = {}
 with torch.no_grad():
     flowNetF = fill.fill_module(base_networks.FlowNet(4)).eval()
-    netG = fill.fill_module(base_networks.FFWM(sn=True)).eval()
+    netG = fill.boost_output_gain(fill.fill_module(base_networks.FFWM(sn=True))).eval()      # image heads x 150: an image of std 0.14 (fill.py)
     netD = fill.fill_module(base_networks.MSDiscriminator(128, sigmoid=False)).eval()
     os.makedirs(os.path.join(HERE, "ckpt"), exist_ok=True)
     # models/base_model.py:172-191 (the CPU branch): torch.save(net.cpu().state_dict(), save_path)
@@ -65,13 +65,17 @@ with torch.no_grad():
     _, _, fake_F128, att = netG(img_S, flow=[flow_F32, flow_F64, flow_F128], return_att=True)
     att = torch.mean(att[:, :64, :, :], (1,), keepdim=True)
     img_GF128 = gf128(fake_F128, img_F)
-    # The guided filter at the END of test_forward is ill-conditioned on this fixture: the closed-form netG produces a nearly constant
-    # image (std 0.006), a = cov / (var + 1e-8) divides by ~3e-5, and the reference's OWN fp32 result is 1.3e-2 away from its float64
-    # evaluation (a 1e-4 change of the input moves the output by 7e-2).  So the fixture also holds (a) that distance, which bounds
-    # what a comparison of img_GF128 can mean, and (b) the same GuidedFilter(32) on a well-conditioned pair (the two input images),
-    # which pins the filter itself to 1e-4.
+    # Round 5's fixture had a nearly constant generated image (std 0.006): the guided filter's a = cov / (var + 1e-8) divided by ~3e-5 and
+    # the reference's OWN fp32 result was 1.3e-2 from its float64 evaluation -- the composed img_GF128 could only be bounded to 0.13.
+    # With the boosted image heads (fill.boost_output_gain) the generated image has a std of 0.14 and the filter is well conditioned.  What
+    # remains is the filter's own fp32 arithmetic: GuidedFilter(32) is cumsum -> window difference over 128-pixel rows / columns, and the
+    # reference's fp32 result is ~2e-4 from its float64 evaluation on ANY image (also on the input pair).  The fixture therefore holds the
+    # float64 output as well: a test can ask for "as close to float64 as the reference's fp32 is" instead of bit-chasing its rounding.
     gf64 = external_function.GuidedFilter(32).double()(fake_F128.double(), img_F.double())
     out["img_GF128_ref_fp32_vs_fp64"] = float((img_GF128.double() - gf64).abs().max())
+    out["img_GF128_fp64"] = packed(gf64, 2)
+    out["fake_F128_std"] = float(fake_F128.std())
+    assert out["fake_F128_std"] >= 0.1 and out["img_GF128_ref_fp32_vs_fp64"] <= 3e-4, (out["fake_F128_std"], out["img_GF128_ref_fp32_vs_fp64"])
     out["gf128_on_images"] = packed(gf128(img_S, img_F), 2)
     out["test_forward"] = {"fake_F128": packed(fake_F128, 2), "img_GF128": packed(img_GF128, 2), "img_S_warp": packed(img_S_warp, 2),
                            "att": packed(att, 2), "flow_F128": packed(flow_F128, 2), "flow_F64": packed(flow_F64, 1),

@@ -531,11 +531,11 @@ def test_reference_written_checkpoint_and_composed_test_forward_on_the_gpu(tmp_p
     worst["img_S_warp"] = tc._packed_close(warped, tf["img_S_warp"], 1e-4)
     worst["fake_F128"] = tc._packed_close(fake, tf["fake_F128"], 1e-4)
     worst["att"] = tc._packed_close(att, tf["att"], 1e-4)
-    # the guided filter: pinned on a well-conditioned pair; the composed output only within what the fixture's conditioning allows
-    # (tests/golden/make_eval_golden.py: the reference's own fp32 result is 1.3e-2 from its float64 evaluation there)
+    # the guided filter: on the input pair, and as the end of the composed forward (round 6: a generated image of std 0.14, the composed
+    # img_GF128 held to 2e-4 and to the reference's own distance from float64 -- round 5's near-constant image only allowed a bound of 0.13)
     with torch.no_grad():
         worst["gf128_on_images"] = tc._packed_close(t.gf[128](b["img_S"], b["img_F"]), gold_eval["gf128_on_images"], 1e-4)
-    worst["img_GF128"] = tc._packed_close(gf, tf["img_GF128"], 10 * gold_eval["img_GF128_ref_fp32_vs_fp64"])
+    worst["img_GF128_vs_fp64"] = tc._gf_close(gf, gold_eval)
     with torch.no_grad():
         score = t.netD(fake)
     ref_score = gold_eval["netD_score_of_fake"]

@@ -1297,7 +1297,10 @@ def test_affine_regularization_loss_matches_reference_golden():
     """AffineRegularizationLoss / MultiAffineRegularizationLoss on the HIP ops against the value the
     reference's own classes produced (tests/golden/make_golden.py: the imported reference module with the
     CUDA ops replaced by their proven CPU identities).  The loss is a sum of squared residuals of grids of
-    magnitude ~128 evaluated in fp32 -- by the reference too -- hence the relative 2e-3."""
+    magnitude ~128 evaluated in fp32 -- by the reference too: its own fp32 value is up to 6e-4 from the float64 evaluation of the same
+    inputs (kz = 3).  Round 6: instead of a flat 2e-3 the fp32 result must be at least as close to float64 as the
+    reference's is: |hip32 - fp64| <= |reference32 - fp64| + 1e-6 scale (the float64 value: the same composition on the HIP ops in
+    float64, itself held to the CPU identities at 1e-9 below)."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import fill
@@ -1309,7 +1312,9 @@ def test_affine_regularization_loss_matches_reference_golden():
         flow = fill.flow_field(2, s, s, "reg_flow%d" % s).to(DEV).requires_grad_(True)
         loss = m(flow)
         ref = float(gold["kz%d" % kz]["loss"])
-        assert abs(float(loss) - ref) <= 2e-3 * (1 + abs(ref)), (kz, float(loss), ref)
+        l64 = float(AffineRegularizationLoss(kz)(flow.detach().double()))
+        assert abs(float(loss) - l64) <= abs(ref - l64) + 1e-6 * (1 + abs(l64)), (kz, float(loss), ref, l64)
+        assert abs(ref - l64) <= 1e-3 * (1 + abs(l64))           # (and the golden is the same loss)
         loss.backward()                                   # the ops' backward kernels at the reference's real sizes
         assert torch.isfinite(flow.grad).all() and float(flow.grad.abs().max()) > 0
     multi = MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3})
@@ -1317,7 +1322,8 @@ def test_affine_regularization_loss_matches_reference_golden():
     flows = [fill.flow_field(2, s, s, "reg_flow%d" % s).to(DEV) for s in (128, 64, 32)]
     ref = float(gold["multi"])
     got = float(multi(flows[::-1]))
-    assert abs(got - ref) <= 2e-3 * (1 + abs(ref)), (got, ref)
+    m64 = float(multi([f.double() for f in flows[::-1]]))
+    assert abs(got - m64) <= abs(ref - m64) + 1e-6 * (1 + abs(m64)), (got, ref, m64)
 
 
 def test_affine_regularization_gradient_matches_identity_ops():
@@ -1361,7 +1367,7 @@ def test_fused_affine_regularization_matches_the_op_composition(dtype):
     import fill
     from ffwm_amd.losses import AffineRegularizationLoss, MultiAffineRegularizationLoss
     gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_modules.pt"))["affine_reg"]
-    tol = 2e-3 if dtype == torch.float32 else 1e-9
+    tol = 1e-3 if dtype == torch.float32 else 1e-9          # fused vs composed in fp32: both carry the cancellation error (6e-4 at kz = 3)
     for kz, s in ((3, 32), (5, 64), (7, 128), (5, 37)):
         flow0 = (fill.flow_field(2, s, s, "reg_flow%d" % s) if s != 37 else
                  torch.rand(3, 2, 37, 41, generator=_gen(kz)) * 2 - 1).to(dtype)
@@ -1371,15 +1377,18 @@ def test_fused_affine_regularization_matches_the_op_composition(dtype):
         lb = AffineRegularizationLoss(kz, fused=False)(b)
         assert abs(float(la) - float(lb)) <= tol * (1 + abs(float(lb))), (kz, float(la), float(lb))
         if s != 37:
+            # against the reference golden: at least as close to the float64 value as the reference's own fp32 result (float64: 1e-9)
             ref = float(gold["kz%d" % kz]["loss"])
-            assert abs(float(la) - ref) <= 2e-3 * (1 + abs(ref)), (kz, float(la), ref)
+            l64 = float(AffineRegularizationLoss(kz, fused=False)(flow0.double().to(DEV)))
+            assert abs(float(la) - l64) <= abs(ref - l64) + 1e-6 * (1 + abs(l64)), (kz, float(la), ref, l64)
         (3 * la).backward()
         (3 * lb).backward()
         assert (a.grad - b.grad).abs().max().item() <= tol * (1 + b.grad.abs().max().item()), kz
     multi = MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3}, fused=True)
     flows = [fill.flow_field(2, s, s, "reg_flow%d" % s).to(DEV, dtype) for s in (128, 64, 32)]
     ref = float(gold["multi"])
-    assert abs(float(multi(flows[::-1])) - ref) <= 2e-3 * (1 + abs(ref))
+    m64 = float(MultiAffineRegularizationLoss({1: 7, 2: 5, 3: 3}, fused=False)([f.double() for f in flows[::-1]]))
+    assert abs(float(multi(flows[::-1])) - m64) <= abs(ref - m64) + 1e-6 * (1 + abs(m64))
 
 
 def test_flownet_pretraining_step_on_gpu_fused_vs_composed_regulariser():

@@ -135,6 +135,18 @@ def _packed_close(got, p, tol):
     return d / scale
 
 
+def _gf_close(gf, gold):
+    """The composed img_GF128 (round 6: generated image of std 0.14): within 2e-4 of the reference's fp32 output -- the distance of that
+    output from the reference's own float64 evaluation, the cumsum arithmetic's fp32 floor -- and at least as close to float64 as 1.5 x
+    the reference's fp32 result is (round 5: a bound of 0.13 on a near-constant image)."""
+    assert gold["fake_F128_std"] >= 0.1 and gold["img_GF128_ref_fp32_vs_fp64"] <= 3e-4
+    _packed_close(gf, gold["test_forward"]["img_GF128"], 2e-4)
+    p = gold["img_GF128_fp64"]
+    d64 = float((gf.detach().cpu().double()[..., ::p["step"], ::p["step"]] - p["sample"]).abs().max())
+    assert d64 <= max(1.5 * gold["img_GF128_ref_fp32_vs_fp64"], 1e-4), (d64, gold["img_GF128_ref_fp32_vs_fp64"])
+    return d64
+
+
 def _prepare_reference_checkpoints(tmp_path, gold, ckpt_dir):
     """A checkpoint directory as the reference's BaseModel.save_networks leaves it: flowNetF = the file the REFERENCE's FlowNet(4) wrote
     (tests/golden/ckpt, committed); netG / netD (65 MB / 4.5 MB: they do not travel) re-derived with the closed form the reference's
@@ -147,7 +159,10 @@ def _prepare_reference_checkpoints(tmp_path, gold, ckpt_dir):
     ep = gold["epoch"]
     shutil.copy(os.path.join(ckpt_dir, "%s_net_flowNetF.pth" % ep), str(tmp_path))
     for name, mod in (("netG", nets.FFWM(sn=True)), ("netD", nets.MSDiscriminator(128, sigmoid=False))):
-        sd = fill.fill_module(mod).state_dict()
+        fill.fill_module(mod)
+        if name == "netG":
+            fill.boost_output_gain(mod)                  # as make_eval_golden.py did to the reference's netG (image heads x 40)
+        sd = mod.state_dict()
         ref = gold["state"][name]
         assert list(sd.keys()) == list(ref.keys()), name          # the reference's names in the reference's ORDER
         for k, v in sd.items():
@@ -189,11 +204,11 @@ def test_a_checkpoint_written_by_the_reference_loads_and_test_forward_matches_th
     _packed_close(warped, tf["img_S_warp"], 1e-5)
     _packed_close(fake, tf["fake_F128"], 1e-4)
     _packed_close(att, tf["att"], 1e-4)
-    # the guided filter: pinned on a well-conditioned pair; the composed output only within what the fixture's conditioning allows
-    # (tests/golden/make_eval_golden.py: the reference's own fp32 result is 1.3e-2 from its float64 evaluation there)
+    # the guided filter: on the input pair, and as the end of the composed forward -- round 6: the fixture's generated image has a std of
+    # 0.14 (fill.boost_output_gain), the filter is well conditioned and img_GF128 is held to the filter's fp32 floor (_gf_close)
     with torch.no_grad():
         _packed_close(t.gf[128](b["img_S"], b["img_F"]), gold["gf128_on_images"], 1e-4)
-    _packed_close(gf, tf["img_GF128"], 10 * gold["img_GF128_ref_fp32_vs_fp64"])
+    _gf_close(gf, gold)
     with torch.no_grad():
         score = t.netD(fake)
     assert float((score - gold["netD_score_of_fake"]).abs().max()) <= 1e-4 * (1 + float(gold["netD_score_of_fake"].abs().max()))
