@@ -34,6 +34,10 @@ namespace ffwm {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef FFWM_CONV_CPC_MULT
+#define FFWM_CONV_CPC_MULT 1
+#endif
+constexpr int kCpcMult = FFWM_CONV_CPC_MULT;      // chunk depth multiplier (experiment: 2 = 72 / 64 / 64 reduction steps per barrier pair)
 
 struct ConvGeo {
     int C, H, W;             // input planes
@@ -67,7 +71,7 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
                 float* __restrict__ out2, const ConvGeo g) {
     constexpr bool PARITY = MODE == 1 || MODE == 2;          // four output-parity classes over the input grid
     constexpr int RS = PARITY ? 4 : R * S;
-    constexpr int CPC = RS == 9 ? 4 : (RS == 16 ? 2 : 8);       // channels per chunk
+    constexpr int CPC = (RS == 9 ? 4 : (RS == 16 ? 2 : 8)) * kCpcMult;       // channels per chunk
     constexpr int KC = CPC * RS;                                  // 36 / 32 / 32 reduction steps per chunk (even: MFMA k = 2)
     constexpr int AP = KC + 1;                                    // As pitch (odd: conflict-free operand reads)
     constexpr int NEA = TM * KC / kBlock, NEB = KC * TN / kBlock; // staged elements per thread
@@ -295,8 +299,17 @@ conv_split_reduce_kernel(const float* __restrict__ ws, const float* __restrict__
         const float* src = ws + plane * HW + p;
         float v[VEC];
         if constexpr (VEC == 4) {
-            float4 s4 = *reinterpret_cast<const float4*>(src);
-            for (int s = 1; s < splitk; ++s) {
+            // eight slots requested before the first is added (the loads are independent, the sum keeps its slot order)
+            float4 s4 = {0.f, 0.f, 0.f, 0.f};
+            int s = 0;
+            for (; s + 8 <= splitk; s += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(src + (s + j) * slot);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s4.x += t[j].x; s4.y += t[j].y; s4.z += t[j].z; s4.w += t[j].w; }
+            }
+            for (; s < splitk; ++s) {
                 const float4 t = *reinterpret_cast<const float4*>(src + s * slot);
                 s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w;
             }
@@ -389,7 +402,7 @@ int conv_plan(const char* fn, int64_t B, int64_t C, int64_t H, int64_t W, int64_
     }
     g.n_tiles = (g.N + tn - 1) / tn;
     g.k_tiles = (g.K + tm - 1) / tm;
-    const int cpc = (mode == 1 || mode == 2) ? 8 : (kernel == 3 ? 4 : 2);          // channels per chunk (conv_fwd_kernel's CPC)
+    const int cpc = ((mode == 1 || mode == 2) ? 8 : (kernel == 3 ? 4 : 2)) * kCpcMult;          // channels per chunk (conv_fwd_kernel's CPC)
     const int chunks_total = (g.C + cpc - 1) / cpc;
     const int64_t tiles = static_cast<int64_t>(g.n_tiles) * g.k_tiles * classes;
     int splitk = 1;
