@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include <type_traits>
 
 namespace ffwm {
 namespace {
@@ -911,11 +912,23 @@ constexpr int kWtRows = kWtRegion / kWtWaves;       // pixel rows per wave: 8
 
 // OVW (round 5): the finished tile is STORED instead of added -- every in-image cell of grad_feat has exactly one owner, so a caller
 // that hands over an uninitialised buffer (flipcat bit 1 of ffwm_warp_backward) saves its zero-fill and this kernel the read of it.
-template <bool FLIP, int CG, bool OVW = false>
-__global__ void __launch_bounds__(kWtThreads)
+// FIX (round 6): 32-bit fixed-point cells instead of doubles, the contribution formed by ONE fused multiply-add,
+// fma(w, g 2^s, 1.5 2^23): its bit pattern is 0x4B400000 + k (k = the contribution rounded to nearest, |k| < 2^22) and ds_add_u32 of
+// the patterns leaves n 0x4B400000 + sum k in a cell that took n corners.  n per cell comes from a count pass over the block's corners
+// (once: the flow is the same for every channel) and stays in a plane of its own; the scale of a channel group is exact -- the group's
+// gradients sit in registers before the first add, max|g| < 2^e is one block reduction -- and bits = min(22, 31 - bitlength(max n))
+// keeps n 2^bits below 2^31 for any flow.  ds_add_u32 retires in half the LDS time of ds_add_f64 (4.3 vs 8.6 clk per wave), the
+// v_cvt_f64_f32 per contribution is gone, the box is half the size.  A group with a NaN / Inf gradient adds its own-tile corners with
+// global atomics behind a flush of zeros.
+template <bool FLIP, int CG, bool OVW = false, bool FIX = false>
+__global__ void __launch_bounds__(kWtThreads, 4)          // two 8-wave blocks per CU: 128 registers
 warp_bwd_feat_tile_kernel(const float* __restrict__ flow, const float* __restrict__ gout, float* __restrict__ gfeat, int C, int H,
                           int W, int ntx, int nty, int groups_per_slab, int cslabs) {
-    __shared__ double acc[CG * kWtTile * kWtTile];
+    using AccT = typename std::conditional<FIX, unsigned, double>::type;
+    constexpr int NC = kWtTile * kWtTile;
+    constexpr unsigned kMagicBits = 0x4B400000u;
+    __shared__ AccT acc[(CG + (FIX ? 1 : 0)) * NC];           // FIX: plane CG = corners per cell
+    __shared__ unsigned redm[(CG > 1 ? CG : 1) * kWtWaves];
     unsigned t = xcd_remap(blockIdx.x, gridDim.x, 1);
     const int tx = t % ntx;
     t /= ntx;
@@ -947,15 +960,38 @@ warp_bwd_feat_tile_kernel(const float* __restrict__ flow, const float* __restric
             const int ci = static_cast<int>(cn.off[q] / 4u);          // cy * W + cx when valid
             const int cy = ci / W, cx = ci - cy * W;
             const bool mine = pin && cn.valid[q] && cx >= X0 && cx < X0 + kWtTile && cy >= Y0 && cy < Y0 + kWtTile;
-            cell[r][q] = mine ? (cy - Y0) * kWtTile + (cx - X0) : -1;
+            cell[r][q] = mine ? ((cy - Y0) * kWtTile + (cx - X0)) * static_cast<int>(sizeof(AccT)) : -1;      // BYTE offset in a plane: the only form kept (an index AND its address cost 32 more registers)
             wgt[r][q] = cn.w[q];
         }
     }
-    for (int i = threadIdx.x; i < CG * kWtTile * kWtTile; i += kWtThreads) acc[i] = 0.0;
+    auto at = [](AccT* plane0, int byte_off) { return reinterpret_cast<AccT*>(reinterpret_cast<char*>(plane0) + byte_off); };
+    for (int i = threadIdx.x; i < (CG + (FIX ? 1 : 0)) * NC; i += kWtThreads) acc[i] = 0;
     __syncthreads();
+    int bits = 22;
+    if constexpr (FIX) {
+        AccT* cnt = acc + CG * NC;
+#pragma unroll
+        for (int r = 0; r < kWtRows; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (cell[r][q] >= 0) __hip_atomic_fetch_add(at(cnt, cell[r][q]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        unsigned pop = 0;
+        for (int i = threadIdx.x; i < NC; i += kWtThreads) pop = max(pop, static_cast<unsigned>(cnt[i]));
+        pop = wave_max(pop);
+        if (lane == 0) redm[wave] = pop;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kWtWaves; ++k) pop = max(pop, redm[k]);
+        bits = __builtin_amdgcn_readfirstlane(min(22, 31 - (32 - __clz(static_cast<int>(pop)))));
+        __syncthreads();                             // (redm is rewritten by the first group)
+    }
 
     const int Co = FLIP ? 2 * C : C;
     const unsigned obytes = static_cast<unsigned>(plane * 4u);
+    int ex_assumed[CG], next_ex[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) ex_assumed[c] = next_ex[c] = 0;
     for (int gi = 0; gi < groups_per_slab; ++gi) {
         const int c0 = (slab * groups_per_slab + gi) * CG;
         if (c0 >= C) break;
@@ -972,27 +1008,163 @@ warp_bwd_feat_tile_kernel(const float* __restrict__ flow, const float* __restric
                 if (FLIP) g[r][c] += buf_ld<float>(rm, moff[r]);
             }
         }
+        float fx_inv[CG];
 #pragma unroll
-        for (int r = 0; r < kWtRows; ++r)
+        for (int c = 0; c < CG; ++c) fx_inv[c] = 0.f;
+        bool exact_path = false;
+        if constexpr (FIX) {
+            // The scale: 2^(bits - e) with max|g| < 2^e over the block's pixels.  Reducing that maximum over the block BEFORE the first add
+            // costs a barrier behind the group's loads -- every add of a two-channel group then waits for the slowest load of the block
+            // (measured: 492 -> 805 us).  So a group ASSUMES the exponent of the previous group's maximum + 1, adds while its loads arrive
+            // (as the double cells did), and the block's true maximum -- its gradients are in registers -- is checked behind the barrier
+            // that ends the adds anyway: above the assumed range (a contribution left the magic-number binade) or more than 3 bits below
+            // it (precision), the planes are cleared and the group is added again with its own exponent.  The first group of a block
+            // has no predecessor: it pays the reduction.
+            // (per CHANNEL: a channel's precision is 2^-bits of ITS largest gradient, whatever its neighbour in the group holds)
+            // (the maxima are folded BEHIND the adds: folding them first would make the first add wait for the last load of the group)
+            auto lane_max = [&](unsigned (&m)[CG]) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (cell[r][q] >= 0) {
+                for (int c = 0; c < CG; ++c) {
+                    m[c] = 0;
 #pragma unroll
-                    for (int c = 0; c < CG; ++c)
-                        __hip_atomic_fetch_add(acc + c * kWtTile * kWtTile + cell[r][q], static_cast<double>(wgt[r][q] * g[r][c]),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int r = 0; r < kWtRows; ++r) m[c] = max(m[c], __float_as_uint(g[r][c]) & 0x7FFFFFFFu);
+                    m[c] = wave_max(m[c]);
                 }
-        __syncthreads();
+            };
+            auto block_max = [&](unsigned (&m)[CG]) {          // redm[c][wave] -> every thread holds the block's maxima
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) redm[c * kWtWaves + wave] = m[c];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < CG; ++c)
+#pragma unroll
+                    for (int k = 0; k < kWtWaves; ++k) m[c] = max(m[c], redm[c * kWtWaves + k]);
+            };
+            if (gi == 0) {
+                unsigned m0[CG];
+                lane_max(m0);
+                block_max(m0);
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    ex_assumed[c] = 0;
+                    if (m0[c] != 0u && m0[c] < 0x7F800000u) (void)frexpf(__uint_as_float(m0[c]), &ex_assumed[c]);
+                }
+                __syncthreads();
+            }
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                float sc[CG];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    const int ex = __builtin_amdgcn_readfirstlane(min(max(ex_assumed[c], -80), 120));
+                    ex_assumed[c] = ex;
+                    sc[c] = ldexpf(1.f, bits - ex);
+                    fx_inv[c] = ldexpf(1.f, ex - bits);
+                }
+#pragma unroll
+                for (int r = 0; r < kWtRows; ++r) {
+                    float gs[CG];
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) gs[c] = g[r][c] * sc[c];        // (exact: a power of two)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (cell[r][q] >= 0) {
+#pragma unroll
+                            for (int c = 0; c < CG; ++c)
+                                __hip_atomic_fetch_add(at(acc + c * NC, cell[r][q]), __float_as_uint(__builtin_fmaf(wgt[r][q], gs[c], 12582912.f)),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                }
+                unsigned mb[CG];
+                lane_max(mb);
+                block_max(mb);                        // (its barrier: the adds of the attempt are in)
+                bool fits = true;
+                exact_path = false;
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    const bool bad = mb[c] >= 0x7F800000u;       // a NaN / Inf gradient among the channel's pixels
+                    exact_path = exact_path || bad;
+                    int ex_true = ex_assumed[c];
+                    if (mb[c] != 0u && !bad) (void)frexpf(__uint_as_float(mb[c]), &ex_true);
+                    ex_true = __builtin_amdgcn_readfirstlane(ex_true);
+                    fits = fits && (mb[c] == 0u || bad || (ex_true <= ex_assumed[c] && ex_true >= ex_assumed[c] - 3));
+                    next_ex[c] = (mb[c] != 0u && !bad) ? ex_true : ex_assumed[c];
+                }
+                if (exact_path) {
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) fx_inv[c] = 0.f;
+                }
+                if (fits || exact_path || attempt == 1) break;
+#pragma unroll
+                for (int c = 0; c < CG; ++c) ex_assumed[c] = next_ex[c];
+                for (int i = threadIdx.x; i < CG * NC; i += kWtThreads) acc[i] = 0;
+                __syncthreads();
+            }
+#pragma unroll
+            for (int c = 0; c < CG; ++c) ex_assumed[c] = next_ex[c] + 1;        // the next group's assumption: this group's exponents + 1
+        } else {
+#pragma unroll
+            for (int r = 0; r < kWtRows; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (cell[r][q] >= 0) {
+#pragma unroll
+                        for (int c = 0; c < CG; ++c)
+                            __hip_atomic_fetch_add(at(acc + c * NC, cell[r][q]), static_cast<AccT>(wgt[r][q] * g[r][c]),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+            __syncthreads();
+        }
         // flush the own tile: coalesced rows of 56 cells, plain read-modify-write (every cell has exactly one owner)
-        for (int i = threadIdx.x; i < CG * kWtTile * kWtTile; i += kWtThreads) {
-            const int c = i / (kWtTile * kWtTile), rem = i - c * kWtTile * kWtTile;
+        for (int i = threadIdx.x; i < CG * NC; i += kWtThreads) {
+            const int c = i / NC, rem = i - c * NC;
             const int cy = Y0 + rem / kWtTile, cx = X0 + rem % kWtTile;
-            const double v = acc[i];
-            acc[i] = 0.0;
+            float v;
+            if constexpr (FIX) {
+                float inv = fx_inv[0];
+#pragma unroll
+                for (int cc = 1; cc < CG; ++cc) inv = c == cc ? fx_inv[cc] : inv;
+                v = inv != 0.f ? static_cast<float>(static_cast<int>(acc[i] - static_cast<unsigned>(acc[CG * NC + rem]) * kMagicBits)) * inv : 0.f;
+            }
+            else v = static_cast<float>(acc[i]);
+            acc[i] = 0;
             if (c0 + c < C && cx < W && cy < H) {
                 float* d = gfeat + (static_cast<size_t>(b) * C + c0 + c) * plane + static_cast<size_t>(cy) * W + cx;
-                if (OVW) *d = static_cast<float>(v);
-                else *d += static_cast<float>(v);
+                if (OVW) *d = v;
+                else *d += v;
+            }
+        }
+        if constexpr (FIX) {
+            if (exact_path) {
+                // own-tile corners of the group by global atomics, behind this block's own stores (no other block writes these cells).
+                // Re-derived from the flow in a ROLLED loop: unrolled over the register arrays of the hot path it costs 67 more registers.
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+#pragma unroll 1
+                for (int r = 0; r < kWtRows; ++r) {
+                    const int y = Y0 - kWtHalo + wave + r * kWtWaves;
+                    if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
+                    Corners<float> cn;
+                    const size_t fo = static_cast<size_t>(y) * W + x;
+                    make_corners<float>(cn, fl[fo], fl[plane + fo], H, W);
+                    float gq[CG];
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) {
+                        gq[c] = c0 + c < C ? g0[static_cast<size_t>(c) * plane + fo] : 0.f;
+                        if (FLIP && c0 + c < C) gq[c] += g0[(static_cast<size_t>(C) + c) * plane + static_cast<size_t>(y) * W + (W - 1 - x)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ci = static_cast<int>(cn.off[q] / 4u);
+                        const int cy = ci / W, cx = ci - cy * W;
+                        if (!(cn.valid[q] && cx >= X0 && cx < X0 + kWtTile && cy >= Y0 && cy < Y0 + kWtTile)) continue;
+#pragma unroll
+                        for (int c = 0; c < CG; ++c)
+                            if (c0 + c < C)
+                                atomic_add(gfeat + (static_cast<size_t>(b) * C + c0 + c) * plane + static_cast<size_t>(cy) * W + cx, cn.w[q] * gq[c]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -1193,7 +1365,11 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
                 LaunchScope ls(scope_at(flip ? "warp_flipcat_bwd_feat_tile" : "warp_bwd_feat_tile", Hi), st,
                                sizeof(T) * static_cast<double>(B) * ((ovw ? 1.0 : 2.0) * C * Hi * Wi + 2.0 * H * W + (flip ? 2.0 : 1.0) * C * H * W));
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-#define FFWM_WT(FL, OV) hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<FL, CG, OV>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs)
+                // 1 = 32-bit fixed-point cells (round 6 experiment, OFF: correct, but hipcc cannot hold the kernel in 128 registers -- 64-104 bytes of
+                // scratch reloaded inside the add loop, each behind an s_waitcnt vmcnt(0): 495 -> 900 us; profiles/r06_warp_feat_fixed_negative.txt)
+                const bool fix = options().warp_feat_fixed == 1;
+#define FFWM_WT(FL, OV) do { if (fix) hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<FL, CG, OV, true>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs); \
+                             else hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<FL, CG, OV, false>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs); } while (0)
                 if (flip) { if (ovw) FFWM_WT(true, true); else FFWM_WT(true, false); }
                 else { if (ovw) FFWM_WT(false, true); else FFWM_WT(false, false); }
 #undef FFWM_WT

@@ -2431,6 +2431,62 @@ def test_winograd_domain_weight_gradient_accumulates_and_blocks():
     assert (once - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
 
 
+@pytest.mark.parametrize("fixed", [1, 0])
+@pytest.mark.parametrize("kind", ["plain", "channel_scales", "nonfinite", "zeros", "contract"])
+def test_warp_backward_feat_fixed_point_cells(oracle, kind, fixed):
+    """Round 6 (option warp_feat_fixed = 1; measured slower than the double cells, so OFF by default -- the test keeps the path honest and
+    runs the same inputs through the default): the owned-tile d(feat) kernel (planes beyond LDS) accumulates in 32-bit fixed-point cells -- contribution = one fma whose
+    bit pattern carries the integer (warp.hip, FIX) -- scaled per CHANNEL by an exponent ASSUMED from the previous channel group and
+    checked against the group's true maximum behind the adds (a miss repeats the group).  channel_scales: neighbouring channels eight
+    orders of magnitude apart in both directions (every group after the first misses and repeats; each channel keeps the precision of
+    its own scale); nonfinite: NaN / Inf gradients land exactly where the oracle puts them (the group's own-tile corners by global
+    atomics); zeros: an all-zero group between non-zero ones; contract: a flow that piles a region's corners onto few cells (the counted
+    population bound).  fixed = 0: the double cells of rounds 3-5 (the default) on the same inputs."""
+    from ffwm_amd import _lib, ops
+    g = _gen(91)
+    B, C, H, W = 1, 12, 150, 200
+    feat = torch.rand(B, C, H, W, generator=g)
+    ident = torch.stack(torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")[::-1]).unsqueeze(0)
+    flow = ident + 0.02 * (torch.rand(B, 2, H, W, generator=g) - 0.5)
+    if kind == "contract":
+        flow = ident * 0.05 + 0.3 + 0.002 * (torch.rand(B, 2, H, W, generator=g) - 0.5)      # the whole image onto a 10 x 8 patch
+    go = torch.rand(B, 2 * C, H, W, generator=g) - 0.3
+    if kind == "channel_scales":
+        sc = torch.tensor([1.0, 1e-4, 1e4, 1e-8, 1e8, 1.0, 1e-6, 1e-6, 3.0, 1e5, 1e-5, 1.0])
+        go = go * torch.cat((sc, sc)).view(1, 2 * C, 1, 1)
+    elif kind == "nonfinite":
+        go[0, 2, 17, 100] = float("nan")
+        go[0, 7, 140, 30] = float("inf")
+        go[0, C + 9, 60, 60] = -float("inf")
+    elif kind == "zeros":
+        go[0, 4:6] = 0
+        go[0, C + 4:C + 6] = 0
+    gfeat_ref, _ = oracle.warp_backward(feat, flow, go, True)
+    _lib.set_option("warp_feat_fixed", fixed)
+    try:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        got = torch.full_like(feat, float("nan"), device=DEV)
+        ops.warp_backward(feat.to(DEV), flow.to(DEV), go.to(DEV), True, got, None, overwrite_feat=True)
+        acc = torch.full_like(feat, 0.5, device=DEV)
+        ops.warp_backward(feat.to(DEV), flow.to(DEV), go.to(DEV), True, acc, None)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        assert any("bwd_feat_tile" in k for k in _lib.prof_collect())
+    finally:
+        _lib.set_option("warp_feat_fixed", 0)
+    for res in (got.cpu(), acc.cpu() - 0.5):
+        fin = torch.isfinite(gfeat_ref)
+        assert torch.equal(torch.isfinite(res), fin), (int((~torch.isfinite(res)).sum()), int((~fin).sum()))
+        for c in range(C):                      # per channel: relative to the channel's own largest gradient
+            m = fin[0, c]
+            if not m.any():
+                continue
+            scale = float(gfeat_ref[0, c][m].abs().max())
+            tol = 2e-5 * scale + (2e-7 if res is not got.cpu() else 0.0)
+            assert float((res[0, c][m] - gfeat_ref[0, c][m]).abs().max()) <= tol, (kind, c, float((res[0, c][m] - gfeat_ref[0, c][m]).abs().max()), scale)
+
+
 @pytest.mark.parametrize("flip", [False, True])
 @pytest.mark.parametrize("shape", [(1, 5, 150, 200), (2, 3, 40, 48), (1, 2, 130, 131)])
 def test_warp_backward_overwrite_mode_needs_no_zero_fill(oracle, shape, flip):
