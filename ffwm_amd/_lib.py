@@ -40,7 +40,7 @@ _SIGNATURES = {
     "ffwm_flow_up_backward": [_p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_conv2d_forward": [_p, _p, _p, _p, _p] + [_i64] * 5 + [_i, _i, _i, _i, _i64, _i64, _i, ctypes.c_double, _p, _i64, _i, _p],
     "ffwm_conv2d_wgrad": [_p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
-    "ffwm_conv2d_wgrad_tiled": [_p, _p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _p],
+    "ffwm_conv2d_wgrad_tiled": [_p, _p, _p, _p] + [_i64] * 7 + [_i, _i, _i, _i, _i, _p],
     "ffwm_conv3x3_winograd_forward": [_p, _p, _p, _p, _p] + [_i64] * 5 + [_i, _i, ctypes.c_double, _i, _p],
     "ffwm_adam_step": [_p, _p, _p, _p, _i64] + [ctypes.c_double] * 4 + [_i64, _i, _p],
     "ffwm_adam_step_device": [_p, _p, _p, _p, _i64] + [ctypes.c_double] * 4 + [_p, _i, _p],

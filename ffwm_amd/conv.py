@@ -125,8 +125,11 @@ class _GradArena:
     """Weight-gradient staging of ONE train step: every hand-written weight-gradient kernel of the step adds into zeroed memory (atomics
     of pixel slices / k tiles), and until round 5 each call cleared its own buffer -- ~270 fill launches per step (torch.zeros here, the
     library's zero-fill in the tiled kernel), 4-8 us each for a few hundred KiB.  Inside `begin()` .. `end()` the buffers are consecutive
-    slices of one tensor that ONE launch clears at the start of the step; the slices are handed to autograd as the layers' gradients (the
-    trainers' parameters own views of flat gradient buffers, so AccumulateGrad adds -- it never keeps a slice).  The first step measures
+    slices of one tensor that ONE launch clears at the start of the step; the slices are handed to autograd as the layers' gradients.
+    Who may keep a slice: with the trainers' flat gradient buffers AccumulateGrad ADDS a slice into the parameter's own view and drops
+    it; in a reducer's gather mode (param.grad is None during backward) autograd INSTALLS the slice as param.grad until the bucket is
+    packed -- which always happens before the next begin(), the only moment a slice's memory is reused (the trainers wrap the
+    step in try / finally so that end() also runs when a step raises).  The first step measures
     the demand with the old per-call fills; a step that asks for more than the arena holds falls back per call, and the arena grows
     behind it (never while a stream is capturing; retired buffers stay alive: a captured graph may still clear and use them)."""
 
@@ -155,6 +158,8 @@ class _GradArena:
         return s
 
     def end(self):
+        if not self.active:
+            return
         self.active = False
         if (self.buf is None or self.need > self.buf.numel()) and self.need > 0 and not torch.cuda.is_current_stream_capturing():
             if self.buf is not None:

@@ -430,7 +430,7 @@ extern "C" int ffwm_conv2d_wgrad(const void* rows, const void* gathered, void* g
 // (16-byte row loads); returns FFWM_ERR_ARG otherwise (callers fall back to ffwm_conv2d_wgrad).
 extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, void* grad_weight, void* grad_bias, int64_t B, int64_t K,
                                        int64_t Ho, int64_t Wo, int64_t C, int64_t H, int64_t W, int kernel, int stride, int pad,
-                                       int dtype, void* stream) {
+                                       int prezeroed, int dtype, void* stream) {
     const char* fn = "ffwm_conv2d_wgrad_tiled";
     FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
     FFWM_REQUIRE(rows && gathered && grad_weight, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
@@ -487,7 +487,7 @@ extern "C" int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, v
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* dw = static_cast<float*>(grad_weight);
     float* gb = static_cast<float*>(grad_bias);
-    if (g.nz > 1 && !options().conv_wgrad_prezeroed) {
+    if (g.nz > 1 && !prezeroed && !options().conv_wgrad_prezeroed) {
         const size_t nw = static_cast<size_t>(g.K) * g.N;
         const bool joined = gb == dw + nw;          // one buffer (ops.conv2d_wgrad_tiled allocates them together): one memset
         if (zero_fill(dw, sizeof(float) * (nw + (joined ? static_cast<size_t>(g.K) : 0)), st)) return FFWM_ERR_LAUNCH;

@@ -1017,7 +1017,10 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 #pragma unroll
     for (int r = 0; r < RPT; ++r) lbase[r] = (v0[r] - vmin) * kRsBoxW + (u0[r] - umin);
     // FIXED: 64 TH pixels, at most one contribution each per cell and channel, every one below 2^kShift after scaling
-    constexpr int kShift = 31 - 6 - (TH >= 16 ? 4 : (TH >= 8 ? 3 : 2));
+    // (one bit of headroom since round 6: 64 TH contributions of magnitude 2^kShift AFTER rounding would reach 2^31 exactly -- ADVICE r5.  The
+    // group-shared scale costs small channels beside a large one relative precision: 2^-kShift of the GROUP's largest gradient per contribution;
+    // the owned-tile kernel that serves the large calls since round 6 sizes its scale by the counted population and keeps 22 bits.)
+    constexpr int kShift = 30 - 6 - (TH >= 16 ? 4 : (TH >= 8 ? 3 : 2));
     // channel groups in runs of 64: a group the box cannot take (FIXED: a non-finite gradient; all of them when the block's taps do not
     // fit the box) is noted in `exact` (block-uniform) and scattered per tap after the run -- ONE instance of that code path
     for (int cbase = c0; cbase < c1; cbase += 256) {

@@ -484,14 +484,10 @@ def conv2d_wgrad_tiled(rows, gathered, kernel, stride, pad, want_bias=False, zer
     gb = buf[n:] if want_bias else None
     lib = _lib.load()
     with _on_device(rows) as stream:
-        if zeroed is not None:
-            lib.ffwm_set_option(b"conv_wgrad_prezeroed", 1)
-        try:
-            _lib.check(lib.ffwm_conv2d_wgrad_tiled(_ptr(rows), _ptr(gathered), _ptr(gw), _ptr(gb), B, K, Ho, Wo, C, H, W, int(kernel),
-                                                   int(stride), int(pad), _dtype_code(rows), stream), "ffwm_conv2d_wgrad_tiled")
-        finally:
-            if zeroed is not None:
-                lib.ffwm_set_option(b"conv_wgrad_prezeroed", 0)
+        # (`prezeroed` is an ARGUMENT since ABI 5: rounds 4-5 toggled a process-global library option around the call -- ADVICE r5)
+        _lib.check(lib.ffwm_conv2d_wgrad_tiled(_ptr(rows), _ptr(gathered), _ptr(gw), _ptr(gb), B, K, Ho, Wo, C, H, W, int(kernel),
+                                               int(stride), int(pad), 1 if zeroed is not None else 0, _dtype_code(rows), stream),
+                   "ffwm_conv2d_wgrad_tiled")
     return gw, gb
 
 
@@ -580,20 +576,29 @@ def conv3x3_winograd_weights_multi(items):
     return out
 
 
-_WINO_SPLIT_CAPPED = None
+_WINO_SPLIT_CAPPED = False
+_WINO_SPLIT_BEFORE_CAP = 1
 
 
 def _sync_winograd_split_mode():
     """torch.use_deterministic_algorithms(True) caps the Winograd kernel's reduction split at TWO pieces: two partial sums meet in a
     zero-filled output by float atomics, and a two-term sum does not depend on the order -- four terms do.  The library
-    option conv_wino_split follows the switch (1 = up to four pieces, 2 = capped); a value of 0 set by hand (never split) is kept."""
-    global _WINO_SPLIT_CAPPED
+    option conv_wino_split (1 = up to four pieces, the default; 2 = capped; 0 = never split) is RAISED to the cap while the switch is on
+    and put back to what it was when it goes off; with the switch off a value set by hand is never touched (the first call
+    used to overwrite a hand-set 2 with 1).  A hipGraph captured before the switch changed keeps the split it was captured with:
+    re-capture (FFWMTrainer.release_graphs()) after changing the switch."""
+    global _WINO_SPLIT_CAPPED, _WINO_SPLIT_BEFORE_CAP
     want = bool(torch.are_deterministic_algorithms_enabled())
-    if want != _WINO_SPLIT_CAPPED:
-        prev = _lib.set_option("conv_wino_split", 2 if want else 1)
+    if want == _WINO_SPLIT_CAPPED:
+        return
+    if want:
+        prev = _lib.set_option("conv_wino_split", 2)
+        _WINO_SPLIT_BEFORE_CAP = prev
         if prev == 0:
-            _lib.set_option("conv_wino_split", 0)
-        _WINO_SPLIT_CAPPED = want
+            _lib.set_option("conv_wino_split", 0)          # never split: already deterministic
+    else:
+        _lib.set_option("conv_wino_split", _WINO_SPLIT_BEFORE_CAP)
+    _WINO_SPLIT_CAPPED = want
 
 
 def conv3x3_winograd_splits(B, C, H, W, K, act=0):

@@ -780,14 +780,17 @@ class FFWMTrainer(object):
         """optimize_parameters (ffwm_model.py:151-160): forward, D step, G step."""
         if self._graphs is not None:
             return self._step_graphed(b, batch_increment)
-        self._seg_forward_and_D(b)
-        self._reduce_D()
-        self._seg_stepD_and_G(b)
-        if self.segmented:
-            self._finish_backward_G()
-            self._drop_autograd_graph()
-        self.red_G.finish()
-        self._seg_stepG()
+        try:
+            self._seg_forward_and_D(b)
+            self._reduce_D()
+            self._seg_stepD_and_G(b)
+            if self.segmented:
+                self._finish_backward_G()
+                self._drop_autograd_graph()
+            self.red_G.finish()
+            self._seg_stepG()
+        finally:
+            conv.GRAD_ARENA.end()             # also when the step raised: a later pass outside a step must not carve the arena (ADVICE r5)
         self.titers += batch_increment if batch_increment is not None else b["img_S"].size(0)
         self.losses["D"] = self.loss_D
         return self.losses
@@ -1149,8 +1152,10 @@ class FlowNetTrainer(object):
         loss_lm = self.criterionLD(flows, b["lm_S"], b["lm_F"], gate)
         loss = loss_cor + loss_lm + loss_reg
         self.reducer.zero_grad()
-        loss.backward()
-        conv.GRAD_ARENA.end()
+        try:
+            loss.backward()
+        finally:
+            conv.GRAD_ARENA.end()
         self.losses = {"loss": loss.detach(), "cor": loss_cor.detach(), "reg": loss_reg.detach(), "lm": loss_lm.detach()}
         self.fake_F = self.fake_F.detach()
 

@@ -409,10 +409,12 @@ int ffwm_conv2d_wgrad(const void* rows, const void* gathered, void* grad_weight,
  * 32 pixels; csrc/conv_bwd.hip "tiled variant"): grad_weight is OVERWRITTEN -- the library zero-fills it itself when the pixel
  * range is cut into slices that meet by atomics -- and grad_bias[K] (NULL: not wanted; Conv2d only: the sum of `rows` over batch
  * and pixels = convolution_backward's grad_bias) comes out of the same pass.  Needs Ho * Wo % 4 == 0 and a 16-byte aligned `rows`
- * (status FFWM_ERR_ARG otherwise: use ffwm_conv2d_wgrad). */
+ * (status FFWM_ERR_ARG otherwise: use ffwm_conv2d_wgrad).  prezeroed != 0 (ABI 5): grad_weight / grad_bias arrive ZEROED (slices of a gradient
+ * arena cleared by one launch per step) and a sliced launch skips its own zero-fill -- an argument since ABI 5, the process-global
+ * option of ABI 4 was not thread-safe. */
 int ffwm_conv2d_wgrad_tiled(const void* rows, const void* gathered, void* grad_weight, void* grad_bias, int64_t B, int64_t K,
-                            int64_t Ho, int64_t Wo, int64_t C, int64_t H, int64_t W, int kernel, int stride, int pad, int dtype,
-                            void* stream);
+                            int64_t Ho, int64_t Wo, int64_t C, int64_t H, int64_t W, int kernel, int stride, int pad, int prezeroed,
+                            int dtype, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2, 3x3) on the fp32 MFMA units (csrc/conv_winograd.hip): the
  * forward (data_gradient = 0: weight [K, C, 3, 3]) or the data gradient (data_gradient = 1: input = grad_output with C =

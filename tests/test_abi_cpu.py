@@ -68,9 +68,9 @@ def test_argument_errors_are_reported_before_launch(hiplib):
     assert hiplib.ffwm_conv3x3_winograd_workspace_bytes(0, 5) == 0
     rc = hiplib.ffwm_conv2d_wgrad(None, None, None, 1, 8, 4, 4, 8, 4, 4, 3, 1, 1, 0, None)
     assert rc == -1
-    rc = hiplib.ffwm_conv2d_wgrad_tiled(None, None, None, None, 1, 8, 4, 4, 8, 4, 4, 3, 1, 1, 0, None)
+    rc = hiplib.ffwm_conv2d_wgrad_tiled(None, None, None, None, 1, 8, 4, 4, 8, 4, 4, 3, 1, 1, 0, 0, None)
     assert rc == -1 and b"NULL" in hiplib.ffwm_last_error()
-    rc = hiplib.ffwm_conv2d_wgrad_tiled(p, p, p, None, 1, 8, 3, 3, 8, 3, 3, 3, 1, 1, 0, None)        # 9 pixels per plane: not a multiple of 4
+    rc = hiplib.ffwm_conv2d_wgrad_tiled(p, p, p, None, 1, 8, 3, 3, 8, 3, 3, 3, 1, 1, 0, 0, None)        # 9 pixels per plane: not a multiple of 4
     assert rc == -1 and b"multiple of 4" in hiplib.ffwm_last_error()
     rc = hiplib.ffwm_l1_multi(None, 0, None, None, 1, 0, None)
     assert rc == -1

@@ -39,7 +39,7 @@ if os.environ.get("FFWM_PROBE_TRACE") == "1":
         buf = ARENA[slot]
         gw, gb = buf[:n].view(K, C, kernel, kernel), (buf[n:n + K] if want_bias else None)
         L.check(L.load().ffwm_conv2d_wgrad_tiled(rows.data_ptr(), gathered.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None,
-                                                  B, K, Ho, Wo, C, H, W, kernel, stride, pad, 0, torch.cuda.current_stream().cuda_stream), "wgrad")
+                                                  B, K, Ho, Wo, C, H, W, kernel, stride, pad, 0, 0, torch.cuda.current_stream().cuda_stream), "wgrad")
         return gw, gb
 
     def _traced(rows, gathered, kernel, stride, pad, want_bias=False):
