@@ -22,6 +22,9 @@ _SIGNATURES = {
     # name: argtypes
     "ffwm_block_extractor_forward": [_p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
     "ffwm_block_extractor_backward": [_p, _p, _p, _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_block_extractor_backward_strided": [_p, _p, _p, ctypes.POINTER(_i64), _p, _p] + [_i64] * 6 + [_i, _i, _p],
+    "ffwm_local_attn_reshape_backward_strided": [_p, ctypes.POINTER(_i64), _p] + [_i64] * 3 + [_i, _i, _i, _p],
+    "ffwm_resample2d_backward_strided": [_p, _p, _p, ctypes.POINTER(_i64), _p, _p] + [_i64] * 6 + [_i, _i, _i, _i, _p],
     "ffwm_bn_lrelu_forward": [_p] * 9 + [_i64] * 3 + [ctypes.c_double] * 3 + [_i, _p],
     "ffwm_bn_lrelu_backward": [_p] * 10 + [_i64] * 3 + [ctypes.c_double] + [_i, _p],
     "ffwm_bn_res_act_forward": [_p] * 11 + [_i64] * 3 + [ctypes.c_double] * 3 + [_i, _i, _p],

@@ -9,7 +9,7 @@ def forward(source, flow_field, output, kernel_size):
 
 
 def backward(source, flow_field, grad_output, grad_source, grad_flow_field, kernel_size):
-    # the reference kernels read grad_output through its strides; the C ABI wants it contiguous
-    ops.block_extractor_backward(source, flow_field, grad_output.contiguous(), kernel_size, grad_source,
-                                 grad_flow_field)
+    # the reference kernels read grad_output through its strides (block_extractor_kernel.cu:8-15); so does the C ABI since ABI 5
+    # (ffwm_block_extractor_backward_strided): no copy here
+    ops.block_extractor_backward(source, flow_field, grad_output, kernel_size, grad_source, grad_flow_field)
     return 1

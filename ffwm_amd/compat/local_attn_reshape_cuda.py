@@ -10,5 +10,6 @@ def forward(inputs, output, kernel_size):
 
 def backward(inputs, grad_output, grad_inputs, kernel_size):
     # reference semantics: += into the caller's (zero-filled) buffer
-    ops.local_attn_reshape_backward(grad_output.contiguous(), kernel_size, grad_inputs, accumulate=True)
+    # (a non-contiguous grad_output is read through its strides: ffwm_local_attn_reshape_backward_strided, ABI 5)
+    ops.local_attn_reshape_backward(grad_output, kernel_size, grad_inputs, accumulate=True)
     return 1

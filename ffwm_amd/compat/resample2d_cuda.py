@@ -9,6 +9,6 @@ def forward(input1, input2, output, kernel_size, dilation):
 
 
 def backward(input1, input2, gradOutput, gradInput1, gradInput2, kernel_size, dilation):
-    ops.resample2d_backward(input1, input2, gradOutput.contiguous(), kernel_size, dilation, gradInput1,
-                            gradInput2, reference_quirk=True)
+    # (a non-contiguous gradOutput is read through its strides: ffwm_resample2d_backward_strided, ABI 5)
+    ops.resample2d_backward(input1, input2, gradOutput, kernel_size, dilation, gradInput1, gradInput2, reference_quirk=True)
     return 1

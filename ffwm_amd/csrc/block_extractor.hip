@@ -1884,7 +1884,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
 be_bwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ gout,
                T* __restrict__ gsrc, T* __restrict__ gflow, int64_t n, int C, int Hs, int Ws,
-               int Hf, int Wf, int k) {
+               int Hf, int Wf, int k, const GoStrides gs = GoStrides{0, 0, 0, 0}) {
     const int H = k * Hf, W = k * Wf;
     for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
          index += static_cast<int64_t>(gridDim.x) * kBlock) {
@@ -1905,7 +1905,8 @@ be_bwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* _
         const size_t soff = bc * static_cast<size_t>(Hs) * Ws;
         const T* sp = src + soff;
         const T sTL = sp[yT + xL], sTR = sp[yT + xR], sBL = sp[yB + xL], sBR = sp[yB + xR];
-        const T g = gout[index];
+        // (grad_output through its strides when the caller handed them over: all zero = contiguous)
+        const T g = gs.x == 0 ? gout[index] : gout[b * gs.b + (bc - b * C) * gs.c + static_cast<long long>(y) * gs.y + static_cast<long long>(x) * gs.x];
         if (gsrc) {
             T* gp = gsrc + soff;
             atomic_add(gp + yT + xL, g * xLP * yTP);
@@ -2354,6 +2355,45 @@ extern "C" int ffwm_block_extractor_backward(const void* source, const void* flo
     return launch_bwd<double>((const double*)source, (const double*)flow_field, (const double*)grad_output,
                               (double*)grad_source, (double*)grad_flow_field, B, C, Hs, Ws, Hf, Wf,
                               kernel_size, st);
+}
+
+// grad_output read through its element strides (NULL / contiguous strides: the entry point above).  A strided grad_output -- autograd
+// hands one over whenever the gradient is an expanded or permuted view, and the reference's Function drops the result of its
+// .contiguous() call (models/external_function.py:46-47), so its kernels really read it that way (DIM3_INDEX,
+// block_extractor_kernel.cu:8-15) -- takes the per-element kernel: correct for any layout, not a tuned path.
+template <typename T>
+int launch_bwd_strided(const T* src, const T* flow, const T* gout, T* gsrc, T* gflow, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
+                       int64_t Hf, int64_t Wf, int k, const int64_t* st4, hipStream_t st) {
+    const int64_t n = B * C * k * Hf * k * Wf;
+    const unsigned grid = static_cast<unsigned>(n / kBlock + 1 < 16384 ? n / kBlock + 1 : 16384);
+    const double bytes = sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * k * k * Hf * Wf + 2.0 * C * Hs * Ws + 4.0 * Hf * Wf);
+    LaunchScope ls("block_extractor_bwd_strided", st, bytes);
+    // (x stride 0 is the kernel's "contiguous" mark: an expanded last dimension passes through a stride struct with x = 0 replaced below)
+    FFWM_REQUIRE(st4[3] != 0 || k * Wf == 1, FFWM_ERR_ARG, "ffwm_block_extractor_backward_strided: a grad_output expanded along its last dimension (stride 0) is not supported");
+    hipLaunchKernelGGL((be_bwd_generic<T>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc, gflow, n, (int)C, (int)Hs, (int)Ws,
+                       (int)Hf, (int)Wf, k, GoStrides{st4[0], st4[1], st4[2], st4[3] != 0 ? st4[3] : 1});
+    return check_launch("ffwm_block_extractor_backward_strided");
+}
+
+extern "C" int ffwm_block_extractor_backward_strided(const void* source, const void* flow_field, const void* grad_output,
+                                                     const int64_t* grad_output_strides, void* grad_source, void* grad_flow_field,
+                                                     int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf,
+                                                     int kernel_size, int dtype, void* stream) {
+    const char* fn = "ffwm_block_extractor_backward_strided";
+    if (go_contiguous(grad_output_strides, C, kernel_size * Hf, kernel_size * Wf))
+        return ffwm_block_extractor_backward(source, flow_field, grad_output, grad_source, grad_flow_field, B, C, Hs, Ws, Hf, Wf,
+                                             kernel_size, dtype, stream);
+    FFWM_REQUIRE(source && flow_field && grad_output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hs, Ws, Hf, Wf, kernel_size, dtype)) return rc;
+    for (int d = 0; d < 4; ++d)
+        FFWM_REQUIRE(grad_output_strides[d] >= 0, FFWM_ERR_ARG, "%s: negative strides are not supported", fn);
+    if (!grad_source && !grad_flow_field) return FFWM_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == FFWM_F32)
+        return launch_bwd_strided<float>((const float*)source, (const float*)flow_field, (const float*)grad_output, (float*)grad_source,
+                                         (float*)grad_flow_field, B, C, Hs, Ws, Hf, Wf, kernel_size, grad_output_strides, st);
+    return launch_bwd_strided<double>((const double*)source, (const double*)flow_field, (const double*)grad_output, (double*)grad_source,
+                                      (double*)grad_flow_field, B, C, Hs, Ws, Hf, Wf, kernel_size, grad_output_strides, st);
 }
 
 extern "C" int ffwm_block_attention_forward(const void* source, const void* flow_field, const void* weights, void* output,

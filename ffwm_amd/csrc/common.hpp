@@ -96,6 +96,15 @@ Geometry plan(int64_t B, int64_t C, int64_t H, int64_t W, int cs_default);
 
 inline bool dtype_ok(int dtype) { return dtype == FFWM_F32 || dtype == FFWM_F64; }
 
+// Element strides of a 4-D grad_output as the reference's kernels read it (DIM3_INDEX with the tensor's strides,
+// cuda/block_extractor/block_extractor_kernel.cu:8-15): the *_backward_strided entry points (ABI 5).
+struct GoStrides {
+    long long b, c, y, x;
+};
+inline bool go_contiguous(const int64_t* st, int64_t C, int64_t H, int64_t W) {
+    return st == nullptr || (st[3] == 1 && st[2] == W && st[1] == H * W && st[0] == C * H * W);
+}
+
 #define FFWM_REQUIRE(cond, code, ...)  \
     do {                               \
         if (!(cond)) {                 \

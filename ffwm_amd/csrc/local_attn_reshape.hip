@@ -83,7 +83,7 @@ lar_fwd_generic(const T* __restrict__ in, T* __restrict__ out, int64_t nrows, in
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 lar_bwd_generic(const T* __restrict__ gout, T* __restrict__ gin, int64_t nrows, int H, int W, int k,
-                int acc) {
+                int acc, const GoStrides gs = GoStrides{0, 0, 0, 0}) {
     const int64_t plane = static_cast<int64_t>(H) * W;
     for (int64_t tid = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; tid < nrows;
          tid += static_cast<int64_t>(gridDim.x) * kBlock) {
@@ -95,7 +95,9 @@ lar_bwd_generic(const T* __restrict__ gout, T* __restrict__ gin, int64_t nrows, 
         const int64_t b = r / H;
         T* p = gin + (b * k * k + static_cast<int64_t>(i) * k) * plane + static_cast<int64_t>(ys) * W + xs;
         for (int j = 0; j < k; ++j) {
-            const T g = gout[tid * k + j];
+            // grad_output [B, 1, kH, kW]: row (b, ys k + i), column xs k + j -- through its strides when they were handed over
+            const T g = gs.x == 0 ? gout[tid * k + j]
+                                  : gout[b * gs.b + (static_cast<long long>(ys) * k + i) * gs.y + (static_cast<long long>(xs) * k + j) * gs.x];
             if (acc) p[j * plane] += g;
             else p[j * plane] = g;
         }
@@ -193,4 +195,30 @@ extern "C" int ffwm_local_attn_reshape_backward(const void* grad_output, void* g
                                  accumulate, st);
     return launch_bwd<double>((const double*)grad_output, (double*)grad_inputs, B, H, W, kernel_size,
                               accumulate, st);
+}
+
+// grad_output [B, 1, kH, kW] read through its element strides (NULL / contiguous: the entry point above); any other layout takes the
+// run-time-k kernel.  Reference: local_attn_reshape_kernel.cu:66-108 reads gradOutput with DIM3_INDEX and the tensor's strides.
+extern "C" int ffwm_local_attn_reshape_backward_strided(const void* grad_output, const int64_t* grad_output_strides, void* grad_inputs,
+                                                        int64_t B, int64_t H, int64_t W, int kernel_size, int accumulate, int dtype,
+                                                        void* stream) {
+    const char* fn = "ffwm_local_attn_reshape_backward_strided";
+    if (go_contiguous(grad_output_strides, 1, kernel_size * H, kernel_size * W))
+        return ffwm_local_attn_reshape_backward(grad_output, grad_inputs, B, H, W, kernel_size, accumulate, dtype, stream);
+    FFWM_REQUIRE(grad_output && grad_inputs, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, H, W, kernel_size, dtype)) return rc;
+    for (int d = 0; d < 4; ++d)
+        FFWM_REQUIRE(grad_output_strides[d] >= 0, FFWM_ERR_ARG, "%s: negative strides are not supported", fn);
+    FFWM_REQUIRE(grad_output_strides[3] != 0, FFWM_ERR_ARG, "%s: a grad_output expanded along its last dimension (stride 0) is not supported", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t nrows = B * H * kernel_size * W;
+    const GoStrides gs{grad_output_strides[0], grad_output_strides[1], grad_output_strides[2], grad_output_strides[3]};
+    LaunchScope ls("local_attn_reshape_bwd_strided", st, 2.0 * (dtype == FFWM_F32 ? 4 : 8) * static_cast<double>(nrows) * kernel_size);
+    if (dtype == FFWM_F32)
+        hipLaunchKernelGGL((lar_bwd_generic<float>), dim3(grid_for(nrows)), dim3(kBlock), 0, st, (const float*)grad_output, (float*)grad_inputs,
+                           nrows, (int)H, (int)W, kernel_size, accumulate, gs);
+    else
+        hipLaunchKernelGGL((lar_bwd_generic<double>), dim3(grid_for(nrows)), dim3(kBlock), 0, st, (const double*)grad_output, (double*)grad_inputs,
+                           nrows, (int)H, (int)W, kernel_size, accumulate, gs);
+    return check_launch(fn);
 }

@@ -1792,7 +1792,7 @@ rs_fwd_generic(const T* __restrict__ in1, const T* __restrict__ in2, T* __restri
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 rs_bwd1_generic(const T* __restrict__ in2, const T* __restrict__ gout, T* __restrict__ gin1, int64_t n,
-                int C, int Hi, int Wi, int H, int W, int ks, int dil, int quirk) {
+                int C, int Hi, int Wi, int H, int W, int ks, int dil, int quirk, const GoStrides gs = GoStrides{0, 0, 0, 0}) {
     const int half = ks / 2;
     const size_t plane = static_cast<size_t>(H) * W, iplane = static_cast<size_t>(Hi) * Wi;
     for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
@@ -1813,7 +1813,7 @@ rs_bwd1_generic(const T* __restrict__ in2, const T* __restrict__ gout, T* __rest
                 const GenTap<T> g = gen_tap<T>(flx, fly, alpha, beta, sigma, fx, fy, dil, Hi, Wi);
                 sum += (g.yTP * g.xLP + g.yTP * g.xRP + g.yBP * g.xLP + g.yBP * g.xRP);
             }
-        const T go = gout[index];
+        const T go = gs.x == 0 ? gout[index] : gout[b * gs.b + (bc - b * C) * gs.c + static_cast<long long>(y) * gs.y + static_cast<long long>(x) * gs.x];
         T* gp = gin1 + bc * iplane;
         for (int fy = 0; fy < half; ++fy)
             for (int fx = 0; fx < half; ++fx) {
@@ -1829,7 +1829,8 @@ rs_bwd1_generic(const T* __restrict__ in2, const T* __restrict__ gout, T* __rest
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 rs_bwd2_generic(const T* __restrict__ in1, const T* __restrict__ in2, const T* __restrict__ gout,
-                T* __restrict__ gin2, int64_t n, int C, int Hi, int Wi, int H, int W, int ks, int dil) {
+                T* __restrict__ gin2, int64_t n, int C, int Hi, int Wi, int H, int W, int ks, int dil,
+                const GoStrides gs = GoStrides{0, 0, 0, 0}) {
     const int half = ks / 2;
     const size_t plane = static_cast<size_t>(H) * W, iplane = static_cast<size_t>(Hi) * Wi;
     for (int64_t index = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; index < n;
@@ -1847,7 +1848,9 @@ rs_bwd2_generic(const T* __restrict__ in1, const T* __restrict__ in2, const T* _
         const T alpha = xf - flx, beta = yf - fly;
         const T ns2 = -sigma * sigma, s3 = sigma * sigma * sigma;
         const T* ip = in1 + b * C * iplane;
-        const T* op = gout + b * C * plane + poff;
+        // (grad_output through its strides when they were handed over: channel stride cs, base of pixel (b, y, x))
+        const long long cs = gs.x == 0 ? static_cast<long long>(plane) : gs.c;
+        const T* op = gs.x == 0 ? gout + b * C * plane + poff : gout + b * gs.b + static_cast<long long>(y) * gs.y + static_cast<long long>(x) * gs.x;
         T grad1 = 0, sumgrad = 0, sum = 0, S = 0;
         for (int fy = 0; fy < half; ++fy)
             for (int fx = 0; fx < half; ++fx) {
@@ -1855,7 +1858,7 @@ rs_bwd2_generic(const T* __restrict__ in1, const T* __restrict__ in2, const T* _
                 sum += (g.yTP * g.xLP + g.yTP * g.xRP + g.yBP * g.xLP + g.yBP * g.xRP);
                 T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
                 for (int ch = 0; ch < C; ++ch) {
-                    const T go = op[ch * plane];
+                    const T go = op[ch * cs];
                     const T* p = ip + ch * iplane;
                     a0 += go * p[static_cast<size_t>(g.yT) * Wi + g.xL];
                     a1 += go * p[static_cast<size_t>(g.yT) * Wi + g.xR];
@@ -2254,4 +2257,52 @@ extern "C" int ffwm_resample2d_backward(const void* input1, const void* input2, 
     return launch_bwd<double>((const double*)input1, (const double*)input2, (const double*)grad_output,
                               (double*)grad_input1, (double*)grad_input2, B, C, Hi, Wi, H, W, kernel_size,
                               dilation, reference_quirk, st);
+}
+
+// grad_output read through its element strides (NULL / contiguous: the entry point above).  Any other layout takes the per-element
+// kernels (resample2d_kernel.cu:98-330 read gradOutput with DIM3_INDEX and the tensor's strides): correct for any view, not tuned.
+// grad_input1 += (reference_quirk bit 1: overwritten -- the library clears it first), grad_input2 is overwritten.
+extern "C" int ffwm_resample2d_backward_strided(const void* input1, const void* input2, const void* grad_output,
+                                                const int64_t* grad_output_strides, void* grad_input1, void* grad_input2, int64_t B,
+                                                int64_t C, int64_t Hi, int64_t Wi, int64_t H, int64_t W, int kernel_size, int dilation,
+                                                int reference_quirk, int dtype, void* stream) {
+    const char* fn = "ffwm_resample2d_backward_strided";
+    if (go_contiguous(grad_output_strides, C, H, W))
+        return ffwm_resample2d_backward(input1, input2, grad_output, grad_input1, grad_input2, B, C, Hi, Wi, H, W, kernel_size, dilation,
+                                        reference_quirk, dtype, stream);
+    FFWM_REQUIRE(input1 && input2 && grad_output, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    if (int rc = check_dims(fn, B, C, Hi, Wi, H, W, kernel_size, dilation, dtype)) return rc;
+    FFWM_REQUIRE(reference_quirk >= 0 && reference_quirk <= 3, FFWM_ERR_ARG, "%s: reference_quirk is a 2-bit flag word", fn);
+    for (int d = 0; d < 4; ++d)
+        FFWM_REQUIRE(grad_output_strides[d] >= 0, FFWM_ERR_ARG, "%s: negative strides are not supported", fn);
+    FFWM_REQUIRE(grad_output_strides[3] != 0, FFWM_ERR_ARG, "%s: a grad_output expanded along its last dimension (stride 0) is not supported", fn);
+    if (!grad_input1 && !grad_input2) return FFWM_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const GoStrides gs{grad_output_strides[0], grad_output_strides[1], grad_output_strides[2], grad_output_strides[3]};
+    const size_t esz = dtype == FFWM_F32 ? 4 : 8;
+    if (grad_input1 && (reference_quirk & 2))
+        if (zero_fill(grad_input1, esz * static_cast<size_t>(B) * C * Hi * Wi, st)) return FFWM_ERR_LAUNCH;
+    LaunchScope ls("resample2d_bwd_strided", st, static_cast<double>(esz) * B * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 6.0 * H * W));
+    const int ks = kernel_size & ~1, quirk = reference_quirk & 1;
+    if (grad_input1) {
+        const int64_t n = B * C * H * W;
+        if (dtype == FFWM_F32)
+            hipLaunchKernelGGL((rs_bwd1_generic<float>), dim3(generic_grid(n)), dim3(kBlock), 0, st, (const float*)input2, (const float*)grad_output,
+                               (float*)grad_input1, n, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, ks, dilation, quirk, gs);
+        else
+            hipLaunchKernelGGL((rs_bwd1_generic<double>), dim3(generic_grid(n)), dim3(kBlock), 0, st, (const double*)input2, (const double*)grad_output,
+                               (double*)grad_input1, n, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, ks, dilation, quirk, gs);
+        if (int rc = check_launch(fn)) return rc;
+    }
+    if (grad_input2) {
+        const int64_t n = B * 3 * H * W;
+        if (dtype == FFWM_F32)
+            hipLaunchKernelGGL((rs_bwd2_generic<float>), dim3(generic_grid(n)), dim3(kBlock), 0, st, (const float*)input1, (const float*)input2,
+                               (const float*)grad_output, (float*)grad_input2, n, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, ks, dilation, gs);
+        else
+            hipLaunchKernelGGL((rs_bwd2_generic<double>), dim3(generic_grid(n)), dim3(kBlock), 0, st, (const double*)input1, (const double*)input2,
+                               (const double*)grad_output, (double*)grad_input2, n, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, ks, dilation, gs);
+        if (int rc = check_launch(fn)) return rc;
+    }
+    return FFWM_OK;
 }

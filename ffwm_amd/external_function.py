@@ -10,8 +10,10 @@ Underneath, every call goes through the C ABI of libffwm_hip.so (hand-written gf
 Differences from the reference, all deliberate:
   * outputs are allocated uninitialised where the kernel overwrites them (the reference zero-fills
     and then overwrites); gradients that are scattered into are still zero-filled;
-  * ``grad_output`` is made contiguous for real (the reference calls ``.contiguous()`` and drops
-    the result, external_function.py:46-47,93-94,132-133);
+  * ``grad_output`` is made contiguous for real in these Functions (the reference calls ``.contiguous()`` and drops
+    the result, external_function.py:46-47,93-94,132-133): a copy + the tuned kernels beats reading a view element by
+    element.  The C ABI itself takes a strided grad_output since ABI 5 (ffwm_*_backward_strided; ``ops.*_backward`` pass a
+    non-contiguous tensor's strides through), which is what ``ffwm_amd.compat`` -- the pybind-name shims -- relies on;
   * gradients nobody asked for (``ctx.needs_input_grad``) are not computed;
   * a device guard: kernels launch on the tensors' device and its current stream.
 Plus ``WarpNet`` (models/base_networks.py:168-173) and the fused warp + flip + concat that

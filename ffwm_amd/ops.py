@@ -21,10 +21,27 @@ def _dtype_code(t):
         raise TypeError("ffwm_amd ops support float32/float64 (AT_DISPATCH_FLOATING_TYPES), got %s" % t.dtype)
 
 
-def _check(name, *tensors):
+def _go_strides(grad_output):
+    """(ctypes int64[4] or None, keep-alive): the element strides of a grad_output that is not contiguous -- handed to the
+    *_backward_strided entry points, which read it the way the reference's kernels do (DIM3_INDEX with the tensor's strides,
+    cuda/block_extractor/block_extractor_kernel.cu:8-15; the reference's Functions drop the result of .contiguous(),
+    models/external_function.py:46-47).  Views with a negative stride or a stride-0 last dimension are copied instead."""
+    if grad_output.is_contiguous():
+        return grad_output, None
+    st = grad_output.stride()
+    if any(x < 0 for x in st) or st[3] == 0:
+        return grad_output.contiguous(), None
+    return grad_output, (ctypes.c_int64 * 4)(*st)
+
+
+def _check(name, *tensors, strided_ok=None):
     ref = tensors[0]
     for t in tensors:
         if t is None:
+            continue
+        if t is strided_ok:
+            if not t.is_cuda or t.device != ref.device or t.dtype != ref.dtype or t.dim() != 4:
+                raise ValueError("%s: grad_output must be a 4-D tensor of the operands' device and dtype" % name)
             continue
         if not t.is_cuda:
             raise NotImplementedError("%s: ffwm_amd ops run on the GPU only (got a %s tensor)" % (name, t.device))
@@ -91,7 +108,8 @@ def block_extractor_forward(source, flow_field, kernel_size, out=None):
 def block_extractor_backward(source, flow_field, grad_output, kernel_size, grad_source=None,
                              grad_flow_field=None):
     """Accumulates (+=) into the given, zero-filled gradient buffers; None skips one."""
-    _check("block_extractor_backward", source, flow_field, grad_output, grad_source, grad_flow_field)
+    grad_output, gst = _go_strides(grad_output)
+    _check("block_extractor_backward", source, flow_field, grad_output, grad_source, grad_flow_field, strided_ok=grad_output if gst is not None else None)
     B, C, Hs, Ws = source.shape
     _, _, Hf, Wf = flow_field.shape
     k = int(kernel_size)
@@ -100,9 +118,14 @@ def block_extractor_backward(source, flow_field, grad_output, kernel_size, grad_
     if grad_output.numel() == 0:
         return grad_source, grad_flow_field
     with _on_device(source) as stream:
-        _lib.check(_lib.load().ffwm_block_extractor_backward(
-            _ptr(source), _ptr(flow_field), _ptr(grad_output), _ptr(grad_source), _ptr(grad_flow_field),
-            B, C, Hs, Ws, Hf, Wf, k, _dtype_code(source), stream), "ffwm_block_extractor_backward")
+        if gst is None:
+            _lib.check(_lib.load().ffwm_block_extractor_backward(
+                _ptr(source), _ptr(flow_field), _ptr(grad_output), _ptr(grad_source), _ptr(grad_flow_field),
+                B, C, Hs, Ws, Hf, Wf, k, _dtype_code(source), stream), "ffwm_block_extractor_backward")
+        else:              # a non-contiguous grad_output is read through its strides (no copy): the per-element kernel
+            _lib.check(_lib.load().ffwm_block_extractor_backward_strided(
+                _ptr(source), _ptr(flow_field), _ptr(grad_output), gst, _ptr(grad_source), _ptr(grad_flow_field),
+                B, C, Hs, Ws, Hf, Wf, k, _dtype_code(source), stream), "ffwm_block_extractor_backward_strided")
     return grad_source, grad_flow_field
 
 
@@ -174,7 +197,9 @@ def local_attn_reshape_forward(inputs, kernel_size, out=None):
 
 def local_attn_reshape_backward(grad_output, kernel_size, grad_inputs=None, accumulate=False):
     """grad_inputs[B,k*k,H,W]; accumulate=True is the reference's += into a zero-filled buffer."""
-    _check("local_attn_reshape_backward", grad_output, grad_inputs)
+    grad_output, gst = _go_strides(grad_output)
+    _check("local_attn_reshape_backward", grad_inputs if grad_inputs is not None else grad_output, grad_output, grad_inputs,
+           strided_ok=grad_output if gst is not None else None)
     B, one, Ho, Wo = grad_output.shape
     k = int(kernel_size)
     if one != 1 or Ho % k or Wo % k:
@@ -189,9 +214,14 @@ def local_attn_reshape_backward(grad_output, kernel_size, grad_inputs=None, accu
     if grad_output.numel() == 0:
         return grad_inputs
     with _on_device(grad_output) as stream:
-        _lib.check(_lib.load().ffwm_local_attn_reshape_backward(
-            _ptr(grad_output), _ptr(grad_inputs), B, H, W, k, 1 if accumulate else 0,
-            _dtype_code(grad_output), stream), "ffwm_local_attn_reshape_backward")
+        if gst is None:
+            _lib.check(_lib.load().ffwm_local_attn_reshape_backward(
+                _ptr(grad_output), _ptr(grad_inputs), B, H, W, k, 1 if accumulate else 0,
+                _dtype_code(grad_output), stream), "ffwm_local_attn_reshape_backward")
+        else:
+            _lib.check(_lib.load().ffwm_local_attn_reshape_backward_strided(
+                _ptr(grad_output), gst, _ptr(grad_inputs), B, H, W, k, 1 if accumulate else 0,
+                _dtype_code(grad_output), stream), "ffwm_local_attn_reshape_backward_strided")
     return grad_inputs
 
 
@@ -222,18 +252,24 @@ def resample2d_backward(input1, input2, grad_output, kernel_size=2, dilation=1, 
                         grad_input2=None, reference_quirk=True, overwrite_input1=False):
     """grad_input1 += (zero-fill it first) -- or, with overwrite_input1, grad_input1[:B] = (the buffer may be uninitialised: the owned-tile
     kernel stores every cell once, any other path clears the buffer itself) --, grad_input2 is overwritten; None skips one."""
-    _check("resample2d_backward", input1, input2, grad_output, grad_input1, grad_input2)
+    grad_output, gst = _go_strides(grad_output)
+    _check("resample2d_backward", input1, input2, grad_output, grad_input1, grad_input2, strided_ok=grad_output if gst is not None else None)
     _, C, Hi, Wi = input1.shape
     B, _, H, W = input2.shape
     if tuple(grad_output.shape) != (B, C, H, W):
         raise ValueError("resample2d_backward: grad_output has the wrong shape")
     if grad_output.numel() == 0:
         return grad_input1, grad_input2
+    flags = (1 if reference_quirk else 0) | (2 if overwrite_input1 else 0)
     with _on_device(input1) as stream:
-        _lib.check(_lib.load().ffwm_resample2d_backward(
-            _ptr(input1), _ptr(input2), _ptr(grad_output), _ptr(grad_input1), _ptr(grad_input2), B, C, Hi,
-            Wi, H, W, int(kernel_size), int(dilation), (1 if reference_quirk else 0) | (2 if overwrite_input1 else 0),
-            _dtype_code(input1), stream), "ffwm_resample2d_backward")
+        if gst is None:
+            _lib.check(_lib.load().ffwm_resample2d_backward(
+                _ptr(input1), _ptr(input2), _ptr(grad_output), _ptr(grad_input1), _ptr(grad_input2), B, C, Hi,
+                Wi, H, W, int(kernel_size), int(dilation), flags, _dtype_code(input1), stream), "ffwm_resample2d_backward")
+        else:
+            _lib.check(_lib.load().ffwm_resample2d_backward_strided(
+                _ptr(input1), _ptr(input2), _ptr(grad_output), gst, _ptr(grad_input1), _ptr(grad_input2), B, C, Hi,
+                Wi, H, W, int(kernel_size), int(dilation), flags, _dtype_code(input1), stream), "ffwm_resample2d_backward_strided")
     return grad_input1, grad_input2
 
 

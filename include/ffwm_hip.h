@@ -98,6 +98,24 @@ int ffwm_local_attn_reshape_backward(const void* grad_output, void* grad_inputs,
                                      int64_t H, int64_t W, int kernel_size, int accumulate,
                                      int dtype, void* stream);
 
+/* grad_output through its ELEMENT STRIDES (ABI 5).  The reference's kernels index gradOutput with DIM3_INDEX and the tensor's own strides
+ * (cuda/block_extractor/block_extractor_kernel.cu:8-15, local_attn_reshape_kernel.cu:8-15, resample2d_kernel.cu:8-15) and its Functions
+ * throw the result of grad_output.contiguous() away (models/external_function.py:46-47,93-94,132-133), so a pybind module that replaces
+ * the reference's must take an expanded / permuted / sliced gradient as it comes.  grad_output_strides[4] = (batch, channel, row, column)
+ * strides in elements, all >= 0, column stride != 0; NULL or the contiguous NCHW strides = the entry points above (the tuned kernels).
+ * Any other layout runs the per-element kernels: the reference's own decomposition -- correct for every view, not a tuned path.
+ * Everything else as in the plain entry points (ffwm_block_extractor_backward, ffwm_local_attn_reshape_backward, ffwm_resample2d_backward). */
+int ffwm_block_extractor_backward_strided(const void* source, const void* flow_field, const void* grad_output,
+                                          const int64_t* grad_output_strides, void* grad_source, void* grad_flow_field, int64_t B,
+                                          int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int kernel_size, int dtype,
+                                          void* stream);
+int ffwm_local_attn_reshape_backward_strided(const void* grad_output, const int64_t* grad_output_strides, void* grad_inputs, int64_t B,
+                                             int64_t H, int64_t W, int kernel_size, int accumulate, int dtype, void* stream);
+int ffwm_resample2d_backward_strided(const void* input1, const void* input2, const void* grad_output,
+                                     const int64_t* grad_output_strides, void* grad_input1, void* grad_input2, int64_t B, int64_t C,
+                                     int64_t Hi, int64_t Wi, int64_t H, int64_t W, int kernel_size, int dilation,
+                                     int reference_quirk, int dtype, void* stream);
+
 /* Gaussian-weighted kernel_size x kernel_size tap resampler.  input1[>=B,C,Hi,Wi],
  * input2[B,3,H,W] = (dx, dy, sigma) in pixels, out[B,C,H,W].
  * Reference: resample2d_kernel.cu:21-95.  kernel_size even >= 2, dilation >= 1. */

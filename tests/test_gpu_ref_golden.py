@@ -178,6 +178,95 @@ def test_live_block_extractor_and_reshape_cfg5_slice_against_the_reference_exten
     assert torch.equal(ops.local_attn_reshape_forward(attn, 3), r_ref)
 
 
+def _strided_views(shape, g, kind, dtype=torch.float32):
+    """A grad_output of `shape` [B, C, H, W] that is NOT contiguous: a permuted NHWC buffer, a slice of a wider buffer, or a batch
+    dimension expanded from one sample (stride 0) -- what autograd hands a backward when the gradient is a view."""
+    B, C, H, W = shape
+    if kind == "hw_transposed":
+        return torch.rand(B, C, W, H, generator=g, dtype=dtype).to(DEV).transpose(2, 3)
+    if kind == "nhwc":
+        return torch.rand(B, H, W, C, generator=g, dtype=dtype).to(DEV).permute(0, 3, 1, 2)
+    if kind == "slice":
+        return torch.rand(B, C + 3, H + 2, W + 5, generator=g, dtype=dtype).to(DEV)[:, 2:2 + C, 1:1 + H, 3:3 + W]
+    return torch.rand(1, C, H, W, generator=g, dtype=dtype).to(DEV).expand(B, C, H, W)
+
+
+@pytest.mark.parametrize("kind", ["hw_transposed"])
+def test_live_strided_grad_output_against_the_reference_extensions(ref_mods, kind):
+    """VERDICT r5 (missing 2) / SURVEY 8(b): the reference's kernels read grad_output through the tensor's strides (DIM3_INDEX,
+    block_extractor_kernel.cu:8-15) and its Functions throw the .contiguous() result away (models/external_function.py:46-47), so the
+    modules that stand in for its pybind extensions must take a non-contiguous gradient AS IT COMES.  Since ABI 5 the compat modules pass
+    the strides to the *_backward_strided entry points (no copy): here the reference's own extensions and ffwm_amd.compat get the SAME
+    strided tensor, caller-allocated zero-filled outputs on both sides, for all three ops.
+    Which views: the reference decomposes its flat thread index with the STRIDES of dimensions 0 and 1 as if they were sizes
+    (`dim_chw = DIM0(grad_output_stride)`, block_extractor_kernel.cu:116-121), so its own result is only meaningful while those two
+    strides are the contiguous ones -- a transposed (H, W) pair is the non-contiguous view it handles; NHWC, sliced and expanded
+    gradients (a stride of 0 divides by zero there) are held to the CPU oracle in the next test instead."""
+    from ffwm_amd.compat import block_extractor_cuda, local_attn_reshape_cuda, resample2d_cuda
+    g = torch.Generator().manual_seed(1)
+    # block_extractor: source [2, 5, 20, 24], k = 3
+    src = torch.rand(2, 5, 20, 24, generator=g).to(DEV)
+    flow = (torch.rand(2, 2, 20, 24, generator=g) * 4 - 2).to(DEV)
+    go = _strided_views((2, 5, 60, 72), g, kind)
+    assert not go.is_contiguous()
+    gs_ref, gf_ref = torch.zeros_like(src), torch.zeros_like(flow)
+    ref_mods["block_extractor"].backward(src, flow, go, gs_ref, gf_ref, 3)
+    gs, gf = torch.zeros_like(src), torch.zeros_like(flow)
+    assert block_extractor_cuda.backward(src, flow, go, gs, gf, 3) == 1
+    assert _rel(gs, gs_ref) <= 4 * G1["f32"] and _rel(gf, gf_ref) <= G2["f32"]
+    gs_c, gf_c = torch.zeros_like(src), torch.zeros_like(flow)
+    block_extractor_cuda.backward(src, flow, go.contiguous(), gs_c, gf_c, 3)                 # the tuned kernels on a copy: the same gradients
+    assert _rel(gs, gs_c) <= 4 * G1["f32"] and _rel(gf, gf_c) <= G2["f32"]
+    # local_attn_reshape: inputs [2, 9, 14, 10] -> grad_output [2, 1, 42, 30]
+    inp = torch.rand(2, 9, 14, 10, generator=g).to(DEV)
+    go = _strided_views((2, 1, 42, 30), g, kind)
+    gi_ref = torch.zeros_like(inp)
+    ref_mods["local_attn_reshape"].backward(inp, go, gi_ref, 3)
+    gi = torch.zeros_like(inp)
+    assert local_attn_reshape_cuda.backward(inp, go, gi, 3) == 1
+    assert torch.equal(gi, gi_ref)
+    # resample2d: ks 4, [2, 6, 18, 22]
+    in1 = torch.rand(2, 6, 18, 22, generator=g).to(DEV)
+    in2 = torch.cat((torch.rand(2, 2, 18, 22, generator=g) * 6 - 3, torch.full((2, 1, 18, 22), 2.0)), 1).to(DEV)
+    go = _strided_views((2, 6, 18, 22), g, kind)
+    g1_ref, g2_ref = torch.zeros_like(in1), torch.zeros_like(in2)
+    ref_mods["resample2d"].backward(in1, in2, go, g1_ref, g2_ref, 4, 1)
+    g1, g2 = torch.zeros_like(in1), torch.zeros_like(in2)
+    assert resample2d_cuda.backward(in1, in2, go, g1, g2, 4, 1) == 1
+    assert _rel(g1, g1_ref) <= G1["f32"] and _rel(g2, g2_ref) <= G2["f32"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_strided_grad_output_equals_the_contiguous_path(oracle, dtype):
+    """The same without oracle/_ref (always runs): ops.* with a strided grad_output (the per-element kernels behind the *_strided entry
+    points) against the CPU oracle on the materialised tensor, fp32 and fp64, incl. a stride-0 batch dimension and `+=` semantics."""
+    from ffwm_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for kind in ("nhwc", "slice", "expand", "hw_transposed"):
+        src = torch.rand(2, 4, 12, 16, generator=g, dtype=dtype)
+        flow = torch.rand(2, 2, 12, 16, generator=g, dtype=dtype) * 4 - 2
+        go = _strided_views((2, 4, 36, 48), g, kind, dtype)
+        assert not go.is_contiguous()
+        gs_ref, gf_ref = oracle.block_extractor_backward(src, flow, go.cpu().contiguous(), 3)
+        gs, gf = torch.full_like(src, 0.5, device=DEV), torch.zeros_like(flow, device=DEV)
+        ops.block_extractor_backward(src.to(DEV), flow.to(DEV), go, 3, gs, gf)
+        tol = 1e-5 if dtype == torch.float32 else 1e-12
+        assert float((gs.cpu() - 0.5 - gs_ref).abs().max()) <= tol * (1 + float(gs_ref.abs().max()))
+        assert float((gf.cpu() - gf_ref).abs().max()) <= 10 * tol * (1 + float(gf_ref.abs().max()))
+        in1 = torch.rand(2, 4, 12, 16, generator=g, dtype=dtype)
+        in2 = torch.cat((torch.rand(2, 2, 12, 16, generator=g, dtype=dtype) * 6 - 3, torch.full((2, 1, 12, 16), 1.5, dtype=dtype)), 1)
+        go = _strided_views((2, 4, 12, 16), g, kind, dtype)
+        g1_ref, g2_ref = oracle.resample2d_backward(in1, in2, go.cpu().contiguous(), 4, 1)
+        g1 = torch.full_like(in1, float("nan"), device=DEV)
+        g2 = torch.empty_like(in2, device=DEV)
+        ops.resample2d_backward(in1.to(DEV), in2.to(DEV), go, 4, 1, g1, g2, overwrite_input1=True)
+        assert float((g1.cpu() - g1_ref).abs().max()) <= tol * (1 + float(g1_ref.abs().max()))
+        assert float((g2.cpu() - g2_ref).abs().max()) <= 100 * tol * (1 + float(g2_ref.abs().max()))
+        go = _strided_views((2, 1, 36, 48), g, "slice" if kind == "nhwc" else kind, dtype)
+        gi = ops.local_attn_reshape_backward(go, 3)
+        assert torch.equal(gi.cpu(), oracle.local_attn_reshape_backward(go.cpu().contiguous(), 3))
+
+
 def test_perceptual_correctness_resample2d_branch_against_the_oracle_composition(oracle):
     """The one call site of resample2d in the reference: PerceptualCorrectness.calculate_loss with
     use_bilinear_sampling=False -> Resample2d(4, 1, sigma=2) (models/losses.py:329,356-359).  The HIP Function
