@@ -145,7 +145,8 @@ def emit_lines(result):
             final[k] = result[k]
     wa = (result.get("subpaths") or {}).get("warp_attention_path") or result.get("warp_attention_path")
     if isinstance(wa, dict):
-        final["warp_attention_path"] = {k: wa[k] for k in ("fwd_img_per_s", "fwd_bwd_img_per_s", "fp32_ceiling_img_per_s") if k in wa}
+        final["warp_attention_path"] = {k: wa[k] for k in ("fwd_img_per_s", "fwd_bwd_img_per_s", "fwd_bwd_ms", "own_kernel_ms_per_pass", "top5",
+                                                         "fp32_ceiling_img_per_s") if k in wa}
     if ops_rows:
         # [us, fraction of the roofline] per stand-alone operator launch at BASELINE's configurations (OPS_ROWS)
         final["ops"] = ops_rows
@@ -565,6 +566,11 @@ def hot_rows_summary(rows):
             "kernels": [{k: r[k] for k in ("kernel", "launches", "avg_us", "alg_MB", "GBps", "frac_hbm_peak")} for r in hot]}
 
 
+def _top_kernels(rows, passes, n):
+    rows = sorted(rows, key=lambda r: -r["total_ms"])[:n]
+    return [[r["kernel"], round(r["launches"] / passes, 1), round(r["total_ms"] / passes * 1e3, 1)] for r in rows]
+
+
 def run_warp_attention(dev, bs, steps, warmup, world, seed=1, graph=True, route=True):
     """netG's warp-attention module alone (base_networks.py:323-333): warp + flip + cat (HIP) -> att convs -> multiply,
     three levels, batch `bs`.  Returns forward-only and forward + backward figures."""
@@ -631,7 +637,11 @@ def run_warp_attention(dev, bs, steps, warmup, world, seed=1, graph=True, route=
             "note": "the att convs are %.1f GFLOP per image forward + backward as a DIRECT sum: %.0f img/s at the fp32 MFMA peak; the Winograd "
                     "kernels execute 2.25 x fewer multiplications, so that figure is a yardstick, not a bound" % (fl["total"] / bs / 1e9, ceil_fb),
             "warp_fwd": hot_rows_summary(kernel_rows(rows_f, "warp_attention fwd")),
-            "warp_fwd_bwd": hot_rows_summary(kernel_rows(rows_b, "warp_attention fwd+bwd"))}, dt_b, rows_b
+            "warp_fwd_bwd": hot_rows_summary(kernel_rows(rows_b, "warp_attention fwd+bwd")),
+            # where a forward + backward pass goes: the hand-written kernels with the most time per pass (HIP events of 3 eager passes,
+            # [kernel, launches per pass, us per pass]) and their sum beside the replayed pass's wall time -- the rest is vendor / ATen
+            "top5": _top_kernels(kernel_rows(rows_b, "warp_attention fwd+bwd"), 3, 5),
+            "own_kernel_ms_per_pass": round(sum(r["total_ms"] for r in kernel_rows(rows_b, "warp_attention fwd+bwd")) / 3, 3)}, dt_b, rows_b
 
 
 def run_flownet(dev, bs, steps, warmup, world, path, seed=1):

@@ -15,7 +15,7 @@ from . import ops
 
 
 import os as _os0
-_WGRAD_W64 = _os0.environ.get("FFWM_WGRAD_W64", "0") == "1"
+_WGRAD_W64 = _os0.environ.get("FFWM_WGRAD_W64", "1") == "1"      # round 6: on -- the 64-pixel layers with aligned channel counts (att convs of the 64 x 64 level) reach the Winograd-domain kernel: warp + attention sub-path 1902 -> 1940 img/s, train step unchanged
 
 
 class _Conv3x3MfmaWgrad(Function):
