@@ -46,7 +46,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP32_PEAK = 157.3e12       # FLOP/s, fp32 vector/MFMA
 REF_TRAIN_FLOP_PER_IMG = 444e9   # the REFERENCE's step, ~222 GMAC per image (quoted for comparison only)
-PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_traffic.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(p)),
+PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc_traffic.json" % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(p)),
                 os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"))            # the newest committed counter passes
 # launch scopes of the SURVEY 8 a1-a6 operators (ffwm_prof_* names)
 HOT_PATH_PREFIXES = ("warp", "resample2d", "block_extractor", "local_attn_reshape", "block_attention")

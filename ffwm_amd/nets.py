@@ -12,6 +12,8 @@ import math
 
 import os
 
+import os as _os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -217,7 +219,9 @@ class FFWM(nn.Module):
                                                      ResidualBlock(c, c, activ="sigmoid", sn=sn)))
         self.warpNet = WarpNet()
         self._fused = warp_flipcat if warp_flipcat is not None else WarpFlipCat()
-        self._multi = warp_flipcat is None           # the HIP path: all levels' warps in one multi-problem launch
+        # the HIP path: all levels' warps in one multi-problem launch (FFWM_WARP_MULTI=0: a launch per level, issued where the decoder needs
+        # it -- its backward then runs right behind the attention convs' that produced its grad_output, on warm caches)
+        self._multi = warp_flipcat is None and _os.environ.get("FFWM_WARP_MULTI", "1") != "0"
         self.fuse_gate = False                       # residual.fuse_residual: `skip * att_i(skip)` with its sigmoid tail as one kernel
 
     def _skip(self, feat, flow):
@@ -244,10 +248,10 @@ class FFWM(nn.Module):
             # the encoder does not need the flows: a caller that computes them on another HIP stream passes a function that joins
             # that stream and returns them (trainer.FFWMTrainer.forward: flowNetF beside the encoder)
             flow = flow()
-        skips = self._skips(enc, flow)
+        skips = self._skips(enc, flow) if self._multi else None
         for i in range(self.layers):
             dec = getattr(self, "d%d" % i)(fdec)
-            skip = skips[i]
+            skip = skips[i] if skips is not None else self._skip(enc[self.layers - 1 - i], flow[i])
             if self.fuse_gate:
                 from .residual import gated
                 skip, att = gated(getattr(self, "att%d" % i), skip)

@@ -1,4 +1,4 @@
-"""Local half of the profile refresh: gpurun_out/refresh/ (tools/refresh_profiles.sh) -> profiles/r05_*.
+"""Local half of the profile refresh: gpurun_out/refresh/ (tools/r06/refresh.sh; rounds 2-5: tools/refresh_profiles.sh) -> profiles/r06_*.
 
     python tools/fold_profiles.py [gpurun_out/refresh]
 
@@ -38,6 +38,8 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "local_attn_reshape_bwd": "lar_bwd_kernel<float, 3, false>",
     "local_attn_reshape_fwd": "lar_fwd_kernel<float, 3>",
     "resample2d_bwd_input1_plane": "rs_bwd1_plane_kernel<float, 2>",
+    "resample2d_bwd_input1_owned": ("rs_bwd1_owned_kernel<2>", "rs_bwd1_far_kernel<2>"),        # round 6: one scope over both launches
+    "conv_fwd_split_reduce": "conv_split_reduce_kernel<4>",
     "resample2d_bwd_input2": "rs_bwd2_kernel<float, 2>",
     "resample2d_bwd_input2_lds": "rs_bwd2_lds_kernel<2,",
     "resample2d_fwd_lds": "rs_fwd_lds_kernel<2,",
@@ -74,7 +76,30 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "block_attention_bwd_weights": "be_fwd_lds_kernel<float, 3, 4, 2>",
 }
 FETCH_CORRECTION = 2.0
-ROUND = "r05"
+ROUND = "r06"
+
+
+def calibration(src):
+    """FETCH_SIZE / WRITE_SIZE of THIS refresh's calibration passes (tools/pmc_calib.py: bias_act_kernel reads and writes 262,144 KiB with
+    16-byte accesses, 262,080 KiB with 4-byte ones) beside the byte counts they must show: the measured ratio is what justifies
+    `fetch_correction` (round 5 left this object empty)."""
+    cal = {"fetch_correction": FETCH_CORRECTION, "expected_KiB_each_way": {"bias_act_kernel<0, 4>": 262144.0, "bias_act_kernel<0, 1>": 262080.0}}
+    path = os.path.join(src, "pmc_calibration_raw.json")
+    if not os.path.exists(path):
+        cal["measured"] = "no calibration pass in this refresh"
+        return cal
+    raw = json.load(open(path))
+    meas = {}
+    for k, v in raw.items():
+        for frag in cal["expected_KiB_each_way"]:
+            if frag in k:
+                exp = cal["expected_KiB_each_way"][frag]
+                meas[frag] = {"FETCH_SIZE_KiB": round(v.get("FETCH_SIZE", 0.0), 1), "WRITE_SIZE_KiB": round(v.get("WRITE_SIZE", 0.0), 1),
+                              "dispatches": v.get("dispatches"),
+                              "fetch_reported_over_read": round(v.get("FETCH_SIZE", 0.0) / exp, 4) if exp else None,
+                              "write_reported_over_written": round(v.get("WRITE_SIZE", 0.0) / exp, 4) if exp else None}
+    cal["measured"] = meas or "calibration kernels not found in the counter output"
+    return cal
 
 
 def main():
@@ -94,8 +119,7 @@ def main():
                   "(profiles/r01_kbench_pmc_raw.json): a 1.2 GB copy (1,179,648 KiB read + written) reports FETCH_SIZE 589,824 "
                   "KiB and WRITE_SIZE 1,179,648 KiB, so traffic_bytes = (2 x fetch_KiB + write_KiB) x 1024.  Scopes without a "
                   "non-zero FETCH_SIZE and WRITE_SIZE measurement are omitted.",
-        "_calibration": {"copy_1.2GB_expected_KiB_each_way": 1179648, "copy_fetch_KiB": 589824.0, "copy_write_KiB": 1179648.0,
-                         "fetch_correction": FETCH_CORRECTION},
+        "_calibration": calibration(src),
     }
     dropped = []
     for scope, frag in sorted(SCOPES.items()):
@@ -148,7 +172,7 @@ def main():
               ("flowtrain_bench.json", "_bench_flowtrain.json"), ("ops_bench.json", "_bench_ops.json"),
               ("winograd_sq_192.txt", "_winograd_sq_counters_192.txt"), ("winograd_sq_256.txt", "_winograd_sq_counters_256.txt"),
               ("winograd_mem_192.txt", "_winograd_mem_counters_192.txt"), ("winograd_mem_256.txt", "_winograd_mem_counters_256.txt"),
-              ("winograd_vs_vendor.txt", "_winograd_vs_vendor.txt"), ("winograd_layers_of_the_step.txt", "_winograd_layers_of_the_step.txt"),
+              ("winograd_vs_vendor.txt", "_winograd_vs_vendor.txt"), ("pmc_calibration_raw.json", "_pmc_calibration_raw.json"), ("winograd_layers_of_the_step.txt", "_winograd_layers_of_the_step.txt"),
               ("train_step_per_step.txt", "_train_step_per_step.txt"), ("train_step_eager_per_step.txt", "_train_step_eager_per_step.txt"),
               ("bwd_layers.txt", "_bwd_layers.txt"), ("warp_step_sweep.txt", "_warp_step_sweep.txt"), ("ab_results.txt", "_ab_switches.txt"),
               ("rs_bwd1.txt", "_resample2d_bwd_input1_variants.txt"), ("host_probe.txt", "_host_issue_vs_drain.txt"),
