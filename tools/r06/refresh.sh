@@ -24,7 +24,7 @@ trace() {   # tag window-ms extra-steady-args -- bench-args...
 }
 trace train_step 200 "" --steps 6 --warmup 3 --no-kernels
 python $R/tools/step_trace.py $(find /tmp/kt_train_step -name "*kernel_trace.csv" | head -1) --steps 3 --top 60 > $OUT/train_step_per_step.txt 2>&1
-trace ops 0 "--by-shape --include ffwm:: --skip-first 2" --workload ops --steps 10 --warmup 3
+FFWM_BENCH_SKIP_FALLBACK=1 trace ops 0 "--by-shape --include ffwm:: --skip-first 2" --workload ops --steps 10 --warmup 3
 trace warp 0 "--by-shape --include ffwm:: --skip-first 2" --workload warp --steps 40 --warmup 10 --no-kernels
 trace warpatt 30 "" --workload warpatt --steps 20 --warmup 5 --no-kernels
 trace flownet 15 "" --workload flownet --steps 40 --warmup 10 --no-kernels
