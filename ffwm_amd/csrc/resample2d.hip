@@ -1130,9 +1130,9 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 // The tile kernel above lets the boxes of neighbouring blocks overlap and folds every non-zero box cell into grad_input1 with a
 // global atomic: ~1.8 per pixel and channel, which issue at about one lane per clock and CU -- 445 us of the 1.23 ms at
 // [8, 64, 512, 512] (profiles/r05_rs_bwd1_ablation.txt), an order of magnitude more per lane than an LDS atomic (4.3 clk per wave).
-// Here every cell of grad_input1 has exactly ONE owner: a block of 8 waves owns an OW x OH tile of the input plane (54 x 54 at ks 4)
-// and visits the 64 x 64 PIXELS of the tile grown by M = 3 + ks/2 -- every pixel whose floor offset is within +-3 of its own position
-// and can therefore reach the tile.  A pixel near a tile edge is visited by up to four blocks (x 1.4 pixel visits, x 1.4 LDS
+// Here every cell of grad_input1 has exactly ONE owner: a block of 8 waves owns an OW x OH tile of the input plane (54 x 38 at ks 4)
+// and visits the 64 x 48 PIXELS of the tile grown by M = 3 + ks/2 -- every pixel whose floor offset is within +-3 of its own position
+// and can therefore reach the tile.  A pixel near a tile edge is visited by up to four blocks (x 1.5 pixel visits, x 1.5 LDS
 // atomics); each keeps the taps that land in ITS tile (after the reference's clamp to the image).  A tap ROW outside the tile is skipped
 // under the exec mask, a tap COLUMN outside it goes to a per-lane dump cell behind the box (a shared ring cell was the first version:
 // the 5 + 5 margin lanes of every wave row met on it and every LDS atomic paid a 5-way same-address conflict -- 2.0 ms instead of 0.9).  The box is flushed with plain coalesced
@@ -1149,17 +1149,24 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 // A group with a NaN / Inf gradient scatters its own-tile taps with global atomics behind a flush of zeros.
 // Weights: w_tap / sum = (wy / sum_y) (wx / sum_x) held as 4 + 4 factors per pixel (8 registers instead of 16): sum = sum_y sum_x up to
 // rounding (resample2d_kernel.cu:87 adds the 16 products), SAFE_DIV's zero case kept per factor.
+#ifndef FFWM_RS_OWN_THREADS
+#define FFWM_RS_OWN_THREADS 512
+#endif
 template <int HALF>
 struct RsOwn {
     static constexpr int NT = 2 * HALF;
     static constexpr int D = 3;                    // |floor offset| served on the fast path
     static constexpr int M = D + HALF;             // margin of the pixel region around the owned tile
-    static constexpr int RW = 64, RH = 64;         // pixel region of a block
+#ifndef FFWM_RS_OWN_RH
+#define FFWM_RS_OWN_RH 48          // measured: 48 rows (6 pixels per lane) 705 / 981 us smooth / random, 64 rows (8 per lane: 16 more registers of per-pixel state, scratch in the add loop) 786 / 947
+#endif
+    static constexpr int RW = 64, RH = FFWM_RS_OWN_RH;         // pixel region of a block
     static constexpr int OW = RW - 2 * M, OH = RH - 2 * M;
-    static constexpr int BP = OW + 2, BH = OH + 2; // box = tile + a ring that swallows what belongs to other tiles
-    static constexpr int NCELL = BP * BH + 64;     // + one dump cell per lane: where a tap of another block's tile goes (never read)
-    static constexpr int DUMP = BP * BH;
-    static constexpr int THREADS = 512, NW = THREADS / 64, PPT = RH / NW;
+    static constexpr int NDUMP = 8;                // dump columns behind the tile's: where a tap COLUMN of another block's tile goes (never read)
+    static constexpr int BP = 64;                  // box pitch: OW + NDUMP <= 64
+    static constexpr int NCELL = BP * OH;
+    static constexpr int THREADS = FFWM_RS_OWN_THREADS, NW = THREADS / 64, PPT = RH / NW;
+    static_assert(OW + NDUMP <= BP, "box pitch");
 };
 
 // floor offset of a pixel's tap window: origin cell (u0, v0) of its NT x NT taps; ok = finite and small enough for int arithmetic.
@@ -1174,15 +1181,63 @@ __device__ __forceinline__ bool rs_origin(float dx, float dy, int x, int y, int&
     return ok;
 }
 
+// The normalised separable factors of one pixel (NT - 1 per axis, see rs_bwd1_owned_kernel) as a CALL, not inline: the eight
+// double-precision exponentials of make_rs_taps want ~100 registers while they run, and inlined eight times into the kernel's prologue
+// they pushed the persistent per-pixel state into scratch -- from where the add loop reloaded it, group after group.
 template <int HALF>
-__global__ void __launch_bounds__(RsOwn<HALF>::THREADS, 4)          // two 8-wave blocks per CU: 128 registers
+struct RsFactors {
+    float wy[2 * HALF - 1], wx[2 * HALF - 1];
+    int degenerate;
+};
+template <int HALF>
+__device__ __attribute__((noinline)) RsFactors<HALF> rs_pixel_factors(float dx, float dy, float sgm, int x, int y, int Hi, int Wi, int quirk, int ablate) {
+    constexpr int NT = 2 * HALF;
+    RsFactors<HALF> o;
+    RsTaps<float, HALF> t;
+    if (ablate & 8) {                      // bench-only: no Gaussian weights
+#pragma unroll
+        for (int f = 0; f < NT; ++f) { t.wx[f] = dx; t.wy[f] = dy; }
+    } else {
+        make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
+    }
+    float wxp[NT], wyp[NT];
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int f = 0; f < HALF; ++f) {
+        wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
+        wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
+    }
+#pragma unroll
+    for (int f = 0; f < NT; ++f) { sx += wxp[f]; sy += wyp[f]; }
+#pragma unroll
+    for (int f = 0; f < NT - 1; ++f) {
+        o.wx[f] = static_cast<float>(safe_div<float>(wxp[f], sx));
+        o.wy[f] = static_cast<float>(safe_div<float>(wyp[f], sy));
+    }
+    // every weight of an axis underflowed (sigma -> 0 away from the taps): SAFE_DIV's zero arm makes all products 0 -- the pixel adds
+    // nothing, and the "last = 1 - others" form must not invent a weight for it
+    o.degenerate = (sx == 0.f || sy == 0.f) ? 1 : 0;
+    return o;
+}
+
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+
+// Cells, round 6 second version.  A contribution is formed by ONE fused multiply-add, fma(w, g 2^s, 1.5 2^23): the sum is rounded to
+// the integer grid of the binade [2^23, 2^24) (round to nearest even, what v_cvt_i32_f32 did in a second instruction) and its BIT
+// PATTERN is 0x4B400000 + k with k the signed integer contribution (|k| < 2^22).  ds_add_u32 of the patterns leaves
+// n 0x4B400000 + sum k (mod 2^32) in a cell that took n contributions; n per cell is what the count pass leaves in a fifth plane (the
+// flow, hence n, is the same for every channel), so the flush recovers sum k exactly.  Two channels share a v_pk_fma_f32.
+template <int HALF>
+__global__ void __launch_bounds__(RsOwn<HALF>::THREADS, 4)          // 16 waves per CU: 128 registers
 rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ gout, float* __restrict__ gin1, int C, int Hi, int Wi,
                      int H, int W, int quirk, int overwrite, int tiles_x, int tiles_y, int cslabs, int cs, int remap, int ablate) {
     using G = RsOwn<HALF>;
     constexpr int NT = G::NT, M = G::M, OW = G::OW, OH = G::OH, BP = G::BP, NCELL = G::NCELL, NW = G::NW, PPT = G::PPT;
-    __shared__ int box[4 * NCELL];                 // [4 channels][BH][BP]
+    constexpr unsigned kMagicBits = 0x4B400000u;   // 1.5 * 2^23
+    __shared__ unsigned box[5 * NCELL];            // [4 channels + the tap count][OH][BP]
     __shared__ unsigned redm[NW];
     __shared__ int redp[NW];
+    unsigned* const cnt = box + 4 * NCELL;
 
     unsigned tid = xcd_remap(blockIdx.x, gridDim.x, remap);
     const int tx = tid % tiles_x;
@@ -1195,16 +1250,14 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
     const int X0 = tx * OW, Y0 = ty * OH;          // owned tile (cells of the input plane)
     const int x = X0 - M + lane;                   // this lane's pixel column
     const bool inx = x >= 0 && x < W;
-    // tap coordinate -> box column / row: the reference's clamp to the image, then to the tile + a one-cell ring (both are one clamp:
-    // the intervals overlap), relative to the ring's first cell: 0 and OW + 1 / OH + 1 mean "another block's"
-    const int cxlo = max(0, X0 - 1), cxhi = min(Wi - 1, X0 + OW);
-    const int cylo = max(0, Y0 - 1), cyhi = min(Hi - 1, Y0 + OH);
-    const int dump = G::DUMP + lane;
+    const int dumpc = OW + (lane & (G::NDUMP - 1));
 
     const size_t plane = static_cast<size_t>(H) * W;
     const float* fb = in2 + static_cast<size_t>(b) * 3 * plane;
-    float wyn[PPT][NT], wxn[PPT][NT];
-    int uv[PPT];                                   // (v0 << 16) | (u0 & 0xffff), both relative to the ring origin and clamped to +-2048
+    // the normalised factors of an axis sum to 1: NT - 1 of them are kept, the last one is 1 - the others (absolute error <= 2e-7,
+    // the size of one fixed-point unit) -- 16 registers less per thread, which is what lets the add loop live in 128 without scratch
+    float wyn[PPT][NT - 1], wxn[PPT][NT - 1];
+    int uv[PPT];                                   // (v0 - Y0) << 16 | (u0 - X0) & 0xffff, clamped to +-2048 (enough: see colx)
     unsigned livemask = 0;
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
@@ -1213,185 +1266,221 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
         int u0 = 0, v0 = 0;
         bool ok = false;
 #pragma unroll
-        for (int f = 0; f < NT; ++f) wyn[r][f] = wxn[r][f] = 0.f;
+        for (int f = 0; f < NT - 1; ++f) wyn[r][f] = wxn[r][f] = 0.f;
+        bool degenerate = false;
         if (live_px) {
             const size_t poff = static_cast<size_t>(y) * W + x;
             const float dx = fb[poff], dy = fb[plane + poff], sgm = fb[2 * plane + poff];
             ok = rs_origin<HALF>(dx, dy, x, y, u0, v0);
             if (ok) {
-                RsTaps<float, HALF> t;
-                if (ablate & 8) {                      // bench-only: no Gaussian weights
+                const RsFactors<HALF> fc = rs_pixel_factors<HALF>(dx, dy, sgm, x, y, Hi, Wi, quirk, ablate);
 #pragma unroll
-                    for (int f = 0; f < NT; ++f) { t.wx[f] = dx; t.wy[f] = dy; }
-                } else
-                make_rs_taps<float, HALF>(t, dx, dy, sgm, x, y, Hi, Wi, 1, quirk != 0);
-                float wxp[NT], wyp[NT];
-                float sx = 0.f, sy = 0.f;
-#pragma unroll
-                for (int f = 0; f < HALF; ++f) {
-                    wxp[HALF - 1 - f] = t.wx[2 * f]; wxp[HALF + f] = t.wx[2 * f + 1];
-                    wyp[HALF - 1 - f] = t.wy[2 * f]; wyp[HALF + f] = t.wy[2 * f + 1];
-                }
-#pragma unroll
-                for (int f = 0; f < NT; ++f) { sx += wxp[f]; sy += wyp[f]; }
-#pragma unroll
-                for (int f = 0; f < NT; ++f) {
-                    wxn[r][f] = static_cast<float>(safe_div<float>(wxp[f], sx));
-                    wyn[r][f] = static_cast<float>(safe_div<float>(wyp[f], sy));
-                }
+                for (int f = 0; f < NT - 1; ++f) { wxn[r][f] = fc.wx[f]; wyn[r][f] = fc.wy[f]; }
+                degenerate = fc.degenerate != 0;
             }
         }
-        const bool on = live_px && ok;
+        const bool on = live_px && ok && !degenerate;
         if (on) livemask |= 1u << r;
-        // a pixel that is dead here (outside the flow grid, or irregular: the far kernel's) parks its window in the ring's corner
-        const int ur = on ? min(max(u0 - (X0 - 1), -2048), 2048) : -2048;
-        const int vr = on ? min(max(v0 - (Y0 - 1), -2048), 2048) : -2048;
+        // (a pixel that is dead here -- outside the flow grid, or irregular: the far kernel's -- is skipped through `livemask`)
+        const int ur = on ? min(max(u0 - X0, -2048), 2048) : 0;
+        const int vr = on ? min(max(v0 - Y0, -2048), 2048) : 0;
         uv[r] = (vr << 16) | (ur & 0xffff);
-        __builtin_amdgcn_sched_barrier(0);         // one pixel's double-precision exponentials at a time: interleaved, the eight chains spill
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // box column / row of tap f of a pixel with packed origin `o`
-    auto colx = [&](int o, int f) { return min(max(static_cast<int>(static_cast<short>(o & 0xffff)) + (X0 - 1) + f, cxlo), cxhi) - (X0 - 1); };
-    auto rowy = [&](int o, int f) { return min(max((o >> 16) + (Y0 - 1) + f, cylo), cyhi) - (Y0 - 1); };
+    // tile-relative column / row of tap f of a pixel with packed origin `o`: the reference's clamp to the image, then the test against
+    // the tile.  (The origin was clamped to +-2048 around the tile: a tap that far out lands on the image border or in another tile either
+    // way, and the border cell is this tile's exactly when the unclamped coordinate would have put it there.)
+    const int ixlo = -X0, ixhi = Wi - 1 - X0, iylo = -Y0, iyhi = Hi - 1 - Y0;
+    auto colx = [&](int o, int f) { return min(max(static_cast<int>(static_cast<short>(o & 0xffff)) + f, ixlo), ixhi); };
+    auto rowy = [&](int o, int f) { return min(max((o >> 16) + f, iylo), iyhi); };
 
-    // ---- population bound: taps per own cell, counted in plane 0
-    for (int i = threadIdx.x; i < 4 * NCELL; i += G::THREADS) box[i] = 0;
+    // ---- taps per own cell (the same for every channel): plane `cnt`
+    for (int i = threadIdx.x; i < 5 * NCELL; i += G::THREADS) box[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
         if (!((livemask >> r) & 1u)) continue;
         int cx[NT], ry[NT];
 #pragma unroll
-        for (int f = 0; f < NT; ++f) { cx[f] = colx(uv[r], f); ry[f] = rowy(uv[r], f); }
+        for (int f = 0; f < NT; ++f) {
+            cx[f] = colx(uv[r], f);
+            cx[f] = static_cast<unsigned>(cx[f]) < static_cast<unsigned>(OW) ? cx[f] : dumpc;
+            ry[f] = rowy(uv[r], f);
+        }
 #pragma unroll
         for (int pr = 0; pr < NT; ++pr) {
-            if (static_cast<unsigned>(ry[pr] - 1) >= static_cast<unsigned>(OH)) continue;
+            if (static_cast<unsigned>(ry[pr]) >= static_cast<unsigned>(OH)) continue;
 #pragma unroll
             for (int pc = 0; pc < NT; ++pc)
-                if (static_cast<unsigned>(cx[pc] - 1) < static_cast<unsigned>(OW))
-                    __hip_atomic_fetch_add(box + ry[pr] * BP + cx[pc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(cnt + ry[pr] * BP + cx[pc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
     int pop = 0;
     for (int i = threadIdx.x; i < OW * OH; i += G::THREADS) {
         const int rr = i / OW, cc = i - rr * OW;
-        pop = max(pop, box[(rr + 1) * BP + cc + 1]);
+        pop = max(pop, static_cast<int>(cnt[rr * BP + cc]));
     }
     pop = wave_max(pop);
     if (lane == 0) redp[wave] = pop;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NW; ++k) pop = max(pop, redp[k]);
-    const int bits = __builtin_amdgcn_readfirstlane(31 - (32 - __clz(pop)));          // pop 2^bits < 2^31 (pop = 0: 31, unused)
-    for (int i = threadIdx.x; i < NCELL; i += G::THREADS) box[i] = 0;                  // plane 0 again (the dump cells keep garbage later: they are never read)
+    // |k| < 2^bits per contribution with pop 2^bits < 2^31 and bits <= 22 (the magic-number binade)
+    const int bits = __builtin_amdgcn_readfirstlane(min(22, 31 - (32 - __clz(pop))));
 
     const int c0 = slab * cs;
     const int c1 = (c0 + cs < C) ? c0 + cs : C;
     const size_t iplane = static_cast<size_t>(Hi) * Wi;
-    const unsigned obytes = static_cast<unsigned>(plane * sizeof(float));
     const float* gp = gout + (static_cast<size_t>(b) * C + c0) * plane;
     float* dp = gin1 + (static_cast<size_t>(b) * C + c0) * iplane;
-    // byte offset of pixel row 0 of this lane in a grad_output plane; row r is 8 W further (dead pixels read 0 through an offset past the plane)
-    const int ybase = Y0 - M + wave;
+    const int ybase = Y0 - M + wave;               // this lane's pixel row r is ybase + 8 r
+    const unsigned prow = static_cast<unsigned>(NW) * W;      // elements between two of its rows
+    const unsigned p0 = static_cast<unsigned>(ybase * W + x); // row 0's element offset, modulo 2^32: p0 + r prow is exact for every pixel that exists (livemask)
 
-    for (int c = c0; c < c1; c += 4) {
+    // max |g| (as magnitude bits) of this lane's pixels in the 4-channel group at channel c: the scale's first pass
+    auto lane_max = [&](int c) {
+        unsigned m = 0;
         const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
+        float v[PPT][4];
+#pragma unroll
+        for (int r = 0; r < PPT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                v[r][q] = (((livemask >> r) & 1u) && c + q < c1) ? g0[static_cast<size_t>(q) * plane + static_cast<unsigned>(p0 + r * prow)] : 0.f;
+#pragma unroll
+        for (int r = 0; r < PPT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = max(m, __float_as_uint(v[r][q]) & 0x7FFFFFFFu);
+        return m;
+    };
+    // ---- the scale of a group.  Exact would be max|g| over the block's pixels BEFORE the first add -- a pass over the group's gradients
+    // whose HBM latency nothing covers (measured: 124 us of 810; as a burst behind the previous group's adds or a row per add step:
+    // worse).  Only the block's FIRST group pays it.  Every later group starts OPTIMISTICALLY with the exponent of the previous group's
+    // true maximum + 1, tracks its own true maximum while it adds (the values pass through the registers anyway), and checks afterwards:
+    // a maximum above the assumed range (a contribution left the magic-number binade: the box holds garbage) or more than 3 bits below it
+    // (precision) clears the box and repeats the group with the exact exponent.  Neighbouring channels of a gradient rarely differ by
+    // 8 x; when they do the group costs twice, never correctness.
+    unsigned mb = wave_max((ablate & 4) ? 0x3F800000u : lane_max(c0));
+    if (lane == 0) redm[wave] = mb;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; ++k) mb = max(mb, redm[k]);
+    int ex_assumed = 0;
+    (void)frexpf(__uint_as_float(mb), &ex_assumed);     // max|g| of the first group < 2^ex_assumed (garbage for 0 / NaN / Inf: the check below repeats)
+    __syncthreads();                                    // (redm is rewritten below)
+
+    bool repeated = false;
+    for (int c = c0; c < c1;) {
+        const float* g0 = gp + static_cast<size_t>(c - c0) * plane;
+        const int nch = c1 - c < 4 ? c1 - c : 4;
+        bool exact_path = false, usable = false;
+        float fx_inv = 0.f;
+        // (buffer loads: a wave-uniform resource per channel + ONE 32-bit offset per pixel row.  Plain pointer loads let hipcc turn the 32
+        // addresses of a group into 32 loop-carried 64-bit pointers -- 64 registers, and the per-pixel state went to scratch)
+        const unsigned obytes = static_cast<unsigned>(plane * sizeof(float));
         const rsrc_t rg0 = make_rsrc(g0, obytes);
-        const rsrc_t rg1 = make_rsrc(g0 + plane, c + 1 < c1 ? obytes : 0u);
-        const rsrc_t rg2 = make_rsrc(g0 + 2 * plane, c + 2 < c1 ? obytes : 0u);
-        const rsrc_t rg3 = make_rsrc(g0 + 3 * plane, c + 3 < c1 ? obytes : 0u);
-        // pass 1 over the group's gradients: max|g| of the block's pixels (the exact scale).  The values are NOT kept: 32 registers more
-        // would cost the second resident block (128 registers per thread at two 8-wave blocks per CU); pass 2 reads them again, from L2.
-        auto pix_off = [&](int r) {
-            return ((livemask >> r) & 1u) ? (static_cast<unsigned>(ybase + r * NW) * W + static_cast<unsigned>(x)) * 4u : 0xFFFFFFF0u;
+        const rsrc_t rg1 = make_rsrc(g0 + plane, nch > 1 ? obytes : 0u);
+        const rsrc_t rg2 = make_rsrc(g0 + 2 * plane, nch > 2 ? obytes : 0u);
+        const rsrc_t rg3 = make_rsrc(g0 + 3 * plane, nch > 3 ? obytes : 0u);
+        auto load_row = [&](int r, float (&dst)[4]) {
+            const unsigned po = ((livemask >> r) & 1u) ? static_cast<unsigned>(p0 + r * prow) * 4u : 0xFFFFFFF0u;      // dead pixels read 0
+            dst[0] = buf_ld<float>(rg0, po); dst[1] = buf_ld<float>(rg1, po);
+            dst[2] = buf_ld<float>(rg2, po); dst[3] = buf_ld<float>(rg3, po);
         };
-        unsigned mb = 0;
-        if (ablate & 4) mb = 0x3F800000u;              // bench-only: no first pass over the gradients
-        else {
-            float g[PPT][4];
-#pragma unroll
-            for (int r = 0; r < PPT; ++r) {
-                const unsigned po = pix_off(r);
-                g[r][0] = buf_ld<float>(rg0, po); g[r][1] = buf_ld<float>(rg1, po);
-                g[r][2] = buf_ld<float>(rg2, po); g[r][3] = buf_ld<float>(rg3, po);
-            }
-#pragma unroll
-            for (int r = 0; r < PPT; ++r)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mb = max(mb, __float_as_uint(g[r][q]) & 0x7FFFFFFFu);
-        }
-        mb = wave_max(mb);
-        if (lane == 0) redm[wave] = mb;
-        __syncthreads();                               // (also: the box is clear -- the count pass / the previous group's flush)
-#pragma unroll
-        for (int k = 0; k < NW; ++k) mb = max(mb, redm[k]);
-        const bool exact_path = mb >= 0x7F800000u;      // a NaN / Inf gradient among this group's pixels
-        int ex = 0;
-        (void)frexpf(__uint_as_float(mb), &ex);         // max|g| < 2^ex
-        const bool usable = mb != 0u && ex > -90 && !exact_path;
-        const float sc = usable ? ldexpf(1.f, bits - ex) : 0.f;
-        const float fx_inv = usable ? ldexpf(1.f, ex - bits) : 0.f;
-        if (usable) {
+        {
+            const int ex = __builtin_amdgcn_readfirstlane(min(max(ex_assumed, -80), 120));
+            const float sc = ldexpf(1.f, bits - ex);
+            fx_inv = ldexpf(1.f, ex - bits);
+            unsigned mt = 0;                            // this lane's true max|g| of the group
             float gn[4];
-            {
-                const unsigned po = pix_off(0);
-                gn[0] = buf_ld<float>(rg0, po); gn[1] = buf_ld<float>(rg1, po); gn[2] = buf_ld<float>(rg2, po); gn[3] = buf_ld<float>(rg3, po);
-            }
+            load_row(0, gn);
 #pragma unroll
             for (int r = 0; r < PPT; ++r) {
-                const float gx = gn[0] * sc, gy = gn[1] * sc, gz = gn[2] * sc, gw = gn[3] * sc;   // (exact: a power of two)
-                if (r + 1 < PPT) {
-                    const unsigned po = pix_off(r + 1);
-                    gn[0] = buf_ld<float>(rg0, po); gn[1] = buf_ld<float>(rg1, po); gn[2] = buf_ld<float>(rg2, po); gn[3] = buf_ld<float>(rg3, po);
-                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mt = max(mt, __float_as_uint(gn[q]) & 0x7FFFFFFFu);
+                const rs_f2 ga = {gn[0] * sc, gn[1] * sc}, gb = {gn[2] * sc, gn[3] * sc};       // (exact: a power of two)
+                if (r + 1 < PPT) load_row(r + 1, gn);
+                __builtin_amdgcn_sched_barrier(0);
                 if (!((livemask >> r) & 1u)) continue;
-                // the pixel's origin and factors pass through an opaque register copy: everything derived from them (4 + 4 box
-                // offsets, 16 weight products) is channel-invariant, and hipcc would hoist all of it out of the channel loop -- 24
-                // registers per pixel, 192 per thread, 932 bytes of scratch
+                // the pixel's origin and factors pass through an opaque register copy: everything derived from them (box offsets, 16
+                // weight products) is channel-invariant, and hipcc would hoist all of it out of the channel loop -- 24 registers per pixel
                 int o = uv[r];
                 asm volatile("" : "+v"(o));
                 float wy4[NT], wx4[NT];
+                float ry1 = 1.f, rx1 = 1.f;
 #pragma unroll
-                for (int f = 0; f < NT; ++f) {
+                for (int f = 0; f < NT - 1; ++f) {
                     wy4[f] = wyn[r][f]; wx4[f] = wxn[r][f];
                     asm volatile("" : "+v"(wy4[f]), "+v"(wx4[f]));
+                    ry1 -= wy4[f]; rx1 -= wx4[f];
                 }
+                wy4[NT - 1] = ry1; wx4[NT - 1] = rx1;
                 int cx[NT], ry[NT];
 #pragma unroll
                 for (int f = 0; f < NT; ++f) {
                     cx[f] = colx(o, f);
-                    cx[f] = static_cast<unsigned>(cx[f] - 1) < static_cast<unsigned>(OW) ? cx[f] : -1;
+                    cx[f] = static_cast<unsigned>(cx[f]) < static_cast<unsigned>(OW) ? cx[f] : dumpc;          // another tile's column: a dump column
                     ry[f] = rowy(o, f);
                 }
+                const rs_f2 magic = {12582912.f, 12582912.f};
 #pragma unroll
                 for (int pr = 0; pr < NT; ++pr) {
-                    if (static_cast<unsigned>(ry[pr] - 1) >= static_cast<unsigned>(OH)) continue;          // a tap row of another tile
-                    const int rb = ry[pr] * BP;
+                    if (static_cast<unsigned>(ry[pr]) >= static_cast<unsigned>(OH)) continue;              // a tap row of another tile
+                    unsigned* rowp = box + ry[pr] * BP;
 #pragma unroll
                     for (int pc = 0; pc < NT; ++pc) {
                         const float wq = wy4[pr] * wx4[pc];
-                        int* cell = box + (cx[pc] >= 0 ? rb + cx[pc] : dump);
-                        if (ablate & 1) { if (wq * gx + wq * gy + wq * gz + wq * gw == 12345.f) box[0] = 1; continue; }      // bench-only: no LDS atomics
-                        __hip_atomic_fetch_add(cell, __float2int_rn(wq * gx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(cell + NCELL, __float2int_rn(wq * gy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(cell + 2 * NCELL, __float2int_rn(wq * gz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(cell + 3 * NCELL, __float2int_rn(wq * gw), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const rs_f2 wq2 = {wq, wq};
+                        const rs_f2 ka = __builtin_elementwise_fma(wq2, ga, magic), kb = __builtin_elementwise_fma(wq2, gb, magic);
+                        unsigned* cell = rowp + cx[pc];
+                        if (ablate & 1) { if (ka.x + ka.y + kb.x + kb.y == 12345.f) box[0] = 1; continue; }      // bench-only: no LDS atomics
+                        __hip_atomic_fetch_add(cell, __float_as_uint(ka.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(cell + NCELL, __float_as_uint(ka.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(cell + 2 * NCELL, __float_as_uint(kb.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(cell + 3 * NCELL, __float_as_uint(kb.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one pixel at a time: interleaved, the eight unrolled steps want 237 registers
+            }
+            mt = wave_max(mt);
+            if (lane == 0) redm[wave] = mt;
+            __syncthreads();                            // every contribution of the attempt is in the box; the waves' maxima are out
+#pragma unroll
+            for (int k = 0; k < NW; ++k) mt = max(mt, redm[k]);
+            exact_path = mt >= 0x7F800000u;              // a NaN / Inf gradient among this group's pixels
+            int ex_true = ex;
+            if (mt != 0u && !exact_path) (void)frexpf(__uint_as_float(mt), &ex_true);       // max|g| < 2^ex_true
+            ex_true = __builtin_amdgcn_readfirstlane(ex_true);
+            const bool fits = ex_true <= ex && ex_true >= ex - 3 && ex_true > -80 && ex_true < 120;
+            usable = !exact_path && (mt == 0u || fits);
+            ex_assumed = mt != 0u && !exact_path ? ex_true + 1 : ex;       // the next group's assumption
+            if (!usable && !exact_path && !(ablate & 4)) {
+                if (repeated) {
+                    exact_path = true;                  // (cannot happen: a repeat runs with the true exponent; defensive)
+                } else {
+                    // the SAME group again with the exact exponent: clear the four channel planes, do not advance c
+                    repeated = true;
+                    ex_assumed = ex_true;
+                    for (int i = threadIdx.x; i < 4 * NCELL; i += G::THREADS) box[i] = 0;
+                    __syncthreads();
+                    continue;
                 }
             }
         }
-        __syncthreads();
+        repeated = false;
+        if (!usable && !exact_path) usable = true;      // (ablate & 4 only)
         // flush the owned cells: plain coalesced stores, no other block touches them
-        const int nch = c1 - c < 4 ? c1 - c : 4;
         for (int i = threadIdx.x; i < OW * OH; i += G::THREADS) {
             const int rr = i / OW, cc = i - rr * OW;
             const int gy = Y0 + rr, gx = X0 + cc;
-            const int bi = (rr + 1) * BP + cc + 1;
+            const int bi = rr * BP + cc;
             const bool in_img = gy < Hi && gx < Wi;
+            const unsigned nb = cnt[bi] * kMagicBits;
             float* dst = dp + static_cast<size_t>(c - c0) * iplane + static_cast<size_t>(gy) * Wi + gx;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v = static_cast<float>(box[q * NCELL + bi]) * fx_inv;
+                const float v = usable ? static_cast<float>(static_cast<int>(box[q * NCELL + bi] - nb)) * fx_inv : 0.f;
                 box[q * NCELL + bi] = 0;
                 if (q < nch && in_img && !(ablate & 2)) {
                     float* d = dst + static_cast<size_t>(q) * iplane;
@@ -1447,6 +1536,7 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
             }
         }
         __syncthreads();
+        c += 4;
     }
 }
 
