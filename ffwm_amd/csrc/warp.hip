@@ -1171,6 +1171,251 @@ warp_bwd_feat_tile_kernel(const float* __restrict__ flow, const float* __restric
     }
 }
 
+// Round 6, second form of the fixed-point owned-tile kernel: the per-pixel state is 3 registers instead of 10.  The first form kept, for
+// each of a lane's eight pixels, four cell indices, four weights and two load offsets (80 registers); with the fixed-point machinery on
+// top hipcc spilled into the add loop (495 -> 900 us).  Here a pixel keeps ONE packed word -- the tile-relative position of its
+// north-west corner, which of the four corners land in the own tile, whether the pixel exists -- and its two fractions (tx, ty); the four
+// cells are one LDS address + the immediates {0, 4, 224, 228}, the weights four products formed where they are used, the load offsets
+// come from the row index.  24 registers of state leave room for FOUR channels per group (half the barriers and flush passes per byte).
+// Cells / scale / count plane / retry: as in warp_bwd_feat_tile_kernel<.., FIX>.
+template <bool FLIP, int CG, bool OVW>
+__global__ void __launch_bounds__(kWtThreads, 4)
+warp_bwd_feat_tile2_kernel(const float* __restrict__ flow, const float* __restrict__ gout, float* __restrict__ gfeat, int C, int H,
+                           int W, int ntx, int nty, int groups_per_slab, int cslabs) {
+    constexpr int NC = kWtTile * kWtTile;
+    constexpr int PITCH = kWtTile;
+    constexpr unsigned kMagicBits = 0x4B400000u;
+    // box rows / columns carry a one-cell apron on the north and west (the NW corner of a pixel may sit at -1 while its SE corner is the
+    // tile's cell 0): the address of the NW corner is formed unconditionally, only `mine` corners are touched
+    __shared__ unsigned acc[(CG + 1) * NC + PITCH + 8];
+    __shared__ unsigned redm[CG * kWtWaves];
+    unsigned* const box = acc + PITCH + 4;                   // cell (0, 0) of plane 0; (-1, -1) is still inside the array
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, 1);
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int X0 = tx * kWtTile, Y0 = ty * kWtTile;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int x = X0 - kWtHalo + lane;
+    const size_t plane = static_cast<size_t>(H) * W;
+    const float* fl = flow + static_cast<size_t>(b) * 2 * plane;
+    const bool xin = x >= 0 && x < W;
+
+    // per pixel: packed = (cy0 + 1) << 8 | (cx0 + 1) | mine bits << 16 | exists << 20, with (cx0, cy0) the NW corner relative to the tile
+    int packed[kWtRows];
+    float fxs[kWtRows], fys[kWtRows];
+#pragma unroll
+    for (int r = 0; r < kWtRows; ++r) {
+        const int y = Y0 - kWtHalo + wave + r * kWtWaves;
+        const bool pin = xin && y >= 0 && y < H;
+        Corners<float> cn;
+        const size_t fo = static_cast<size_t>(pin ? y : 0) * W + (pin ? x : 0);
+        make_corners<float>(cn, fl[fo], fl[plane + fo], H, W);
+        int mine = 0, cx0 = 0, cy0 = 0;
+        bool have = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = static_cast<int>(cn.off[q] / 4u);          // cy * W + cx when valid
+            const int cy = ci / W, cx = ci - cy * W;
+            const bool m = pin && cn.valid[q] && cx >= X0 && cx < X0 + kWtTile && cy >= Y0 && cy < Y0 + kWtTile;
+            if (m) {
+                mine |= 1 << q;
+                if (!have) { cx0 = cx - X0 - (q & 1); cy0 = cy - Y0 - (q >> 1); have = true; }       // -> the NW corner's position
+            }
+        }
+        packed[r] = ((cy0 + 1) << 8) | (cx0 + 1) | (mine << 16) | (pin ? 1 << 20 : 0);
+        fxs[r] = cn.dxw[1];                                  // ix - x0: the east corners' factor; the west ones take 1 - it
+        fys[r] = cn.dyw[1];
+    }
+    for (int i = threadIdx.x; i < (CG + 1) * NC + PITCH + 8; i += kWtThreads) acc[i] = 0;
+    __syncthreads();
+    unsigned* const cnt = box + CG * NC;
+    constexpr int kOffs[4] = {0, 1, PITCH, PITCH + 1};
+#pragma unroll
+    for (int r = 0; r < kWtRows; ++r) {
+        const int pk = packed[r];
+        unsigned* nw = cnt + (((pk >> 8) & 0xff) - 1) * PITCH + ((pk & 0xff) - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if ((pk >> (16 + q)) & 1) __hip_atomic_fetch_add(nw + kOffs[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    unsigned pop = 0;
+    for (int i = threadIdx.x; i < NC; i += kWtThreads) pop = max(pop, cnt[i]);
+    pop = wave_max(pop);
+    if (lane == 0) redm[wave] = pop;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWtWaves; ++k) pop = max(pop, redm[k]);
+    const int bits = __builtin_amdgcn_readfirstlane(min(22, 31 - (32 - __clz(static_cast<int>(pop)))));
+    __syncthreads();
+
+    const int Co = FLIP ? 2 * C : C;
+    const unsigned obytes = static_cast<unsigned>(plane * 4u);
+    const int ybase = Y0 - kWtHalo + wave;
+    int ex_assumed[CG], next_ex[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) ex_assumed[c] = next_ex[c] = 0;
+    for (int gi = 0; gi < groups_per_slab; ++gi) {
+        const int c0 = (slab * groups_per_slab + gi) * CG;
+        if (c0 >= C) break;
+        const float* g0 = gout + (static_cast<size_t>(b) * Co + c0) * plane;
+        // (requesting a group's gradients one group ahead was tried: 32 more registers of loads in flight, 144-388 bytes of scratch, 498 -> 955 us)
+        float g[kWtRows][CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const unsigned nb = c0 + c < C ? obytes : 0u;            // a channel past C reads zeros
+            const rsrc_t rd = make_rsrc(g0 + static_cast<size_t>(c) * plane, nb);
+            const rsrc_t rm = make_rsrc(g0 + (static_cast<size_t>(C) + c) * plane, FLIP ? nb : 0u);
+#pragma unroll
+            for (int r = 0; r < kWtRows; ++r) {
+                const bool pin = (packed[r] >> 20) & 1;
+                const int y = ybase + r * kWtWaves;
+                const unsigned po = pin ? static_cast<unsigned>(y * W + x) * 4u : kOob;
+                const unsigned mo = pin ? static_cast<unsigned>(y * W + (W - 1 - x)) * 4u : kOob;
+                g[r][c] = buf_ld<float>(rd, po);
+                if (FLIP) g[r][c] += buf_ld<float>(rm, mo);
+            }
+        }
+        float fx_inv[CG];
+        bool exact_path = false;
+        auto lane_max = [&](unsigned (&m)[CG]) {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                m[c] = 0;
+#pragma unroll
+                for (int r = 0; r < kWtRows; ++r) m[c] = max(m[c], __float_as_uint(g[r][c]) & 0x7FFFFFFFu);
+                m[c] = wave_max(m[c]);
+            }
+        };
+        auto block_max = [&](unsigned (&m)[CG]) {
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < CG; ++c) redm[c * kWtWaves + wave] = m[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CG; ++c)
+#pragma unroll
+                for (int k = 0; k < kWtWaves; ++k) m[c] = max(m[c], redm[c * kWtWaves + k]);
+        };
+        if (gi == 0) {
+            unsigned m0[CG];
+            lane_max(m0);
+            block_max(m0);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                ex_assumed[c] = 0;
+                if (m0[c] != 0u && m0[c] < 0x7F800000u) (void)frexpf(__uint_as_float(m0[c]), &ex_assumed[c]);
+            }
+            __syncthreads();
+        }
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            float sc[CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const int ex = __builtin_amdgcn_readfirstlane(min(max(ex_assumed[c], -80), 120));
+                ex_assumed[c] = ex;
+                sc[c] = ldexpf(1.f, bits - ex);
+                fx_inv[c] = ldexpf(1.f, ex - bits);
+            }
+#pragma unroll
+            for (int r = 0; r < kWtRows; ++r) {
+                int pk = packed[r];
+                asm volatile("" : "+v"(pk));           // (the address and the four weights are channel-group invariant: not to be hoisted)
+                if (!((pk >> 16) & 15)) continue;
+                unsigned* nw = box + (((pk >> 8) & 0xff) - 1) * PITCH + ((pk & 0xff) - 1);
+                const float ex_ = fxs[r], ey_ = fys[r], wx_ = 1.f - ex_, wy_ = 1.f - ey_;
+                const float wq[4] = {wx_ * wy_, ex_ * wy_, wx_ * ey_, ex_ * ey_};
+                float gs[CG];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) gs[c] = g[r][c] * sc[c];        // (exact: a power of two)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((pk >> (16 + q)) & 1) {
+#pragma unroll
+                        for (int c = 0; c < CG; ++c)
+                            __hip_atomic_fetch_add(nw + c * NC + kOffs[q], __float_as_uint(__builtin_fmaf(wq[q], gs[c], 12582912.f)),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+            }
+            unsigned mb[CG];
+            lane_max(mb);
+            block_max(mb);                        // (its barrier: the adds of the attempt are in)
+            bool fits = true;
+            exact_path = false;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                const bool bad = mb[c] >= 0x7F800000u;       // a NaN / Inf gradient among the channel's pixels
+                exact_path = exact_path || bad;
+                int ex_true = ex_assumed[c];
+                if (mb[c] != 0u && !bad) (void)frexpf(__uint_as_float(mb[c]), &ex_true);
+                ex_true = __builtin_amdgcn_readfirstlane(ex_true);
+                fits = fits && (mb[c] == 0u || bad || (ex_true <= ex_assumed[c] && ex_true >= ex_assumed[c] - 3));
+                next_ex[c] = (mb[c] != 0u && !bad) ? ex_true : ex_assumed[c];
+            }
+            if (exact_path) {
+#pragma unroll
+                for (int c = 0; c < CG; ++c) fx_inv[c] = 0.f;
+            }
+            if (fits || exact_path || attempt == 1) break;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) ex_assumed[c] = next_ex[c];
+            for (int i = threadIdx.x; i < CG * NC; i += kWtThreads) box[i] = 0;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int c = 0; c < CG; ++c) ex_assumed[c] = next_ex[c] + 1;        // the next group's assumption: this group's exponents + 1
+        // flush the own tile: coalesced rows of 56 cells (every cell has exactly one owner)
+        for (int i = threadIdx.x; i < CG * NC; i += kWtThreads) {
+            const int c = i / NC, rem = i - c * NC;
+            const int cy = Y0 + rem / kWtTile, cx = X0 + rem % kWtTile;
+            float inv = fx_inv[0];
+#pragma unroll
+            for (int cc = 1; cc < CG; ++cc) inv = c == cc ? fx_inv[cc] : inv;
+            const float v = inv != 0.f ? static_cast<float>(static_cast<int>(box[i] - cnt[rem] * kMagicBits)) * inv : 0.f;
+            box[i] = 0;
+            if (c0 + c < C && cx < W && cy < H) {
+                float* d = gfeat + (static_cast<size_t>(b) * C + c0 + c) * plane + static_cast<size_t>(cy) * W + cx;
+                if (OVW) *d = v;
+                else *d += v;
+            }
+        }
+        if (exact_path) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+#pragma unroll 1
+            for (int r = 0; r < kWtRows; ++r) {
+                const int y = ybase + r * kWtWaves;
+                if (!(xin && y >= 0 && y < H)) continue;
+                Corners<float> cn;
+                const size_t fo = static_cast<size_t>(y) * W + x;
+                make_corners<float>(cn, fl[fo], fl[plane + fo], H, W);
+                float gq[CG];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    gq[c] = c0 + c < C ? g0[static_cast<size_t>(c) * plane + fo] : 0.f;
+                    if (FLIP && c0 + c < C) gq[c] += g0[(static_cast<size_t>(C) + c) * plane + static_cast<size_t>(y) * W + (W - 1 - x)];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ci = static_cast<int>(cn.off[q] / 4u);
+                    const int cy = ci / W, cx = ci - cy * W;
+                    if (!(cn.valid[q] && cx >= X0 && cx < X0 + kWtTile && cy >= Y0 && cy < Y0 + kWtTile)) continue;
+#pragma unroll
+                    for (int c = 0; c < CG; ++c)
+                        if (c0 + c < C)
+                            atomic_add(gfeat + (static_cast<size_t>(b) * C + c0 + c) * plane + static_cast<size_t>(cy) * W + cx, cn.w[q] * gq[c]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <bool FLIP>
 __global__ void __launch_bounds__(kBlock)
 warp_bwd_feat_far_kernel(const float* __restrict__ flow, const float* __restrict__ gout, float* __restrict__ gfeat, int C, int H, int W,
@@ -1339,8 +1584,14 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
         if (gfeat && Hi == H && Wi == W && options().scatter_variant != 1) {
             // planes beyond LDS, resolution kept: owned tiles + the far complement (no contended global atomics)
             constexpr int CG = 2;
+            // warp_feat_fixed: 0 = double cells, two channels per group (rounds 3-5, the default); 1 = fixed-point cells on that kernel (900 us:
+            // scratch in the add loop); 3 / 4 = fixed-point cells with a compact per-pixel state (3 registers instead of 10), four / two channels
+            // per group: 551-588 / 498-528 us against the double cells' 474-535 on the same boxes -- the kernel is not bound by its LDS
+            // atomics (profiles/r06_warp_feat_fixed_negative.txt), so all of them stay options
+            const int fixmode = options().warp_feat_fixed;
+            const int cgx = fixmode == 3 ? 4 : CG;        // (4 = the compact kernel with two channels per group)
             const int ntx = static_cast<int>((W + kWtTile - 1) / kWtTile), nty = static_cast<int>((H + kWtTile - 1) / kWtTile);
-            const int groups = static_cast<int>((C + CG - 1) / CG);
+            const int groups = static_cast<int>((C + cgx - 1) / cgx);
             int gps = groups;                                       // channel groups per block: split until >= 3 blocks per CU
             while (gps > 1 && B * ntx * nty * ((groups + gps - 1) / gps) < 768) gps = (gps + 1) / 2;
             // ... and on towards ~12 blocks per CU while a block keeps >= 8 groups: two 8-wave blocks are resident per CU (119 registers),
@@ -1367,11 +1618,21 @@ int launch_bwd(const T* feat, const T* flow, const T* gout, T* gfeat, T* gflow, 
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
                 // 1 = 32-bit fixed-point cells (round 6 experiment, OFF: correct, but hipcc cannot hold the kernel in 128 registers -- 64-104 bytes of
                 // scratch reloaded inside the add loop, each behind an s_waitcnt vmcnt(0): 495 -> 900 us; profiles/r06_warp_feat_fixed_negative.txt)
-                const bool fix = options().warp_feat_fixed == 1;
+                const bool fix = fixmode == 1;
 #define FFWM_WT(FL, OV) do { if (fix) hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<FL, CG, OV, true>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs); \
                              else hipLaunchKernelGGL((warp_bwd_feat_tile_kernel<FL, CG, OV, false>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs); } while (0)
-                if (flip) { if (ovw) FFWM_WT(true, true); else FFWM_WT(true, false); }
+#define FFWM_WT2(FL, OV) hipLaunchKernelGGL((warp_bwd_feat_tile2_kernel<FL, 4, OV>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs)
+                if (fixmode == 3) {
+                    if (flip) { if (ovw) FFWM_WT2(true, true); else FFWM_WT2(true, false); }
+                    else { if (ovw) FFWM_WT2(false, true); else FFWM_WT2(false, false); }
+                } else if (fixmode == 4) {
+#define FFWM_WT3(FL, OV) hipLaunchKernelGGL((warp_bwd_feat_tile2_kernel<FL, 2, OV>), dim3(grid), dim3(kWtThreads), 0, st, (const float*)flow, (const float*)gout, (float*)gfeat, (int)C, (int)H, (int)W, ntx, nty, gps, cslabs)
+                    if (flip) { if (ovw) FFWM_WT3(true, true); else FFWM_WT3(true, false); }
+                    else { if (ovw) FFWM_WT3(false, true); else FFWM_WT3(false, false); }
+#undef FFWM_WT3
+                } else if (flip) { if (ovw) FFWM_WT(true, true); else FFWM_WT(true, false); }
                 else { if (ovw) FFWM_WT(false, true); else FFWM_WT(false, false); }
+#undef FFWM_WT2
 #undef FFWM_WT
             }
             if (int rc = check_launch("ffwm_warp_backward(feat, tiles)")) return rc;

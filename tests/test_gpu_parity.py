@@ -2446,7 +2446,7 @@ def test_winograd_domain_weight_gradient_accumulates_and_blocks():
     assert (once - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
 
 
-@pytest.mark.parametrize("fixed", [1, 0])
+@pytest.mark.parametrize("fixed", [3, 1, 0])
 @pytest.mark.parametrize("kind", ["plain", "channel_scales", "nonfinite", "zeros", "contract"])
 def test_warp_backward_feat_fixed_point_cells(oracle, kind, fixed):
     """Round 6 (option warp_feat_fixed = 1; measured slower than the double cells, so OFF by default -- the test keeps the path honest and

@@ -12,7 +12,7 @@ wo = torch.rand(32, 128, 256, 256, generator=g).to(dev)
 gfeat, gflow = torch.empty_like(feat), torch.zeros_like(nflow)
 flush = torch.empty(128 << 20, device=dev)
 for rep in range(2):
-    for mode in (0, 1):
+    for mode in ([int(a) for a in sys.argv[1:]] or [0, 3]):
         _lib.set_option("warp_feat_fixed", mode)
         for _ in range(2):
             ops.warp_backward(feat, nflow, wo, True, gfeat, gflow, overwrite_feat=True)
