@@ -1152,6 +1152,9 @@ rs_bwd1_tile_kernel(const float* __restrict__ in2, const float* __restrict__ gou
 #ifndef FFWM_RS_OWN_THREADS
 #define FFWM_RS_OWN_THREADS 512
 #endif
+#ifndef FFWM_RS_OWN_LDSW
+#define FFWM_RS_OWN_LDSW 0          // 1: the per-pixel factors and origins in LDS instead of registers (one block per CU: use with 1024 threads)
+#endif
 template <int HALF>
 struct RsOwn {
     static constexpr int NT = 2 * HALF;
@@ -1234,7 +1237,18 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
     using G = RsOwn<HALF>;
     constexpr int NT = G::NT, M = G::M, OW = G::OW, OH = G::OH, BP = G::BP, NCELL = G::NCELL, NW = G::NW, PPT = G::PPT;
     constexpr unsigned kMagicBits = 0x4B400000u;   // 1.5 * 2^23
+#if FFWM_RS_OWN_LDSW
+    // [4 channels + the tap count][OH][BP], then the per-pixel state: 2 (NT - 1) factor planes + the packed origins, [plane][pixel] with
+    // pixel = r THREADS + thread (a wave reads 64 consecutive dwords: conflict-free).  One 16-wave block per CU, NO per-pixel registers.
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_own_smem[];
+    unsigned* const box = reinterpret_cast<unsigned*>(rs_own_smem);
+    float* const fac = reinterpret_cast<float*>(rs_own_smem) + 5 * NCELL;
+#define RS_WY(r, f) fac[((f) * PPT + (r)) * G::THREADS + threadIdx.x]
+#define RS_WX(r, f) fac[((NT - 1 + (f)) * PPT + (r)) * G::THREADS + threadIdx.x]
+#define RS_UV(r) reinterpret_cast<int*>(fac)[((2 * (NT - 1)) * PPT + (r)) * G::THREADS + threadIdx.x]
+#else
     __shared__ unsigned box[5 * NCELL];            // [4 channels + the tap count][OH][BP]
+#endif
     __shared__ unsigned redm[NW];
     __shared__ int redp[NW];
     unsigned* const cnt = box + 4 * NCELL;
@@ -1256,8 +1270,13 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
     const float* fb = in2 + static_cast<size_t>(b) * 3 * plane;
     // the normalised factors of an axis sum to 1: NT - 1 of them are kept, the last one is 1 - the others (absolute error <= 2e-7,
     // the size of one fixed-point unit) -- 16 registers less per thread, which is what lets the add loop live in 128 without scratch
+#if !FFWM_RS_OWN_LDSW
     float wyn[PPT][NT - 1], wxn[PPT][NT - 1];
     int uv[PPT];                                   // (v0 - Y0) << 16 | (u0 - X0) & 0xffff, clamped to +-2048 (enough: see colx)
+#define RS_WY(r, f) wyn[r][f]
+#define RS_WX(r, f) wxn[r][f]
+#define RS_UV(r) uv[r]
+#endif
     unsigned livemask = 0;
 #pragma unroll
     for (int r = 0; r < PPT; ++r) {
@@ -1266,7 +1285,7 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
         int u0 = 0, v0 = 0;
         bool ok = false;
 #pragma unroll
-        for (int f = 0; f < NT - 1; ++f) wyn[r][f] = wxn[r][f] = 0.f;
+        for (int f = 0; f < NT - 1; ++f) RS_WY(r, f) = RS_WX(r, f) = 0.f;
         bool degenerate = false;
         if (live_px) {
             const size_t poff = static_cast<size_t>(y) * W + x;
@@ -1275,7 +1294,7 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
             if (ok) {
                 const RsFactors<HALF> fc = rs_pixel_factors<HALF>(dx, dy, sgm, x, y, Hi, Wi, quirk, ablate);
 #pragma unroll
-                for (int f = 0; f < NT - 1; ++f) { wxn[r][f] = fc.wx[f]; wyn[r][f] = fc.wy[f]; }
+                for (int f = 0; f < NT - 1; ++f) { RS_WX(r, f) = fc.wx[f]; RS_WY(r, f) = fc.wy[f]; }
                 degenerate = fc.degenerate != 0;
             }
         }
@@ -1284,7 +1303,7 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
         // (a pixel that is dead here -- outside the flow grid, or irregular: the far kernel's -- is skipped through `livemask`)
         const int ur = on ? min(max(u0 - X0, -2048), 2048) : 0;
         const int vr = on ? min(max(v0 - Y0, -2048), 2048) : 0;
-        uv[r] = (vr << 16) | (ur & 0xffff);
+        RS_UV(r) = (vr << 16) | (ur & 0xffff);
         __builtin_amdgcn_sched_barrier(0);
     }
     // tile-relative column / row of tap f of a pixel with packed origin `o`: the reference's clamp to the image, then the test against
@@ -1303,9 +1322,9 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
         int cx[NT], ry[NT];
 #pragma unroll
         for (int f = 0; f < NT; ++f) {
-            cx[f] = colx(uv[r], f);
+            cx[f] = colx(RS_UV(r), f);
             cx[f] = static_cast<unsigned>(cx[f]) < static_cast<unsigned>(OW) ? cx[f] : dumpc;
-            ry[f] = rowy(uv[r], f);
+            ry[f] = rowy(RS_UV(r), f);
         }
 #pragma unroll
         for (int pr = 0; pr < NT; ++pr) {
@@ -1405,13 +1424,13 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
                 if (!((livemask >> r) & 1u)) continue;
                 // the pixel's origin and factors pass through an opaque register copy: everything derived from them (box offsets, 16
                 // weight products) is channel-invariant, and hipcc would hoist all of it out of the channel loop -- 24 registers per pixel
-                int o = uv[r];
+                int o = RS_UV(r);
                 asm volatile("" : "+v"(o));
                 float wy4[NT], wx4[NT];
                 float ry1 = 1.f, rx1 = 1.f;
 #pragma unroll
                 for (int f = 0; f < NT - 1; ++f) {
-                    wy4[f] = wyn[r][f]; wx4[f] = wxn[r][f];
+                    wy4[f] = RS_WY(r, f); wx4[f] = RS_WX(r, f);
                     asm volatile("" : "+v"(wy4[f]), "+v"(wx4[f]));
                     ry1 -= wy4[f]; rx1 -= wx4[f];
                 }
@@ -1539,6 +1558,9 @@ rs_bwd1_owned_kernel(const float* __restrict__ in2, const float* __restrict__ go
         c += 4;
     }
 }
+#undef RS_WY
+#undef RS_WX
+#undef RS_UV
 
 // The complement of rs_bwd1_owned_kernel: (pixel, tap) pairs whose pixel is not visited by the block that owns the tap's cell.
 template <int HALF>
@@ -2095,11 +2117,19 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
             LaunchScope ls("resample2d_bwd_input1_owned", st, bytes1);      // both launches: the tiles and their far complement
             {
                 const unsigned grid = static_cast<unsigned>(spatial * cslabs);
+#if FFWM_RS_OWN_LDSW
+                const size_t lds1 = 4u * (5u * RsOwn<1>::NCELL + (2u * (RsOwn<1>::NT - 1) + 1u) * RsOwn<1>::PPT * RsOwn<1>::THREADS);
+                const size_t lds2 = 4u * (5u * RsOwn<2>::NCELL + (2u * (RsOwn<2>::NT - 1) + 1u) * RsOwn<2>::PPT * RsOwn<2>::THREADS);
+                allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_owned_kernel<1>));
+                allow_large_lds(reinterpret_cast<const void*>(rs_bwd1_owned_kernel<2>));
+#else
+                const size_t lds1 = 0, lds2 = 0;
+#endif
                 if (half == 1)
-                    hipLaunchKernelGGL((rs_bwd1_owned_kernel<1>), dim3(grid), dim3(RsOwn<1>::THREADS), 0, st, (const float*)in2, (const float*)gout,
+                    hipLaunchKernelGGL((rs_bwd1_owned_kernel<1>), dim3(grid), dim3(RsOwn<1>::THREADS), lds1, st, (const float*)in2, (const float*)gout,
                                        (float*)gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, quirk, overwrite ? 1 : 0, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
                 else
-                    hipLaunchKernelGGL((rs_bwd1_owned_kernel<2>), dim3(grid), dim3(RsOwn<2>::THREADS), 0, st, (const float*)in2, (const float*)gout,
+                    hipLaunchKernelGGL((rs_bwd1_owned_kernel<2>), dim3(grid), dim3(RsOwn<2>::THREADS), lds2, st, (const float*)in2, (const float*)gout,
                                        (float*)gin1, (int)C, (int)Hi, (int)Wi, (int)H, (int)W, quirk, overwrite ? 1 : 0, tiles_x, tiles_y, cslabs, cs, remap, options().ablate);
             }
             if (int rc = check_launch("ffwm_resample2d_backward(input1, owned tiles)")) return rc;
