@@ -2224,6 +2224,549 @@ ba_bwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* _
     }
 }
 
+// ------------------------------------------------------------------------------ block attention backward by linearity (round 6)
+// be_bwd_tile2_kernel<.., FUSED> + be_fwd_lds_kernel<.., MODE 2> spend ~350 VALU instructions per (pixel, channel) -- VALU-bound at 0.12 of
+// the HBM roofline -- although the k x k window of the fused operator is (g_c / k^2) w_ij with a channel-INDEPENDENT w.  By linearity
+// everything channel-independent moves out of the channel loop:
+//   * d(flow), d(weights) (ba_bwd_pix_kernel): with  P = sum_c (g_c / k^2) S_c  over the (K+1)^2 source neighbourhood of a pixel -- 16 LDS
+//     reads + 16 fmas per channel --   d(w_ij) = bilinear_ij(P),   d(flow_x) = sum_ij w_ij d/dx bilinear_ij(P),   d(flow_y) likewise, once
+//     per pixel and channel slab (11 global atomics).  A block keeps P of its 64 x TH pixels in registers while it walks its slab of
+//     channels in LDS-staged groups of CG clamp-extended source boxes; no scatter, no third launch (the samples again for d(weights)).
+//   * d(source) (ba_bwd_src_kernel): the (K+1)^2 cell coefficients  Kc = Wy^T w Wx  are formed once per pixel; a channel adds
+//     (g_c / k^2) Kc to its fixed-point cells.  A block owns the 64 x TH flow pixels of a tile and CS channels, LDS box [CS][AH][AP] (tile
+//     grown by the halo H = 4), flushed like be_bwd_tile2_kernel's (border folds in 64 bits, one global atomic per non-zero in-image
+//     cell).  The fixed-point scale of a channel comes from the EXACT block maximum of |g_c / k^2| max_ij |w_ij| over the tile's pixels
+//     (a pass over the block's g and w in front of the scatter), one bit of margin for the rounding of the coefficient sums; the
+//     population bound is counted as in be_bwd_tile2_kernel.  A channel whose maximum is not finite (NaN / Inf gradient or weight) or
+//     zero takes the per-tap global atomics of the reference for every pixel of the block.
+// Pixels that do not fit the box (flow wider than the halo, a floor that disagrees between taps, NaN flow): d(source) by
+// be_bwd_far2_kernel<.., FUSED> as before, d(flow) / d(weights) in ba_bwd_pix_kernel from global loads, tap by tap.
+// (First cut, one kernel for all three with P per slab of 4 channels: 594 us -- 216 of them the 11 atomics per pixel and 4-channel slab,
+// 144 the flush atomics; tools/r06/ba_bwd_time.py, profiles/r06_ba_bwd_linearity.txt.)
+struct BaTaps {
+    float wxr[3], wyb[3];
+    int au, av;
+    bool fit;
+};
+template <int AP, int AH>
+__device__ __forceinline__ BaTaps ba_taps(float fx0, float fy0, int xf, int yf, int ax0, int ay0, bool inside) {
+    constexpr int K = 3;
+    BaTaps t;
+    float flx0 = 0, fly0 = 0;
+    bool regular = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const float dx = (fx0 + static_cast<float>(j - K / 2)) + static_cast<float>(xf);
+        const float dy = (fy0 + static_cast<float>(j - K / 2)) + static_cast<float>(yf);
+        const float fxl = floor_t(dx), fyl = floor_t(dy);
+        if (j == 0) { flx0 = fxl; fly0 = fyl; }
+        regular = regular & (fxl == flx0 + static_cast<float>(j)) & (fyl == fly0 + static_cast<float>(j));
+        t.wxr[j] = dx - fxl;
+        t.wyb[j] = dy - fyl;
+    }
+    const float lim = static_cast<float>(1 << 20);
+    regular = regular & (flx0 > -lim) & (flx0 < lim) & (fly0 > -lim) & (fly0 < lim);   // rejects NaN too
+    t.au = (regular ? static_cast<int>(flx0) : 0) - ax0;
+    t.av = (regular ? static_cast<int>(fly0) : 0) - ay0;
+    t.fit = inside & regular & (static_cast<unsigned>(t.au) <= static_cast<unsigned>(AP - 1 - K)) &
+            (static_cast<unsigned>(t.av) <= static_cast<unsigned>(AH - 1 - K));
+    return t;
+}
+
+#ifndef FFWM_BA_ABLATE
+#define FFWM_BA_ABLATE 0      // bench-only (tools/r06/ba_bwd_time.py): 1 no LDS atomics, 2 no flush atomics (ba_bwd_src_kernel); 4 no d(flow) / d(weights) atomics, 8 no P accumulation (ba_bwd_pix_kernel)
+#endif
+template <int TH, int NT, int CS>
+__global__ void __launch_bounds__(NT, 4)
+ba_bwd_src_kernel(const float* __restrict__ flow, const float* __restrict__ attn, const float* __restrict__ gout, float* __restrict__ gsrc,
+                  int C, int Hs, int Ws, int Hf, int Wf, int ntx, int nty, int cslabs, int remap) {
+    using T = float;
+    constexpr int K = 3, H = 4, RW = kTileRW, NW = NT / kWave, PPT = TH / NW;
+    constexpr int AP = RW + 2 * H, AH = TH + 2 * H, NA = AP * AH;
+    constexpr unsigned E = sizeof(T);
+    constexpr float kInvKK = 1.f / static_cast<float>(K * K);
+    static_assert(TH % NW == 0, "rows per wave");
+    __shared__ unsigned box[CS * NA];
+    __shared__ unsigned red[NW][CS];
+    __shared__ int cred[NW];
+    int* const A = reinterpret_cast<int*>(box);
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int x0 = tx * RW, y0 = ty * TH;
+    const int ax0 = x0 - H, ay0 = y0 - H;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int xf = x0 + lane;
+    const bool xin = xf < Wf;
+    const int c0 = slab * CS;
+    const int nc = (c0 + CS < C) ? CS : C - c0;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const unsigned sbytes = static_cast<unsigned>(splane * E);
+    const unsigned fpb = static_cast<unsigned>(fplane * E);
+    T* gp = gsrc + (static_cast<size_t>(b) * C + c0) * splane;
+    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, 2 * fpb);
+    const rsrc_t ratt = make_rsrc(attn + static_cast<size_t>(b) * K * K * fplane, K * K * fpb);
+    const rsrc_t rg = make_rsrc(gout + (static_cast<size_t>(b) * C + c0) * fplane, static_cast<unsigned>(nc) * fpb);   // channels >= nc read 0
+    const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;
+    const bool foldL = ax0 < 0, foldR = Ws - ax0 < AP;
+    const bool foldT = ay0 < 0, foldB = Hs - ay0 < AH;
+
+    for (int i = threadIdx.x; i < NA; i += NT) A[i] = 0;
+    __syncthreads();
+    struct PixLoad {
+        T fx, fy;
+        T w[K * K];
+        T g[CS];
+    };
+    const int xfc = min(xf, Wf - 1);
+    auto request = [&](int r, PixLoad& d) {
+        const int yfc = min(y0 + wave + r * NW, Hf - 1);       // rows outside the flow image shadow a valid one
+        const unsigned fo = (static_cast<unsigned>(yfc) * Wf + xfc) * E;
+        d.fx = buf_ld<T>(rfl, fo);
+        d.fy = buf_ld<T>(rfl, fo + fpb);
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) d.w[q] = buf_ld<T>(ratt, fo + static_cast<unsigned>(q) * fpb);
+#pragma unroll
+        for (int c = 0; c < CS; ++c) d.g[c] = buf_ld<T>(rg, fo + static_cast<unsigned>(c) * fpb);
+    };
+
+    // ---- one pass over the tile's pixels: the channels' maxima and the population count
+    unsigned mb[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) mb[c] = 0;
+    {
+        PixLoad nxt;
+        request(0, nxt);
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r) {
+            const int yf = y0 + wave + r * NW;
+            PixLoad cur = nxt;
+            if (r + 1 < PPT) request(r + 1, nxt);
+            if (!(xin && yf < Hf)) continue;
+            {
+                // the population bound: pixels per neighbourhood origin, counted in the first plane of the box (be_bwd_tile2_kernel's head)
+                const BaTaps tp = ba_taps<AP, AH>(cur.fx, cur.fy, xf, yf, ax0, ay0, inside);
+                if (tp.fit) __hip_atomic_fetch_add(A + tp.av * AP + tp.au, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            unsigned wm = 0;
+#pragma unroll
+            for (int q = 0; q < K * K; ++q) wm = max(wm, __builtin_bit_cast(unsigned, cur.w[q]) & 0x7FFFFFFFu);
+            const T wmax = __builtin_bit_cast(T, wm);
+#pragma unroll
+            for (int c = 0; c < CS; ++c)
+                mb[c] = max(mb[c], __builtin_bit_cast(unsigned, (cur.g[c] * kInvKK) * wmax) & 0x7FFFFFFFu);   // NaN / Inf patterns rank above every finite one
+        }
+    }
+    __syncthreads();
+    int fx_bits;
+    {
+        int cm = 0;
+        for (int i = threadIdx.x; i < NA; i += NT) cm = max(cm, A[i]);
+        cm = wave_max(cm);
+        if (lane == 0) cred[wave] = cm;
+        __syncthreads();                                    // (also: every count has been read before the box is zeroed)
+        cm = cred[0];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) cm = max(cm, cred[w2]);
+        const int blen = 32 - __clz(cm);
+        fx_bits = __builtin_amdgcn_readfirstlane(min(22, 31 - 4 - blen));          // 16 cmax 2^bits < 2^31; 22: one bit of margin on the bound
+    }
+    // the channels' scales: block maximum of |g_c / k^2| max|w|, 2 x margin
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        const unsigned m = wave_max(mb[c]);
+        if (lane == 0) red[wave][c] = m;
+    }
+    __syncthreads();
+    T fx_scale[CS], fx_inv[CS];
+    bool exact[CS], nothing[CS];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        unsigned m = red[0][c];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) m = max(m, red[w2][c]);
+        m = __builtin_amdgcn_readfirstlane(m);
+        const T thr = 2 * __builtin_bit_cast(T, m);
+        int ex = 0;
+        (void)frexpf(thr, &ex);
+        exact[c] = !(thr >= 0) || !(thr < 1e37f) || (m != 0 && ex < -100);   // NaN, Inf, denormal range: the exact per-tap path
+        nothing[c] = m == 0;                                                // every (g_c / k^2) w of the tile is +-0: nothing to add
+        fx_scale[c] = exact[c] ? 1.f : ldexpf(1.f, fx_bits - ex);
+        fx_inv[c] = exact[c] ? 1.f : ldexpf(1.f, ex - fx_bits);
+    }
+    for (int i = threadIdx.x; i < CS * NA; i += NT) A[i] = 0;
+    __syncthreads();
+
+    // ---- the scatter: the cell coefficients Kc = Wy^T w Wx once per pixel, (g_c / k^2) Kc into the channel's fixed-point cells
+    if (inside) {
+        PixLoad nxt;
+        request(0, nxt);
+#pragma unroll 1
+        for (int r = 0; r < PPT; ++r) {
+            const int yf = y0 + wave + r * NW;
+            PixLoad cur = nxt;
+            if (r + 1 < PPT) request(r + 1, nxt);
+            if (!(xin && yf < Hf)) continue;
+            const BaTaps tp = ba_taps<AP, AH>(cur.fx, cur.fy, xf, yf, ax0, ay0, inside);
+            if (!tp.fit) continue;                           // be_bwd_far2_kernel's pixel
+            T xl[K], yt[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                xl[j] = 1 - tp.wxr[j];
+                yt[j] = 1 - tp.wyb[j];
+            }
+            T txc[K][K + 1];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+#pragma unroll
+                for (int c2 = 0; c2 <= K; ++c2) {
+                    T v = 0;
+                    if (c2 < K) v = cur.w[i * K + c2] * xl[c2];
+                    if (c2 > 0) v = (c2 < K) ? fma_t<T>(cur.w[i * K + c2 - 1], tp.wxr[c2 - 1], v) : cur.w[i * K + c2 - 1] * tp.wxr[c2 - 1];
+                    txc[i][c2] = v;
+                }
+            }
+            T Kc[(K + 1) * (K + 1)];
+#pragma unroll
+            for (int r2 = 0; r2 <= K; ++r2) {
+#pragma unroll
+                for (int c2 = 0; c2 <= K; ++c2) {
+                    T v = 0;
+                    if (r2 < K) v = txc[r2][c2] * yt[r2];
+                    if (r2 > 0) v = (r2 < K) ? fma_t<T>(txc[r2 - 1][c2], tp.wyb[r2 - 1], v) : txc[r2 - 1][c2] * tp.wyb[r2 - 1];
+                    Kc[r2 * (K + 1) + c2] = v;
+                }
+            }
+            int* ap = A + tp.av * AP + tp.au;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                if (c >= nc) break;
+                if (nothing[c]) continue;
+                if (!exact[c]) {
+                    const T gs = (cur.g[c] * kInvKK) * fx_scale[c];
+#pragma unroll
+                    for (int q = 0; q < ((FFWM_BA_ABLATE & 1) ? 1 : (K + 1) * (K + 1)); ++q)
+                        __hip_atomic_fetch_add(ap + c * NA + (q / (K + 1)) * AP + (q % (K + 1)), __float2int_rn(gs * Kc[q]), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    // the reference's per-tap scatter for this pixel and channel (non-finite or all-zero gradients: rare)
+                    const T gd = cur.g[c] * kInvKK;
+                    T* gplane_c = gp + static_cast<size_t>(c) * splane;
+                    const unsigned pixb = (static_cast<unsigned>(yf) * Wf + xf) * E;
+#pragma unroll 1
+                    for (int i = 0; i < K; ++i) {
+                        const Tap1<T> ty1 = make_tap<T>(cur.fy, i - K / 2, yf, Hs);
+#pragma unroll 1
+                        for (int j = 0; j < K; ++j) {
+                            const Tap1<T> tx1 = make_tap<T>(cur.fx, j - K / 2, xf, Ws);
+                            const T gv = gd * buf_ld<T>(ratt, pixb + static_cast<unsigned>(i * K + j) * fpb);
+                            const unsigned rT = ty1.lo * static_cast<unsigned>(Ws) * E, rB = ty1.hi * static_cast<unsigned>(Ws) * E;
+                            const unsigned cL = tx1.lo * E, cR = tx1.hi * E;
+                            atomic_add_off(gplane_c, rT + cL, gv * tx1.wlo * ty1.wlo);
+                            atomic_add_off(gplane_c, rT + cR, gv * tx1.whi * ty1.wlo);
+                            atomic_add_off(gplane_c, rB + cL, gv * tx1.wlo * ty1.whi);
+                            atomic_add_off(gplane_c, rB + cR, gv * tx1.whi * ty1.whi);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!inside) return;
+    // ---- border folds (64-bit sums; a total that does not fit a cell goes straight to grad_source) and the flush
+    if (foldL || foldR) {
+        for (int e = threadIdx.x; e < nc * AH; e += NT) {
+            const int c = e / AH, row = e - c * AH;
+            int* arow = A + c * NA + row * AP;
+            const int cy = ay0 + row;
+            if (foldL) {
+                long long s = 0;
+                for (int u = 0; u < -ax0; ++u) s += arow[u];
+                // (fx_inv is indexed by a run-time channel below: selected without a scratch array)
+                const long long tot = static_cast<long long>(arow[-ax0]) + s;
+                if (tot >= -2147483647LL && tot <= 2147483647LL) arow[-ax0] = static_cast<int>(tot);
+                else {
+                    arow[-ax0] = 0;
+                    T iv = fx_inv[0];
+#pragma unroll
+                    for (int q = 1; q < CS; ++q) iv = (c == q) ? fx_inv[q] : iv;
+                    atomic_add(gp + static_cast<size_t>(c) * splane + static_cast<size_t>(min(max(cy, 0), Hs - 1)) * Ws, static_cast<T>(tot) * iv);
+                }
+            }
+            if (foldR) {
+                long long s = 0;
+                for (int u = Ws - ax0; u < AP; ++u) s += arow[u];
+                const long long tot = static_cast<long long>(arow[Ws - 1 - ax0]) + s;
+                if (tot >= -2147483647LL && tot <= 2147483647LL) arow[Ws - 1 - ax0] = static_cast<int>(tot);
+                else {
+                    arow[Ws - 1 - ax0] = 0;
+                    T iv = fx_inv[0];
+#pragma unroll
+                    for (int q = 1; q < CS; ++q) iv = (c == q) ? fx_inv[q] : iv;
+                    atomic_add(gp + static_cast<size_t>(c) * splane + static_cast<size_t>(min(max(cy, 0), Hs - 1)) * Ws + (Ws - 1), static_cast<T>(tot) * iv);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (foldT || foldB) {
+        for (int e = threadIdx.x; e < nc * AP; e += NT) {
+            const int c = e / AP, col = e - c * AP;
+            const int cx = ax0 + col;
+            if (cx < 0 || cx >= Ws) continue;               // (the out-of-image columns are already part of the border columns)
+            int* acol = A + c * NA + col;
+            T iv = fx_inv[0];
+#pragma unroll
+            for (int q = 1; q < CS; ++q) iv = (c == q) ? fx_inv[q] : iv;
+            if (foldT) {
+                long long s = 0;
+                for (int v = 0; v < -ay0; ++v) s += acol[v * AP];
+                const long long tot = static_cast<long long>(acol[-ay0 * AP]) + s;
+                if (tot >= -2147483647LL && tot <= 2147483647LL) acol[-ay0 * AP] = static_cast<int>(tot);
+                else {
+                    acol[-ay0 * AP] = 0;
+                    atomic_add(gp + static_cast<size_t>(c) * splane + cx, static_cast<T>(tot) * iv);
+                }
+            }
+            if (foldB) {
+                long long s = 0;
+                for (int v = Hs - ay0; v < AH; ++v) s += acol[v * AP];
+                const long long tot = static_cast<long long>(acol[(Hs - 1 - ay0) * AP]) + s;
+                if (tot >= -2147483647LL && tot <= 2147483647LL) acol[(Hs - 1 - ay0) * AP] = static_cast<int>(tot);
+                else {
+                    acol[(Hs - 1 - ay0) * AP] = 0;
+                    atomic_add(gp + static_cast<size_t>(c) * splane + static_cast<size_t>(Hs - 1) * Ws + cx, static_cast<T>(tot) * iv);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            if (c >= nc) break;
+            T* gplane = gp + static_cast<size_t>(c) * splane;
+            const T iv = fx_inv[c];
+            // (every in-image cell by a global atomic: the interior cells by read-modify-write, old values requested in front of the
+            // scatter, measured 263 -> 304 us -- profiles/r06_ba_bwd_linearity.txt)
+            // wave w flushes box rows w, w + NW, ..: lane -> column (row tests are scalar), the 2 H columns past the 64th afterwards
+            const int cxl = ax0 + lane;
+            const bool cxin = cxl >= 0 && cxl < Ws;
+#pragma unroll 1
+            for (int arow = wave; arow < AH; arow += NW) {
+                const int cy = ay0 + arow;
+                if (cy < 0 || cy >= Hs) continue;
+                const int a = A[c * NA + arow * AP + lane];
+                if (a != 0 && cxin && !(FFWM_BA_ABLATE & 2)) atomic_add(gplane + static_cast<size_t>(cy) * Ws + cxl, static_cast<T>(a) * iv);
+            }
+#pragma unroll 1
+            for (int e = tid; e < AH * 2 * H; e += NT) {
+                const int arow = e / (2 * H), acol = RW + (e & (2 * H - 1));
+                const int cx = ax0 + acol, cy = ay0 + arow;
+                const int a = A[c * NA + arow * AP + acol];
+                if (a != 0 && cx >= 0 && cx < Ws && cy >= 0 && cy < Hs && !(FFWM_BA_ABLATE & 2))
+                    atomic_add(gplane + static_cast<size_t>(cy) * Ws + cx, static_cast<T>(a) * iv);
+            }
+        }
+    }
+}
+
+
+// d(flow), d(weights) of ONE pixel over `nc` channels, every tap on its own from global memory (ba_bwd_generic's arithmetic).
+__device__ __attribute__((noinline)) void ba_pixel_by_taps(const float* sp, rsrc_t rga, rsrc_t ratt, float* gwb, int nc, int Hs, int Ws,
+                                                           size_t splane, unsigned fpb, float fx0, float fy0, int xf, int yf, unsigned pix,
+                                                           float& gx_out, float& gy_out) {
+    using T = float;
+    constexpr int K = 3;
+    constexpr unsigned E = sizeof(T);
+    constexpr float kInvKK = 1.f / static_cast<float>(K * K);
+    T gx = 0, gy = 0;
+#pragma unroll 1
+    for (int c = 0; c < nc; ++c) {
+        const T gd = buf_ld<T>(rga, pix * E + static_cast<unsigned>(c) * fpb) * kInvKK;
+        const T* spc = sp + static_cast<size_t>(c) * splane;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
+#pragma unroll 1
+            for (int j = 0; j < K; ++j) {
+                const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
+                const size_t rT = static_cast<size_t>(ty1.lo) * Ws, rB = static_cast<size_t>(ty1.hi) * Ws;
+                const T sTL = spc[rT + tx1.lo], sTR = spc[rT + tx1.hi], sBL = spc[rB + tx1.lo], sBR = spc[rB + tx1.hi];
+                const T wij = buf_ld<T>(ratt, pix * E + static_cast<unsigned>(i * K + j) * fpb);
+                const T g1 = gd * wij;
+                gy += g1 * (-tx1.wlo * sTL - tx1.whi * sTR + tx1.wlo * sBL + tx1.whi * sBR);
+                gx += g1 * (-ty1.wlo * sTL - ty1.whi * sBL + ty1.wlo * sTR + ty1.whi * sBR);
+                if (gwb) {
+                    T s1 = (tx1.wlo * ty1.wlo) * sTL;
+                    s1 = fma_t<T>(tx1.whi * ty1.wlo, sTR, s1);
+                    s1 = fma_t<T>(tx1.wlo * ty1.whi, sBL, s1);
+                    s1 = fma_t<T>(tx1.whi * ty1.whi, sBR, s1);
+                    atomic_add_off(gwb, pix * E + static_cast<unsigned>(i * K + j) * fpb, gd * s1);
+                }
+            }
+        }
+    }
+    gx_out = gx;
+    gy_out = gy;
+}
+
+template <int TH, int CG, int WPE>
+__global__ void __launch_bounds__(kBlock, WPE)
+ba_bwd_pix_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ attn,
+                  const float* __restrict__ gout, float* __restrict__ gflow, float* __restrict__ gw, int C, int Hs, int Ws, int Hf, int Wf,
+                  int ntx, int nty, int cslabs, int cs, int remap) {
+    using T = float;
+    constexpr int K = 3, H = 4, RW = kTileRW, NW = kBlock / kWave, PPT = TH / NW, NP = (K + 1) * (K + 1);
+    constexpr int AP = RW + 2 * H, AH = TH + 2 * H, NA = AP * AH;
+    constexpr unsigned E = sizeof(T);
+    constexpr float kInvKK = 1.f / static_cast<float>(K * K);
+    __shared__ T S[CG * NA];
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int x0 = tx * RW, y0 = ty * TH;
+    const int ax0 = x0 - H, ay0 = y0 - H;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int xf = x0 + lane;
+    const bool xin = xf < Wf;
+    const int c0 = slab * cs;
+    const int nc = (c0 + cs < C) ? cs : C - c0;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const unsigned sbytes = static_cast<unsigned>(splane * E);
+    const unsigned fpb = static_cast<unsigned>(fplane * E);
+    const T* sp = src + (static_cast<size_t>(b) * C + c0) * splane;
+    const T* gop = gout + (static_cast<size_t>(b) * C + c0) * fplane;
+    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, 2 * fpb);
+    const rsrc_t ratt = make_rsrc(attn + static_cast<size_t>(b) * K * K * fplane, K * K * fpb);
+    const rsrc_t rga = make_rsrc(gop, static_cast<unsigned>(nc) * fpb);      // the slab's gradients: channels past it read 0 (host: cs fplane 4 < 2^31)
+    const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;
+
+    // the pixels of this thread: where their neighbourhood starts in a staged box (< 0: no pixel / not in the box)
+    int nbo[PPT];
+    unsigned fo[PPT];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int yf = y0 + wave + r * NW;
+        const bool live = xin && yf < Hf;
+        fo[r] = (static_cast<unsigned>(min(yf, Hf - 1)) * Wf + min(xf, Wf - 1)) * E;
+        const BaTaps tp = ba_taps<AP, AH>(buf_ld<T>(rfl, fo[r]), buf_ld<T>(rfl, fo[r] + fpb), xf, yf, ax0, ay0, inside);
+        nbo[r] = live ? (tp.fit ? tp.av * AP + tp.au : -1) : -2;
+    }
+    T P[PPT][NP];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) P[r][q] = 0;
+
+    static_assert(AH % NW == 0 && AH * 2 * H <= kBlock, "staging layout");
+    const int tid = threadIdx.x;
+    const unsigned gxa = static_cast<unsigned>(min(max(ax0 + lane, 0), Ws - 1)) * E;
+    const unsigned xoff = tid < AH * 2 * H ? (static_cast<unsigned>(min(max(ay0 + tid / (2 * H), 0), Hs - 1)) * Ws +
+                                              static_cast<unsigned>(min(max(ax0 + RW + (tid & (2 * H - 1)), 0), Ws - 1))) * E
+                                           : 0xFFFFFFF0u;
+#pragma unroll 1
+    for (int cg = 0; cg < nc; cg += CG) {
+        // this group's gradients (channels past the slab read 0) -- requested before the boxes are staged
+        // (ONE resource for the slab and a loop-VARIANT channel offset: per-group resources make the PPT x CG offsets loop invariants
+        // that hipcc keeps in as many registers)
+        const unsigned goff = static_cast<unsigned>(cg) * fpb;
+        T g[PPT][CG];
+#pragma unroll
+        for (int r = 0; r < PPT; ++r)
+#pragma unroll
+            for (int c = 0; c < CG; ++c) g[r][c] = buf_ld<T>(rga, nbo[r] >= 0 ? fo[r] + goff + static_cast<unsigned>(c) * fpb : 0xFFFFFFF0u);
+        __syncthreads();                                   // the previous group's boxes have been read
+        // wave w stages box rows w, w + NW, ..: lane -> column (one row offset per load, a scalar), the 2 H columns past the 64th by the
+        // first AH * 2 H threads
+#pragma unroll 1
+        for (int c = 0; c < CG; ++c) {
+            const bool have = cg + c < nc;
+            const rsrc_t rs = make_rsrc(sp + static_cast<size_t>(have ? cg + c : 0) * splane, have ? sbytes : 0u);
+            T st[AH / NW], sx;
+#pragma unroll
+            for (int rr = 0; rr < AH / NW; ++rr) {
+                const int gy = min(max(ay0 + wave + rr * NW, 0), Hs - 1);
+                st[rr] = buf_ld<T>(rs, (static_cast<unsigned>(gy) * Ws) * E + gxa);
+            }
+            sx = buf_ld<T>(rs, xoff);
+            T* Sc = S + c * NA;
+#pragma unroll
+            for (int rr = 0; rr < AH / NW; ++rr) Sc[(wave + rr * NW) * AP + lane] = st[rr];
+            if (tid < AH * 2 * H) Sc[(tid / (2 * H)) * AP + RW + (tid & (2 * H - 1))] = sx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            if (nbo[r] < 0) continue;
+            const T* nb = S + nbo[r];
+#pragma unroll
+            for (int c = 0; c < ((FFWM_BA_ABLATE & 8) ? 1 : CG); ++c) {
+                const T gd = g[r][c] * kInvKK;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) P[r][q] = fma_t<T>(gd, nb[c * NA + (q / (K + 1)) * AP + (q % (K + 1))], P[r][q]);
+                __builtin_amdgcn_sched_barrier(0);          // one channel's 16 reads in flight, not the whole group's (registers)
+            }
+        }
+    }
+    // d(weights), d(flow) of the thread's pixels
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        if (nbo[r] == -2) continue;
+        const int yf = y0 + wave + r * NW;
+        const unsigned pix = static_cast<unsigned>(yf) * Wf + xf;
+        const T fx0 = buf_ld<T>(rfl, fo[r]), fy0 = buf_ld<T>(rfl, fo[r] + fpb);
+        T gx = 0, gy = 0;
+        if (nbo[r] >= 0) {
+            const BaTaps tp = ba_taps<AP, AH>(fx0, fy0, xf, yf, ax0, ay0, inside);
+            T w[K * K];
+#pragma unroll
+            for (int q = 0; q < K * K; ++q) w[q] = buf_ld<T>(ratt, fo[r] + static_cast<unsigned>(q) * fpb);
+            T xl[K], yt[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                xl[j] = 1 - tp.wxr[j];
+                yt[j] = 1 - tp.wyb[j];
+            }
+            T* gwp = gw ? gw + static_cast<size_t>(b) * K * K * fplane : nullptr;      // (block-uniform base + 32-bit byte offsets)
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const T TL = P[r][i * (K + 1) + j], TR = P[r][i * (K + 1) + j + 1];
+                    const T BL = P[r][(i + 1) * (K + 1) + j], BR = P[r][(i + 1) * (K + 1) + j + 1];
+                    const T top = fma_t<T>(tp.wxr[j], TR, xl[j] * TL), bot = fma_t<T>(tp.wxr[j], BR, xl[j] * BL);
+                    const T lef = fma_t<T>(tp.wyb[i], BL, yt[i] * TL), rig = fma_t<T>(tp.wyb[i], BR, yt[i] * TR);
+                    gy = fma_t<T>(w[i * K + j], bot - top, gy);
+                    gx = fma_t<T>(w[i * K + j], rig - lef, gx);
+                    if (gwp && !(FFWM_BA_ABLATE & 4)) atomic_add_off(gwp, fo[r] + static_cast<unsigned>(i * K + j) * fpb, fma_t<T>(tp.wyb[i], bot, yt[i] * top));
+                }
+            }
+        } else {
+            // every tap on its own from global memory, like the reference (rare; a called function: its registers are not the hot path's)
+            ba_pixel_by_taps(sp, rga, ratt, gw ? gw + static_cast<size_t>(b) * K * K * fplane : nullptr, nc, Hs, Ws, splane, fpb, fx0, fy0, xf, yf, pix, gx, gy);
+        }
+        if (gflow && !(FFWM_BA_ABLATE & 4)) {
+            atomic_add_off(gflow + static_cast<size_t>(b) * 2 * fplane, fo[r], gx);
+            atomic_add_off(gflow + static_cast<size_t>(b) * 2 * fplane, fo[r] + fpb, gy);
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // one pixel at a time (registers)
+    }
+}
+
 template <typename T>
 int launch_attn_fwd(const T* src, const T* flow, const T* wts, T* out, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
                     int64_t Hf, int64_t Wf, int k, hipStream_t st) {
@@ -2258,14 +2801,16 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
                     int64_t C, int64_t Hs, int64_t Ws, int64_t Hf, int64_t Wf, int k, hipStream_t st) {
     const double bytes = sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hf * Wf + 2.0 * C * Hs * Ws + (4.0 + k * k) * Hf * Wf);
     if constexpr (sizeof(T) == 4) {
+        // (rounds 4-5's route -- be_bwd_tile2_kernel<.., FUSED> + be_fwd_lds_kernel<.., MODE 2> -- is gone: 1.5 x slower, and round 6's wide-flow
+        // test found its d(weights) launch wrong where flows leave the forward kernel's LDS window)
         if (k == 3 && gsrc && options().be_bwd_variant != 9) {
-            const int h = options().be_bwd_halo > 4 ? 8 : 4;
-            const TileGeo geo{kTileRW, 32, h, 32};
-            const int ntx = static_cast<int>(((Ws > Wf ? Ws : Wf) + geo.TW - 1) / geo.TW);
-            const int nty = static_cast<int>(((Hs > Hf ? Hs : Hf) + geo.TH - 1) / geo.TH);
-            int cs = options().channel_slab > 0 ? options().channel_slab : 4;
-            if (cs > C) cs = static_cast<int>(C);
-            const int cslabs = static_cast<int>((C + cs - 1) / cs);
+            const int mode = options().ba_bwd_fused;
+            const int th = mode == 2 ? 16 : 32;
+            const int nts = mode == 3 ? 512 : 256;
+            constexpr int csf = 4;
+            const TileGeo geo{kTileRW, th, 4, th};
+            const int ntx = static_cast<int>((Wf + kTileRW - 1) / kTileRW), nty = static_cast<int>((Hf + th - 1) / th);
+            const int cslabs = static_cast<int>((C + csf - 1) / csf);
             const Geometry gf = plan(B, C, Hf, Wf, 32);
             {
                 LaunchScope ls("block_attention_bwd_far", st, sizeof(T) * 2.0 * B * Hf * Wf);
@@ -2273,40 +2818,44 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
                                    (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, gf.tiles_x, gf.tiles_y, gf.cslabs, gf.cs, geo, wts);
             }
             if (int rc = check_launch("ffwm_block_attention_backward(far)")) return rc;
+            FFWM_REQUIRE(B * ntx * nty * static_cast<int64_t>(cslabs) < (1LL << 31), FFWM_ERR_SIZE, "ffwm_block_attention_backward: grid too large");
             {
-                LaunchScope ls("block_attention_bwd_tile2", st, bytes);
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-                const int flush_rmw = options().be_bwd_flush == 1 ? 1 : 0;
-                if (h == 8)
-                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 8, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
-                                       gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
-                                       options().xcd_remap, wts, 0, flush_rmw);
-                else if (options().be_bwd_fixed != 2)
-                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, true, false, 1>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
-                                       gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
-                                       options().xcd_remap, wts, 0, flush_rmw);
-                else
-                    hipLaunchKernelGGL((be_bwd_tile2_kernel<3, 32, 4, true>), dim3(grid), dim3(kBlock), 0, st, src, flow, gout, gsrc,
-                                       gflow, (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, cs,
-                                       options().xcd_remap, wts, 0, flush_rmw);
+                LaunchScope ls("block_attention_bwd_src", st, sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hf * Wf + 1.0 * C * Hs * Ws + (2.0 + k * k) * Hf * Wf));
+#define FFWM_BA_SRC(TH_, NT_)                                                                                                  \
+    hipLaunchKernelGGL((ba_bwd_src_kernel<TH_, NT_, csf>), dim3(grid), dim3(NT_), 0, st, flow, wts, gout, gsrc, (int)C, (int)Hs, \
+                       (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, options().xcd_remap)
+                if (th == 16) FFWM_BA_SRC(16, 256);
+                else if (nts == 512) FFWM_BA_SRC(32, 512);
+                else FFWM_BA_SRC(32, 256);
+#undef FFWM_BA_SRC
             }
-            if (int rc = check_launch("ffwm_block_attention_backward(tile)")) return rc;
-            if (gw) {
-                // the samples once more, reduced over the channels: same traffic as the forward minus its output
-                const Geometry g = plan(B, C, Hf, Wf, 16);
-                const int rpt = Hf >= 64 ? 4 : 1;
-                const int th = (kBlock / kWave) * rpt;
-                const int tyl = static_cast<int>((Hf + th - 1) / th);
-                const unsigned gridl = static_cast<unsigned>(B * g.tiles_x * tyl * g.cslabs);
-                LaunchScope ls("block_attention_bwd_weights", st,
-                               sizeof(T) * static_cast<double>(B) * (C * Hs * Ws + (2.0 + k * k) * Hf * Wf + static_cast<double>(C) * Hf * Wf));
-                if (rpt == 4)
-                    hipLaunchKernelGGL((be_fwd_lds_kernel<float, 3, 4, 2>), dim3(gridl), dim3(kBlock), 0, st, src, flow, gw, (int)C,
-                                       (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, options().xcd_remap, 0, 0, gout);
-                else
-                    hipLaunchKernelGGL((be_fwd_lds_kernel<float, 3, 1, 2>), dim3(gridl), dim3(kBlock), 0, st, src, flow, gw, (int)C,
-                                       (int)Hs, (int)Ws, (int)Hf, (int)Wf, g.tiles_x, tyl, g.cslabs, g.cs, options().xcd_remap, 0, 0, gout);
-                return check_launch("ffwm_block_attention_backward(weights)");
+            if (int rc = check_launch("ffwm_block_attention_backward(source)")) return rc;
+            if (gflow || gw) {
+                // d(flow), d(weights): tiles of 64 x 16 pixels, as many channels per block as still fill the chip four times over
+                const int cga = options().ba_bwd_pix == 1 || options().ba_bwd_pix == 3 ? 8 : 4;
+                const int pm = options().ba_bwd_pix;                                   // (common.hpp)
+                const int tha = pm == 1 || pm == 4 ? 8 : 16;
+                const int ntya = static_cast<int>((Hf + tha - 1) / tha);
+                const int64_t tiles = B * ntx * ntya;
+                int64_t want = (4LL * device_cus() + tiles - 1) / tiles;               // slabs
+                if (want < 1) want = 1;
+                int csa = static_cast<int>((C + want - 1) / want);
+                csa = (csa + cga - 1) / cga * cga;
+                while (csa > cga && static_cast<int64_t>(csa) * Hf * Wf * 4 >= (1LL << 31)) csa -= cga;       // 32-bit byte offsets over a slab of grad_output
+                const int slabsa = static_cast<int>((C + csa - 1) / csa);
+                const unsigned grid = static_cast<unsigned>(tiles * slabsa);
+                LaunchScope ls("block_attention_bwd_pix", st, sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hf * Wf + 1.0 * C * Hs * Ws + (4.0 + 2.0 * k * k) * Hf * Wf));
+#define FFWM_BA_PIX(TH_, CG_, WPE_)                                                                                                     \
+    hipLaunchKernelGGL((ba_bwd_pix_kernel<TH_, CG_, WPE_>), dim3(grid), dim3(kBlock), 0, st, src, flow, wts, gout, gflow, gw, (int)C, \
+                       (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, ntya, slabsa, csa, options().xcd_remap)
+                if (pm == 1) FFWM_BA_PIX(8, 8, 4);
+                else if (pm == 2) FFWM_BA_PIX(16, 4, 4);
+                else if (pm == 3) FFWM_BA_PIX(16, 8, 3);
+                else if (pm == 4) FFWM_BA_PIX(8, 4, 4);
+                else FFWM_BA_PIX(16, 4, 3);
+#undef FFWM_BA_PIX
+                return check_launch("ffwm_block_attention_backward(pixels)");
             }
             return FFWM_OK;
         }

@@ -219,6 +219,86 @@ def test_block_attention_matches_the_composition(oracle, case, dtype):
     _close(gw, gw_ref, tol, relative=True)
 
 
+BA_LIN_CASES = [
+    (2, 13, 70, 130, 70, 130, 3, 1.5, 30),      # ragged tiles, channel slabs with a remainder
+    (1, 6, 96, 200, 96, 200, 3, 6.0, 32),       # flows wider than the halo: most pixels leave the box (far kernel + per-tap d(flow) / d(weights))
+    (1, 3, 40, 72, 33, 65, 3, 2.0, 33),         # source larger than the flow field
+    (1, 9, 33, 65, 40, 72, 3, 2.0, 34),         # flow field larger than the source: folds onto the border
+]
+
+
+@pytest.mark.parametrize("fused,pix", [(1, 0), (2, 1), (3, 2), (1, 4), (3, 3)])
+@pytest.mark.parametrize("case", BA_LIN_CASES)
+def test_block_attention_backward_by_linearity(oracle, case, fused, pix):
+    """Round 6: d(source) from per-pixel cell coefficients Wy^T w Wx (ba_bwd_src_kernel), d(flow) / d(weights) from P = sum_c g_c S_c
+    (ba_bwd_pix_kernel), in every tile / thread / channel-group variant, against the composition of the reference's operators,
+    accumulating into non-zero gradients.  (The wide-flow case is the one that showed rounds 4-5's d(weights) launch to be wrong by 0.2 relative
+    when flows leave the forward kernel's LDS window -- that launch is gone.)"""
+    from ffwm_amd import ops, _lib
+    src, flow, _, k = _be_inputs(case, torch.float32)
+    B, C, Hf, Wf = src.shape[0], src.shape[1], flow.shape[2], flow.shape[3]
+    g = _gen(200 + case[8])
+    w = torch.randn(B, k * k, Hf, Wf, generator=g)
+    go = torch.randn(B, C, Hf, Wf, generator=g)
+    out_ref, gs_ref, gf_ref, gw_ref = _attention_reference(oracle, src, flow, w, k, go)
+    _close(ops.block_attention_forward(src.to(DEV), flow.to(DEV), w.to(DEV), k), out_ref, FWD_TOL[torch.float32])
+    base = [torch.randn(src.shape, generator=g), torch.randn(flow.shape, generator=g), torch.randn(w.shape, generator=g)]   # the gradients ACCUMULATE
+    gs, gf, gw = (t.to(DEV) for t in base)
+    for key, v in (("ba_bwd_fused", fused), ("ba_bwd_pix", pix)):
+        _lib.set_option(key, v)
+    try:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        ops.block_attention_backward(src.to(DEV), flow.to(DEV), w.to(DEV), go.to(DEV), k, gs, gf, gw)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        rows = _lib.prof_collect()
+    finally:
+        for key, v in (("ba_bwd_fused", 3), ("ba_bwd_pix", 2)):
+            _lib.set_option(key, v)
+    assert "block_attention_bwd_src" in rows and "block_attention_bwd_pix" in rows
+    tol = 1e-4 if case[7] >= 100 else BWD_TOL[torch.float32]
+    for got, ref, b0 in ((gs, gs_ref, base[0]), (gf, gf_ref, base[1]), (gw, gw_ref, base[2])):
+        _close(got.cpu() - b0, ref, tol, relative=True)
+
+
+@pytest.mark.parametrize("kind", ["nonfinite", "zeros", "one_channel_zero", "huge", "tiny", "heavy_tail"])
+def test_block_attention_backward_by_linearity_scales(oracle, kind):
+    """The per-channel fixed-point scale of ba_bwd_src_kernel is the tile's exact maximum of |g_c / k^2| max|w|: channels without a finite
+    maximum take the per-tap atomics (non-finite values land where the reference's do), an all-zero channel adds nothing, magnitudes at
+    both ends of the float range and a log-normal gradient keep the relative accuracy."""
+    from ffwm_amd import ops
+    g = _gen(61)
+    B, C, H, W = 1, 6, 100, 140
+    src = torch.rand(B, C, H, W, generator=g)
+    flow = (torch.rand(B, 2, H, W, generator=g) * 2 - 1) * 2.0
+    w = torch.rand(B, 9, H, W, generator=g)
+    go = torch.randn(B, C, H, W, generator=g)
+    if kind == "nonfinite":
+        go[0, 0, 10, 10] = float("nan")
+        go[0, 2, 50, 70] = float("inf")
+        w[0, 4, 80, 100] = -float("inf")
+    elif kind == "zeros":
+        go.zero_()
+    elif kind == "one_channel_zero":
+        go[0, 3].zero_()
+    elif kind == "huge":
+        go = go * 1e30
+    elif kind == "tiny":
+        go = go * 1e-30
+    elif kind == "heavy_tail":
+        go = go * torch.exp(4 * torch.randn(B, C, H, W, generator=g))
+    _, gs_ref, gf_ref, gw_ref = _attention_reference(oracle, src, flow, w, 3, go)
+    gs, gf, gw = torch.zeros_like(src, device=DEV), torch.zeros_like(flow, device=DEV), torch.zeros_like(w, device=DEV)
+    ops.block_attention_backward(src.to(DEV), flow.to(DEV), w.to(DEV), go.to(DEV), 3, gs, gf, gw)
+    for name, got, ref in (("gs", gs.cpu(), gs_ref), ("gf", gf.cpu(), gf_ref), ("gw", gw.cpu(), gw_ref)):
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isfinite(got), fin), "%s: %d non-finite elements, the reference has %d" % (name, int((~torch.isfinite(got)).sum()), int((~fin).sum()))
+        if fin.any():
+            scale = 1e-37 + float(ref[fin].abs().max())
+            assert float((got[fin] - ref[fin]).abs().max()) <= 2e-5 * scale, (kind, name, float((got[fin] - ref[fin]).abs().max()) / scale)
+
+
 def test_block_attention_module_softmax_and_partial_grads(oracle):
     """BlockAttention(softmax=True) through autograd, including the d(flow)-only and d(weights)-only calls."""
     import torch.nn.functional as F
