@@ -2821,7 +2821,7 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
             FFWM_REQUIRE(B * ntx * nty * static_cast<int64_t>(cslabs) < (1LL << 31), FFWM_ERR_SIZE, "ffwm_block_attention_backward: grid too large");
             {
                 const unsigned grid = static_cast<unsigned>(B * ntx * nty * cslabs);
-                LaunchScope ls("block_attention_bwd_src", st, sizeof(T) * static_cast<double>(B) * (static_cast<double>(C) * Hf * Wf + 1.0 * C * Hs * Ws + (2.0 + k * k) * Hf * Wf));
+                LaunchScope ls("block_attention_bwd_src", st, bytes);        // (the OPERATOR's algorithmic bytes: bench.py prices the sum of the three scopes' times against them)
 #define FFWM_BA_SRC(TH_, NT_)                                                                                                  \
     hipLaunchKernelGGL((ba_bwd_src_kernel<TH_, NT_, csf>), dim3(grid), dim3(NT_), 0, st, flow, wts, gout, gsrc, (int)C, (int)Hs, \
                        (int)Ws, (int)Hf, (int)Wf, ntx, nty, cslabs, options().xcd_remap)
