@@ -2832,13 +2832,14 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
             }
             if (int rc = check_launch("ffwm_block_attention_backward(source)")) return rc;
             if (gflow || gw) {
-                // d(flow), d(weights): tiles of 64 x 16 pixels, as many channels per block as still fill the chip four times over
+                // d(flow), d(weights): as many channels per block as still give every CU its resident blocks
                 const int cga = options().ba_bwd_pix == 1 || options().ba_bwd_pix == 3 ? 8 : 4;
                 const int pm = options().ba_bwd_pix;                                   // (common.hpp)
-                const int tha = pm == 1 || pm == 4 ? 8 : 16;
+                const int tha = pm == 1 || pm >= 4 ? 8 : 16;
                 const int ntya = static_cast<int>((Hf + tha - 1) / tha);
                 const int64_t tiles = B * ntx * ntya;
-                int64_t want = (4LL * device_cus() + tiles - 1) / tiles;               // slabs
+                const int wpe = pm == 5 ? 6 : ((pm == 0 || pm == 3) ? 3 : 4);   // resident blocks per CU
+                int64_t want = (static_cast<int64_t>(wpe) * device_cus() + tiles - 1) / tiles;               // slabs: one resident round of blocks
                 if (want < 1) want = 1;
                 int csa = static_cast<int>((C + want - 1) / want);
                 csa = (csa + cga - 1) / cga * cga;
@@ -2853,6 +2854,7 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
                 else if (pm == 2) FFWM_BA_PIX(16, 4, 4);
                 else if (pm == 3) FFWM_BA_PIX(16, 8, 3);
                 else if (pm == 4) FFWM_BA_PIX(8, 4, 4);
+                else if (pm == 5) FFWM_BA_PIX(8, 4, 6);
                 else FFWM_BA_PIX(16, 4, 3);
 #undef FFWM_BA_PIX
                 return check_launch("ffwm_block_attention_backward(pixels)");

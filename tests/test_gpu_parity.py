@@ -227,7 +227,7 @@ BA_LIN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("fused,pix", [(1, 0), (2, 1), (3, 2), (1, 4), (3, 3)])
+@pytest.mark.parametrize("fused,pix", [(1, 0), (2, 1), (3, 2), (1, 4), (3, 3), (2, 5)])
 @pytest.mark.parametrize("case", BA_LIN_CASES)
 def test_block_attention_backward_by_linearity(oracle, case, fused, pix):
     """Round 6: d(source) from per-pixel cell coefficients Wy^T w Wx (ba_bwd_src_kernel), d(flow) / d(weights) from P = sum_c g_c S_c
