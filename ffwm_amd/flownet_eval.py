@@ -17,12 +17,13 @@ The dense 3x3 / 4x4 convolutions stay on MIOpen (fp32 Winograd / implicit GEMM o
 snapshotted at construction: build it from a network in `.eval()` and rebuild after the weights change.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, ops
 
 LRELU, TANH, NONE = 1, 2, 0
 
@@ -145,6 +146,8 @@ class FoldedFlowNet(object):
         # to 1 so that EVERY stride-2 / transposed / small-plane layer of a narrow FlowNet runs on the hand-written kernel
         self.mfma_min_channels = int(mfma_min_channels)
         self.arena = Arena()
+        self.own_winograd = os.environ.get("FFWM_FLOWNET_OWN_WINOGRAD", "1") != "0"
+        self._wino = {}
         if net.training:
             raise ValueError("FoldedFlowNet folds eval-mode BatchNorm statistics: call net.eval() first")
         p = next(net.parameters())
@@ -176,6 +179,11 @@ class FoldedFlowNet(object):
             # tools/conv_layers.py: faster than the vendor kernel + epilogue everywhere except the >= 64 x 64 stride-1
             # layers and the thin 18 / 34-channel ones): hand-written MFMA kernel with the epilogue fused
             return conv_mfma(x, w, b, stride[0], padding[0], transposed, LRELU, slope, dst=dst, dst2=dst2, arena=self.arena)
+        if (self.own_winograd and not transposed and stride[0] == 1 and padding[0] == 1 and tuple(w.shape[2:]) == (3, 3)
+                and dst is None and dst2 is None):
+            # the >= 64 x 64 stride-1 layers (conv0, conv1_1, inter_conv1, inter_conv0): the library's fp32 Winograd F(2x2, 3x3) kernel
+            # with bias + LeakyReLU in its output transform; the transformed (folded) weights are kept per layer
+            return ops.conv3x3_winograd(x, w, b, act=LRELU, slope=slope, frozen=self._wino.setdefault(name, {}))
         h = F.conv_transpose2d(x, w, None, stride, padding) if transposed else F.conv2d(x, w, None, stride, padding)
         if dst is None and dst2 is None:
             return bias_act(h, b, LRELU, slope=slope)
