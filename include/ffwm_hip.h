@@ -281,7 +281,10 @@ int ffwm_block_attention_forward(const void* source, const void* flow_field, con
 
 /* grad_source[B,C,Hs,Ws] +=, grad_flow_field[B,2,Hf,Wf] +=, grad_weights[B,k*k,Hf,Wf] += for
  * grad_output[B,C,Hf,Wf]; any of the three may be NULL.  The extractor's grad_output window is
- * (grad_output / k^2) * weights_ij, formed in registers. */
+ * (grad_output / k^2) * weights_ij -- a channel-independent window times one number per channel, so (round 6) grad_source comes from
+ * per-pixel cell coefficients Wy^T w Wx scaled per channel, grad_flow_field and grad_weights from P = sum_c (g_c / k^2) S_c over the
+ * (k+1)^2 source neighbourhood: two launches for fp32 / k = 3 with grad_source wanted (csrc/block_extractor.hip: ba_bwd_src_kernel,
+ * ba_bwd_pix_kernel), the per-element kernel otherwise. */
 int ffwm_block_attention_backward(const void* source, const void* flow_field, const void* weights,
                                   const void* grad_output, void* grad_source, void* grad_flow_field,
                                   void* grad_weights, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int64_t Hf,
