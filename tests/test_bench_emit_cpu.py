@@ -75,12 +75,25 @@ def test_last_line_carries_the_per_config_operator_rows():
     assert tuple(d)[:len(CONTRACT)] == CONTRACT
     ops = d["ops"]
     for k in ("cfg1_rs_fwd", "cfg1_rs_bwd1", "cfg1_rs_bwd2", "cfg5_be_fwd", "cfg5_be_bwd", "cfg5_lar", "warp_fwd@256", "warp_bwd_flow@256",
-              "flownet_fwd_cfg2", "cfg5_battn_bwd", "rs_bwd1@512", "warp_bwd_feat@256"):
+              "flownet_fwd_cfg2", "rs_bwd1@512", "warp_bwd_feat@256"):
         assert k in ops and len(ops[k]) == 2 and ops[k][0] > 0, (k, ops.get(k))
     # the figures are the rows' own: round 4's cfg-5 extractor forward (211 us = 0.80 by HIP events), backward 596 us = 0.31
     assert abs(ops["cfg5_be_fwd"][0] - 211.05) < 0.01 and abs(ops["cfg5_be_bwd"][1] - 0.3105) < 1e-4
     assert abs(ops["flownet_fwd_cfg2"][0] - 897.2) < 0.1
     assert "after the timed region" in d["roofline"]["rows_from"]
+
+
+def test_block_attention_backward_row_is_the_sum_of_its_launches():
+    """Round 6: cfg5_battn_bwd = far + d(source) + d(flow, weights) launches, priced against the operator's bytes (the first scope's)."""
+    where = "cfg5/GPU block attention k=3 backward"
+    rows = [{"kernel": "block_attention_bwd_src", "where": where, "avg_us": 260.0, "alg_MB": 416.0, "frac_hbm_peak": 0.2},
+            {"kernel": "block_attention_bwd_pix", "where": where, "avg_us": 120.0, "alg_MB": 300.0, "frac_hbm_peak": 0.3},
+            {"kernel": "block_attention_bwd_far", "where": where, "avg_us": 8.0, "alg_MB": 2.0, "frac_hbm_peak": 0.01},
+            {"kernel": "block_attention_bwd_src", "where": "timed region", "avg_us": 1.0, "alg_MB": 1.0, "frac_hbm_peak": 0.5}]
+    ops = bench.ops_summary(rows)
+    assert ops["cfg5_battn_bwd"][0] == 388.0
+    assert abs(ops["cfg5_battn_bwd"][1] - 416e6 / 388e-6 / bench.HBM_PEAK) < 1e-4
+    assert "cfg5_battn_bwd" not in bench.ops_summary(rows[1:])          # without the d(source) launch there is no row
 
 
 def test_operator_rows_survive_the_size_limit_longer_than_the_optional_objects():

@@ -34,5 +34,5 @@ def test_kernel_statistics_of_this_round_hold_the_library_kernels():
         with open(ops) as f:
             text = f.read()
         for k in ("be_fwd_lds_kernel", "be_bwd_tile2_kernel", "rs_fwd_lds_kernel", "rs_bwd1_owned_kernel", "warp_fwd_lds_kernel",
-                  "warp_bwd_flow_lds_kernel", "warp_bwd_feat_tile_kernel"):
+                  "warp_bwd_flow_lds_kernel", "warp_bwd_feat_tile_kernel", "ba_bwd_src_kernel", "ba_bwd_pix_kernel"):
             assert k in text, k
