@@ -60,6 +60,7 @@ struct Options {
     int rs_bwd1_fixed = 0;       // resample2d d_input1 tile kernel: 0 = 32-bit fixed-point box cells (round 5), 2 = double cells
     int be_bwd_fixed = 0;        // block_extractor / block attention shared-cell backward: 0 = 32-bit fixed-point accumulator cells (round 5), 2 = double cells
     int rs_bwd1_owned = 0;       // resample2d d_input1, large calls: 0 = owned tiles + far complement, plain stores (round 6), 2 = the shared-cell tile kernel with its fold atomics (rounds 3-5)
+    int rs_bwd1_owned_min_pixels = 0;    // owned tiles for calls of at least this many pixels (B H W); 0 = 2^18
     int rs_bwd1_owned_blocks = 0; // owned tiles: the channel slab is halved until the launch has this many blocks (0 = 2048)
     int warp_feat_fixed = 0;     // warp d(feat) owned-tile kernel: 0 = double cells, 1 = 32-bit fixed-point cells (round 6 experiment: slower -- register spills)
     int ba_bwd_fused = 3;        // block attention backward, ba_bwd_src_kernel's tile rows / threads: 1 = 32 / 256, 2 = 16 / 256, 3 = 32 / 512 (tools/r06/ba_bwd_time.py)

@@ -2102,7 +2102,7 @@ int launch_bwd(const T* in1, const T* in2, const T* gout, T* gin1, T* gin2, int6
         // Round 6: owned tiles (rs_bwd1_owned_kernel + rs_bwd1_far_kernel) for the calls the shared-cell tile kernel served: fp32, dilation 1,
         // kernel_size 2 / 4, >= 2^18 pixels, planes of >= 32 rows.  rs_bwd1_owned: 0 = on, 2 = off (rounds 3-5's kernels).
         if (gin1 && dil == 1 && (half == 1 || half == 2) && options().scatter_variant == 0 && options().rs_bwd1_variant == 0 &&
-            options().rs_bwd1_owned != 2 && B * H * W >= (1 << 18) && H >= 32 && Hi >= 32 &&
+            options().rs_bwd1_owned != 2 && B * H * W >= (options().rs_bwd1_owned_min_pixels > 0 ? options().rs_bwd1_owned_min_pixels : (1 << 18)) && H >= 32 && Hi >= 32 &&
             static_cast<int64_t>(Hi) * Wi < (1LL << 29) && static_cast<int64_t>(H) * W < (1LL << 29)) {
             const double bytes1 = sizeof(T) * static_cast<double>(B) * (C * (static_cast<double>(H) * W + 2.0 * Hi * Wi) + 3.0 * H * W);
             const int ow = half == 1 ? RsOwn<1>::OW : RsOwn<2>::OW, oh = half == 1 ? RsOwn<1>::OH : RsOwn<2>::OH;

@@ -320,6 +320,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "rs_bwd1_owned")) slot = &o.rs_bwd1_owned;
     else if (!strcmp(key, "warp_feat_fixed")) slot = &o.warp_feat_fixed;
     else if (!strcmp(key, "rs_bwd1_owned_blocks")) slot = &o.rs_bwd1_owned_blocks;
+    else if (!strcmp(key, "rs_bwd1_owned_min_pixels")) slot = &o.rs_bwd1_owned_min_pixels;
     else if (!strcmp(key, "rs_bwd1_fixed")) slot = &o.rs_bwd1_fixed;
     else if (!strcmp(key, "rs_bwd1_rpt")) slot = &o.rs_bwd1_rpt;
     else if (!strcmp(key, "warp_feat_gps")) slot = &o.warp_feat_gps;
