@@ -2629,7 +2629,10 @@ ba_bwd_pix_kernel(const float* __restrict__ src, const float* __restrict__ flow,
     constexpr int AP = RW + 2 * H, AH = TH + 2 * H, NA = AP * AH;
     constexpr unsigned E = sizeof(T);
     constexpr float kInvKK = 1.f / static_cast<float>(K * K);
-    __shared__ T S[CG * NA];
+    static_assert(CG % 4 == 0, "channels per group: whole float4s");
+    // the staged boxes, CHANNEL-INNERMOST: S[cell][CG] -- one ds_read_b128 brings four channels of a cell (the wide-read rate: twice the
+    // bytes per clock of four ds_read_b32, a quarter of the instructions)
+    __shared__ __attribute__((aligned(16))) T S[CG * NA];
     unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
     const int tx = t % ntx;
     t /= ntx;
@@ -2690,35 +2693,58 @@ ba_bwd_pix_kernel(const float* __restrict__ src, const float* __restrict__ flow,
 #pragma unroll
             for (int c = 0; c < CG; ++c) g[r][c] = buf_ld<T>(rga, nbo[r] >= 0 ? fo[r] + goff + static_cast<unsigned>(c) * fpb : 0xFFFFFFF0u);
         __syncthreads();                                   // the previous group's boxes have been read
-        // wave w stages box rows w, w + NW, ..: lane -> column (one row offset per load, a scalar), the 2 H columns past the 64th by the
-        // first AH * 2 H threads
-#pragma unroll 1
-        for (int c = 0; c < CG; ++c) {
-            const bool have = cg + c < nc;
-            const rsrc_t rs = make_rsrc(sp + static_cast<size_t>(have ? cg + c : 0) * splane, have ? sbytes : 0u);
-            T st[AH / NW], sx;
+        // wave w stages box rows w, w + NW, ..: lane -> column (one row offset per load, a scalar); a thread loads the CG channels of its
+        // cell and writes them with ds_write_b128; the 2 H columns past the 64th by the first AH * 2 H threads
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int rr = 0; rr < AH / NW; ++rr) {
-                const int gy = min(max(ay0 + wave + rr * NW, 0), Hs - 1);
-                st[rr] = buf_ld<T>(rs, (static_cast<unsigned>(gy) * Ws) * E + gxa);
+        for (int h4 = 0; h4 < CG / 4; ++h4) {
+            rsrc_t rs[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool have = cg + h4 * 4 + c < nc;
+                rs[c] = make_rsrc(sp + static_cast<size_t>(have ? cg + h4 * 4 + c : 0) * splane, have ? sbytes : 0u);
             }
-            sx = buf_ld<T>(rs, xoff);
-            T* Sc = S + c * NA;
+            constexpr int RPW = AH / NW, HALF = (RPW + 1) / 2;       // rows per wave, in two batches (registers)
 #pragma unroll
-            for (int rr = 0; rr < AH / NW; ++rr) Sc[(wave + rr * NW) * AP + lane] = st[rr];
-            if (tid < AH * 2 * H) Sc[(tid / (2 * H)) * AP + RW + (tid & (2 * H - 1))] = sx;
+            for (int r0 = 0; r0 < RPW; r0 += HALF) {
+                f32x4 st[HALF];
+#pragma unroll
+                for (int rr = 0; rr < HALF; ++rr) {
+                    if (r0 + rr >= RPW) break;
+                    const int gy = min(max(ay0 + wave + (r0 + rr) * NW, 0), Hs - 1);
+                    const unsigned off = (static_cast<unsigned>(gy) * Ws) * E + gxa;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) st[rr][c] = buf_ld<T>(rs[c], off);
+                }
+#pragma unroll
+                for (int rr = 0; rr < HALF; ++rr) {
+                    if (r0 + rr >= RPW) break;
+                    *reinterpret_cast<f32x4*>(S + (((wave + (r0 + rr) * NW) * AP + lane) * CG + h4 * 4)) = st[rr];
+                }
+            }
+            f32x4 sx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sx[c] = buf_ld<T>(rs[c], xoff);
+            if (tid < AH * 2 * H) *reinterpret_cast<f32x4*>(S + (((tid / (2 * H)) * AP + RW + (tid & (2 * H - 1))) * CG + h4 * 4)) = sx;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < PPT; ++r) {
             if (nbo[r] < 0) continue;
-            const T* nb = S + nbo[r];
+            const T* nb = S + nbo[r] * CG;
+            T gd[CG];
 #pragma unroll
-            for (int c = 0; c < ((FFWM_BA_ABLATE & 8) ? 1 : CG); ++c) {
-                const T gd = g[r][c] * kInvKK;
+            for (int c = 0; c < CG; ++c) gd[c] = ((FFWM_BA_ABLATE & 8) && c > 0) ? 0.f : g[r][c] * kInvKK;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) P[r][q] = fma_t<T>(gd, nb[c * NA + (q / (K + 1)) * AP + (q % (K + 1))], P[r][q]);
-                __builtin_amdgcn_sched_barrier(0);          // one channel's 16 reads in flight, not the whole group's (registers)
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int h4 = 0; h4 < CG / 4; ++h4) {
+                    if ((FFWM_BA_ABLATE & 8) && (q & 3)) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(nb + ((q / (K + 1)) * AP + (q % (K + 1))) * CG + h4 * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) P[r][q] = fma_t<T>(gd[h4 * 4 + c], v[c], P[r][q]);
+                }
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // four cells' reads in flight, not sixteen (registers)
             }
         }
     }

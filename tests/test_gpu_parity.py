@@ -254,7 +254,7 @@ def test_block_attention_backward_by_linearity(oracle, case, fused, pix):
         _lib.prof_enable(False)
         rows = _lib.prof_collect()
     finally:
-        for key, v in (("ba_bwd_fused", 3), ("ba_bwd_pix", 2)):
+        for key, v in (("ba_bwd_fused", 3), ("ba_bwd_pix", 4)):
             _lib.set_option(key, v)
     assert "block_attention_bwd_src" in rows and "block_attention_bwd_pix" in rows
     tol = 1e-4 if case[7] >= 100 else BWD_TOL[torch.float32]
