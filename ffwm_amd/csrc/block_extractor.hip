@@ -2793,11 +2793,213 @@ ba_bwd_pix_kernel(const float* __restrict__ src, const float* __restrict__ flow,
     }
 }
 
+// The fused forward of ONE pixel over `nc` channels, every tap on its own from global memory (ba_fwd_generic's arithmetic).
+__device__ __attribute__((noinline)) void ba_pixel_forward_by_taps(const float* sp, rsrc_t ratt, float* op, int nc, int Hs, int Ws, size_t splane,
+                                                                   unsigned fpb, float fx0, float fy0, int xf, int yf, unsigned pix) {
+    using T = float;
+    constexpr int K = 3;
+    constexpr unsigned E = sizeof(T);
+#pragma unroll 1
+    for (int c = 0; c < nc; ++c) {
+        const T* spc = sp + static_cast<size_t>(c) * splane;
+        T osum = 0;
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {
+            const Tap1<T> ty1 = make_tap<T>(fy0, i - K / 2, yf, Hs);
+            const size_t rT = static_cast<size_t>(ty1.lo) * Ws, rB = static_cast<size_t>(ty1.hi) * Ws;
+#pragma unroll 1
+            for (int j = 0; j < K; ++j) {
+                const Tap1<T> tx1 = make_tap<T>(fx0, j - K / 2, xf, Ws);
+                T s1 = (tx1.wlo * ty1.wlo) * spc[rT + tx1.lo];
+                s1 = fma_t<T>(tx1.whi * ty1.wlo, spc[rT + tx1.hi], s1);
+                s1 = fma_t<T>(tx1.wlo * ty1.whi, spc[rB + tx1.lo], s1);
+                s1 = fma_t<T>(tx1.whi * ty1.whi, spc[rB + tx1.hi], s1);
+                osum = add_rn(osum, mul_rn(s1, buf_ld<T>(ratt, pix * E + static_cast<unsigned>(i * K + j) * fpb)));
+            }
+        }
+        op[static_cast<size_t>(c) * (fpb / E) + pix] = osum / static_cast<T>(K * K);
+    }
+}
+
+// The fused FORWARD on the same layout (round 6): out_c = sum over the (K+1)^2 neighbourhood of coef S_c with the channel-independent
+// coefficients  coef = Wy^T (w / k^2) Wx  kept in registers; boxes staged channel-innermost, one ds_read_b128 per cell and four channels.
+template <int TH, int CG, int WPE>
+__global__ void __launch_bounds__(kBlock, WPE)
+ba_fwd_pix_kernel(const float* __restrict__ src, const float* __restrict__ flow, const float* __restrict__ attn,
+                  float* __restrict__ out, int C, int Hs, int Ws, int Hf, int Wf,
+                  int ntx, int nty, int cslabs, int cs, int remap) {
+    using T = float;
+    constexpr int K = 3, H = 4, RW = kTileRW, NW = kBlock / kWave, PPT = TH / NW, NP = (K + 1) * (K + 1);
+    constexpr int AP = RW + 2 * H, AH = TH + 2 * H, NA = AP * AH;
+    constexpr unsigned E = sizeof(T);
+    constexpr float kInvKK = 1.f / static_cast<float>(K * K);
+    static_assert(CG % 4 == 0, "channels per group: whole float4s");
+    // the staged boxes, CHANNEL-INNERMOST: S[cell][CG] -- one ds_read_b128 brings four channels of a cell (the wide-read rate: twice the
+    // bytes per clock of four ds_read_b32, a quarter of the instructions)
+    __shared__ __attribute__((aligned(16))) T S[CG * NA];
+    unsigned t = xcd_remap(blockIdx.x, gridDim.x, remap);
+    const int tx = t % ntx;
+    t /= ntx;
+    const int ty = t % nty;
+    t /= nty;
+    const int slab = t % cslabs;
+    const int b = t / cslabs;
+    const int x0 = tx * RW, y0 = ty * TH;
+    const int ax0 = x0 - H, ay0 = y0 - H;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int xf = x0 + lane;
+    const bool xin = xf < Wf;
+    const int c0 = slab * cs;
+    const int nc = (c0 + cs < C) ? cs : C - c0;
+    const size_t splane = static_cast<size_t>(Hs) * Ws;
+    const size_t fplane = static_cast<size_t>(Hf) * Wf;
+    const unsigned sbytes = static_cast<unsigned>(splane * E);
+    const unsigned fpb = static_cast<unsigned>(fplane * E);
+    const T* sp = src + (static_cast<size_t>(b) * C + c0) * splane;
+    T* op = out + (static_cast<size_t>(b) * C + c0) * fplane;
+    const rsrc_t rfl = make_rsrc(flow + static_cast<size_t>(b) * 2 * fplane, 2 * fpb);
+    const rsrc_t ratt = make_rsrc(attn + static_cast<size_t>(b) * K * K * fplane, K * K * fpb);
+    const bool inside = ax0 <= Ws - 1 && ay0 <= Hs - 1;
+
+    // the pixels of this thread: where their neighbourhood starts in a staged box (< 0: no pixel / not in the box) and the (K+1)^2 cell
+    // coefficients  coef = Wy^T (w / k^2) Wx  of the fused operator (channel-independent: formed once)
+    int nbo[PPT];
+    unsigned fo[PPT];
+    T coef[PPT][NP];
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        const int yf = y0 + wave + r * NW;
+        const bool live = xin && yf < Hf;
+        fo[r] = (static_cast<unsigned>(min(yf, Hf - 1)) * Wf + min(xf, Wf - 1)) * E;
+        const BaTaps tp = ba_taps<AP, AH>(buf_ld<T>(rfl, fo[r]), buf_ld<T>(rfl, fo[r] + fpb), xf, yf, ax0, ay0, inside);
+        nbo[r] = live ? (tp.fit ? tp.av * AP + tp.au : -1) : -2;
+        T w[K * K];
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) w[q] = buf_ld<T>(ratt, fo[r] + static_cast<unsigned>(q) * fpb) * kInvKK;
+        T txc[K][K + 1];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int c2 = 0; c2 <= K; ++c2) {
+                T v = 0;
+                if (c2 < K) v = w[i * K + c2] * (1 - tp.wxr[c2]);
+                if (c2 > 0) v = (c2 < K) ? fma_t<T>(w[i * K + c2 - 1], tp.wxr[c2 - 1], v) : w[i * K + c2 - 1] * tp.wxr[c2 - 1];
+                txc[i][c2] = v;
+            }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 <= K; ++r2) {
+#pragma unroll
+            for (int c2 = 0; c2 <= K; ++c2) {
+                T v = 0;
+                if (r2 < K) v = txc[r2][c2] * (1 - tp.wyb[r2]);
+                if (r2 > 0) v = (r2 < K) ? fma_t<T>(txc[r2 - 1][c2], tp.wyb[r2 - 1], v) : txc[r2 - 1][c2] * tp.wyb[r2 - 1];
+                coef[r][r2 * (K + 1) + c2] = v;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(AH % NW == 0 && AH * 2 * H <= kBlock, "staging layout");
+    const int tid = threadIdx.x;
+    const unsigned gxa = static_cast<unsigned>(min(max(ax0 + lane, 0), Ws - 1)) * E;
+    const unsigned xoff = tid < AH * 2 * H ? (static_cast<unsigned>(min(max(ay0 + tid / (2 * H), 0), Hs - 1)) * Ws +
+                                              static_cast<unsigned>(min(max(ax0 + RW + (tid & (2 * H - 1)), 0), Ws - 1))) * E
+                                           : 0xFFFFFFF0u;
+#pragma unroll 1
+    for (int cg = 0; cg < nc; cg += CG) {
+        __syncthreads();                                   // the previous group's boxes have been read
+        // wave w stages box rows w, w + NW, ..: lane -> column (one row offset per load, a scalar); a thread loads the CG channels of its
+        // cell and writes them with ds_write_b128; the 2 H columns past the 64th by the first AH * 2 H threads
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int h4 = 0; h4 < CG / 4; ++h4) {
+            rsrc_t rs[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool have = cg + h4 * 4 + c < nc;
+                rs[c] = make_rsrc(sp + static_cast<size_t>(have ? cg + h4 * 4 + c : 0) * splane, have ? sbytes : 0u);
+            }
+            constexpr int RPW = AH / NW, HALF = (RPW + 1) / 2;       // rows per wave, in two batches (registers)
+#pragma unroll
+            for (int r0 = 0; r0 < RPW; r0 += HALF) {
+                f32x4 st[HALF];
+#pragma unroll
+                for (int rr = 0; rr < HALF; ++rr) {
+                    if (r0 + rr >= RPW) break;
+                    const int gy = min(max(ay0 + wave + (r0 + rr) * NW, 0), Hs - 1);
+                    const unsigned off = (static_cast<unsigned>(gy) * Ws) * E + gxa;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) st[rr][c] = buf_ld<T>(rs[c], off);
+                }
+#pragma unroll
+                for (int rr = 0; rr < HALF; ++rr) {
+                    if (r0 + rr >= RPW) break;
+                    *reinterpret_cast<f32x4*>(S + (((wave + (r0 + rr) * NW) * AP + lane) * CG + h4 * 4)) = st[rr];
+                }
+            }
+            f32x4 sx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sx[c] = buf_ld<T>(rs[c], xoff);
+            if (tid < AH * 2 * H) *reinterpret_cast<f32x4*>(S + (((tid / (2 * H)) * AP + RW + (tid & (2 * H - 1))) * CG + h4 * 4)) = sx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PPT; ++r) {
+            if (nbo[r] < 0) continue;
+            const T* nb = S + nbo[r] * CG;
+            T acc[CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) acc[c] = 0;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int h4 = 0; h4 < CG / 4; ++h4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(nb + ((q / (K + 1)) * AP + (q % (K + 1))) * CG + h4 * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[h4 * 4 + c] = fma_t<T>(coef[r][q], v[c], acc[h4 * 4 + c]);
+                }
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            const rsrc_t ro = make_rsrc(op, static_cast<unsigned>(nc) * fpb);      // channels past the slab: stores dropped
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                ElemRow<T, 1> v1;
+                v1.v[0] = acc[c];
+                buf_store_row<T, 1>(ro, fo[r] + static_cast<unsigned>(cg + c) * fpb, v1);
+            }
+        }
+    }
+    // the pixels outside the box: every tap on its own from global memory (rare)
+#pragma unroll
+    for (int r = 0; r < PPT; ++r) {
+        if (nbo[r] != -1) continue;
+        const int yf = y0 + wave + r * NW;
+        ba_pixel_forward_by_taps(sp, ratt, op, nc, Hs, Ws, splane, fpb, buf_ld<T>(rfl, fo[r]), buf_ld<T>(rfl, fo[r] + fpb), xf, yf,
+                                 static_cast<unsigned>(yf) * Wf + xf);
+    }
+}
+
 template <typename T>
 int launch_attn_fwd(const T* src, const T* flow, const T* wts, T* out, int64_t B, int64_t C, int64_t Hs, int64_t Ws,
                     int64_t Hf, int64_t Wf, int k, hipStream_t st) {
     const double bytes = sizeof(T) * static_cast<double>(B) * (C * Hs * Ws + (2.0 + k * k) * Hf * Wf + static_cast<double>(C) * Hf * Wf);
     if constexpr (sizeof(T) == 4) {
+        if (k == 3 && options().be_fwd_variant != 9 && options().ba_fwd_pix != 0 && Hs * Ws < (1LL << 29)) {
+            constexpr int tha = 8, cga = 4;
+            const int ntx = static_cast<int>((Wf + kTileRW - 1) / kTileRW), ntya = static_cast<int>((Hf + tha - 1) / tha);
+            const int64_t tiles = B * ntx * ntya;
+            int64_t want = (4LL * device_cus() + tiles - 1) / tiles;                   // slabs: one resident round of blocks
+            if (want < 1) want = 1;
+            int csa = static_cast<int>((C + want - 1) / want);
+            csa = (csa + cga - 1) / cga * cga;
+            while (csa > cga && static_cast<int64_t>(csa) * Hf * Wf * 4 >= (1LL << 31)) csa -= cga;       // 32-bit byte offsets over a slab of the output
+            const int slabsa = static_cast<int>((C + csa - 1) / csa);
+            FFWM_REQUIRE(tiles * slabsa < (1LL << 31), FFWM_ERR_SIZE, "ffwm_block_attention_forward: grid too large");
+            LaunchScope ls("block_attention_fwd_lds", st, bytes);
+            hipLaunchKernelGGL((ba_fwd_pix_kernel<tha, cga, 4>), dim3(static_cast<unsigned>(tiles * slabsa)), dim3(kBlock), 0, st, src, flow, wts, out,
+                               (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, ntya, slabsa, csa, options().xcd_remap);
+            return check_launch("ffwm_block_attention_forward");
+        }
         if (k == 3 && options().be_fwd_variant != 9) {
             const Geometry g = plan(B, C, Hf, Wf, 16);
             const int rpt = Hf >= 64 ? 4 : 1;

@@ -71,7 +71,7 @@ SCOPES = {   # launch scope -> kernel-name fragment (template arguments included
     "warp_flipcat_bwd_feat_tile@256": "warp_bwd_feat_tile_kernel<true, 2,",
     "warp_flipcat_bwd_feat_far@256": "warp_bwd_feat_far_kernel<true>",
     "warp_flipcat_bwd_flow@256": "warp_bwd_kernel<float, true>",
-    "block_attention_fwd_lds": "be_fwd_lds_kernel<float, 3, 4, 1>",
+    "block_attention_fwd_lds": "ba_fwd_pix_kernel<",
     # round 6: the block attention backward by linearity
     "block_attention_bwd_src": "ba_bwd_src_kernel<",
     "block_attention_bwd_pix": "ba_bwd_pix_kernel<",

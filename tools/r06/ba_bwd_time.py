@@ -40,3 +40,21 @@ for name, fl in (("random", rnd), ("smooth", sm)):
         rows = {k.replace("block_attention_bwd_", ""): round(v["avg_ms"] * 1e3, 1) for k, v in _lib.prof_collect().items()}
         print("%-6s mode %d %s total %.1f  rel diff to the first mode (gs, gf, gw) %s" % (name, m, rows, sum(rows.values()), ["%.1e" % e for e in err]))
 _lib.set_option("ba_bwd_fused", 3)
+# the forward: ba_fwd_pix_kernel (1) against rounds 3-5's be_fwd_lds_kernel<.., MODE 1> (0)
+bo = torch.empty(B, C, H, W, device=dev)
+for name, fl in (("random", rnd), ("smooth", sm)):
+    ref = None
+    for m in (0, 1):
+        _lib.set_option("ba_fwd_pix", m)
+        for _ in range(2):
+            ops.block_attention_forward(src, fl, wts, 3, out=bo)
+        res = bo.clone()
+        ref = res if ref is None else ref
+        torch.cuda.synchronize(); _lib.prof_reset(); _lib.prof_enable(True)
+        for _ in range(6):
+            flush.sum()
+            ops.block_attention_forward(src, fl, wts, 3, out=bo)
+        torch.cuda.synchronize(); _lib.prof_enable(False)
+        rows = {k: round(v["avg_ms"] * 1e3, 1) for k, v in _lib.prof_collect().items()}
+        print("%-6s forward ba_fwd_pix %d %s  rel diff to 0: %.1e" % (name, m, rows, float((res - ref).abs().max() / ref.abs().max())))
+_lib.set_option("ba_fwd_pix", 1)
