@@ -267,7 +267,10 @@ extern "C" int ffwm_flow_head_forward(const void* x, const void* weight, const v
         hipLaunchKernelGGL((flow_head_kernel<P>), dim3(static_cast<unsigned>(B * tiles)), dim3(kBlock), 0, st,         \
                            (const float*)x, (const float*)weight, (const float*)bias, (float*)y, (int)C, (int)H, (int)W, tiles); \
     } while (0)
-    if (HW >= 64) FFWM_FH(64); else if (HW >= 16) FFWM_FH(16); else FFWM_FH(4);
+    // the widest pixel tile that still gives ~100 blocks: a head's C x 9 taps run serially in C / (256 / P) steps per thread, and the
+    // 8 x 8 / 16 x 16 levels of FlowNet (256 / 128 channels, batch 6) had 6 / 24 blocks of 64 pixels walking 64 / 32 channels each
+    auto blocks = [&](int64_t P) { return B * ((HW + P - 1) / P); };
+    if (HW >= 64 && blocks(64) >= 96) FFWM_FH(64); else if (HW >= 16 && blocks(16) >= 96) FFWM_FH(16); else FFWM_FH(4);
 #undef FFWM_FH
     return check_launch(fn);
 }
