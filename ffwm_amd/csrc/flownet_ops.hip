@@ -308,7 +308,9 @@ extern "C" int ffwm_flow_head_backward(const void* y, const void* grad_y, const 
                            (const float*)y, (const float*)grad_y, (const float*)weight, (float*)grad_z, (float*)grad_x, (int)C, (int)H, \
                            (int)W, tiles);                                                                             \
     } while (0)
-    if (HW >= 64) FFWM_FHB(64); else if (HW >= 16) FFWM_FHB(16); else FFWM_FHB(4);
+    // (the forward's rule: the widest pixel tile that still gives ~100 blocks)
+    auto blocks = [&](int64_t P) { return B * ((HW + P - 1) / P); };
+    if (HW >= 64 && blocks(64) >= 96) FFWM_FHB(64); else if (HW >= 16 && blocks(16) >= 96) FFWM_FHB(16); else FFWM_FHB(4);
 #undef FFWM_FHB
     return check_launch(fn);
 }
