@@ -3031,7 +3031,7 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
     if constexpr (sizeof(T) == 4) {
         // (rounds 4-5's route -- be_bwd_tile2_kernel<.., FUSED> + be_fwd_lds_kernel<.., MODE 2> -- is gone: 1.5 x slower, and round 6's wide-flow
         // test found its d(weights) launch wrong where flows leave the forward kernel's LDS window)
-        if (k == 3 && gsrc && options().be_bwd_variant != 9) {
+        if (k == 3 && options().be_bwd_variant != 9 && Hs * Ws < (1LL << 29)) {
             const int mode = options().ba_bwd_fused;
             const int th = mode == 2 ? 16 : 32;
             const int nts = mode == 3 ? 512 : 256;
@@ -3040,6 +3040,7 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
             const int ntx = static_cast<int>((Wf + kTileRW - 1) / kTileRW), nty = static_cast<int>((Hf + th - 1) / th);
             const int cslabs = static_cast<int>((C + csf - 1) / csf);
             const Geometry gf = plan(B, C, Hf, Wf, 32);
+            if (gsrc) {                          // (the two halves are independent: a call that wants only d(flow) / d(weights) runs the pixel kernel alone)
             {
                 LaunchScope ls("block_attention_bwd_far", st, sizeof(T) * 2.0 * B * Hf * Wf);
                 hipLaunchKernelGGL((be_bwd_far2_kernel<float, 3, true>), dim3(gf.grid), dim3(kBlock), 0, st, flow, gout, gsrc,
@@ -3059,6 +3060,7 @@ int launch_attn_bwd(const T* src, const T* flow, const T* wts, const T* gout, T*
 #undef FFWM_BA_SRC
             }
             if (int rc = check_launch("ffwm_block_attention_backward(source)")) return rc;
+            }
             if (gflow || gw) {
                 // d(flow), d(weights): as many channels per block as still give every CU its resident blocks
                 const int cga = options().ba_bwd_pix == 1 || options().ba_bwd_pix == 3 ? 8 : 4;

@@ -267,6 +267,32 @@ def test_block_attention_backward_by_linearity(oracle, case, fused, pix):
         _close(got.cpu() - b0, ref, tol, relative=True)
 
 
+def test_block_attention_backward_partial_outputs_take_the_tuned_kernels(oracle):
+    """The two halves of the backward are independent launches: a call without grad_source runs the pixel kernel alone (rounds 4-5: the
+    per-element kernel), a call with grad_source only runs the scatter alone."""
+    from ffwm_amd import ops, _lib
+    case = BA_LIN_CASES[0]
+    src, flow, _, k = _be_inputs(case, torch.float32)
+    B, C, Hf, Wf = src.shape[0], src.shape[1], flow.shape[2], flow.shape[3]
+    g = _gen(300)
+    w = torch.randn(B, k * k, Hf, Wf, generator=g)
+    go = torch.randn(B, C, Hf, Wf, generator=g)
+    _, gs_ref, gf_ref, gw_ref = _attention_reference(oracle, src, flow, w, k, go)
+    for want in ((False, True, True), (False, False, True), (False, True, False), (True, False, False)):
+        bufs = [torch.zeros_like(t, device=DEV) if n else None for t, n in zip((src, flow, w), want)]
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        ops.block_attention_backward(src.to(DEV), flow.to(DEV), w.to(DEV), go.to(DEV), k, *bufs)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        rows = _lib.prof_collect()
+        assert "block_attention_bwd_generic" not in rows, (want, list(rows))
+        assert ("block_attention_bwd_src" in rows) == want[0] and ("block_attention_bwd_pix" in rows) == (want[1] or want[2]), (want, list(rows))
+        for got, ref in zip(bufs, (gs_ref, gf_ref, gw_ref)):
+            if got is not None:
+                _close(got, ref, BWD_TOL[torch.float32], relative=True)
+
+
 @pytest.mark.parametrize("kind", ["nonfinite", "zeros", "one_channel_zero", "huge", "tiny", "heavy_tail"])
 def test_block_attention_backward_by_linearity_scales(oracle, kind):
     """The per-channel fixed-point scale of ba_bwd_src_kernel is the tile's exact maximum of |g_c / k^2| max|w|: channels without a finite
