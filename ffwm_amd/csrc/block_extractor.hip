@@ -2985,10 +2985,11 @@ int launch_attn_fwd(const T* src, const T* flow, const T* wts, T* out, int64_t B
     const double bytes = sizeof(T) * static_cast<double>(B) * (C * Hs * Ws + (2.0 + k * k) * Hf * Wf + static_cast<double>(C) * Hf * Wf);
     if constexpr (sizeof(T) == 4) {
         if (k == 3 && options().be_fwd_variant != 9 && options().ba_fwd_pix != 0 && Hs * Ws < (1LL << 29)) {
-            constexpr int tha = 8, cga = 4;
+            const int fm = options().ba_fwd_pix;                                       // 1: 64 x 8 pixels, 4 channels per group; 2: 64 x 16, 4; 3: 64 x 8, 8; 4: 64 x 8, 4, 6 blocks per CU
+            const int tha = fm == 2 ? 16 : 8, cga = fm == 3 ? 8 : 4, wpe = fm == 4 ? 6 : 4;
             const int ntx = static_cast<int>((Wf + kTileRW - 1) / kTileRW), ntya = static_cast<int>((Hf + tha - 1) / tha);
             const int64_t tiles = B * ntx * ntya;
-            int64_t want = (4LL * device_cus() + tiles - 1) / tiles;                   // slabs: one resident round of blocks
+            int64_t want = (static_cast<int64_t>(wpe) * device_cus() + tiles - 1) / tiles;                   // slabs: one resident round of blocks
             if (want < 1) want = 1;
             int csa = static_cast<int>((C + want - 1) / want);
             csa = (csa + cga - 1) / cga * cga;
@@ -2996,8 +2997,14 @@ int launch_attn_fwd(const T* src, const T* flow, const T* wts, T* out, int64_t B
             const int slabsa = static_cast<int>((C + csa - 1) / csa);
             FFWM_REQUIRE(tiles * slabsa < (1LL << 31), FFWM_ERR_SIZE, "ffwm_block_attention_forward: grid too large");
             LaunchScope ls("block_attention_fwd_lds", st, bytes);
-            hipLaunchKernelGGL((ba_fwd_pix_kernel<tha, cga, 4>), dim3(static_cast<unsigned>(tiles * slabsa)), dim3(kBlock), 0, st, src, flow, wts, out,
-                               (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, ntya, slabsa, csa, options().xcd_remap);
+#define FFWM_BA_FWD(TH_, CG_, WPE_)                                                                                                             \
+    hipLaunchKernelGGL((ba_fwd_pix_kernel<TH_, CG_, WPE_>), dim3(static_cast<unsigned>(tiles * slabsa)), dim3(kBlock), 0, st, src, flow, wts, out, \
+                       (int)C, (int)Hs, (int)Ws, (int)Hf, (int)Wf, ntx, ntya, slabsa, csa, options().xcd_remap)
+            if (fm == 2) FFWM_BA_FWD(16, 4, 4);
+            else if (fm == 3) FFWM_BA_FWD(8, 8, 4);
+            else if (fm == 4) FFWM_BA_FWD(8, 4, 6);
+            else FFWM_BA_FWD(8, 4, 4);
+#undef FFWM_BA_FWD
             return check_launch("ffwm_block_attention_forward");
         }
         if (k == 3 && options().be_fwd_variant != 9) {

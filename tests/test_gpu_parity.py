@@ -241,7 +241,7 @@ def test_block_attention_backward_by_linearity(oracle, case, fused, pix):
     w = torch.randn(B, k * k, Hf, Wf, generator=g)
     go = torch.randn(B, C, Hf, Wf, generator=g)
     out_ref, gs_ref, gf_ref, gw_ref = _attention_reference(oracle, src, flow, w, k, go)
-    for fwd_pix in (1, 0):           # round 6's forward on the channel-innermost boxes, rounds 3-5's kernel
+    for fwd_pix in (1, 2, 3, 4, 0):  # round 6's forward on the channel-innermost boxes (tile / group / occupancy variants), rounds 3-5's kernel
         _lib.set_option("ba_fwd_pix", fwd_pix)
         try:
             _close(ops.block_attention_forward(src.to(DEV), flow.to(DEV), w.to(DEV), k), out_ref, FWD_TOL[torch.float32])

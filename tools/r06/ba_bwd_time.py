@@ -44,7 +44,7 @@ _lib.set_option("ba_bwd_fused", 3)
 bo = torch.empty(B, C, H, W, device=dev)
 for name, fl in (("random", rnd), ("smooth", sm)):
     ref = None
-    for m in (0, 1):
+    for m in (0, 1, 2, 3, 4):
         _lib.set_option("ba_fwd_pix", m)
         for _ in range(2):
             ops.block_attention_forward(src, fl, wts, 3, out=bo)
