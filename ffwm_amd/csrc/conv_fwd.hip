@@ -409,7 +409,10 @@ int conv_plan(const char* fn, int64_t B, int64_t C, int64_t H, int64_t W, int64_
     if (may_split && tiles < 256) {
         // 768 workgroups; 384 for the transposed convolutions and for <= 32 output pixels (profiles/r05_conv_fwd_split_target.txt, measured
         // with the slices meeting by atomics; option conv_fwd_split_target overrides)
-        const int target = options().conv_fwd_split_target > 0 ? options().conv_fwd_split_target : ((mode == 1 || g.N <= 32) ? 384 : 768);
+        // (round 6, slices meeting in workspace slots -- gpurun_out/conv_layers_split_r06.txt, per layer incl. the reduce pass: 256 for <= 96 output
+        // pixels per class (conv5 / conv5_1 / conv6 / conv6_1 / deconv5 / deconv4: -1.5 ... -7 us each))
+        const int by_shape = g.N <= 96 ? 256 : (mode == 1 ? 384 : 768);
+        const int target = options().conv_fwd_split_target > 0 ? options().conv_fwd_split_target : by_shape;
         splitk = static_cast<int>((target + tiles - 1) / tiles);
         if (splitk > chunks_total) splitk = chunks_total;
         if (splitk < 1) splitk = 1;
