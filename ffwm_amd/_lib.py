@@ -38,6 +38,7 @@ _SIGNATURES = {
     "ffwm_bias_relu_forward": [_p, _p, _p] + [_i64] * 3 + [_i, _p],
     "ffwm_bias_act_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, ctypes.c_double, _i, _p],
     "ffwm_flow_head_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
+    "ffwm_conv_thin_forward": [_p, _p, _p, _p] + [_i64] * 5 + [_i, ctypes.c_double, _i, _p],
     "ffwm_flow_up_forward": [_p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_flow_head_backward": [_p, _p, _p, _p, _p] + [_i64] * 4 + [_i, _p],
     "ffwm_flow_up_backward": [_p, _p, _p] + [_i64] * 4 + [_i, _p],

@@ -63,6 +63,7 @@ struct Options {
     int rs_bwd1_owned_min_pixels = 0;    // owned tiles for calls of at least this many pixels (B H W); 0 = 2^18
     int rs_bwd1_owned_blocks = 0; // owned tiles: the channel slab is halved until the launch has this many blocks (0 = 2048)
     int warp_feat_fixed = 0;     // warp d(feat) owned-tile kernel: 0 = double cells, 1 = 32-bit fixed-point cells (round 6 experiment: slower -- register spills)
+    int conv_thin_variant = 0;   // ffwm_conv_thin_forward (3 x 3): 0 = by shape, 1 / 2 = 8 / 16 output channels per lane, +4 = one input channel per step (no grouped prefetch)
     int ba_fwd_pix = 1;          // block attention forward: 1-4 = ba_fwd_pix_kernel (channel-innermost boxes, coefficients in registers; pixel rows / channels per group / blocks per CU 8/4/4, 16/4/4, 8/8/4, 8/4/6: 65-86 us at cfg-5), 0 = rounds 3-5's be_fwd_lds_kernel<.., MODE 1> (98-117 us)
     int ba_bwd_fused = 3;        // block attention backward, ba_bwd_src_kernel's tile rows / threads: 1 = 32 / 256, 2 = 16 / 256, 3 = 32 / 512 (tools/r06/ba_bwd_time.py)
     int ba_bwd_pix = 4;          // ba_bwd_pix_kernel's pixel rows / channels per group / waves per SIMD: 0 = 16 / 4 / 3, 1 = 8 / 8 / 4, 2 = 16 / 4 / 4, 3 = 16 / 8 / 3, 4 = 8 / 4 / 4, 5 = 8 / 4 / 6 (tools/r06/ba_bwd_time.py)

@@ -219,6 +219,72 @@ unsigned ew_grid(int64_t n) {
     return static_cast<unsigned>(blocks > 256 * 32 ? 256 * 32 : (blocks < 1 ? 1 : blocks));
 }
 
+
+// ------------------------------------------------------------------------------ thin-channel layers, direct (round 6)
+// FlowNet's full-resolution layers have 6 ... 34 input and 16 ... 64 output channels (conv0 6 -> 64, inter_conv1 34 -> 32, inter_conv0
+// 18 -> 16 at 64^2 / 128^2): a 64 x 64 MFMA tile is mostly padding there (11-16 TFLOP/s on the Winograd kernel, 21-30 us per layer).  Here a lane owns ONE pixel and KT output channels in registers, walks the
+// input channels with the 3 x 3 window in registers, and takes the weights -- pre-arranged [C][taps][K] by the host, wave-uniform -- as scalar
+// operands of its FMAs.  A wave = 64 consecutive pixels of a row (coalesced loads and stores); no LDS, no barriers.
+template <int KT, int G>
+__global__ void __launch_bounds__(kBlock)
+conv3x3_direct_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                      int C, int H, int W, int K, int segs_x, int nseg, int act, float slope) {
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int seg = blockIdx.x * (kBlock / kWave) + wave;
+    if (seg >= nseg) return;
+    const int kg = blockIdx.y * KT;
+    const int xs = seg % segs_x, row = seg / segs_x;          // row = b * H + yy
+    const int b = row / H, yy = row - b * H;
+    const int xx = xs * kWave + lane;
+    const bool live = xx < W;
+    const int HW = H * W;
+    const rsrc_t rx = make_rsrc(x + static_cast<size_t>(b) * C * HW, static_cast<unsigned>(static_cast<size_t>(C) * HW * 4));   // channels past C read 0
+    unsigned off[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+        off[t] = (live && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) ? static_cast<unsigned>(y2 * W + x2) * 4u : 0xFFFFFFF0u;
+    }
+    float acc[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+    const unsigned cstep = static_cast<unsigned>(HW) * 4u;
+    // G channels' windows per step, the next step's requested before this one's FMAs (a wave has no neighbours to hide a load behind)
+    float in[G][9], nx[G][9];
+    auto request = [&](int c0, float (&d)[G][9]) {
+#pragma unroll
+        for (int gch = 0; gch < G; ++gch) {
+            const unsigned co = static_cast<unsigned>(c0 + gch) * cstep;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) d[gch][t] = buf_ld<float>(rx, (c0 + gch < C && off[t] != 0xFFFFFFF0u) ? off[t] + co : 0xFFFFFFF0u);
+        }
+    };
+    request(0, in);
+    for (int c = 0; c < C; c += G) {
+        request(c + G, nx);
+#pragma unroll
+        for (int gch = 0; gch < G; ++gch) {
+            if (c + gch >= C) break;
+            const float* wp = w + (static_cast<size_t>(c + gch) * 9) * K + kg;          // wave-uniform: scalar loads
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int k = 0; k < KT; ++k) acc[k] = __builtin_fmaf(wp[t * K + k], in[gch][t], acc[k]);
+        }
+#pragma unroll
+        for (int gch = 0; gch < G; ++gch)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) in[gch][t] = nx[gch][t];
+    }
+    if (!live) return;
+    float* yp = y + (static_cast<size_t>(b) * K + kg) * HW + static_cast<size_t>(yy) * W + xx;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const float v = acc[k] + (bias ? bias[kg + k] : 0.f);
+        yp[static_cast<size_t>(k) * HW] = act == 1 ? (v > 0.f ? v : v * slope) : v;
+    }
+}
+
 }  // namespace
 }  // namespace ffwm
 
@@ -328,5 +394,34 @@ extern "C" int ffwm_flow_up_backward(const void* grad_out, const void* weight, v
     LaunchScope ls("flownet_flow_up_bwd", st, 4.0 * (B * 10.0 * H * W));
     hipLaunchKernelGGL(flow_up_bwd_kernel, dim3(ew_grid(total)), dim3(kBlock), 0, st, (const float*)grad_out, (const float*)weight,
                        (float*)grad_x, total, (int)H, (int)W, grad_out_batch_stride);
+    return check_launch(fn);
+}
+
+// Thin-channel Conv2d(C, K, 3, 1, 1) by the direct kernel above.  weight_ctk: the layer's weights re-arranged by the host to [C][3][3][K] (from
+// Conv2d's [K][C][3][3]), K a multiple of 8; act = 1: LeakyReLU(negative_slope) behind the bias; output [B, K, H, W] contiguous.
+// (A direct kernel for the 4 x 4 / stride-2 transposed thin layers -- a lane per 2 x 2 output quad -- was built and measured 47-86 us against
+// conv_fwd.hip's 27-34: not kept.  The 3 x 3 kernel wins where C <= 18: conv0 19 vs 24 us, inter_conv0 18 vs 30; at 34 -> 32 it loses, 26 vs 21.)
+extern "C" int ffwm_conv_thin_forward(const void* x, const void* weight_ctk, const void* bias, void* y, int64_t B, int64_t C, int64_t H, int64_t W,
+                                      int64_t K, int act, double negative_slope, int dtype, void* stream) {
+    const char* fn = "ffwm_conv_thin_forward";
+    FFWM_REQUIRE(dtype == FFWM_F32, FFWM_ERR_DTYPE, "%s: float32 only", fn);
+    FFWM_REQUIRE(x && weight_ctk && y, FFWM_ERR_ARG, "%s: NULL tensor pointer", fn);
+    FFWM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && K > 0 && K % 8 == 0, FFWM_ERR_ARG, "%s: bad sizes (K must be a multiple of 8)", fn);
+    FFWM_REQUIRE(C * H * W < (1LL << 29) && B * H * ((W + 63) / 64) < (1LL << 30), FFWM_ERR_SIZE, "%s: plane too large", fn);
+    FFWM_REQUIRE(act == 0 || act == 1, FFWM_ERR_ARG, "%s: act must be 0 or 1", fn);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int segs_x = static_cast<int>((W + kWave - 1) / kWave);
+    const int nseg = static_cast<int>(B * H * segs_x);
+    const int per = kBlock / kWave;
+    int kt = K % 16 == 0 ? 16 : 8;          // output channels per lane
+    const int v = options().conv_thin_variant;           // bench: 1 = 8 channels per lane, 2 = 16, +4 = one channel per step instead of three
+    if (v & 3) kt = (v & 3) == 1 ? 8 : (K % 16 == 0 ? 16 : 8);
+    const dim3 grid(static_cast<unsigned>((nseg + per - 1) / per), static_cast<unsigned>(K / kt));
+    LaunchScope ls("flownet_conv_thin", st, 4.0 * (B * C * H * W + static_cast<double>(B) * K * H * W), 2.0 * B * H * W * K * C * 9);
+#define FFWM_CT2(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(kBlock), 0, st, (const float*)x, (const float*)weight_ctk, (const float*)bias, (float*)y, (int)C, \
+                       (int)H, (int)W, (int)K, segs_x, nseg, act, (float)negative_slope)
+    if (v & 4) { if (kt == 8) FFWM_CT2((conv3x3_direct_kernel<8, 1>)); else FFWM_CT2((conv3x3_direct_kernel<16, 1>)); }
+    else { if (kt == 8) FFWM_CT2((conv3x3_direct_kernel<8, 3>)); else FFWM_CT2((conv3x3_direct_kernel<16, 3>)); }
+#undef FFWM_CT2
     return check_launch(fn);
 }

@@ -318,6 +318,7 @@ int ffwm_set_option(const char* key, int value) {
     else if (!strcmp(key, "ba_bwd_fused")) slot = &o.ba_bwd_fused;
     else if (!strcmp(key, "ba_bwd_pix")) slot = &o.ba_bwd_pix;
     else if (!strcmp(key, "ba_fwd_pix")) slot = &o.ba_fwd_pix;
+    else if (!strcmp(key, "conv_thin_variant")) slot = &o.conv_thin_variant;
     else if (!strcmp(key, "rs_bwd1_owned")) slot = &o.rs_bwd1_owned;
     else if (!strcmp(key, "warp_feat_fixed")) slot = &o.warp_feat_fixed;
     else if (!strcmp(key, "rs_bwd1_owned_blocks")) slot = &o.rs_bwd1_owned_blocks;

@@ -69,6 +69,24 @@ def flow_head(x, weight, bias):
     return y
 
 
+def thin_weights(weight):
+    """A thin 3 x 3 layer's weights in the direct kernel's [C][3][3][K] arrangement (from Conv2d's [K, C, 3, 3])."""
+    return weight.detach().permute(1, 2, 3, 0).contiguous()
+
+
+def conv_thin(x, weight_ctk, bias, act, slope=0.2):
+    """Conv2d(C, K, 3, 1, 1) + bias + LeakyReLU on the direct thin-channel kernel (csrc/flownet_ops.hip)."""
+    B, C, H, W = x.shape
+    K = weight_ctk.shape[-1]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and weight_ctk.is_contiguous() and K % 8 == 0
+            and tuple(weight_ctk.shape[:3]) == (C, 3, 3)):
+        raise ValueError("conv_thin: float32 contiguous GPU tensors, weights [C, 3, 3, K] with K % 8 == 0")
+    y = torch.empty(B, K, H, W, device=x.device, dtype=x.dtype)
+    _lib.check(_lib.load().ffwm_conv_thin_forward(x.data_ptr(), weight_ctk.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                  B, C, H, W, K, int(act), float(slope), _lib.F32, _stream(x)), "ffwm_conv_thin_forward")
+    return y
+
+
 def flow_up(flow, weight, bias, out):
     """out: [B, 2, 2H, 2W] view whose samples are contiguous (the last two channels of a concatenation buffer)."""
     B, _, H, W = flow.shape
@@ -147,6 +165,8 @@ class FoldedFlowNet(object):
         self.mfma_min_channels = int(mfma_min_channels)
         self.arena = Arena()
         self.own_winograd = os.environ.get("FFWM_FLOWNET_OWN_WINOGRAD", "1") != "0"
+        self.thin_direct = os.environ.get("FFWM_FLOWNET_THIN_DIRECT", "1") != "0"
+        self._thin = {}
         self._wino = {}
         if net.training:
             raise ValueError("FoldedFlowNet folds eval-mode BatchNorm statistics: call net.eval() first")
@@ -173,6 +193,13 @@ class FoldedFlowNet(object):
     # conv (no bias: it is added by the epilogue) -> bias + LeakyReLU, in place and / or into a cat slice
     def _block(self, name, x, dst=None, dst2=None):
         transposed, w, b, stride, padding, slope = self.blocks[name]
+        if (self.thin_direct and dst is None and dst2 is None and not transposed and tuple(w.shape[2:]) == (3, 3) and stride[0] == 1
+                and padding[0] == 1 and x.size(1) <= 18 and w.size(0) % 8 == 0 and x.size(2) * x.size(3) >= 4096 and x.is_contiguous()):
+            # the thin full-resolution layers (conv0 6 -> 64, inter_conv0 18 -> 16): direct kernel, a pixel and 16 output channels per lane
+            wt = self._thin.get(name)
+            if wt is None:
+                wt = self._thin[name] = thin_weights(w)
+            return conv_thin(x, wt, b, LRELU, slope)
         if self.mfma_conv and (transposed or stride[0] == 2 or x.size(2) <= 32) and x.size(1) >= self.mfma_min_channels:
             # the layers MIOpen wraps in layout transposes (stride-2 convolutions, transposed convolutions), the
             # weight-streaming 2 x 2 ... 8 x 8 tail and the 16 x 16 / 32 x 32 stride-1 layers (measured per layer,

@@ -380,6 +380,13 @@ int ffwm_bias_relu_forward(const void* h, const void* bias, void* y, int64_t B, 
 int ffwm_bias_act_forward(const void* h, const void* bias, void* y, void* y2, int64_t B, int64_t C, int64_t HW,
                           int64_t y_batch_stride, int64_t y2_batch_stride, int act, double negative_slope, int dtype,
                           void* stream);
+/* FlowNet's thin-channel full-resolution 3 x 3 layers (models/base_networks.py:64-112: conv0 6 -> 64, inter_conv0 18 -> 16) by a direct
+ * kernel: a lane owns one pixel and 8 / 16 output channels, weights as scalar operands.  weight_ctk = the layer's weights re-arranged by
+ * the host from Conv2d's [K][C][3][3] to [C][3][3][K]; K % 8 == 0.  Conv2d(C, K, 3, 1, 1) -> y[B,K,H,W] contiguous; act = 1:
+ * LeakyReLU(negative_slope) after the bias (bias may be NULL).  fp32. */
+int ffwm_conv_thin_forward(const void* x, const void* weight_ctk, const void* bias, void* y, int64_t B, int64_t C, int64_t H, int64_t W,
+                           int64_t K, int act, double negative_slope, int dtype, void* stream);
+
 /* predict_flow* (base_networks.py:45-49): y[B,2,H,W] = tanh(conv2d(x[B,C,H,W], weight[2,C,3,3], bias[2], stride 1, pad 1)) */
 int ffwm_flow_head_forward(const void* x, const void* weight, const void* bias, void* y, int64_t B, int64_t C, int64_t H,
                            int64_t W, int dtype, void* stream);

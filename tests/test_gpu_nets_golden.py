@@ -568,3 +568,29 @@ def test_reference_written_checkpoint_and_composed_test_forward_on_the_gpu(tmp_p
     assert float((score.cpu() - ref_score).abs().max()) <= 1e-4 * (1 + float(ref_score.abs().max()))
     # the identity feature of the evaluation path (ffwm_model.py:191-202) runs on the loaded generator's output
     assert t.identity_feature(fake).shape[0] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 6])
+@pytest.mark.parametrize("B,C,H,W,K", [(2, 6, 40, 72, 64), (3, 34, 64, 64, 32), (1, 18, 33, 130, 16), (2, 5, 7, 9, 8), (1, 7, 16, 64, 24)])
+def test_thin_channel_direct_convolution_matches_aten(B, C, H, W, K, variant):
+    """Round 6: FlowNet's thin full-resolution 3 x 3 layers on the direct kernel (a pixel and 8 / 16 output channels per lane, scalar weights,
+    three or one input channels per step): Conv2d(C, K, 3, 1, 1) + bias + LeakyReLU against ATen in float64, ragged widths, no bias."""
+    import torch.nn.functional as F
+    from ffwm_amd import flownet_eval as fe, _lib
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * 0.2
+    b = torch.randn(K, generator=g)
+    ref0 = F.conv2d(x.double(), w.double(), None, 1, 1)
+    ref = F.leaky_relu(ref0 + b.double().view(1, -1, 1, 1), 0.2)
+    wt = fe.thin_weights(w.cuda())
+    tol = 2e-6 * max(1.0, (C * 9) ** 0.5 / 4)
+    _lib.set_option("conv_thin_variant", variant)
+    try:
+        out = fe.conv_thin(x.cuda(), wt, b.cuda(), fe.LRELU, 0.2)
+        plain = fe.conv_thin(x.cuda(), wt, None, fe.NONE)
+    finally:
+        _lib.set_option("conv_thin_variant", 0)
+    assert float((out.cpu().double() - ref).abs().max()) <= tol * float(ref.abs().max())
+    assert float((plain.cpu().double() - ref0).abs().max()) <= tol * float(ref0.abs().max())
