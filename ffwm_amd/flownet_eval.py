@@ -166,6 +166,8 @@ class FoldedFlowNet(object):
         self.arena = Arena()
         self.own_winograd = os.environ.get("FFWM_FLOWNET_OWN_WINOGRAD", "1") != "0"
         self.thin_direct = os.environ.get("FFWM_FLOWNET_THIN_DIRECT", "1") != "0"
+        self.fork = os.environ.get("FFWM_FLOWNET_FORK", "1") != "0"
+        self._side = None
         self._thin = {}
         self._wino = {}
         if net.training:
@@ -235,24 +237,41 @@ class FoldedFlowNet(object):
             else:
                 f = self._block("conv%d_1" % L, f)
             skips[L] = f
-        flow = flow_head(f, *self.heads[6])
+        # Decoder.  deconv_L reads the concatenation of level L + 1 and so does inter_conv_{L+1} -> predict_flow_{L+1} -> upsampled_flow: two
+        # independent chains per level that meet in level L's concatenation buffer.  Round 6: the transposed convolution runs on a side stream
+        # (a parallel branch of the captured graph) next to the flow chain -- each kernel alone is latency-bound at these sizes.
         flows = {}
-        cat = None
+        cur = torch.cuda.current_stream(x.device)
+        side = None
+        if self.fork:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=x.device)
+            side = self._side
+        feat, cat = f, None
         for L in range(5, -1, -1):
-            src = f if L == 5 else cat
             cd = self.blocks["deconv%d" % L][1].size(1)
-            hs = src.size(2) * 2
+            hs = feat.size(2) * 2
             if L >= 3:
                 buf = cats[L]
                 cs = buf.size(1) - cd - 2
             else:
                 cs = 0
                 buf = torch.empty(B, cd + 2, hs, hs, device=x.device, dtype=x.dtype)
-            self._block("deconv%d" % L, src, dst=buf[:, cs:cs + cd])
+            if side is not None:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._block("deconv%d" % L, feat, dst=buf[:, cs:cs + cd])
+            else:
+                self._block("deconv%d" % L, feat, dst=buf[:, cs:cs + cd])
+            if L == 5:
+                flow = flow_head(f, *self.heads[6])
+            else:
+                flow = flows[L + 1] = flow_head(self._block("inter_conv%d" % (L + 1), cat), *self.heads[L + 1])
             flow_up(flow, *self.ups[L], out=buf[:, cs + cd:])
-            cat = buf
-            flow = flow_head(self._block("inter_conv%d" % L, cat), *self.heads[L])
-            flows[L] = flow
+            if side is not None:
+                cur.wait_stream(side)
+            feat = cat = buf
+        flows[0] = flow_head(self._block("inter_conv0", cat), *self.heads[0])
         return flows[0], flows[1], flows[2]
 
     @torch.no_grad()
