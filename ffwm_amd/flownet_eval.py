@@ -13,7 +13,9 @@ launches at batch 6, 80 % of them under 10 us: the step is bound by launches and
 * the whole forward replayed from ONE captured hipGraph (`graph=True`), removing the host launch cost of the remaining
   ~110 kernels.
 
-The dense 3x3 / 4x4 convolutions stay on MIOpen (fp32 Winograd / implicit GEMM on the matrix cores).  Weights are
+Since round 6 no vendor convolution is left in this path: stride-2 / transposed / small-plane layers run on csrc/conv_fwd.hip (fp32 MFMA
+implicit GEMM, reduction splits through workspace slots), the 64 x 64+ stride-1 layers on the library's Winograd kernel, conv0 / inter_conv0
+on a direct thin-channel kernel, and the decoder's transposed convolutions on a side stream beside the flow chain.  Weights are
 snapshotted at construction: build it from a network in `.eval()` and rebuild after the weights change.
 """
 import ctypes
