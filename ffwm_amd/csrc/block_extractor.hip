@@ -2135,11 +2135,13 @@ int check_dims(const char* fn, int64_t B, int64_t C, int64_t Hs, int64_t Ws, int
 //     out = avg_pool2d(BlockExtractor(source, flow, k) * LocalAttnReshape(weights, k), k, k)
 // never needs the k^2-fold expanded tensors: out[b,c,y,x] = (sum_ij s_ij(c) * w_ij) / k^2 with the k x k
 // bilinear samples s_ij of pixel (y, x) and its k^2 attention weights w[b, i k + j, y, x].
-//   forward            be_fwd_lds_kernel<.., MODE 1>: same LDS-staged sampling, one store per pixel and channel
-//   d(source), d(flow) be_bwd_far2_kernel / be_bwd_tile2_kernel<.., FUSED>: grad_output window (g / k^2) w_ij in registers
-//   d(weights)         be_fwd_lds_kernel<.., MODE 2>: the samples again, reduced over the channel slab in
-//                      registers, one atomic per (pixel, ij, slab)
-// Everything else (float64, k > 4, no d(source) wanted) runs the literal per-pixel kernels below.
+// Round 6 (fp32, k = 3): by linearity in the channel-independent window (section further down)
+//   forward              ba_fwd_pix_kernel: coefficients Wy^T (w / k^2) Wx per pixel, boxes channel-innermost, one ds_read_b128 per cell
+//   d(source)            be_bwd_far2_kernel<.., FUSED> (pixels outside their box) + ba_bwd_src_kernel
+//   d(flow), d(weights)  ba_bwd_pix_kernel
+// Rounds 3-5's kernels: be_fwd_lds_kernel<.., MODE 1> is still the forward behind option ba_fwd_pix = 0; be_bwd_tile2_kernel<.., FUSED> and
+// be_fwd_lds_kernel<.., MODE 2> (d(source) + d(flow); d(weights)) are no longer instantiated -- the branches stay in the templates.
+// Everything else (float64, k != 3) runs the literal per-pixel kernels below.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
 ba_fwd_generic(const T* __restrict__ src, const T* __restrict__ flow, const T* __restrict__ wts, T* __restrict__ out,
