@@ -75,6 +75,7 @@ flow_head_kernel(const float* __restrict__ x, const float* __restrict__ w, const
     }
     float a0 = 0.f, a1 = 0.f;
     const float* xb = x + static_cast<int64_t>(b) * C * HW;
+#pragma unroll 4
     for (int c = split; c < C; c += S) {
         const float* xc = xb + static_cast<int64_t>(c) * HW;
         const float* w0 = w + static_cast<int64_t>(c) * 9;                       // w[0][c][:][:]
