@@ -162,7 +162,7 @@ def emit_lines(result):
         # [us, fraction of the roofline] per stand-alone operator launch at BASELINE's configurations (OPS_ROWS)
         final["ops"] = ops_rows
         final["ops_note"] = ("[avg us, frac of 8 TB/s] per stand-alone launch, HIP events; cold caches (512 MiB read between launches) except "
-                             "cfg1 / lar (cache-resident sizes); flownet: [us/fwd bs6, frac of 157 TF]")
+                             "cfg1 / lar (cache-resident sizes); battn_bwd: the WHOLE backward (3 launches); flownet: [us/fwd bs6, frac of 157 TF]")
     if isinstance(final.get("roofline"), dict) and result.get("kernel_rows_from"):
         final["roofline"]["rows_from"] = result["kernel_rows_from"]
     line = json.dumps(final)
